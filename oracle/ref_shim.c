@@ -1,0 +1,302 @@
+/*
+ * ref_shim.c -- capture harness around the REAL gnuais reference objects.
+ *
+ * TEST INFRASTRUCTURE ONLY.  This file is linked (by oracle/Makefile) together
+ * with the reference's own, unmodified translation units compiled in place
+ * from /root/reference/src (filter.c, receiver.c, protodec.c and their
+ * support files) into oracle/_ref/libgnuais_ref.so.  Nothing from the
+ * reference is copied into this repository; this file only *calls* the
+ * reference's public functions and records what they do, so that
+ *   - oracle/ais_oracle.c (the CPU restatement) can be pinned against the real
+ *     code on arbitrary inputs (tests/test_oracle_vs_ref.py), and
+ *   - tests/golden/make_golden.py can emit golden vectors.
+ *
+ * Tap points:
+ *   floats : filter_run_buf()      reference src/filter.c:106-143
+ *   bits   : --wrap=protodec_decode  (called from src/receiver.c:130)
+ *   frames : observed from the same wrap (receivedframes moves, protodec.c:1103)
+ *
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may
+ * load the resulting library.
+ */
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#include <stdio.h>
+
+#include "receiver.h"   /* reference header: struct receiver, receiver_run   */
+#include "filter.h"     /* reference header: struct filter, filter_run_buf   */
+#include "protodec.h"   /* reference header: struct demod_state_t            */
+#include "cfg.h"        /* reference header: skip_type[]                     */
+
+/* ------------------------------------------------------------------ */
+/* capture buffers                                                     */
+
+typedef struct {
+	uint32_t channel;     /* index of the ref receiver that produced it   */
+	uint32_t end_bit;     /* number of bits fed to protodec before the
+	                         STOPSIGN bit that closed the frame           */
+	uint16_t nbits;       /* bufferlen handed to protodec_getdata          */
+	uint8_t  flags;       /* 1 = CRC ok (always 1 here)                    */
+	uint8_t  payload[53]; /* on-air bytes: bit i of byte j = buffer[8j+i]  */
+} ref_frame_t;
+
+#define MAX_RX 4096
+
+static struct receiver *g_rx[MAX_RX];
+static uint32_t g_bits_seen[MAX_RX];
+static int g_nrx = 0;
+
+static uint8_t *g_bits = NULL;          /* captured bits of g_bit_rx only */
+static size_t g_bits_n = 0, g_bits_cap = 0;
+static int g_bit_rx = -1;               /* which receiver's bits to keep, -2 = all (in call order) */
+
+static ref_frame_t *g_frames = NULL;
+static size_t g_frames_n = 0, g_frames_cap = 0;
+
+
+static int rx_index_of_decoder(struct demod_state_t *d)
+{
+	int i;
+	for (i = 0; i < g_nrx; i++)
+		if (g_rx[i] && g_rx[i]->decoder == d)
+			return i;
+	return -1;
+}
+
+/* ------------------------------------------------------------------ */
+/* link-time wraps                                                     */
+
+void __real_protodec_decode(char *in, int count, struct demod_state_t *d);
+
+/* A CRC-valid frame is recognised from the outside: receivedframes moves
+ * (protodec.c:1103) during a step that started in ST_STOPSIGN, where the frame
+ * length is bufferpos - 22 (protodec.c:1096) and d->rbuffer was just filled by
+ * protodec_calculate_crc (protodec.c:150-162).  protodec_getdata() is called
+ * from inside the same translation unit, so it cannot be link-wrapped. */
+static void record_frame(int idx, int bufferlen, struct demod_state_t *d)
+{
+	ref_frame_t *f;
+	int j, i, nbytes;
+
+	if (g_frames_n == g_frames_cap) {
+		g_frames_cap = g_frames_cap ? g_frames_cap * 2 : 1024;
+		g_frames = realloc(g_frames, g_frames_cap * sizeof(*g_frames));
+	}
+	f = &g_frames[g_frames_n++];
+	memset(f, 0, sizeof(*f));
+	f->channel = (uint32_t) idx;
+	f->end_bit = idx >= 0 ? g_bits_seen[idx] : 0;
+	f->nbits = (uint16_t) bufferlen;
+	f->flags = 1;
+	nbytes = bufferlen / 8;
+	if (nbytes > 53)
+		nbytes = 53;
+	/* d->rbuffer holds the payload MSB-first per byte; fold it back to the
+	 * on-air bytes (bit i of byte j = buffer[8j+i], protodec.c:138-143) */
+	for (j = 0; j < nbytes; j++) {
+		unsigned v = 0;
+		for (i = 0; i < 8; i++)
+			v |= (unsigned) (d->rbuffer[8 * j + i] & 1) << (7 - i);
+		f->payload[j] = (uint8_t) v;
+	}
+}
+
+void __wrap_protodec_decode(char *in, int count, struct demod_state_t *d)
+{
+	int idx = rx_index_of_decoder(d);
+	int i;
+	if (idx >= 0 && (g_bit_rx == idx || g_bit_rx == -2)) {
+		for (i = 0; i < count; i++) {
+			if (g_bits_n == g_bits_cap) {
+				g_bits_cap = g_bits_cap ? g_bits_cap * 2 : 65536;
+				g_bits = realloc(g_bits, g_bits_cap);
+			}
+			g_bits[g_bits_n++] = (uint8_t) in[i];
+		}
+	}
+	/* the reference always calls with count == 1 (receiver.c:130); feed one
+	 * bit at a time so the per-bit bookkeeping is exact for any count */
+	for (i = 0; i < count; i++) {
+		int pre_len = (d->state == ST_STOPSIGN) ? d->bufferpos - 22 : -1;
+		int pre_rx = d->receivedframes;
+		__real_protodec_decode(in + i, 1, d);
+		if (d->receivedframes != pre_rx)
+			record_frame(idx, pre_len, d);
+		if (idx >= 0)
+			g_bits_seen[idx]++;
+	}
+}
+
+/* ------------------------------------------------------------------ */
+/* exported control surface (ctypes)                                   */
+
+void ref_reset_all(void)
+{
+	int i;
+	for (i = 0; i < g_nrx; i++) {
+		if (g_rx[i]) {
+			/* the reference leaks the decoder (receiver.c:76-82); tidy up */
+			free(g_rx[i]->decoder->buffer);
+			free(g_rx[i]->decoder->rbuffer);
+			free(g_rx[i]->decoder->serbuffer);
+			free(g_rx[i]->decoder->ipcbuffer);
+			free(g_rx[i]->decoder->nmea);
+			free(g_rx[i]->decoder);
+			free_receiver(g_rx[i]);
+			g_rx[i] = NULL;
+		}
+		g_bits_seen[i] = 0;
+	}
+	g_nrx = 0;
+	g_bits_n = 0;
+	g_frames_n = 0;
+	g_bit_rx = -1;
+}
+
+/* stdout text of protodec_getdata on/off; when off every type is skipped */
+void ref_set_text(int on)
+{
+	int i;
+	for (i = 0; i <= MAX_AIS_PACKET_TYPE; i++)
+		skip_type[i] = on ? 0 : 1;
+}
+
+/* create a reference receiver exactly as ais.c:139-147 does */
+int ref_receiver_new(char name, int num_ch, int ch_ofs)
+{
+	if (g_nrx >= MAX_RX)
+		return -1;
+	g_rx[g_nrx] = init_receiver(name, num_ch, ch_ofs, NULL, NULL);
+	g_bits_seen[g_nrx] = 0;
+	return g_nrx++;
+}
+
+/* drive the unmodified reference functions with
+ * another tap table / pllinc through the public structs */
+int ref_receiver_set_params(int idx, const float *taps, int n_taps, unsigned pllinc)
+{
+	if (idx < 0 || idx >= g_nrx)
+		return -1;
+	if (taps && n_taps > 0) {
+		filter_free(g_rx[idx]->filter);
+		g_rx[idx]->filter = filter_init(n_taps, (float *) taps);
+	}
+	if (pllinc)
+		g_rx[idx]->pllinc = pllinc;
+	return 0;
+}
+
+void ref_receiver_run(int idx, short *buf, int len)
+{
+	receiver_run(g_rx[idx], buf, len);
+}
+
+/* run every receiver over an interleaved stream in chunks the way the main
+ * loop does (ais.c:214-247): chunk, then receiver 0..n-1 */
+void ref_run_stream(short *buf, int total_len, int chunk)
+{
+	int pos = 0, i;
+	while (pos < total_len) {
+		int n = total_len - pos;
+		int stride = g_nrx ? g_rx[0]->num_ch : 1;
+		if (n > chunk)
+			n = chunk;
+		for (i = 0; i < g_nrx; i++)
+			receiver_run(g_rx[i], buf + (size_t) pos * stride, n);
+		pos += n;
+	}
+}
+
+int ref_get_taps(int idx, float *out, int max)
+{
+	int n = g_rx[idx]->filter->length, i;
+	for (i = 0; i < n && i < max; i++)
+		out[i] = g_rx[idx]->filter->taps[i];
+	return n;
+}
+
+void ref_get_pll(int idx, unsigned *pll, int *prev, int *lastbit)
+{
+	*pll = g_rx[idx]->pll;
+	*prev = g_rx[idx]->prev;
+	*lastbit = g_rx[idx]->lastbit;
+}
+
+void ref_get_counters(int idx, int *received, int *lost, int *lost2)
+{
+	*received = g_rx[idx]->decoder->receivedframes;
+	*lost = g_rx[idx]->decoder->lostframes;
+	*lost2 = g_rx[idx]->decoder->lostframes2;
+}
+
+/* FSM snapshot used to pin the restatement's carry state */
+void ref_get_fsm(int idx, int *out7)
+{
+	struct demod_state_t *d = g_rx[idx]->decoder;
+	out7[0] = d->state;
+	out7[1] = d->nstartsign;
+	out7[2] = d->antallpreamble;
+	out7[3] = d->antallenner;
+	out7[4] = d->bitstuff;
+	out7[5] = d->last;
+	out7[6] = d->bufferpos;
+}
+
+void ref_capture_bits_of(int idx) { g_bit_rx = idx; g_bits_n = 0; }
+size_t ref_bits_count(void) { return g_bits_n; }
+const uint8_t *ref_bits_ptr(void) { return g_bits; }
+void ref_bits_clear(void) { g_bits_n = 0; }
+
+size_t ref_frames_count(void) { return g_frames_n; }
+const ref_frame_t *ref_frames_ptr(void) { return g_frames; }
+void ref_frames_clear(void) { g_frames_n = 0; }
+int ref_frame_size(void) { return (int) sizeof(ref_frame_t); }
+
+/* filter_run_buf() on a private filter: floats + maxval per chunk */
+int ref_filter_stream(const float *taps, int n_taps, short *in, int step,
+		      int total_len, int chunk, float *out, short *maxvals)
+{
+	struct filter *f = filter_init(n_taps, (float *) taps);
+	int pos = 0, c = 0;
+	while (pos < total_len) {
+		int n = total_len - pos;
+		if (n > chunk)
+			n = chunk;
+		short m = filter_run_buf(f, in + (size_t) pos * step, out + pos, step, n);
+		if (maxvals)
+			maxvals[c] = m;
+		c++;
+		pos += n;
+	}
+	filter_free(f);
+	return c;
+}
+
+/* feed raw bits to a fresh reference decoder (protodec_decode parity) */
+void ref_decode_bits(int idx, const uint8_t *bits, int n)
+{
+	int i;
+	for (i = 0; i < n; i++) {
+		char b = (char) bits[i];
+		protodec_decode(&b, 1, g_rx[idx]->decoder);
+	}
+}
+
+extern unsigned short protodec_sdlc_crc(const unsigned char *data, unsigned len);
+unsigned ref_sdlc_crc(const unsigned char *data, unsigned len)
+{
+	return protodec_sdlc_crc(data, len);
+}
+
+/* timed loop for bench.py's cpu_baseline (kind "reference"): every receiver
+ * over the whole interleaved stream, text off.  Returns frames received. */
+long ref_bench_run(short *buf, int total_len, int chunk)
+{
+	int i;
+	long tot = 0;
+	ref_run_stream(buf, total_len, chunk);
+	for (i = 0; i < g_nrx; i++)
+		tot += g_rx[i]->decoder->receivedframes;
+	return tot;
+}
