@@ -1,0 +1,112 @@
+"""Deterministic input builders shared by the golden-vector generator and the
+parity tests (CPU oracle and HIP path see exactly the same integers)."""
+from __future__ import annotations
+
+import numpy as np
+
+from gnuais_amd import synth
+
+
+def chain_48k(n_slots: int = 5):
+    """2 channels (A: sigma 1000, B: sigma 3000), every slot occupied except one."""
+    n = n_slots * 1280
+
+    def pick(skip):
+        def f(rng, slot):
+            return None if slot == skip else synth.random_position_report(rng)
+        return f
+
+    a, _ = synth.make_stream(n, seed=1001, channel=0, sigma=1000.0, payloads=pick(2))
+    b, _ = synth.make_stream(n, seed=1001, channel=1, sigma=3000.0, payloads=pick(1))
+    return np.stack([a, b], axis=1)
+
+
+def chain_192k(n_slots: int = 3):
+    n = n_slots * 5120
+    x, _ = synth.make_stream(n, seed=1002, channel=0, sps=20, sigma=1000.0, occupancy=1.0)
+    return x[:, None].copy()
+
+
+def long_messages():
+    """Type-5 style 424-bit payloads (two slots), a 432-bit one that the deframer must
+    drop (> 426 bits, protodec.c:1024-1026), a 1-byte and a 0-byte payload."""
+    rng0 = np.random.default_rng(77)
+    plan = {0: 53, 2: 54, 4: 1, 5: 0, 6: 21, 7: 52}
+
+    def f(rng, slot):
+        if slot not in plan:
+            return None
+        return bytes(rng0.integers(0, 256, plan[slot], dtype=np.uint8))
+
+    x, _ = synth.make_stream(8 * 1280, seed=1003, channel=0, sigma=500.0, payloads=f)
+    return x[:, None].copy()
+
+
+def fir_kats():
+    """FIR known-answer inputs (SURVEY.md 'hard parts'): single +-1 / +-full-scale
+    samples in silence (only the subnormal and tiny taps contribute around the
+    edges of the response), full-scale random noise and an alternating full-scale
+    pattern (both sensitive to FMA contraction and to summation order)."""
+    out = {}
+    for name, v in (("imp_p1", 1), ("imp_m1", -1), ("imp_max", 32767), ("imp_min", -32768)):
+        x = np.zeros(120, dtype=np.int16)
+        x[40] = v
+        out[name] = x
+    rng = np.random.default_rng(5)
+    out["noise_full"] = rng.integers(-32768, 32768, 4096).astype(np.int16)
+    alt = np.empty(512, dtype=np.int16)
+    alt[0::2] = 32767
+    alt[1::2] = -32768
+    out["alternating"] = alt
+    out["ramp"] = np.arange(-300, 300, dtype=np.int16)
+    return out
+
+
+def _stuffed(payload: bytes, good_crc=True, stuff=True):
+    bits = synth.hdlc_frame_bits(payload, stuff=stuff)
+    if not good_crc:
+        bits = bits.copy()
+        bits[24 + 8 + 3] ^= 1
+    return bits
+
+
+def fsm_bit_cases():
+    """Bit sequences for protodec_decode parity (one byte per bit)."""
+    rng = np.random.default_rng(11)
+    cases = {}
+    cases["random_p50"] = rng.integers(0, 2, 30000, dtype=np.uint8)
+    cases["random_p70"] = (rng.random(30000) < 0.7).astype(np.uint8)
+    cases["random_p30"] = (rng.random(30000) < 0.3).astype(np.uint8)
+    cases["alternating"] = (np.arange(5000) & 1).astype(np.uint8)
+    frames = []
+    for n in (21, 21, 1, 2, 53, 54, 60, 0, 12):
+        frames.append(_stuffed(bytes(rng.integers(0, 256, n, dtype=np.uint8))))
+        frames.append(rng.integers(0, 2, int(rng.integers(0, 40)), dtype=np.uint8))
+    frames.append(_stuffed(bytes(rng.integers(0, 256, 21, dtype=np.uint8)), good_crc=False))
+    frames.append(_stuffed(bytes([0xFF] * 21)))                      # heavy stuffing
+    frames.append(_stuffed(bytes([0xFF] * 21), stuff=False))         # abort: 7+ ones
+    # payload length not a multiple of 8: drop 3 bits before the closing flag
+    odd = _stuffed(bytes(rng.integers(0, 256, 21, dtype=np.uint8)))
+    frames.append(np.concatenate([odd[:-11], odd[-8:]]))
+    # back-to-back frames sharing nothing, then a frame preceded by a short preamble
+    frames.append(_stuffed(bytes(rng.integers(0, 256, 21, dtype=np.uint8))))
+    frames.append(synth.hdlc_frame_bits(bytes(rng.integers(0, 256, 21, dtype=np.uint8)),
+                                        training_bits=10))
+    frames.append(synth.hdlc_frame_bits(bytes(rng.integers(0, 256, 21, dtype=np.uint8)),
+                                        training_bits=40))
+    cases["crafted"] = np.concatenate(frames).astype(np.uint8)
+    # frames embedded in biased noise, many of them
+    parts = []
+    for i in range(60):
+        parts.append((rng.random(int(rng.integers(5, 200))) < 0.5).astype(np.uint8))
+        parts.append(_stuffed(bytes(rng.integers(0, 256, int(rng.choice([11, 21, 21, 21, 53])),
+                                                 dtype=np.uint8)), good_crc=(i % 7 != 3)))
+    cases["mixed"] = np.concatenate(parts).astype(np.uint8)
+    return cases
+
+
+def crc_cases():
+    rng = np.random.default_rng(3)
+    c = [b"123456789", b"", b"\x00", b"\xff\xff", bytes(range(58))]
+    c += [bytes(rng.integers(0, 256, int(n), dtype=np.uint8)) for n in rng.integers(1, 58, 20)]
+    return c

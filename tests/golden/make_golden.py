@@ -1,0 +1,107 @@
+#!/usr/bin/env python3
+"""Generate the golden vectors under tests/golden/ from the REAL reference.
+
+Runs only in the build container: it needs oracle/_ref/libgnuais_ref.so, i.e.
+the unmodified gnuais translation units compiled in place from /root/reference
+(recipe: oracle/Makefile).  The fixtures are data only -- int16 inputs and the
+reference's outputs on them (fp32 bit patterns, recovered bits, frames,
+counters, final PLL/FSM state).  Re-run with:  python tests/golden/make_golden.py
+"""
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(HERE))
+sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+
+import cases  # noqa: E402
+from gnuais_amd import params  # noqa: E402
+from oracle_lib import reference  # noqa: E402
+
+
+def frames_raw(f):
+    return np.frombuffer(f.tobytes(), dtype=np.uint8).reshape(-1, 64).copy()
+
+
+def run_chain(x, taps=None, pllinc=0, chunk=1020):
+    """Full chain through the reference; one receiver per interleaved channel."""
+    ref = reference()
+    n_ch = x.shape[1]
+    ref.add_receivers(n_ch, taps=taps, pllinc=pllinc)
+    t = ref.taps(0)
+    out = {"x": x, "taps": t.view(np.uint32), "pllinc": np.uint32(pllinc or params.PLLINC_48K)}
+    # floats: filter_run_buf on a private filter per channel
+    filt = np.zeros(x.shape, dtype=np.uint32)
+    maxv = np.zeros(n_ch, dtype=np.int16)
+    for c in range(n_ch):
+        f, mv = ref.filter_stream(t, x[:, c].copy(), 1, x.shape[0], x.shape[0])
+        filt[:, c] = f.view(np.uint32)
+        maxv[c] = mv[0]
+    out["filtered_u32"] = filt
+    out["maxval"] = maxv
+    # bits: one pass per channel so each channel's bit stream is captured alone
+    for c in range(n_ch):
+        ref.reset()
+        ref.add_receivers(n_ch, taps=taps, pllinc=pllinc)
+        ref.run_stream(x, chunk, capture_bits_of=c)
+        out[f"bits{c}"] = ref.bits()
+    out["frames"] = frames_raw(ref.frames())
+    out["counters"] = ref.counters()
+    out["pll"] = np.array([ref.pll(c) for c in range(n_ch)], dtype=np.int64)
+    out["fsm"] = np.array([list(ref.fsm(c).values()) for c in range(n_ch)], dtype=np.int32)
+    return out
+
+
+def main():
+    ref = reference()
+    # 1. full chain, 48 kHz, 2 channels (config C1 shape)
+    np.savez_compressed(os.path.join(HERE, "chain_48k.npz"), **run_chain(cases.chain_48k()))
+    # 2. full chain, 192 kHz parameters (config C5 shape), 1 channel
+    np.savez_compressed(os.path.join(HERE, "chain_192k.npz"),
+                        **run_chain(cases.chain_192k(), taps=params.taps_192k(),
+                                    pllinc=params.PLLINC_192K, chunk=4096))
+    # 3. long / odd-length messages
+    np.savez_compressed(os.path.join(HERE, "chain_long.npz"), **run_chain(cases.long_messages()))
+    # 4. FIR known answers
+    ref = reference()
+    ref.add_receivers(1)
+    taps = ref.taps(0)
+    kat = {"taps": taps.view(np.uint32)}
+    for name, x in cases.fir_kats().items():
+        f, mv = ref.filter_stream(taps, x, 1, x.size, 1020)
+        kat["x_" + name] = x
+        kat["y_" + name] = f.view(np.uint32)
+        kat["m_" + name] = mv
+    t192 = params.taps_192k()
+    x = cases.fir_kats()["noise_full"]
+    f, mv = ref.filter_stream(t192, x, 1, x.size, 1000)
+    kat["taps192"] = t192.view(np.uint32)
+    kat["y192_noise_full"] = f.view(np.uint32)
+    np.savez_compressed(os.path.join(HERE, "fir_kat.npz"), **kat)
+    # 5. CRC-16
+    blobs = cases.crc_cases()
+    crc = {"data": np.frombuffer(b"".join(blobs), dtype=np.uint8),
+           "lens": np.array([len(b) for b in blobs], dtype=np.int32),
+           "crc": np.array([ref.sdlc_crc(b) for b in blobs], dtype=np.uint16)}
+    np.savez_compressed(os.path.join(HERE, "crc16.npz"), **crc)
+    # 6. deframer on raw bit sequences (protodec_decode)
+    fsm = {}
+    for name, bits in cases.fsm_bit_cases().items():
+        ref = reference()
+        ref.add_receivers(1)
+        ref.decode_bits(0, bits)
+        fsm["bits_" + name] = np.packbits(bits)
+        fsm["n_" + name] = np.int64(bits.size)
+        fsm["frames_" + name] = frames_raw(ref.frames())
+        fsm["counters_" + name] = ref.counters()[0]
+        fsm["fsm_" + name] = np.array(list(ref.fsm(0).values()), dtype=np.int32)
+    np.savez_compressed(os.path.join(HERE, "deframer_bits.npz"), **fsm)
+    for f in sorted(os.listdir(HERE)):
+        if f.endswith(".npz"):
+            print(f, os.path.getsize(os.path.join(HERE, f)))
+
+
+if __name__ == "__main__":
+    main()
