@@ -1,0 +1,566 @@
+// gnuais_capi.hip -- host side of the C ABI declared in include/gnuais_hip.h.
+//
+// Owns the per-batch device state (FIR history, PLL phase, deframer state,
+// frame ring) and sequences the kernels of one receiver_run() pass:
+//   K1 fir_slice -> history update -> K2a pll_nrzi -> K2b hdlc_crc
+// all on the caller's stream.  No CPU implementation of the chain exists here:
+// without a usable HIP device every entry point fails with GNUAIS_E_HIP.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/gnuais_hip.h"
+#include "kernels.h"
+
+using namespace gnuais;
+
+namespace gnuais {
+namespace scalar { hipError_t launch_fir_slice(const FirLaunch &a, hipStream_t stream); }
+namespace packed { hipError_t launch_fir_slice(const FirLaunch &a, hipStream_t stream); }
+}
+
+static thread_local std::string g_err;
+
+static int fail(int code, const char *what, hipError_t e = hipSuccess)
+{
+    char buf[512];
+    if (e != hipSuccess)
+        snprintf(buf, sizeof buf, "%s: %s", what, hipGetErrorString(e));
+    else
+        snprintf(buf, sizeof buf, "%s", what);
+    g_err = buf;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                          \
+    do {                                                                       \
+        hipError_t e_ = (expr);                                                \
+        if (e_ != hipSuccess) return fail(GNUAIS_E_HIP, #expr, e_);            \
+    } while (0)
+
+// src/receiver.c:39-49, first half of the symmetric table (double literals that
+// round to fp32 on assignment, exactly as the reference's static float array)
+static const double k_tap_half[18] = {
+    2.5959e-55, 2.9479e-49, 1.4741e-43, 3.2462e-38, 3.1480e-33, 1.3443e-28,
+    2.5280e-24, 2.0934e-20, 7.6339e-17, 1.2259e-13, 8.6690e-11, 2.6996e-08,
+    3.7020e-06, 2.2355e-04, 5.9448e-03, 6.9616e-02, 3.5899e-01, 8.1522e-01};
+
+struct gnuais_batch {
+    int device = 0;
+    int N = 0, NT = 0, NE = 0, d = 0;
+    uint32_t pllinc = 0;
+    int max_len = 0, frame_cap = 0;
+    int sgn_words = 0, bits_words = 0;
+    std::vector<float> taps;
+    float te[64] = {0};
+    // device state
+    int16_t *hist[2] = {nullptr, nullptr};
+    int hist_cur = 0;
+    uint32_t *sgn = nullptr, *pll = nullptr, *bits = nullptr, *nbits = nullptr;
+    uint32_t *ctl = nullptr, *buf = nullptr, *frame_count = nullptr;
+    int32_t *counters = nullptr;
+    int *maxval = nullptr;
+    gnuais_frame *frames = nullptr;
+    float *d_taps = nullptr;
+    int16_t *stage_x = nullptr;
+    size_t stage_bytes = 0;
+    // options
+    int fir_T = 512;
+    int fir_variant = 0;            // 0 scalar VALU, 1 packed VALU
+    bool timing = false;
+    hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    bool timed_last = false;
+    hipStream_t last_stream = nullptr;
+    int last_len = 0;
+};
+
+static int set_device(const gnuais_batch *b)
+{
+    HIP_TRY(hipSetDevice(b->device));
+    return GNUAIS_OK;
+}
+
+extern "C" {
+
+const char *gnuais_last_error(void) { return g_err.c_str(); }
+const char *gnuais_version(void) { return "gnuais-hip 0.1 (gfx950)"; }
+
+int gnuais_default_taps(float *out36)
+{
+    if (!out36) return fail(GNUAIS_E_ARG, "gnuais_default_taps: NULL");
+    for (int k = 0; k < 18; ++k) {
+        out36[k] = (float) k_tap_half[k];
+        out36[35 - k] = (float) k_tap_half[k];
+    }
+    return 36;
+}
+
+void gnuais_batch_destroy(gnuais_batch *b)
+{
+    if (!b) return;
+    (void) hipSetDevice(b->device);
+    void *ptrs[] = {b->hist[0], b->hist[1], b->sgn, b->pll, b->bits, b->nbits, b->ctl, b->buf,
+                    b->frame_count, b->counters, b->maxval, b->frames, b->d_taps, b->stage_x};
+    for (void *p : ptrs)
+        if (p) (void) hipFree(p);
+    for (auto &e : b->ev)
+        if (e) (void) hipEventDestroy(e);
+    delete b;
+}
+
+int gnuais_batch_create(gnuais_batch **out, int device, int n_channels, const float *taps,
+                        int n_taps, unsigned pllinc, int max_len, int frame_capacity)
+{
+    if (!out) return fail(GNUAIS_E_ARG, "create: out is NULL");
+    *out = nullptr;
+    if (n_channels <= 0 || max_len <= 0) return fail(GNUAIS_E_ARG, "create: n_channels/max_len");
+    if (taps && (n_taps <= 0 || n_taps > GNUAIS_MAX_TAPS)) return fail(GNUAIS_E_ARG, "create: n_taps");
+    if (pllinc > 0xffffu) return fail(GNUAIS_E_ARG, "create: pllinc must be < 0x10000");
+    int ndev = 0;
+    HIP_TRY(hipGetDeviceCount(&ndev));
+    if (ndev <= 0) return fail(GNUAIS_E_HIP, "create: no HIP device");
+    if (device < 0 || device >= ndev) return fail(GNUAIS_E_ARG, "create: device index");
+    HIP_TRY(hipSetDevice(device));
+
+    gnuais_batch *b = new gnuais_batch;
+    b->device = device;
+    b->N = n_channels;
+    if (taps) {
+        b->taps.assign(taps, taps + n_taps);
+    } else {
+        b->taps.resize(36);
+        gnuais_default_taps(b->taps.data());
+    }
+    b->NT = (int) b->taps.size();
+    b->pllinc = pllinc ? pllinc : (0x10000u / 5u);     // receiver.c:69
+    b->max_len = max_len;
+    b->frame_cap = frame_capacity > 0 ? frame_capacity : std::max(4096, n_channels * 48);
+
+    // trim exactly-zero taps at both ends (exact, see fir_slice.hip)
+    int k0 = 0, k1 = b->NT - 1;
+    while (k0 < b->NT - 1 && b->taps[k0] == 0.0f) ++k0;
+    while (k1 > k0 && b->taps[k1] == 0.0f) --k1;
+    b->NE = k1 - k0 + 1;
+    b->d = b->NT - k0;
+    if (b->NE <= 64)
+        for (int j = 0; j < b->NE; ++j) b->te[j] = b->taps[k0 + j];
+
+    b->sgn_words = (max_len + 31) / 32;
+    // at most one slice per sample step of (pllinc + pllinc/16)/65536
+    const uint64_t step = (uint64_t) b->pllinc + b->pllinc / 16;
+    b->bits_words = (int) (((uint64_t) max_len * step / 65536 + 2 + 31) / 32) + 1;
+
+    const size_t N = (size_t) b->N;
+    hipError_t e = hipSuccess;
+    auto alloc = [&](void **p, size_t bytes) {
+        if (e == hipSuccess) e = hipMalloc(p, bytes);
+        if (e == hipSuccess) e = hipMemset(*p, 0, bytes);
+    };
+    alloc((void **) &b->hist[0], sizeof(int16_t) * N * b->NT);
+    alloc((void **) &b->hist[1], sizeof(int16_t) * N * b->NT);
+    alloc((void **) &b->sgn, sizeof(uint32_t) * N * b->sgn_words);
+    alloc((void **) &b->pll, sizeof(uint32_t) * N);
+    alloc((void **) &b->bits, sizeof(uint32_t) * N * b->bits_words);
+    alloc((void **) &b->nbits, sizeof(uint32_t) * N);
+    alloc((void **) &b->ctl, sizeof(uint32_t) * N * HDLC_CTL_WORDS);
+    alloc((void **) &b->buf, sizeof(uint32_t) * N * HDLC_BUF_WORDS);
+    alloc((void **) &b->frame_count, sizeof(uint32_t) * 2);
+    alloc((void **) &b->counters, sizeof(int32_t) * N * 3);
+    alloc((void **) &b->maxval, sizeof(int) * N);
+    alloc((void **) &b->frames, sizeof(gnuais_frame) * (size_t) b->frame_cap);
+    alloc((void **) &b->d_taps, sizeof(float) * b->NT);
+    if (e == hipSuccess)
+        e = hipMemcpy(b->d_taps, b->taps.data(), sizeof(float) * b->NT, hipMemcpyHostToDevice);
+    for (auto &ev : b->ev)
+        if (e == hipSuccess) e = hipEventCreate(&ev);
+    if (e != hipSuccess) {
+        gnuais_batch_destroy(b);
+        return fail(GNUAIS_E_HIP, "create: device allocation", e);
+    }
+    if (const char *v = getenv("GNUAIS_FIR_VARIANT")) b->fir_variant = atoi(v);
+    if (const char *v = getenv("GNUAIS_FIR_T")) b->fir_T = std::max(64, atoi(v) / 32 * 32);
+    *out = b;
+    int rc = gnuais_batch_reset(b);
+    if (rc != GNUAIS_OK) {
+        gnuais_batch_destroy(b);
+        *out = nullptr;
+    }
+    return rc;
+}
+
+int gnuais_batch_reset(gnuais_batch *b)
+{
+    if (!b) return fail(GNUAIS_E_ARG, "reset: NULL batch");
+    if (int rc = set_device(b)) return rc;
+    const size_t N = (size_t) b->N;
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemset(b->hist[0], 0, sizeof(int16_t) * N * b->NT));   // filter.c:62
+    HIP_TRY(hipMemset(b->hist[1], 0, sizeof(int16_t) * N * b->NT));
+    b->hist_cur = 0;
+    HIP_TRY(hipMemset(b->pll, 0, sizeof(uint32_t) * N));              // receiver.c:66-71
+    HIP_TRY(hipMemset(b->nbits, 0, sizeof(uint32_t) * N));
+    HIP_TRY(hipMemset(b->buf, 0, sizeof(uint32_t) * N * HDLC_BUF_WORDS));
+    HIP_TRY(hipMemset(b->counters, 0, sizeof(int32_t) * N * 3));      // protodec.c:62-64
+    HIP_TRY(hipMemset(b->maxval, 0, sizeof(int) * N));
+    HIP_TRY(hipMemset(b->frame_count, 0, sizeof(uint32_t) * 2));
+    HIP_TRY(launch_hdlc_reset(b->ctl, b->N, nullptr));                // protodec.c:87-100
+    HIP_TRY(hipDeviceSynchronize());
+    b->last_len = 0;
+    return GNUAIS_OK;
+}
+
+int gnuais_batch_set_option(gnuais_batch *b, const char *name, int value)
+{
+    if (!b || !name) return fail(GNUAIS_E_ARG, "set_option: NULL");
+    if (!strcmp(name, "fir_T")) {
+        if (value < 64 || value % 32) return fail(GNUAIS_E_ARG, "fir_T must be a multiple of 32, >= 64");
+        b->fir_T = value;
+    } else if (!strcmp(name, "fir_variant")) {
+        if (value < 0 || value > 1) return fail(GNUAIS_E_ARG, "fir_variant must be 0 or 1");
+        b->fir_variant = value;
+    } else {
+        return fail(GNUAIS_E_ARG, "set_option: unknown option");
+    }
+    return GNUAIS_OK;
+}
+
+static void fill_fir(const gnuais_batch *b, FirLaunch &f, const int16_t *x, int len, float *dump)
+{
+    memset(&f, 0, sizeof f);
+    f.x = x;
+    f.hist = b->hist[b->hist_cur];
+    f.sgn = b->sgn;
+    f.dump = dump;
+    f.maxval = b->maxval;
+    f.d_taps = b->d_taps;
+    memcpy(f.te, b->te, sizeof f.te);
+    f.N = b->N;
+    f.L = len;
+    f.T = b->fir_T;
+    f.NT = b->NT;
+    f.NE = b->NE;
+    f.d = b->d;
+}
+
+static int run_fir(gnuais_batch *b, const int16_t *x, int len, float *dump, hipStream_t s)
+{
+    FirLaunch f;
+    fill_fir(b, f, x, len, dump);
+    HIP_TRY(hipMemsetAsync(b->maxval, 0, sizeof(int) * (size_t) b->N, s));
+    if (b->NE != 32)
+        HIP_TRY(launch_fir_generic(f, s));
+    else if (b->fir_variant == 1)
+        HIP_TRY(packed::launch_fir_slice(f, s));
+    else
+        HIP_TRY(scalar::launch_fir_slice(f, s));
+    return GNUAIS_OK;
+}
+
+static int run_history(gnuais_batch *b, const int16_t *x, int len, hipStream_t s)
+{
+    HIP_TRY(launch_fir_history(x, b->hist[b->hist_cur], b->hist[b->hist_cur ^ 1], b->N, len,
+                               b->NT, s));
+    b->hist_cur ^= 1;
+    return GNUAIS_OK;
+}
+
+int gnuais_batch_run(gnuais_batch *b, const int16_t *d_samples, int len, void *stream)
+{
+    if (!b || !d_samples) return fail(GNUAIS_E_ARG, "run: NULL argument");
+    if (len <= 0 || len > b->max_len) return fail(GNUAIS_E_ARG, "run: len out of range (max_len)");
+    if (int rc = set_device(b)) return rc;
+    hipStream_t s = (hipStream_t) stream;
+    const bool tm = b->timing;
+    if (tm) HIP_TRY(hipEventRecord(b->ev[0], s));
+    if (int rc = run_fir(b, d_samples, len, nullptr, s)) return rc;
+    if (tm) HIP_TRY(hipEventRecord(b->ev[1], s));
+    if (int rc = run_history(b, d_samples, len, s)) return rc;
+    PllLaunch p;
+    p.sgn = b->sgn; p.pll = b->pll; p.bits = b->bits; p.nbits = b->nbits;
+    p.N = b->N; p.L = len; p.bits_words = b->bits_words; p.pllinc = b->pllinc;
+    if (tm) HIP_TRY(hipEventRecord(b->ev[2], s));
+    HIP_TRY(launch_pll_nrzi(p, s));
+    if (tm) HIP_TRY(hipEventRecord(b->ev[3], s));
+    HdlcLaunch h;
+    h.bits = b->bits; h.nbits = b->nbits; h.ctl = b->ctl; h.buf = b->buf;
+    h.counters = b->counters; h.frames = b->frames; h.frame_count = b->frame_count;
+    h.frame_cap = (uint32_t) b->frame_cap; h.N = b->N; h.bits_words = b->bits_words;
+    HIP_TRY(launch_hdlc_crc(h, s));
+    if (tm) HIP_TRY(hipEventRecord(b->ev[4], s));
+    b->timed_last = tm;
+    b->last_stream = s;
+    b->last_len = len;
+    return GNUAIS_OK;
+}
+
+int gnuais_batch_sync(gnuais_batch *b)
+{
+    if (!b) return fail(GNUAIS_E_ARG, "sync: NULL batch");
+    if (int rc = set_device(b)) return rc;
+    HIP_TRY(hipStreamSynchronize(b->last_stream));
+    return GNUAIS_OK;
+}
+
+static int ensure_stage(gnuais_batch *b, size_t bytes)
+{
+    if (b->stage_bytes >= bytes) return GNUAIS_OK;
+    if (b->stage_x) HIP_TRY(hipFree(b->stage_x));
+    b->stage_x = nullptr;
+    b->stage_bytes = 0;
+    HIP_TRY(hipMalloc((void **) &b->stage_x, bytes));
+    b->stage_bytes = bytes;
+    return GNUAIS_OK;
+}
+
+int gnuais_batch_run_host(gnuais_batch *b, const int16_t *h_samples, int len)
+{
+    if (!b || !h_samples) return fail(GNUAIS_E_ARG, "run_host: NULL argument");
+    if (len <= 0 || len > b->max_len) return fail(GNUAIS_E_ARG, "run_host: len out of range");
+    if (int rc = set_device(b)) return rc;
+    const size_t bytes = sizeof(int16_t) * (size_t) len * (size_t) b->N;
+    if (int rc = ensure_stage(b, bytes)) return rc;
+    HIP_TRY(hipMemcpy(b->stage_x, h_samples, bytes, hipMemcpyHostToDevice));
+    if (int rc = gnuais_batch_run(b, b->stage_x, len, nullptr)) return rc;
+    return gnuais_batch_sync(b);
+}
+
+int gnuais_batch_filter(gnuais_batch *b, const int16_t *d_samples, int len, float *d_out,
+                        void *stream)
+{
+    if (!b || !d_samples || !d_out) return fail(GNUAIS_E_ARG, "filter: NULL argument");
+    if (len <= 0 || len > b->max_len) return fail(GNUAIS_E_ARG, "filter: len out of range");
+    if (int rc = set_device(b)) return rc;
+    hipStream_t s = (hipStream_t) stream;
+    if (int rc = run_fir(b, d_samples, len, d_out, s)) return rc;
+    if (int rc = run_history(b, d_samples, len, s)) return rc;
+    b->last_stream = s;
+    b->timed_last = false;
+    return GNUAIS_OK;
+}
+
+int gnuais_batch_decode_bits(gnuais_batch *b, const uint8_t *h_bits, int stride,
+                             const int32_t *h_count)
+{
+    if (!b || !h_bits || !h_count || stride <= 0) return fail(GNUAIS_E_ARG, "decode_bits: argument");
+    if (int rc = set_device(b)) return rc;
+    const int N = b->N, chunk = b->bits_words * 32;
+    int maxc = 0;
+    for (int c = 0; c < N; ++c) {
+        if (h_count[c] < 0 || h_count[c] > stride) return fail(GNUAIS_E_ARG, "decode_bits: count");
+        maxc = std::max(maxc, h_count[c]);
+    }
+    std::vector<uint32_t> words((size_t) b->bits_words * N), nb(N);
+    for (int pos = 0; pos < maxc; pos += chunk) {
+        std::fill(words.begin(), words.end(), 0u);
+        for (int c = 0; c < N; ++c) {
+            const int n = std::max(0, std::min(chunk, h_count[c] - pos));
+            nb[c] = (uint32_t) n;
+            const uint8_t *src = h_bits + (size_t) c * stride + pos;
+            for (int k = 0; k < n; ++k)
+                if (src[k] & 1) words[(size_t) (k >> 5) * N + c] |= 1u << (k & 31);
+        }
+        HIP_TRY(hipMemcpy(b->bits, words.data(), words.size() * 4, hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(b->nbits, nb.data(), nb.size() * 4, hipMemcpyHostToDevice));
+        HdlcLaunch h;
+        h.bits = b->bits; h.nbits = b->nbits; h.ctl = b->ctl; h.buf = b->buf;
+        h.counters = b->counters; h.frames = b->frames; h.frame_count = b->frame_count;
+        h.frame_cap = (uint32_t) b->frame_cap; h.N = N; h.bits_words = b->bits_words;
+        HIP_TRY(launch_hdlc_crc(h, nullptr));
+        HIP_TRY(hipDeviceSynchronize());
+    }
+    b->last_stream = nullptr;
+    return GNUAIS_OK;
+}
+
+int gnuais_batch_last_bits(gnuais_batch *b, uint8_t *h_bits, int stride, int32_t *h_count)
+{
+    if (!b || !h_bits || !h_count || stride <= 0) return fail(GNUAIS_E_ARG, "last_bits: argument");
+    if (int rc = gnuais_batch_sync(b)) return rc;
+    const int N = b->N;
+    std::vector<uint32_t> words((size_t) b->bits_words * N), nb(N);
+    HIP_TRY(hipMemcpy(words.data(), b->bits, words.size() * 4, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(nb.data(), b->nbits, nb.size() * 4, hipMemcpyDeviceToHost));
+    for (int c = 0; c < N; ++c) {
+        const int n = (int) std::min<uint32_t>(nb[c], (uint32_t) b->bits_words * 32);
+        h_count[c] = n;
+        if (n > stride) return fail(GNUAIS_E_ARG, "last_bits: stride too small");
+        uint8_t *dst = h_bits + (size_t) c * stride;
+        for (int k = 0; k < n; ++k) dst[k] = (words[(size_t) (k >> 5) * N + c] >> (k & 31)) & 1u;
+    }
+    return GNUAIS_OK;
+}
+
+int gnuais_batch_drain_frames(gnuais_batch *b, gnuais_frame *h_out, int max, int *n_out)
+{
+    if (!b || !n_out || (max > 0 && !h_out)) return fail(GNUAIS_E_ARG, "drain_frames: argument");
+    *n_out = 0;
+    if (int rc = gnuais_batch_sync(b)) return rc;
+    uint32_t cnt[2] = {0, 0};
+    HIP_TRY(hipMemcpy(cnt, b->frame_count, sizeof cnt, hipMemcpyDeviceToHost));
+    const uint32_t have = std::min<uint32_t>(cnt[0], (uint32_t) b->frame_cap);
+    if ((uint32_t) max < have) return fail(GNUAIS_E_ARG, "drain_frames: output buffer too small");
+    if (have)
+        HIP_TRY(hipMemcpy(h_out, b->frames, sizeof(gnuais_frame) * have, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemset(b->frame_count, 0, sizeof cnt));
+    // reference order within the drained span: receiver (channel) 0..N-1, then time
+    std::sort(h_out, h_out + have, [](const gnuais_frame &x, const gnuais_frame &y) {
+        return x.channel != y.channel ? x.channel < y.channel : x.end_bit < y.end_bit;
+    });
+    *n_out = (int) have;
+    if (cnt[1] || cnt[0] > (uint32_t) b->frame_cap)
+        return fail(GNUAIS_E_OVERFLOW, "drain_frames: frame ring overflowed, frames were dropped");
+    return GNUAIS_OK;
+}
+
+int gnuais_batch_pending_frames(gnuais_batch *b, int *n_out)
+{
+    if (!b || !n_out) return fail(GNUAIS_E_ARG, "pending_frames: argument");
+    if (int rc = gnuais_batch_sync(b)) return rc;
+    uint32_t cnt[2] = {0, 0};
+    HIP_TRY(hipMemcpy(cnt, b->frame_count, sizeof cnt, hipMemcpyDeviceToHost));
+    *n_out = (int) std::min<uint32_t>(cnt[0], (uint32_t) b->frame_cap);
+    return GNUAIS_OK;
+}
+
+int gnuais_batch_counters(gnuais_batch *b, gnuais_counters *h_out)
+{
+    if (!b || !h_out) return fail(GNUAIS_E_ARG, "counters: argument");
+    if (int rc = gnuais_batch_sync(b)) return rc;
+    const int N = b->N;
+    std::vector<int32_t> v((size_t) N * 3);
+    HIP_TRY(hipMemcpy(v.data(), b->counters, v.size() * 4, hipMemcpyDeviceToHost));
+    for (int c = 0; c < N; ++c) {
+        h_out[c].receivedframes = v[c];
+        h_out[c].lostframes = v[(size_t) N + c];
+        h_out[c].lostframes2 = v[(size_t) 2 * N + c];
+    }
+    return GNUAIS_OK;
+}
+
+int gnuais_batch_total_received(gnuais_batch *b, long long *total)
+{
+    if (!b || !total) return fail(GNUAIS_E_ARG, "total_received: argument");
+    if (int rc = gnuais_batch_sync(b)) return rc;
+    std::vector<int32_t> v((size_t) b->N);
+    HIP_TRY(hipMemcpy(v.data(), b->counters, v.size() * 4, hipMemcpyDeviceToHost));
+    long long t = 0;
+    for (int32_t x : v) t += x;
+    *total = t;
+    return GNUAIS_OK;
+}
+
+int gnuais_batch_maxval(gnuais_batch *b, int16_t *h_out)
+{
+    if (!b || !h_out) return fail(GNUAIS_E_ARG, "maxval: argument");
+    if (int rc = gnuais_batch_sync(b)) return rc;
+    std::vector<int> v((size_t) b->N);
+    HIP_TRY(hipMemcpy(v.data(), b->maxval, v.size() * 4, hipMemcpyDeviceToHost));
+    for (int c = 0; c < b->N; ++c) h_out[c] = (int16_t) v[c];
+    return GNUAIS_OK;
+}
+
+int gnuais_batch_pll_state(gnuais_batch *b, gnuais_pll_state *h_out)
+{
+    if (!b || !h_out) return fail(GNUAIS_E_ARG, "pll_state: argument");
+    if (int rc = gnuais_batch_sync(b)) return rc;
+    std::vector<uint32_t> v((size_t) b->N);
+    HIP_TRY(hipMemcpy(v.data(), b->pll, v.size() * 4, hipMemcpyDeviceToHost));
+    for (int c = 0; c < b->N; ++c) {
+        h_out[c].pll = v[c] & 0xffffu;
+        h_out[c].prev = (v[c] >> 16) & 1;
+        h_out[c].lastbit = (v[c] >> 17) & 1;
+    }
+    return GNUAIS_OK;
+}
+
+int gnuais_batch_fsm_state(gnuais_batch *b, gnuais_fsm_state *h_out)
+{
+    if (!b || !h_out) return fail(GNUAIS_E_ARG, "fsm_state: argument");
+    if (int rc = gnuais_batch_sync(b)) return rc;
+    std::vector<uint32_t> v((size_t) b->N);
+    HIP_TRY(hipMemcpy(v.data(), b->ctl, v.size() * 4, hipMemcpyDeviceToHost));
+    for (int c = 0; c < b->N; ++c) {
+        const uint32_t w = v[c];
+        h_out[c].state = w & 7;
+        h_out[c].nstartsign = (w >> 3) & 15;
+        h_out[c].antallpreamble = (w >> 7) & 15;
+        h_out[c].antallenner = (w >> 11) & 7;
+        h_out[c].bitstuff = (w >> 14) & 1;
+        h_out[c].last = (w >> 15) & 1;
+        h_out[c].bufferpos = (w >> 16) & 511;
+    }
+    return GNUAIS_OK;
+}
+
+int gnuais_batch_history(gnuais_batch *b, int16_t *h_out)
+{
+    if (!b || !h_out) return fail(GNUAIS_E_ARG, "history: argument");
+    if (int rc = gnuais_batch_sync(b)) return rc;
+    const int N = b->N, NT = b->NT;
+    std::vector<int16_t> v((size_t) N * NT);
+    HIP_TRY(hipMemcpy(v.data(), b->hist[b->hist_cur], v.size() * 2, hipMemcpyDeviceToHost));
+    for (int c = 0; c < N; ++c)
+        for (int k = 0; k < NT; ++k) h_out[(size_t) c * NT + k] = v[(size_t) k * N + c];
+    return GNUAIS_OK;
+}
+
+int gnuais_batch_n_channels(const gnuais_batch *b) { return b ? b->N : 0; }
+int gnuais_batch_n_taps(const gnuais_batch *b) { return b ? b->NT : 0; }
+
+int gnuais_batch_set_timing(gnuais_batch *b, int on)
+{
+    if (!b) return fail(GNUAIS_E_ARG, "set_timing: NULL batch");
+    b->timing = on != 0;
+    return GNUAIS_OK;
+}
+
+int gnuais_batch_last_timing(gnuais_batch *b, float *ms4)
+{
+    if (!b || !ms4) return fail(GNUAIS_E_ARG, "last_timing: argument");
+    if (!b->timed_last) return fail(GNUAIS_E_STATE, "last_timing: timing was not enabled for the last run");
+    if (int rc = gnuais_batch_sync(b)) return rc;
+    HIP_TRY(hipEventElapsedTime(&ms4[0], b->ev[0], b->ev[1]));
+    HIP_TRY(hipEventElapsedTime(&ms4[1], b->ev[2], b->ev[3]));
+    HIP_TRY(hipEventElapsedTime(&ms4[2], b->ev[3], b->ev[4]));
+    HIP_TRY(hipEventElapsedTime(&ms4[3], b->ev[0], b->ev[4]));
+    return GNUAIS_OK;
+}
+
+int gnuais_crc16_batch(int device, const uint8_t *h_data, int stride, const int32_t *h_len,
+                       int n_msgs, uint16_t *h_crc)
+{
+    if (!h_data || !h_len || !h_crc || stride <= 0 || n_msgs <= 0)
+        return fail(GNUAIS_E_ARG, "crc16_batch: argument");
+    HIP_TRY(hipSetDevice(device));
+    uint8_t *d_data = nullptr;
+    int32_t *d_len = nullptr;
+    uint16_t *d_crc = nullptr;
+    hipError_t e = hipMalloc((void **) &d_data, (size_t) stride * n_msgs);
+    if (e == hipSuccess) e = hipMalloc((void **) &d_len, sizeof(int32_t) * n_msgs);
+    if (e == hipSuccess) e = hipMalloc((void **) &d_crc, sizeof(uint16_t) * n_msgs);
+    if (e == hipSuccess) e = hipMemcpy(d_data, h_data, (size_t) stride * n_msgs, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(d_len, h_len, sizeof(int32_t) * n_msgs, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = launch_crc16(d_data, stride, d_len, n_msgs, d_crc, nullptr);
+    if (e == hipSuccess) e = hipMemcpy(h_crc, d_crc, sizeof(uint16_t) * n_msgs, hipMemcpyDeviceToHost);
+    (void) hipFree(d_data);
+    (void) hipFree(d_len);
+    (void) hipFree(d_crc);
+    if (e != hipSuccess) return fail(GNUAIS_E_HIP, "crc16_batch", e);
+    return GNUAIS_OK;
+}
+
+int gnuais_tile_channels(const int16_t *d_base, int n_base, int len, int16_t *d_out,
+                         int n_channels, void *stream)
+{
+    if (!d_base || !d_out || n_base <= 0 || len <= 0 || n_channels <= 0)
+        return fail(GNUAIS_E_ARG, "tile_channels: argument");
+    HIP_TRY(launch_tile_channels(d_base, n_base, len, d_out, n_channels, (hipStream_t) stream));
+    return GNUAIS_OK;
+}
+
+} // extern "C"

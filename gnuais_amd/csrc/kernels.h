@@ -1,0 +1,60 @@
+// kernels.h -- internal launch interface between the C-ABI host code
+// (gnuais_capi.hip) and the gfx950 kernels.  Not installed.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace gnuais {
+
+// ---- K1: FIR + slicer (fir_slice.hip) -------------------------------------
+struct FirLaunch {
+    const int16_t *x;      // [L][N] interleaved input
+    const int16_t *hist;   // [NT][N] previous call's last NT samples, oldest first
+    uint32_t *sgn;         // [ceil(L/32)][N] sign words, bit 31 = oldest sample
+    float *dump;           // optional [L][N] filter output
+    int *maxval;           // [N] peak positive sample (atomicMax; zeroed by the caller)
+    const float *d_taps;   // device copy of all NT taps (generic kernel)
+    float te[64];          // trimmed taps (specialised kernel)
+    int N, L, T;           // T: outputs per wave, multiple of 32
+    int NT, NE, d;         // out[n] = sum_j te[j] * x[n - d + j], j < NE
+};
+hipError_t launch_fir_generic(const FirLaunch &a, hipStream_t stream);
+hipError_t launch_fir_history(const int16_t *x, const int16_t *hist_in, int16_t *hist_out,
+                              int N, int L, int NT, hipStream_t stream);
+
+// ---- K2a: PLL clock recovery + NRZI (pll_nrzi.hip) ------------------------
+struct PllLaunch {
+    const uint32_t *sgn;   // [ceil(L/32)][N]
+    uint32_t *pll;         // [N] phase, prev sign (bit 16), lastbit (bit 17) packed
+    uint32_t *bits;        // [bits_words][N] recovered bits, bit k of a channel at
+                           //   word k/32, bit position k%32 (LSB first)
+    uint32_t *nbits;       // [N] bits recovered this call
+    int N, L, bits_words;
+    uint32_t pllinc;
+};
+hipError_t launch_pll_nrzi(const PllLaunch &a, hipStream_t stream);
+
+// ---- K2b: HDLC deframer + CRC-16 (hdlc_crc.hip) ---------------------------
+struct HdlcLaunch {
+    const uint32_t *bits;  // as above
+    const uint32_t *nbits; // [N]
+    uint32_t *ctl;         // [HDLC_CTL_WORDS][N] control state
+    uint32_t *buf;         // [HDLC_BUF_WORDS][N] frame bit buffer (bit k at word k/32, LSB first)
+    int32_t *counters;     // [3][N] receivedframes, lostframes, lostframes2
+    void *frames;          // gnuais_frame[frame_cap]
+    uint32_t *frame_count; // [2]: frames appended, overflow flag
+    uint32_t frame_cap;
+    int N, bits_words;
+};
+constexpr int HDLC_CTL_WORDS = 5;
+constexpr int HDLC_BUF_WORDS = 15;   // 449 bits max (protodec.c:1024)
+hipError_t launch_hdlc_crc(const HdlcLaunch &a, hipStream_t stream);
+hipError_t launch_hdlc_reset(uint32_t *ctl, int N, hipStream_t stream);
+
+// ---- utilities (util.hip) ---------------------------------------------------
+hipError_t launch_tile_channels(const int16_t *base, int n_base, int len, int16_t *out,
+                                int n_channels, hipStream_t stream);
+hipError_t launch_crc16(const uint8_t *data, int stride, const int32_t *len, int n,
+                        uint16_t *crc, hipStream_t stream);
+
+} // namespace gnuais

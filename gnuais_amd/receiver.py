@@ -1,0 +1,193 @@
+"""Host-side mirror of the reference receiver interface over the HIP batch.
+
+The reference creates one `struct receiver` per audio channel with
+init_receiver(name, num_ch, ch_ofs, ...) (src/receiver.c:52-74) and calls
+receiver_run(rx, buf, len) once per channel on the same interleaved buffer
+(src/ais.c:237-247).  `ReceiverBatch` is those N receivers at once: the same
+buffer layout, the same carried state, the same counters, one launch.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional
+
+import numpy as np
+
+from . import lib as _lib
+from .lib import COUNTERS_DTYPE, FRAME_DTYPE, FSM_DTYPE, PLL_DTYPE, check
+
+
+def _is_torch(x) -> bool:
+    return type(x).__module__.startswith("torch")
+
+
+class ReceiverBatch:
+    """N independent AIS receivers on one MI355X.
+
+    n_channels  -- num_ch of the interleaved input (receiver.c:102,107)
+    taps/pllinc -- filter_init() table and rx->pllinc; None/0 = reference values
+    max_len     -- largest len (frames per channel) of one run() call
+    """
+
+    def __init__(self, n_channels: int, taps=None, pllinc: int = 0, max_len: int = 48000,
+                 device: int = 0, frame_capacity: int = 0):
+        self._lib = _lib.load()
+        self._h = C.c_void_p()
+        t = None if taps is None else np.ascontiguousarray(taps, dtype=np.float32)
+        check(self._lib.gnuais_batch_create(C.byref(self._h), device, n_channels,
+                                            None if t is None else t.ctypes.data,
+                                            0 if t is None else int(t.size), pllinc, max_len,
+                                            frame_capacity))
+        self.n_channels = n_channels
+        self.n_taps = self._lib.gnuais_batch_n_taps(self._h)
+        self.max_len = max_len
+        self.device = device
+
+    # -- lifetime -----------------------------------------------------------
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.gnuais_batch_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def reset(self):
+        check(self._lib.gnuais_batch_reset(self._h))
+
+    def set_option(self, name: str, value: int):
+        check(self._lib.gnuais_batch_set_option(self._h, name.encode(), int(value)))
+
+    # -- receiver_run() -------------------------------------------------------
+    def run(self, samples, stream: Optional[int] = None, sync: bool = True):
+        """samples: interleaved int16 [len][n_channels]; a CUDA/HIP torch tensor
+        (used in place, asynchronous on `stream` or torch's current stream) or a
+        numpy array (copied host->device, synchronous)."""
+        if _is_torch(samples):
+            import torch
+            assert samples.is_cuda and samples.dtype == torch.int16 and samples.is_contiguous()
+            assert samples.dim() == 2 and samples.shape[1] == self.n_channels
+            if stream is None:
+                stream = torch.cuda.current_stream(samples.device).cuda_stream
+            check(self._lib.gnuais_batch_run(self._h, samples.data_ptr(), int(samples.shape[0]),
+                                             C.c_void_p(stream)))
+            if sync:
+                self.sync()
+        else:
+            x = np.ascontiguousarray(samples, dtype=np.int16)
+            assert x.ndim == 2 and x.shape[1] == self.n_channels
+            check(self._lib.gnuais_batch_run_host(self._h, x.ctypes.data, int(x.shape[0])))
+
+    def sync(self):
+        check(self._lib.gnuais_batch_sync(self._h))
+
+    # -- stage taps -----------------------------------------------------------
+    def filter(self, samples):
+        """filter_run_buf() for every channel -> float32 [len][n_channels] (torch, device)."""
+        import torch
+        if not _is_torch(samples):
+            samples = torch.from_numpy(np.ascontiguousarray(samples, dtype=np.int16)).to(
+                f"cuda:{self.device}")
+        out = torch.empty(samples.shape, dtype=torch.float32, device=samples.device)
+        stream = torch.cuda.current_stream(samples.device).cuda_stream
+        check(self._lib.gnuais_batch_filter(self._h, samples.data_ptr(), int(samples.shape[0]),
+                                            out.data_ptr(), C.c_void_p(stream)))
+        self.sync()
+        return out
+
+    def decode_bits(self, bits_per_channel):
+        """protodec_decode() for every channel; bits_per_channel: list of uint8 arrays."""
+        assert len(bits_per_channel) == self.n_channels
+        stride = max(1, max(len(b) for b in bits_per_channel))
+        buf = np.zeros((self.n_channels, stride), dtype=np.uint8)
+        cnt = np.zeros(self.n_channels, dtype=np.int32)
+        for c, b in enumerate(bits_per_channel):
+            buf[c, : len(b)] = b
+            cnt[c] = len(b)
+        check(self._lib.gnuais_batch_decode_bits(self._h, buf.ctypes.data, stride, cnt.ctypes.data))
+
+    def last_bits(self):
+        stride = self.max_len // 2 + 64
+        buf = np.zeros((self.n_channels, stride), dtype=np.uint8)
+        cnt = np.zeros(self.n_channels, dtype=np.int32)
+        check(self._lib.gnuais_batch_last_bits(self._h, buf.ctypes.data, stride, cnt.ctypes.data))
+        return [buf[c, : cnt[c]].copy() for c in range(self.n_channels)]
+
+    # -- results --------------------------------------------------------------
+    def pending_frames(self) -> int:
+        n = C.c_int()
+        check(self._lib.gnuais_batch_pending_frames(self._h, C.byref(n)))
+        return n.value
+
+    def drain_frames(self) -> np.ndarray:
+        n = self.pending_frames()
+        out = np.zeros(max(n, 1), dtype=FRAME_DTYPE)
+        got = C.c_int()
+        check(self._lib.gnuais_batch_drain_frames(self._h, out.ctypes.data, int(out.size),
+                                                  C.byref(got)))
+        return out[: got.value].copy()
+
+    def _struct_array(self, fn, dtype):
+        out = np.zeros(self.n_channels, dtype=dtype)
+        check(fn(self._h, out.ctypes.data))
+        return out
+
+    def counters(self) -> np.ndarray:
+        return self._struct_array(self._lib.gnuais_batch_counters, COUNTERS_DTYPE)
+
+    def total_received(self) -> int:
+        t = C.c_longlong()
+        check(self._lib.gnuais_batch_total_received(self._h, C.byref(t)))
+        return t.value
+
+    def pll_state(self) -> np.ndarray:
+        return self._struct_array(self._lib.gnuais_batch_pll_state, PLL_DTYPE)
+
+    def fsm_state(self) -> np.ndarray:
+        return self._struct_array(self._lib.gnuais_batch_fsm_state, FSM_DTYPE)
+
+    def maxval(self) -> np.ndarray:
+        out = np.zeros(self.n_channels, dtype=np.int16)
+        check(self._lib.gnuais_batch_maxval(self._h, out.ctypes.data))
+        return out
+
+    def history(self) -> np.ndarray:
+        out = np.zeros((self.n_channels, self.n_taps), dtype=np.int16)
+        check(self._lib.gnuais_batch_history(self._h, out.ctypes.data))
+        return out
+
+    # -- timing ---------------------------------------------------------------
+    def set_timing(self, on: bool):
+        check(self._lib.gnuais_batch_set_timing(self._h, int(on)))
+
+    def last_timing(self):
+        ms = (C.c_float * 4)()
+        check(self._lib.gnuais_batch_last_timing(self._h, ms))
+        return {"fir_slice": ms[0], "pll_nrzi": ms[1], "hdlc_crc": ms[2], "total": ms[3]}
+
+
+def crc16_batch(messages, device: int = 0) -> np.ndarray:
+    """protodec_sdlc_crc() of each byte string, on the device."""
+    lib = _lib.load()
+    stride = max(1, max(len(m) for m in messages))
+    data = np.zeros((len(messages), stride), dtype=np.uint8)
+    lens = np.zeros(len(messages), dtype=np.int32)
+    for i, m in enumerate(messages):
+        data[i, : len(m)] = np.frombuffer(m, dtype=np.uint8)
+        lens[i] = len(m)
+    out = np.zeros(len(messages), dtype=np.uint16)
+    check(lib.gnuais_crc16_batch(device, data.ctypes.data, stride, lens.ctypes.data,
+                                 len(messages), out.ctypes.data))
+    return out
+
+
+def tile_channels(base, n_channels: int):
+    """Device-side benchmark input builder: base torch int16 [K][L] ->
+    interleaved [L][n_channels]."""
+    import torch
+    assert base.is_cuda and base.dtype == torch.int16 and base.is_contiguous()
+    k, n = base.shape
+    out = torch.empty((n, n_channels), dtype=torch.int16, device=base.device)
+    stream = torch.cuda.current_stream(base.device).cuda_stream
+    check(_lib.load().gnuais_tile_channels(base.data_ptr(), k, n, out.data_ptr(), n_channels,
+                                           C.c_void_p(stream)))
+    return out

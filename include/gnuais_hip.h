@@ -1,0 +1,145 @@
+/*
+ * gnuais_hip.h -- C ABI of the MI355X (gfx950) batch AIS receive chain.
+ *
+ * This is the drop-in boundary for gnuais's per-sample hot path.  Every entry
+ * point cites the reference interface it stands in for (paths relative to the
+ * gnuais tree).  Plain C: opaque handle, plain pointers and sizes, int status.
+ * libgnuais_hip.so is built by gnuais_amd/csrc/Makefile with hipcc for gfx950;
+ * there is no CPU fallback -- every call fails with GNUAIS_E_HIP when no HIP
+ * device is usable.
+ *
+ * One batch = N independent receivers (one per interleaved channel) that the
+ * reference would create with N calls of init_receiver() (src/receiver.c:52-74)
+ * and drive with N calls of receiver_run() per buffer (src/ais.c:237-247).
+ */
+#ifndef GNUAIS_HIP_H
+#define GNUAIS_HIP_H
+
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GNUAIS_OK          0
+#define GNUAIS_E_ARG      -1   /* bad argument                                   */
+#define GNUAIS_E_HIP      -2   /* HIP runtime / device error (see last_error)    */
+#define GNUAIS_E_OVERFLOW -3   /* frame ring overflowed; oldest results kept     */
+#define GNUAIS_E_STATE    -4   /* call sequence error                            */
+
+#define GNUAIS_MAX_TAPS 1023   /* src/filter.h:28 BufferLen 1024 (len < BufferLen) */
+
+/* One CRC-valid HDLC frame = what src/protodec.c:1100-1104 hands to
+ * protodec_getdata(): `nbits` = bufferlen, payload = the bits of d->rbuffer
+ * packed MSB first (AIS bit x = payload[x/8] >> (7 - x%8) & 1).  64 bytes. */
+typedef struct gnuais_frame {
+	uint32_t channel;      /* interleaved channel index (receiver ch_ofs)      */
+	uint32_t end_bit;      /* bits fed to the deframer since reset before the
+	                          bit that closed the frame (orders frames in time) */
+	uint8_t  payload[53];  /* nbits/8 bytes used, rest zero                     */
+	uint8_t  flags;        /* bit0: CRC ok (always set for delivered frames)    */
+	uint16_t nbits;        /* bufferpos - 22, src/protodec.c:1096               */
+} gnuais_frame;
+
+/* per-channel counters: src/protodec.h:58-60, bumped at src/protodec.c:1103,1107,1112,
+ * read by src/ais.c:296-310 */
+typedef struct gnuais_counters {
+	int32_t receivedframes, lostframes, lostframes2;
+} gnuais_counters;
+
+/* per-channel carry of receiver.c's loop: src/receiver.h:38-44 */
+typedef struct gnuais_pll_state {
+	uint32_t pll;
+	int32_t prev, lastbit;
+} gnuais_pll_state;
+
+/* per-channel deframer control state: live fields of struct demod_state_t,
+ * src/protodec.h:44-57.  antallpreamble is reported saturated at 15 (only
+ * "> 14" is ever tested, src/protodec.c:1036). */
+typedef struct gnuais_fsm_state {
+	int32_t state, nstartsign, antallpreamble, antallenner, bitstuff, last, bufferpos;
+} gnuais_fsm_state;
+
+typedef struct gnuais_batch gnuais_batch;
+
+/* ---- lifetime: init_receiver()/free_receiver(), src/receiver.c:52-82 --------
+ * taps/n_taps: filter_init(len, taps) arguments (src/filter.c:57); NULL/0 =
+ *   the reference table (src/receiver.c:39-50).
+ * pllinc: rx->pllinc (src/receiver.c:69); 0 = 0x10000/5.
+ * max_len: largest `len` a run call will be given.
+ * frame_capacity: frames that can be queued between two drains; 0 = default. */
+int  gnuais_batch_create(gnuais_batch **out, int device, int n_channels,
+			 const float *taps, int n_taps, unsigned pllinc,
+			 int max_len, int frame_capacity);
+void gnuais_batch_destroy(gnuais_batch *b);
+/* back to the state init_receiver()+protodec_initialize() leave (src/protodec.c:54-76) */
+int  gnuais_batch_reset(gnuais_batch *b);
+
+/* ---- hot path: receiver_run() for every channel, src/receiver.c:87-135 ------
+ * d_samples: DEVICE pointer, interleaved int16 [len][n_channels] (the layout
+ *   receiver_run reads with step = num_ch, src/receiver.c:102,107).
+ * stream: hipStream_t (NULL = default stream).  Asynchronous; results are
+ *   read after gnuais_batch_sync().  len may exceed the reference's 4096. */
+int  gnuais_batch_run(gnuais_batch *b, const int16_t *d_samples, int len, void *stream);
+/* same from a HOST buffer (what src/ais.c:216-247 holds): copies H2D, runs, syncs */
+int  gnuais_batch_run_host(gnuais_batch *b, const int16_t *h_samples, int len);
+int  gnuais_batch_sync(gnuais_batch *b);
+
+/* ---- stage entry points (parity taps; not needed by a drop-in user) ---------
+ * filter_run_buf(), src/filter.c:106-143: d_out = DEVICE float [len][n_channels];
+ * advances the FIR history exactly like a run call, nothing else. */
+int  gnuais_batch_filter(gnuais_batch *b, const int16_t *d_samples, int len,
+			 float *d_out, void *stream);
+/* protodec_decode(in, count, d), src/protodec.c:988-1122, for every channel:
+ * h_bits = HOST uint8 [n_channels][stride], one byte per bit; h_count[n_channels] */
+int  gnuais_batch_decode_bits(gnuais_batch *b, const uint8_t *h_bits, int stride,
+			      const int32_t *h_count);
+/* recovered (NRZI-decoded) bits of the LAST run call, one byte per bit:
+ * h_bits HOST uint8 [n_channels][stride]; h_count[n_channels] = bits per channel */
+int  gnuais_batch_last_bits(gnuais_batch *b, uint8_t *h_bits, int stride, int32_t *h_count);
+
+/* ---- results ------------------------------------------------------------------
+ * drain queued frames to the host, in the reference's print order within the
+ * drained span (channel 0..N-1, then time).  *n_out = frames written. */
+int  gnuais_batch_drain_frames(gnuais_batch *b, gnuais_frame *h_out, int max, int *n_out);
+int  gnuais_batch_pending_frames(gnuais_batch *b, int *n_out);
+int  gnuais_batch_counters(gnuais_batch *b, gnuais_counters *h_out /* [n_channels] */);
+int  gnuais_batch_total_received(gnuais_batch *b, long long *total);
+/* filter_run_buf()'s return value for the last run: peak positive sample per channel
+ * (src/filter.c:118-119; feeds the level log at src/receiver.c:137-147) */
+int  gnuais_batch_maxval(gnuais_batch *b, int16_t *h_out /* [n_channels] */);
+int  gnuais_batch_pll_state(gnuais_batch *b, gnuais_pll_state *h_out /* [n_channels] */);
+int  gnuais_batch_fsm_state(gnuais_batch *b, gnuais_fsm_state *h_out /* [n_channels] */);
+/* the last n_taps input samples per channel, oldest first (live part of
+ * struct filter.buffer, src/filter.h:60): h_out int16 [n_channels][n_taps] */
+int  gnuais_batch_history(gnuais_batch *b, int16_t *h_out);
+
+int  gnuais_batch_n_channels(const gnuais_batch *b);
+int  gnuais_batch_n_taps(const gnuais_batch *b);
+
+/* ---- misc -------------------------------------------------------------------- */
+/* the reference coefficient table, src/receiver.c:39-50, rounded to fp32 */
+int  gnuais_default_taps(float *out36);
+/* CRC-16/X-25 on the device (protodec_sdlc_crc, src/protodec.c:106-118):
+ * h_data = n_msgs rows of `stride` bytes, h_len[n_msgs]; h_crc[n_msgs] */
+int  gnuais_crc16_batch(int device, const uint8_t *h_data, int stride, const int32_t *h_len,
+			int n_msgs, uint16_t *h_crc);
+/* benchmark input builder: d_out[l][c] = d_base[c % n_base][(l + (c * 7919) % len) % len] */
+int  gnuais_tile_channels(const int16_t *d_base, int n_base, int len, int16_t *d_out,
+			  int n_channels, void *stream);
+/* per-kernel timing of the last run (HIP events on the run's stream), ms:
+ * [0] FIR+slice  [1] PLL+NRZI  [2] HDLC+CRC  [3] whole run.  Needs
+ * gnuais_batch_set_timing(b, 1) before the run. */
+int  gnuais_batch_set_timing(gnuais_batch *b, int on);
+int  gnuais_batch_last_timing(gnuais_batch *b, float *ms4);
+/* tunables: "fir_T" (outputs per wave in K1, multiple of 32), "fir_variant"
+ * (0 = v_mul/v_add, 1 = v_pk_mul/v_pk_add build of K1) */
+int  gnuais_batch_set_option(gnuais_batch *b, const char *name, int value);
+const char *gnuais_last_error(void);
+const char *gnuais_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -37,10 +37,10 @@ typedef struct ais_frame {
 	uint32_t channel;
 	uint32_t end_bit;     /* bits fed to the deframer (since reset) before the
 	                         STOPSIGN bit that closed this frame */
-	uint16_t nbits;       /* bufferpos - 22 (protodec.c:1096) */
-	uint8_t  flags;       /* bit0: CRC ok */
 	uint8_t  payload[53]; /* nbits/8 on-air bytes; AIS bit x (MSB first, the
 	                         reference's rbuffer[x]) = payload[x/8] >> (7 - x%8) & 1 */
+	uint8_t  flags;       /* bit0: CRC ok */
+	uint16_t nbits;       /* bufferpos - 22 (protodec.c:1096) */
 } ais_frame;
 
 /* HDLC deframer carry: the live fields of struct demod_state_t

@@ -36,9 +36,9 @@ typedef struct {
 	uint32_t channel;     /* index of the ref receiver that produced it   */
 	uint32_t end_bit;     /* number of bits fed to protodec before the
 	                         STOPSIGN bit that closed the frame           */
-	uint16_t nbits;       /* bufferlen handed to protodec_getdata          */
-	uint8_t  flags;       /* 1 = CRC ok (always 1 here)                    */
 	uint8_t  payload[53]; /* on-air bytes: bit i of byte j = buffer[8j+i]  */
+	uint8_t  flags;       /* 1 = CRC ok (always 1 here)                    */
+	uint16_t nbits;       /* bufferlen handed to protodec_getdata          */
 } ref_frame_t;
 
 #define MAX_RX 4096

@@ -20,8 +20,8 @@ ORACLE_DIR = os.path.join(ROOT, "oracle")
 ORACLE_SO = os.path.join(ORACLE_DIR, "libais_oracle.so")
 REF_SO = os.path.join(ORACLE_DIR, "_ref", "libgnuais_ref.so")
 
-FRAME_DTYPE = np.dtype([("channel", "<u4"), ("end_bit", "<u4"), ("nbits", "<u2"),
-                        ("flags", "u1"), ("payload", "u1", (53,))])
+FRAME_DTYPE = np.dtype([("channel", "<u4"), ("end_bit", "<u4"), ("payload", "u1", (53,)),
+                        ("flags", "u1"), ("nbits", "<u2")])
 assert FRAME_DTYPE.itemsize == 64
 
 

@@ -1,0 +1,324 @@
+"""Parity of the HIP path (through the C ABI) against the golden vectors and the
+CPU oracle.  Bit-exact everywhere: filter floats are compared as raw 32-bit
+patterns (north_star allows 1e-5 relative; the kernels reproduce the reference
+rounding sequence, so the tolerance used here is 0)."""
+import os
+
+import numpy as np
+import pytest
+
+from gnuais_amd import params, synth
+from oracle_lib import FRAME_DTYPE, Oracle
+
+pytestmark = pytest.mark.gpu
+
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+FSM_KEYS = ("state", "nstartsign", "antallpreamble", "antallenner", "bitstuff", "last", "bufferpos")
+
+
+def load(name):
+    return np.load(os.path.join(G, name + ".npz"))
+
+
+def frames_of(raw):
+    return np.frombuffer(np.ascontiguousarray(raw).tobytes(), dtype=FRAME_DTYPE)
+
+
+def batch(*a, **k):
+    from gnuais_amd import ReceiverBatch
+    return ReceiverBatch(*a, **k)
+
+
+def dev(x):
+    import torch
+    return torch.from_numpy(np.ascontiguousarray(x)).cuda()
+
+
+def fsm_rows(b):
+    f = b.fsm_state()
+    return [[int(r[k]) for k in FSM_KEYS] for r in f]
+
+
+def oracle_fsm_rows(o, n, saturate=True):
+    rows = []
+    for c in range(n):
+        h = o.hdlc(c)
+        r = [h[k] for k in FSM_KEYS]
+        if saturate:
+            r[2] = min(r[2], 15)
+        rows.append(r)
+    return rows
+
+
+# ---------------------------------------------------------------- FIR (K1)
+
+@pytest.mark.parametrize("variant", [0, 1])
+def test_fir_known_answers_bit_exact(variant):
+    g = load("fir_kat")
+    for k in g.files:
+        if not k.startswith("x_"):
+            continue
+        x = g[k]
+        b = batch(1, max_len=int(x.size))
+        b.set_option("fir_variant", variant)
+        y = b.filter(dev(x[:, None])).cpu().numpy()[:, 0]
+        assert np.array_equal(y.view(np.uint32), g["y_" + k[2:]]), (k, variant)
+        # filter_run_buf's return value: peak positive sample of the call
+        assert int(b.maxval()[0]) == int(max(0, x.max()))
+        b.close()
+
+
+def test_fir_192k_generic_taps_bit_exact():
+    g = load("fir_kat")
+    x = g["x_noise_full"]
+    b = batch(1, taps=g["taps192"].view(np.float32), max_len=int(x.size))
+    y = b.filter(dev(x[:, None])).cpu().numpy()[:, 0]
+    assert np.array_equal(y.view(np.uint32), g["y192_noise_full"])
+
+
+@pytest.mark.parametrize("variant", [0, 1])
+def test_fir_many_channels_chunked_vs_oracle(variant):
+    """N not a multiple of 64, chunk lengths not multiples of 32, state carried."""
+    rng = np.random.default_rng(21)
+    n_ch, total = 150, 5000
+    x = rng.integers(-32768, 32768, (total, n_ch)).astype(np.int16)
+    x[:, 3] = 0
+    x[:, 4] = 32767
+    x[:, 5] = -32768
+    o = Oracle(n_ch)
+    want = o.run(x, want_filtered=True)["filtered"]
+    b = batch(n_ch, max_len=2048)
+    b.set_option("fir_variant", variant)
+    b.set_option("fir_T", 256)
+    got = []
+    pos = 0
+    for n in (1, 31, 32, 33, 2048, 700, 5, 1000, 1150):
+        got.append(b.filter(dev(x[pos:pos + n])).cpu().numpy())
+        pos += n
+    assert pos == total
+    got = np.concatenate(got, axis=0)
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+    assert np.array_equal(b.history(), np.stack([o.history(c) for c in range(n_ch)]))
+
+
+# ---------------------------------------------------------------- full chain
+
+@pytest.mark.parametrize("name", ["chain_48k", "chain_192k", "chain_long"])
+def test_full_chain_golden(name):
+    g = load(name)
+    x = g["x"]
+    n_ch = x.shape[1]
+    b = batch(n_ch, taps=g["taps"].view(np.float32), pllinc=int(g["pllinc"]),
+              max_len=int(x.shape[0]))
+    b.run(dev(x))
+    bits = b.last_bits()
+    for c in range(n_ch):
+        assert np.array_equal(bits[c], g[f"bits{c}"]), c
+    assert b.drain_frames().tobytes() == frames_of(g["frames"]).tobytes()
+    cnt = b.counters()
+    assert np.array_equal(np.stack([cnt["receivedframes"], cnt["lostframes"], cnt["lostframes2"]],
+                                   axis=1), g["counters"])
+    p = b.pll_state()
+    assert np.array_equal(np.stack([p["pll"], p["prev"], p["lastbit"]], axis=1), g["pll"])
+    want_fsm = g["fsm"].copy()
+    want_fsm[:, 2] = np.minimum(want_fsm[:, 2], 15)
+    assert fsm_rows(b) == want_fsm.tolist()
+    assert np.array_equal(b.maxval(), g["maxval"])
+
+
+def run_both(x, chunks, n_ch, taps=None, pllinc=0, fir_T=None):
+    o = Oracle(n_ch, taps=taps, pllinc=pllinc)
+    b = batch(n_ch, taps=taps, pllinc=pllinc, max_len=max(chunks))
+    if fir_T:
+        b.set_option("fir_T", fir_T)
+    pos = 0
+    gbits = [[] for _ in range(n_ch)]
+    obits = [[] for _ in range(n_ch)]
+    for n in chunks:
+        seg = x[pos:pos + n]
+        pos += n
+        r = o.run(seg, want_bits=True)
+        b.run(dev(seg))
+        lb = b.last_bits()
+        for c in range(n_ch):
+            gbits[c].append(lb[c])
+            obits[c].append(r["bits"][c])
+    assert pos == x.shape[0]
+    for c in range(n_ch):
+        assert np.array_equal(np.concatenate(gbits[c]), np.concatenate(obits[c])), c
+    assert b.drain_frames().tobytes() == o.frames().tobytes()
+    cnt = b.counters()
+    assert np.array_equal(np.stack([cnt["receivedframes"], cnt["lostframes"], cnt["lostframes2"]],
+                                   axis=1), o.counters())
+    p = b.pll_state()
+    assert [(int(a), int(bb), int(cc)) for a, bb, cc in zip(p["pll"], p["prev"], p["lastbit"])] == \
+        [o.pll(c) for c in range(n_ch)]
+    assert fsm_rows(b) == oracle_fsm_rows(o, n_ch)
+    return o, b
+
+
+def test_chain_vs_oracle_ragged_chunks():
+    n_ch, total = 70, 30 * 1280
+    x = np.stack([synth.make_stream(total, seed=31, channel=c,
+                                    sigma=(500.0, 1000.0, 3000.0, 6000.0, 20000.0)[c % 5])[0]
+                  for c in range(n_ch)], axis=1)
+    chunks = [1020] * 10 + [1, 31, 33, 4096, 4095, 7, 10000]
+    chunks.append(total - sum(chunks))
+    o, b = run_both(x, chunks, n_ch, fir_T=512)
+    assert o.counters()[:, 0].sum() > 300
+
+
+def test_chain_vs_oracle_noise_only_and_extremes():
+    rng = np.random.default_rng(33)
+    total = 40000
+    cols = [rng.normal(0, s, total) for s in (30, 300, 3000, 12000)]
+    cols.append(rng.integers(-32768, 32768, total).astype(np.float64))
+    cols.append(np.zeros(total))
+    cols.append(np.full(total, 32767.0))
+    cols.append(np.where(np.arange(total) // 5 % 2, 9000.0, -9000.0))   # endless 0101... training
+    x = np.clip(np.rint(np.stack(cols, axis=1)), -32768, 32767).astype(np.int16)
+    run_both(x, [total], x.shape[1])
+
+
+def test_chain_192k_vs_oracle():
+    total = 6 * 5120
+    x = np.stack([synth.make_stream(total, seed=35, channel=c, sps=20, sigma=1500.0,
+                                    occupancy=0.8)[0] for c in range(5)], axis=1)
+    run_both(x, [4096, total - 4096], 5, taps=params.taps_192k(), pllinc=params.PLLINC_192K)
+
+
+def test_shards_equal_whole():
+    """channels are independent -- two half batches == one batch."""
+    n_ch, total = 128, 8 * 1280
+    x = np.stack([synth.make_stream(total, seed=37, channel=c)[0] for c in range(n_ch)], axis=1)
+    whole = batch(n_ch, max_len=total)
+    whole.run(dev(x))
+    fw = whole.drain_frames()
+    parts = []
+    for s in range(2):
+        h = batch(n_ch // 2, max_len=total)
+        h.run(dev(x[:, s * 64:(s + 1) * 64]))
+        f = h.drain_frames()
+        f["channel"] += s * 64
+        parts.append(f)
+    assert np.concatenate(parts).tobytes() == fw.tobytes()
+
+
+# ---------------------------------------------------------------- deframer (K2b) + CRC
+
+@pytest.mark.parametrize("name", ["random_p50", "random_p70", "random_p30", "alternating",
+                                  "crafted", "mixed"])
+def test_deframer_golden_bits(name):
+    g = load("deframer_bits")
+    bits = np.unpackbits(g["bits_" + name])[: int(g["n_" + name])]
+    b = batch(1, max_len=4096)      # small bit ring: forces several decode chunks
+    b.decode_bits([bits])
+    cnt = b.counters()[0]
+    assert [int(cnt["receivedframes"]), int(cnt["lostframes"]), int(cnt["lostframes2"])] == \
+        g["counters_" + name].tolist()
+    assert b.drain_frames().tobytes() == frames_of(g["frames_" + name]).tobytes()
+    want = g["fsm_" + name].tolist()
+    want[2] = min(want[2], 15)
+    assert fsm_rows(b)[0] == want
+
+
+def test_deframer_random_vs_oracle_many_channels():
+    rng = np.random.default_rng(41)
+    n_ch = 96
+    streams = []
+    for c in range(n_ch):
+        parts = []
+        for i in range(40):
+            parts.append((rng.random(int(rng.integers(0, 150))) < rng.random()).astype(np.uint8))
+            if rng.random() < 0.7:
+                n = int(rng.choice([0, 1, 11, 21, 21, 40, 53, 54]))
+                fb = synth.hdlc_frame_bits(bytes(rng.integers(0, 256, n, dtype=np.uint8)),
+                                           training_bits=int(rng.integers(0, 40)))
+                if rng.random() < 0.2:
+                    fb[int(rng.integers(0, fb.size))] ^= 1
+                parts.append(fb)
+        streams.append(np.concatenate(parts).astype(np.uint8))
+    o = Oracle(n_ch)
+    for c in range(n_ch):
+        o.decode_bits(c, streams[c])
+    b = batch(n_ch, max_len=48000)
+    b.decode_bits(streams)
+    assert b.drain_frames().tobytes() == o.frames().tobytes()
+    cnt = b.counters()
+    assert np.array_equal(np.stack([cnt["receivedframes"], cnt["lostframes"], cnt["lostframes2"]],
+                                   axis=1), o.counters())
+    assert fsm_rows(b) == oracle_fsm_rows(o, n_ch)
+
+
+def test_crc16_device_known_answers():
+    from gnuais_amd import crc16_batch
+    g = load("crc16")
+    data, pos, msgs = g["data"].tobytes(), 0, []
+    for n in g["lens"]:
+        msgs.append(data[pos:pos + n])
+        pos += n
+    got = crc16_batch(msgs)
+    assert np.array_equal(got, g["crc"])
+    assert int(crc16_batch([b"123456789"])[0]) == 0x906E
+
+
+# ---------------------------------------------------------------- full size (BASELINE C3)
+
+def test_c3_full_size_properties():
+    """16384 channels x 48000 samples, full chain: a random sample of channels is
+    compared bit-exactly with the oracle; the rest through size-independent
+    properties (round trip: every delivered payload was transmitted; frames sorted;
+    counters add up)."""
+    import torch
+    from gnuais_amd import tile_channels
+    n_ch, total, k = 16384, 48000, 256
+    base, placed = synth.make_base_streams(k, total)
+    xb = tile_channels(dev(base), n_ch)
+    b = batch(n_ch, max_len=total)
+    b.run(xb)
+    frames = b.drain_frames()
+    cnt = b.counters()
+    assert int(cnt["receivedframes"].sum()) == len(frames) == b.total_received() > 200000
+    key = frames["channel"].astype(np.int64) << 32 | frames["end_bit"]
+    assert np.all(np.diff(key) > 0)                                  # reference order, no dups
+    sent = [set(p for _, p in pl) for pl in placed]
+    for f in frames[:: max(1, len(frames) // 5000)]:
+        assert f["nbits"] == 168 and bytes(f["payload"][:21]) in sent[int(f["channel"]) % k]
+    # bit-exact on a sample of channels
+    rng = np.random.default_rng(43)
+    pick = np.sort(rng.choice(n_ch, 96, replace=False))
+    xs = xb[:, torch.from_numpy(pick).cuda()].cpu().numpy()
+    assert np.array_equal(xs[:, 0], np.roll(base[pick[0] % k], -synth.rotation_of(int(pick[0]), total)))
+    o = Oracle(len(pick))
+    o.run(xs)
+    fo = o.frames()
+    sel = frames[np.isin(frames["channel"], pick)]
+    remap = {int(c): i for i, c in enumerate(pick)}
+    sel["channel"] = [remap[int(c)] for c in sel["channel"]]
+    assert sel.tobytes() == fo.tobytes()
+    assert np.array_equal(np.stack([cnt["receivedframes"], cnt["lostframes"],
+                                    cnt["lostframes2"]], axis=1)[pick], o.counters())
+
+
+# ---------------------------------------------------------------- API behaviour
+
+def test_argument_errors_are_loud():
+    from gnuais_amd import lib
+    b = batch(4, max_len=100)
+    x = dev(np.zeros((101, 4), dtype=np.int16))
+    with pytest.raises(lib.GnuaisError) as e:
+        b.run(x)
+    assert e.value.code == lib.E_ARG
+    with pytest.raises(lib.GnuaisError):
+        batch(0)
+
+
+def test_reset_restores_initial_state():
+    g = load("chain_48k")
+    x = g["x"]
+    b = batch(2, max_len=int(x.shape[0]))
+    b.run(dev(x))
+    b.drain_frames()
+    b.reset()
+    b.run(dev(x))
+    assert b.drain_frames().tobytes() == frames_of(g["frames"]).tobytes()
