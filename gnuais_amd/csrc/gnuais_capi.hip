@@ -62,7 +62,9 @@ struct gnuais_batch {
     int16_t *hist[2] = {nullptr, nullptr};
     int hist_cur = 0;
     uint32_t *sgn = nullptr, *pll = nullptr, *bits = nullptr, *nbits = nullptr;
-    uint32_t *ctl = nullptr, *buf = nullptr, *frame_count = nullptr;
+    uint32_t *ctl = nullptr, *cand = nullptr, *cand_first = nullptr, *cand_count = nullptr;
+    uint32_t *frame_count = nullptr;
+    int cand_K = 64;
     int32_t *counters = nullptr;
     int *maxval = nullptr;
     gnuais_frame *frames = nullptr;
@@ -104,7 +106,8 @@ void gnuais_batch_destroy(gnuais_batch *b)
 {
     if (!b) return;
     (void) hipSetDevice(b->device);
-    void *ptrs[] = {b->hist[0], b->hist[1], b->sgn, b->pll, b->bits, b->nbits, b->ctl, b->buf,
+    void *ptrs[] = {b->hist[0], b->hist[1], b->sgn, b->pll, b->bits, b->nbits, b->ctl, b->cand,
+                    b->cand_first, b->cand_count,
                     b->frame_count, b->counters, b->maxval, b->frames, b->d_taps, b->stage_x};
     for (void *p : ptrs)
         if (p) (void) hipFree(p);
@@ -168,7 +171,12 @@ int gnuais_batch_create(gnuais_batch **out, int device, int n_channels, const fl
     alloc((void **) &b->bits, sizeof(uint32_t) * N * b->bits_words);
     alloc((void **) &b->nbits, sizeof(uint32_t) * N);
     alloc((void **) &b->ctl, sizeof(uint32_t) * N * HDLC_CTL_WORDS);
-    alloc((void **) &b->buf, sizeof(uint32_t) * N * HDLC_BUF_WORDS);
+    // candidate ring: a frame needs >= 32 bits of preamble+flag, typical load is one
+    // frame per 256 bit times; 64 slots per channel and call cover max_len <= 2^16
+    b->cand_K = std::max(64, b->bits_words / 4);
+    alloc((void **) &b->cand, sizeof(uint32_t) * N * (size_t) b->cand_K * CAND_WORDS);
+    alloc((void **) &b->cand_first, sizeof(uint32_t) * N);
+    alloc((void **) &b->cand_count, sizeof(uint32_t) * N);
     alloc((void **) &b->frame_count, sizeof(uint32_t) * 2);
     alloc((void **) &b->counters, sizeof(int32_t) * N * 3);
     alloc((void **) &b->maxval, sizeof(int) * N);
@@ -204,7 +212,6 @@ int gnuais_batch_reset(gnuais_batch *b)
     b->hist_cur = 0;
     HIP_TRY(hipMemset(b->pll, 0, sizeof(uint32_t) * N));              // receiver.c:66-71
     HIP_TRY(hipMemset(b->nbits, 0, sizeof(uint32_t) * N));
-    HIP_TRY(hipMemset(b->buf, 0, sizeof(uint32_t) * N * HDLC_BUF_WORDS));
     HIP_TRY(hipMemset(b->counters, 0, sizeof(int32_t) * N * 3));      // protodec.c:62-64
     HIP_TRY(hipMemset(b->maxval, 0, sizeof(int) * N));
     HIP_TRY(hipMemset(b->frame_count, 0, sizeof(uint32_t) * 2));
@@ -247,6 +254,15 @@ static void fill_fir(const gnuais_batch *b, FirLaunch &f, const int16_t *x, int 
     f.d = b->d;
 }
 
+static void fill_hdlc(const gnuais_batch *b, HdlcLaunch &h)
+{
+    h.bits = b->bits; h.nbits = b->nbits; h.ctl = b->ctl; h.cand = b->cand;
+    h.cand_first = b->cand_first; h.cand_count = b->cand_count;
+    h.counters = b->counters; h.frames = b->frames; h.frame_count = b->frame_count;
+    h.frame_cap = (uint32_t) b->frame_cap; h.N = b->N; h.bits_words = b->bits_words;
+    h.K = b->cand_K;
+}
+
 static int run_fir(gnuais_batch *b, const int16_t *x, int len, float *dump, hipStream_t s)
 {
     FirLaunch f;
@@ -287,9 +303,7 @@ int gnuais_batch_run(gnuais_batch *b, const int16_t *d_samples, int len, void *s
     HIP_TRY(launch_pll_nrzi(p, s));
     if (tm) HIP_TRY(hipEventRecord(b->ev[3], s));
     HdlcLaunch h;
-    h.bits = b->bits; h.nbits = b->nbits; h.ctl = b->ctl; h.buf = b->buf;
-    h.counters = b->counters; h.frames = b->frames; h.frame_count = b->frame_count;
-    h.frame_cap = (uint32_t) b->frame_cap; h.N = b->N; h.bits_words = b->bits_words;
+    fill_hdlc(b, h);
     HIP_TRY(launch_hdlc_crc(h, s));
     if (tm) HIP_TRY(hipEventRecord(b->ev[4], s));
     b->timed_last = tm;
@@ -367,9 +381,7 @@ int gnuais_batch_decode_bits(gnuais_batch *b, const uint8_t *h_bits, int stride,
         HIP_TRY(hipMemcpy(b->bits, words.data(), words.size() * 4, hipMemcpyHostToDevice));
         HIP_TRY(hipMemcpy(b->nbits, nb.data(), nb.size() * 4, hipMemcpyHostToDevice));
         HdlcLaunch h;
-        h.bits = b->bits; h.nbits = b->nbits; h.ctl = b->ctl; h.buf = b->buf;
-        h.counters = b->counters; h.frames = b->frames; h.frame_count = b->frame_count;
-        h.frame_cap = (uint32_t) b->frame_cap; h.N = N; h.bits_words = b->bits_words;
+        fill_hdlc(b, h);
         HIP_TRY(launch_hdlc_crc(h, nullptr));
         HIP_TRY(hipDeviceSynchronize());
     }
@@ -424,6 +436,14 @@ int gnuais_batch_pending_frames(gnuais_batch *b, int *n_out)
     uint32_t cnt[2] = {0, 0};
     HIP_TRY(hipMemcpy(cnt, b->frame_count, sizeof cnt, hipMemcpyDeviceToHost));
     *n_out = (int) std::min<uint32_t>(cnt[0], (uint32_t) b->frame_cap);
+    return GNUAIS_OK;
+}
+
+int gnuais_batch_discard_frames(gnuais_batch *b, void *stream)
+{
+    if (!b) return fail(GNUAIS_E_ARG, "discard_frames: NULL batch");
+    if (int rc = set_device(b)) return rc;
+    HIP_TRY(hipMemsetAsync(b->frame_count, 0, sizeof(uint32_t) * 2, (hipStream_t) stream));
     return GNUAIS_OK;
 }
 

@@ -1,28 +1,36 @@
-// hdlc_crc.hip -- K2b: HDLC deframer (bit-unstuffing FSM) + CRC-16 for gfx950.
+// hdlc_crc.hip -- K2b: HDLC deframer (flag hunt + bit-unstuffing FSM) and
+// K3: CRC-16 check + frame delivery, for gfx950.
 //
 // Stands in for protodec_decode() (gnuais src/protodec.c:988-1122), for
-// protodec_calculate_crc()/protodec_sdlc_crc() (src/protodec.c:106-167) and for
-// protodec_reset() (src/protodec.c:87-100), for a whole batch of channels.
+// protodec_reset() (src/protodec.c:87-100) and for protodec_calculate_crc() /
+// protodec_sdlc_crc() (src/protodec.c:106-167), for a whole batch of channels.
 //
-// One lane = one channel walking its own recovered bit stream (K2a's output);
-// one wave = 64 adjacent channels.  The five-state machine is reproduced
-// literally, quirks included: `last` is rewritten
-// after every state, `nstartsign++` runs even after a reset in ST_STARTSIGN,
-// frames reset at bufferpos >= 449.
+// K2b -- one lane = one channel walking its own recovered bit stream (K2a's
+// output); one wave = 64 adjacent channels; the wave's bit streams are staged in
+// LDS ([word][lane], conflict-free) so that every lane can advance at its own
+// pace.  The five-state machine of the reference is reproduced exactly -- same
+// states, same counters, same quirks (`last`
+// rewritten after every state, `nstartsign++` even after a reset in
+// ST_STARTSIGN, reset at bufferpos >= 449) -- but not bit by bit: the two states
+// a channel spends its life in are advanced up to 32 bits per step with word
+// logic,
+//   ST_SKURR : "15 alternations then a 0" is a run-length test on x ^ (x << 1);
+//   ST_DATA  : "five 1s" (stuffing / closing flag) likewise; the bits up to the
+//              event are appended to the frame buffer with one funnel shift;
+// and ST_PREAMBLE / ST_STARTSIGN / ST_STOPSIGN take one bit per step (they last
+// ~20 bits per frame).  Lanes are not in lock-step on the bit index, so a wave
+// needs max-over-lanes(steps) iterations, not sum.
 //
-// CRC: the reference recomputes the CRC over the whole frame at the closing
-// flag (464 shift steps).  Here the CRC register runs along with the data bits,
-// delayed by the 6 bits of the closing flag that are stored before it is
-// recognised (0 + five 1s), so that at ST_STOPSIGN it already covers
-// buffer[0 .. bufferpos-6).  The reference checks buffer[0 .. 8*(n/8+2)) with
-// n = bufferpos-22: for n % 8 == 0 that is the same span; otherwise the
-// register is un-clocked n % 8 steps (the CRC LFSR is invertible).  A good frame
-// leaves the X-25 residue: ~crc == 0x0f47 (protodec.c:166), i.e. crc == 0xf0b8.
+// The frame bits go straight into a per-channel ring of candidate records in
+// HBM (fire-and-forget stores, no read-back); a frame that is still open at the
+// end of a call simply continues in the same record at the next call.
 //
-// Frame bits are kept per channel in buf[w][c] (bit k at word k/32, LSB first),
-// which is also their carry between calls; payload byte j of a frame is then
-// simply byte j of that little-endian bit image (protodec.c:138-143 packs the
-// same way), which is what the 64-byte frame record carries.
+// K3 -- one thread per candidate closed in this call: the reference's CRC over
+// n/8 + 2 bytes (bits packed LSB first, protodec.c:138-143), good frame <=>
+// 0x0f47 after the final complement (protodec.c:166).  Taking the CRC out of the
+// sequential walk costs nothing in exactness and turns its 464 shift steps per
+// frame into fully parallel work.  Good frames are appended to the frame ring as
+// 64-byte records and counted in receivedframes, bad ones in lostframes.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -34,186 +42,311 @@ enum { ST_SKURR = 1, ST_PREAMBLE = 2, ST_STARTSIGN = 3, ST_DATA = 4, ST_STOPSIGN
 
 // ctl[0]: state[2:0] nstartsign[6:3] antallpreamble[10:7] antallenner[13:11]
 //         bitstuff[14] last[15] bufferpos[24:16]
-// ctl[1]: running CRC register [15:0]
-// ctl[2]: the last 32 stored data bits, newest at bit 0
-// ctl[3]: partially filled buffer word
-// ctl[4]: bits fed since reset
+// ctl[1]: partially filled frame-buffer word
+// ctl[2]: bits fed since reset
+// ctl[3]: ST_DATA entries since reset (candidate slots handed out)
+constexpr int TW = 240;                 // LDS tile: 240 words x 64 lanes (+1 lookahead row), < 64 KB
+constexpr uint32_t CAND_VALID = 0x10000u;
 
 __global__ void hdlc_reset_kernel(uint32_t *__restrict__ ctl, int N)
 {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= N) return;
-    ctl[c] = ST_SKURR;                      // protodec.c:89-99
-    ctl[(size_t) N + c] = 0xffffu;
+    ctl[c] = ST_SKURR;                  // protodec.c:89-99
+    ctl[(size_t) N + c] = 0;
     ctl[(size_t) 2 * N + c] = 0;
     ctl[(size_t) 3 * N + c] = 0;
-    ctl[(size_t) 4 * N + c] = 0;
 }
 
-__global__ __launch_bounds__(64) void hdlc_crc_kernel(
-    const uint32_t *__restrict__ bits, const uint32_t *__restrict__ nbits,
-    uint32_t *__restrict__ ctl, uint32_t *__restrict__ buf, int32_t *__restrict__ counters,
-    uint32_t *__restrict__ frames, uint32_t *__restrict__ frame_count, uint32_t frame_cap,
-    int N, int bits_words)
+__device__ __forceinline__ uint32_t lowmask(int k)      // k in [0, 32]
 {
-    const int cg = blockIdx.x * 64 + threadIdx.x;
-    if (cg >= N) return;
-    const size_t c = (size_t) cg, n_ = (size_t) N;
+    return k >= 32 ? ~0u : ((1u << k) - 1u);
+}
+__device__ __forceinline__ int ctz32(uint32_t v)        // 32 for v == 0
+{
+    return v ? __ffs((int) v) - 1 : 32;
+}
+__device__ __forceinline__ int clz32(uint32_t v)        // 32 for v == 0
+{
+    return v ? __clz((int) v) : 32;
+}
+
+__global__ __launch_bounds__(64) void hdlc_deframe_kernel(
+    const uint32_t *__restrict__ bits, const uint32_t *__restrict__ nbits,
+    uint32_t *__restrict__ ctl, uint32_t *__restrict__ cand, uint32_t *__restrict__ cand_first,
+    uint32_t *__restrict__ cand_count, int32_t *__restrict__ counters,
+    uint32_t *__restrict__ flags, int N, int bits_words, int K)
+{
+    __shared__ uint32_t tile[(TW + 1) * 64];
+
+    const int lane = threadIdx.x;
+    const int cg = blockIdx.x * 64 + lane;
+    const bool live = cg < N;
+    const size_t c = (size_t) (live ? cg : N - 1), n_ = (size_t) N;
 
     const uint32_t c0 = ctl[c];
     int state = c0 & 7, nstartsign = (c0 >> 3) & 15, antallpreamble = (c0 >> 7) & 15;
-    int antallenner = (c0 >> 11) & 7, bitstuff = (c0 >> 14) & 1, last = (c0 >> 15) & 1;
+    int antallenner = (c0 >> 11) & 7, bitstuff = (c0 >> 14) & 1;
+    uint32_t last = (c0 >> 15) & 1;
     int bufferpos = (c0 >> 16) & 511;
-    uint32_t crc = ctl[n_ + c] & 0xffffu;
-    uint32_t recent = ctl[2 * n_ + c];
-    uint32_t cur = ctl[3 * n_ + c];
-    uint32_t seen = ctl[4 * n_ + c];
-    int received = 0, lost = 0, lost2 = 0;
+    uint32_t cur = ctl[n_ + c];
+    const uint32_t seen0 = ctl[2 * n_ + c];
+    uint32_t nstart = ctl[3 * n_ + c];
+    int lost2 = 0;
 
-    int total = (int) nbits[c];
+    const bool open0 = (state == ST_DATA || state == ST_STOPSIGN);
+    const uint32_t first = nstart - (open0 ? 1u : 0u);      // first slot this call may close
+    uint32_t *rec = cand + ((size_t) c * K + (open0 ? (nstart - 1) % (uint32_t) K : 0u)) * CAND_WORDS;
+    bool rec_ok = open0;
+
+    int total = live ? (int) nbits[c] : 0;
     if (total > bits_words * 32) total = bits_words * 32;
+    int pos = 0;
 
 #define HDLC_RESET()                                                                    \
     do { state = ST_SKURR; nstartsign = 0; antallpreamble = 0; antallenner = 0;        \
          last = 0; bitstuff = 0; bufferpos = 0; } while (0)
 
-    uint32_t word = 0;
-    for (int k = 0; k < total; ++k) {
-        if ((k & 31) == 0) word = bits[(size_t) (k >> 5) * n_ + c];
-        const int x = (int) (word & 1u);
-        word >>= 1;
+    for (int tile0 = 0; tile0 < bits_words; tile0 += TW) {
+        if (!__any(pos < total)) break;
+        // stage TW+1 words per channel (coalesced rows of 64 lanes)
+        for (int r = 0; r <= TW; ++r) {
+            const int w = tile0 + r;
+            tile[r * 64 + lane] = (w < bits_words) ? bits[(size_t) w * n_ + c] : 0u;
+        }
+        const int tile_end = (total < (tile0 + TW) * 32) ? total : (tile0 + TW) * 32;
 
-        switch (state) {
-        case ST_DATA:                                   // protodec.c:995-1028
-            if (bitstuff) {
-                if (x == 1) state = ST_STOPSIGN;
-                bitstuff = 0;
-            } else {
-                if (x == last && x == 1) {
-                    if (++antallenner == 4) { bitstuff = 1; antallenner = 0; }
+        while (pos < tile_end) {
+            const int lw = (pos >> 5) - tile0, sh = pos & 31;
+            const uint32_t lo = tile[lw * 64 + lane], hi = tile[(lw + 1) * 64 + lane];
+            const uint32_t W = sh ? ((lo >> sh) | (hi << (32 - sh))) : lo;   // bit j = x[pos+j]
+            const int nv = (tile_end - pos < 32) ? tile_end - pos : 32;
+            const uint32_t vm = lowmask(nv);
+
+            if (state == ST_SKURR) {
+                // protodec.c:1030-1043, up to nv bits at once.  A bit j = x_j != x_{j-1}.
+                const uint32_t A = W ^ ((W << 1) | last);
+                const uint32_t B2 = A & (A << 1), B4 = B2 & (B2 << 2), B8 = B4 & (B4 << 4);
+                const uint32_t B15 = B8 & (B8 << 7);          // 15 alternations inside the window
+                const int t = ctz32(~A);                       // alternation run from the window start
+                const int need = 14 - antallpreamble;          // run continues the carried count
+                const uint32_t C = lowmask(t) & ~lowmask(need > 0 ? need : 0);
+                const uint32_t TR = (B15 | C) & ~W & vm;       // antallpreamble > 14 && x == 0
+                if (TR) {
+                    pos += ctz32(TR) + 1;
+                    state = ST_PREAMBLE;
+                    antallpreamble = 0;
+                    last = 0;
                 } else {
-                    antallenner = 0;
+                    pos += nv;
+                    last = (W >> (nv - 1)) & 1u;
+                    int ap = (t >= nv) ? antallpreamble + nv : clz32(~(A << (32 - nv)));
+                    antallpreamble = ap > 15 ? 15 : ap;
                 }
-                // buffer[bufferpos++] = x
-                cur |= (uint32_t) x << (bufferpos & 31);
-                if ((bufferpos & 31) == 31) {
-                    buf[(size_t) (bufferpos >> 5) * n_ + c] = cur;
-                    cur = 0;
+            } else if (state == ST_DATA) {
+                if (bitstuff) {                                // protodec.c:996-1007
+                    const uint32_t x = W & 1u;
+                    if (x) state = ST_STOPSIGN;                // sixth 1: closing flag (or abort)
+                    bitstuff = 0;
+                    last = x;
+                    pos += 1;
+                } else {                                       // protodec.c:1008-1027
+                    // m = run of 1s ending at the previous bit (antallenner = m-1 when last = 1)
+                    const int m = last ? antallenner + 1 : 0;
+                    const uint32_t Z2 = W & (W << 1), Z4 = Z2 & (Z2 << 2);
+                    const uint32_t F = Z4 & (W << 4);          // bit j: x[j-4..j] all 1
+                    const int t1 = ctz32(~W);                  // 1s from the window start
+                    int e = ctz32(F);
+                    if (m + t1 >= 5 && 4 - m < e) e = 4 - m;   // run continues the carried count
+                    const int n_ev = e + 1;                    // bits up to the fifth 1, inclusive
+                    const int room = 449 - bufferpos;          // protodec.c:1024
+                    int n = nv;
+                    if (n_ev < n) n = n_ev;
+                    if (room < n) n = room;
+                    // buffer[bufferpos .. bufferpos+n) = x[pos .. pos+n)
+                    const uint32_t sb = W & lowmask(n);
+                    const int bsh = bufferpos & 31;
+                    const uint64_t t64 = (uint64_t) sb << bsh;
+                    cur |= (uint32_t) t64;
+                    if (bsh + n >= 32) {
+                        if (rec_ok) rec[CAND_HDR + (bufferpos >> 5)] = cur;
+                        cur = (uint32_t) (t64 >> 32);
+                    }
+                    bufferpos += n;
+                    pos += n;
+                    const uint32_t xl = (W >> (n - 1)) & 1u;
+                    if (n == room) {                           // bufferpos >= 449: give up the frame
+                        if (rec_ok) rec[0] = 0;
+                        HDLC_RESET();
+                        last = xl;
+                    } else if (n == n_ev) {                    // five 1s: next bit is stuffing or flag
+                        bitstuff = 1;
+                        antallenner = 0;
+                        last = 1;
+                    } else {
+                        const int mm = (t1 >= n) ? m + n : clz32(~(W << (32 - n)));
+                        last = xl;
+                        antallenner = xl ? mm - 1 : 0;
+                    }
                 }
-                recent = (recent << 1) | (uint32_t) x;
-                if (bufferpos >= 6) {                   // CRC runs 6 bits behind
-                    const uint32_t fb = (crc ^ (recent >> 6)) & 1u;
-                    crc = (crc >> 1) ^ (fb ? 0x8408u : 0u);
-                }
-                ++bufferpos;
-                if (bufferpos >= 449) HDLC_RESET();
-            }
-            break;
-
-        case ST_SKURR:                                  // protodec.c:1030-1043
-            if (x != last) { if (antallpreamble < 15) ++antallpreamble; }
-            else antallpreamble = 0;
-            last = x;
-            if (antallpreamble > 14 && x == 0) { state = ST_PREAMBLE; antallpreamble = 0; }
-            break;
-
-        case ST_PREAMBLE:                               // protodec.c:1045-1072
-            if (x != last && nstartsign == 0) {
-                if (antallpreamble < 15) ++antallpreamble;
-            } else if (x == 1) {
-                if (nstartsign == 0) { nstartsign = 3; last = x; }
-                else if (nstartsign == 5) { nstartsign = 6; antallpreamble = 0; state = ST_STARTSIGN; }
-                else ++nstartsign;
             } else {
-                if (nstartsign == 0) nstartsign = 1;
-                else HDLC_RESET();
-            }
-            break;
-
-        case ST_STARTSIGN:                              // protodec.c:1074-1093
-            if (nstartsign >= 7) {
-                if (x == 0) {
-                    state = ST_DATA; nstartsign = 0; antallenner = 0;
-                    bufferpos = 0; cur = 0; crc = 0xffffu; recent = 0;
+                const uint32_t x = W & 1u;
+                bool single = true;
+                if (state == ST_PREAMBLE) {                    // protodec.c:1045-1072
+                    if (nstartsign == 0) {
+                        // the alternating part of the training sequence, all at once
+                        const uint32_t A = W ^ ((W << 1) | last);
+                        int t = ctz32(~A);
+                        if (t > nv) t = nv;
+                        if (t > 0) {
+                            antallpreamble = antallpreamble + t > 15 ? 15 : antallpreamble + t;
+                            last = (W >> (t - 1)) & 1u;
+                            pos += t;
+                            single = false;
+                        }
+                    }
+                    if (single) {
+                        if (x != last && nstartsign == 0) {
+                            if (antallpreamble < 15) ++antallpreamble;
+                        } else if (x == 1) {
+                            if (nstartsign == 0) nstartsign = 3;
+                            else if (nstartsign == 5) { nstartsign = 6; antallpreamble = 0; state = ST_STARTSIGN; }
+                            else ++nstartsign;
+                        } else {
+                            if (nstartsign == 0) nstartsign = 1;
+                            else HDLC_RESET();
+                        }
+                    }
+                } else if (state == ST_STARTSIGN) {            // protodec.c:1074-1093
+                    if (nstartsign >= 7) {
+                        if (x == 0) {
+                            state = ST_DATA; nstartsign = 0; antallenner = 0;
+                            bufferpos = 0; cur = 0;
+                            // open a candidate record for this frame
+                            rec_ok = (nstart - first) < (uint32_t) K;
+                            rec = cand + ((size_t) c * K + nstart % (uint32_t) K) * CAND_WORDS;
+                            if (rec_ok) rec[0] = 0; else flags[1] = 1;
+                            ++nstart;
+                        } else {
+                            HDLC_RESET();
+                        }
+                    } else if (x == 0) {
+                        HDLC_RESET();
+                    }
+                    ++nstartsign;                              // also after a reset
+                } else if (state == ST_STOPSIGN) {             // protodec.c:1095-1115
+                    const int nb = bufferpos - 6 - 16;
+                    if (x == 0 && nb > 0) {
+                        if (rec_ok) {
+                            rec[CAND_HDR + (bufferpos >> 5)] = cur;
+                            rec[1] = seen0 + (uint32_t) pos;
+                            rec[0] = (uint32_t) nb | CAND_VALID;
+                        }
+                    } else {
+                        ++lost2;                               // protodec.c:1112
+                        if (rec_ok) rec[0] = 0;
+                    }
+                    HDLC_RESET();
                 } else {
                     HDLC_RESET();
                 }
-            } else if (x == 0) {
-                HDLC_RESET();
-            }
-            ++nstartsign;                               // also after a reset
-            break;
-
-        case ST_STOPSIGN: {                             // protodec.c:1095-1115
-            const int n = bufferpos - 6 - 16;
-            if (x == 0 && n > 0) {
-                // protodec.c:120-167: CRC over n/8 + 2 bytes
-                uint32_t r = crc;
-                const int back = n & 7;
-                for (int t = 0; t < back; ++t) {        // un-clock the trailing n%8 bits
-                    const uint32_t fb = r >> 15;
-                    const uint32_t bit = (recent >> (6 + t)) & 1u;
-                    r = (((r ^ (fb ? 0x8408u : 0u)) << 1) | (fb ^ bit)) & 0xffffu;
+                if (single) {
+                    last = x;                                  // protodec.c:1119
+                    pos += 1;
                 }
-                if (r == 0xf0b8u) {
-                    ++received;                         // protodec.c:1103
-                    const uint32_t idx = atomicAdd(&frame_count[0], 1u);
-                    if (idx < frame_cap) {
-                        const int nbytes = n >> 3;
-                        const int partial = bufferpos >> 5;   // word still held in `cur`
-                        uint32_t *rec = frames + (size_t) idx * 16;
-                        rec[0] = (uint32_t) cg;
-                        rec[1] = seen;
-#pragma unroll
-                        for (int wq = 0; wq < 14; ++wq) {
-                            uint32_t v = 0;
-                            if (wq * 4 < nbytes) {
-                                v = (wq == partial) ? cur : buf[(size_t) wq * n_ + c];
-                                const int keep = nbytes - wq * 4;     // bytes of this word
-                                if (keep < 4) v &= (1u << (8 * keep)) - 1u;
-                            }
-                            if (wq == 13) v = (v & 0xffu) | (1u << 8) | ((uint32_t) n << 16);
-                            rec[2 + wq] = v;
-                        }
-                    } else {
-                        frame_count[1] = 1;             // overflow: frame dropped, counted
-                    }
-                } else {
-                    ++lost;                             // protodec.c:1107
-                }
-            } else {
-                ++lost2;                                // protodec.c:1112
             }
-            HDLC_RESET();
-            break;
         }
-        default:
-            HDLC_RESET();
-            break;
-        }
-        last = x;                                       // protodec.c:1119
-        ++seen;
     }
 #undef HDLC_RESET
 
-    ctl[c] = (uint32_t) state | ((uint32_t) nstartsign << 3) | ((uint32_t) antallpreamble << 7) |
-             ((uint32_t) antallenner << 11) | ((uint32_t) bitstuff << 14) |
-             ((uint32_t) last << 15) | ((uint32_t) bufferpos << 16);
-    ctl[n_ + c] = crc;
-    ctl[2 * n_ + c] = recent;
-    ctl[3 * n_ + c] = cur;
-    ctl[4 * n_ + c] = seen;
-    if (received) counters[c] += received;
-    if (lost) counters[n_ + c] += lost;
-    if (lost2) counters[2 * n_ + c] += lost2;
+    if (live) {
+        ctl[c] = (uint32_t) state | ((uint32_t) nstartsign << 3) | ((uint32_t) antallpreamble << 7) |
+                 ((uint32_t) antallenner << 11) | ((uint32_t) bitstuff << 14) | (last << 15) |
+                 ((uint32_t) bufferpos << 16);
+        ctl[n_ + c] = cur;
+        ctl[2 * n_ + c] = seen0 + (uint32_t) total;
+        ctl[3 * n_ + c] = nstart;
+        const bool open1 = (state == ST_DATA || state == ST_STOPSIGN);
+        const uint32_t limit = nstart - (open1 ? 1u : 0u);
+        cand_first[c] = first;
+        uint32_t cnt = limit - first;
+        cand_count[c] = cnt > (uint32_t) K ? (uint32_t) K : cnt;
+        if (lost2) counters[2 * n_ + c] += lost2;
+    }
+}
+
+// K3: one thread per (channel, candidate slot closed in this call)
+__global__ void hdlc_crc_kernel(const uint32_t *__restrict__ cand,
+                                const uint32_t *__restrict__ cand_first,
+                                const uint32_t *__restrict__ cand_count,
+                                int32_t *__restrict__ counters, uint32_t *__restrict__ frames,
+                                uint32_t *__restrict__ flags, uint32_t frame_cap, int N, int K)
+{
+    const size_t id = (size_t) blockIdx.x * blockDim.x + threadIdx.x;
+    const int c = (int) (id / (size_t) K), j = (int) (id % (size_t) K);
+    if (c >= N || (uint32_t) j >= cand_count[c]) return;
+    const uint32_t slot = (cand_first[c] + (uint32_t) j) % (uint32_t) K;
+    const uint32_t *rec = cand + ((size_t) c * K + slot) * CAND_WORDS;
+    const uint32_t hdr = rec[0];
+    if (!(hdr & CAND_VALID)) return;                    // frame abandoned before its closing flag
+    const int n = (int) (hdr & 0xffffu);
+    const int nbytes = n >> 3, buflen = nbytes + 2;     // protodec.c:133-134
+    uint32_t w[HDLC_BUF_WORDS];
+#pragma unroll
+    for (int q = 0; q < HDLC_BUF_WORDS; ++q) w[q] = rec[CAND_HDR + q];
+    // protodec.c:106-118 over buflen bytes = 8*buflen buffer bits, LSB first
+    uint32_t crc = 0xffffu;
+#pragma unroll
+    for (int q = 0; q < HDLC_BUF_WORDS; ++q) {
+        const int nbit = 8 * buflen - 32 * q;           // bits of this word inside the span
+        if (nbit > 0) {
+            uint32_t v = w[q];
+            const int lim = nbit < 32 ? nbit : 32;
+            for (int b = 0; b < lim; ++b) {
+                const uint32_t fb = (crc ^ v) & 1u;
+                crc = (crc >> 1) ^ (fb ? 0x8408u : 0u);
+                v >>= 1;
+            }
+        }
+    }
+    const size_t n_ = (size_t) N;
+    if (crc == 0xf0b8u) {                               // ~crc == 0x0f47, protodec.c:166
+        atomicAdd(&counters[c], 1);                     // protodec.c:1103
+        const uint32_t idx = atomicAdd(&flags[0], 1u);
+        if (idx < frame_cap) {
+            uint32_t *out = frames + (size_t) idx * 16;
+            out[0] = (uint32_t) c;
+            out[1] = rec[1];
+#pragma unroll
+            for (int q = 0; q < 14; ++q) {
+                uint32_t v = 0;
+                if (q * 4 < nbytes) {
+                    v = w[q];
+                    const int keep = nbytes - q * 4;
+                    if (keep < 4) v &= (1u << (8 * keep)) - 1u;
+                }
+                if (q == 13) v = (v & 0xffu) | (1u << 8) | ((uint32_t) n << 16);
+                out[2 + q] = v;
+            }
+        } else {
+            flags[1] = 1;                               // ring full: frame dropped, still counted
+        }
+    } else {
+        atomicAdd(&counters[n_ + c], 1);                // protodec.c:1107
+    }
 }
 
 hipError_t launch_hdlc_crc(const HdlcLaunch &a, hipStream_t stream)
 {
-    dim3 grid((a.N + 63) / 64), block(64);
-    hipLaunchKernelGGL(hdlc_crc_kernel, grid, block, 0, stream, a.bits, a.nbits, a.ctl, a.buf,
-                       a.counters, (uint32_t *) a.frames, a.frame_count, a.frame_cap, a.N,
-                       a.bits_words);
+    hipLaunchKernelGGL(hdlc_deframe_kernel, dim3((a.N + 63) / 64), dim3(64), 0, stream, a.bits,
+                       a.nbits, a.ctl, a.cand, a.cand_first, a.cand_count, a.counters,
+                       a.frame_count, a.N, a.bits_words, a.K);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    const size_t threads = (size_t) a.N * (size_t) a.K;
+    hipLaunchKernelGGL(hdlc_crc_kernel, dim3((unsigned) ((threads + 255) / 256)), dim3(256), 0,
+                       stream, a.cand, a.cand_first, a.cand_count, a.counters,
+                       (uint32_t *) a.frames, a.frame_count, a.frame_cap, a.N, a.K);
     return hipGetLastError();
 }
 

@@ -34,20 +34,24 @@ struct PllLaunch {
 };
 hipError_t launch_pll_nrzi(const PllLaunch &a, hipStream_t stream);
 
-// ---- K2b: HDLC deframer + CRC-16 (hdlc_crc.hip) ---------------------------
+// ---- K2b: HDLC deframer, K3: CRC-16 + frame delivery (hdlc_crc.hip) ---------
+constexpr int HDLC_CTL_WORDS = 4;
+constexpr int HDLC_BUF_WORDS = 15;   // 449 bits max (protodec.c:1024)
+constexpr int CAND_HDR = 2;          // [0] nbits | valid flag, [1] end_bit
+constexpr int CAND_WORDS = 18;       // header + 15 buffer words, padded to 72 bytes
 struct HdlcLaunch {
     const uint32_t *bits;  // as above
     const uint32_t *nbits; // [N]
     uint32_t *ctl;         // [HDLC_CTL_WORDS][N] control state
-    uint32_t *buf;         // [HDLC_BUF_WORDS][N] frame bit buffer (bit k at word k/32, LSB first)
+    uint32_t *cand;        // [N][K][CAND_WORDS] per-channel ring of candidate frames
+    uint32_t *cand_first;  // [N] first slot closed in this call
+    uint32_t *cand_count;  // [N] slots closed in this call
     int32_t *counters;     // [3][N] receivedframes, lostframes, lostframes2
     void *frames;          // gnuais_frame[frame_cap]
     uint32_t *frame_count; // [2]: frames appended, overflow flag
     uint32_t frame_cap;
-    int N, bits_words;
+    int N, bits_words, K;
 };
-constexpr int HDLC_CTL_WORDS = 5;
-constexpr int HDLC_BUF_WORDS = 15;   // 449 bits max (protodec.c:1024)
 hipError_t launch_hdlc_crc(const HdlcLaunch &a, hipStream_t stream);
 hipError_t launch_hdlc_reset(uint32_t *ctl, int N, hipStream_t stream);
 

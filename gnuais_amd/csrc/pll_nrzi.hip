@@ -44,50 +44,72 @@ __global__ __launch_bounds__(64) void pll_nrzi_kernel(
     uint32_t outw = 0, outn = 0, wr = 0;
     const int W = (L + 31) >> 5;
 
-    for (int w = 0; w < W; ++w) {
-        const uint32_t S = sgn[(size_t) w * (size_t) N + c];   // bit 31 = oldest
-        const int nv = (L - w * 32 < 32) ? L - w * 32 : 32;
-        // transition word: bit (31-i) = s_i ^ s_{i-1}   (receiver.c:113)
-        uint32_t D = S ^ ((S >> 1) | (prev << 31));
-        uint32_t O = 0;                                         // overflow (slice) marks
-        if (nv == 32) {
+    // The sign words of a channel are N*4 bytes apart, so every lane's load is its
+    // own 4-byte gather; with one wave per SIMD nothing else hides the HBM latency.
+    // Keep PF words in flight: the group for step g+1 is requested before the
+    // group of step g is consumed.
+    constexpr int PF = 8;
+    uint32_t nxt[PF];
 #pragma unroll
-            for (int i = 0; i < 32; ++i) {
-                const bool t = (int32_t) D < 0;
-                D <<= 1;
-                const uint32_t Kt = ((int32_t) P < 0) ? Km : Kp; // receiver.c:114-118
-                const uint32_t K = t ? Kt : INC;
-                const uint32_t Pn = P + K;                        // receiver.c:122
-                O = (O << 1) | (Pn < P ? 1u : 0u);                // receiver.c:124
-                P = Pn;
-            }
-            prev = S & 1u;
-        } else {
-            for (int i = 0; i < nv; ++i) {
-                const bool t = (int32_t) D < 0;
-                D <<= 1;
-                const uint32_t Kt = ((int32_t) P < 0) ? Km : Kp;
-                const uint32_t K = t ? Kt : INC;
-                const uint32_t Pn = P + K;
-                O = (O << 1) | (Pn < P ? 1u : 0u);
-                P = Pn;
-            }
-            O <<= (32 - nv);                                      // left-align like S
-            prev = (S >> (32 - nv)) & 1u;
+    for (int q = 0; q < PF; ++q) nxt[q] = (q < W) ? sgn[(size_t) q * (size_t) N + c] : 0u;
+
+    for (int w0 = 0; w0 < W; w0 += PF) {
+        uint32_t grp[PF];
+#pragma unroll
+        for (int q = 0; q < PF; ++q) grp[q] = nxt[q];
+#pragma unroll
+        for (int q = 0; q < PF; ++q) {
+            const int wn = w0 + PF + q;
+            nxt[q] = (wn < W) ? sgn[(size_t) wn * (size_t) N + c] : 0u;
         }
-        // slice + NRZI at every overflow, oldest first (receiver.c:126-132)
-        while (O) {
-            const int pos = __clz((int) O);
-            const uint32_t level = (S >> (31 - pos)) & 1u;
-            O &= ~(0x80000000u >> pos);
-            const uint32_t b = (level ^ last) ^ 1u;
-            last = level;
-            outw |= b << outn;
-            if (++outn == 32) {
-                if (live && (int) wr < bits_words) bits[(size_t) wr * (size_t) N + cg] = outw;
-                ++wr;
-                outw = 0;
-                outn = 0;
+#pragma unroll
+        for (int q = 0; q < PF; ++q) {
+            const int w = w0 + q;
+            if (w >= W) break;
+            const uint32_t S = grp[q];                          // bit 31 = oldest
+            const int nv = (L - w * 32 < 32) ? L - w * 32 : 32;
+            // transition word: bit (31-i) = s_i ^ s_{i-1}   (receiver.c:113)
+            uint32_t D = S ^ ((S >> 1) | (prev << 31));
+            uint32_t O = 0;                                     // overflow (slice) marks
+            if (nv == 32) {
+#pragma unroll
+                for (int i = 0; i < 32; ++i) {
+                    const bool t = (int32_t) D < 0;
+                    D <<= 1;
+                    const uint32_t Kt = ((int32_t) P < 0) ? Km : Kp; // receiver.c:114-118
+                    const uint32_t K = t ? Kt : INC;
+                    const uint32_t Pn = P + K;                    // receiver.c:122
+                    O = (O << 1) | (Pn < P ? 1u : 0u);            // receiver.c:124
+                    P = Pn;
+                }
+                prev = S & 1u;
+            } else {
+                for (int i = 0; i < nv; ++i) {
+                    const bool t = (int32_t) D < 0;
+                    D <<= 1;
+                    const uint32_t Kt = ((int32_t) P < 0) ? Km : Kp;
+                    const uint32_t K = t ? Kt : INC;
+                    const uint32_t Pn = P + K;
+                    O = (O << 1) | (Pn < P ? 1u : 0u);
+                    P = Pn;
+                }
+                O <<= (32 - nv);                                  // left-align like S
+                prev = (S >> (32 - nv)) & 1u;
+            }
+            // slice + NRZI at every overflow, oldest first (receiver.c:126-132)
+            while (O) {
+                const int pos = __clz((int) O);
+                const uint32_t level = (S >> (31 - pos)) & 1u;
+                O &= ~(0x80000000u >> pos);
+                const uint32_t b = (level ^ last) ^ 1u;
+                last = level;
+                outw |= b << outn;
+                if (++outn == 32) {
+                    if (live && (int) wr < bits_words) bits[(size_t) wr * (size_t) N + cg] = outw;
+                    ++wr;
+                    outw = 0;
+                    outn = 0;
+                }
             }
         }
     }

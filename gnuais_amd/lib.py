@@ -38,6 +38,7 @@ SYMBOLS = {
     "gnuais_batch_last_bits": (_I, [_P, _P, _I, _P]),
     "gnuais_batch_drain_frames": (_I, [_P, _P, _I, C.POINTER(_I)]),
     "gnuais_batch_pending_frames": (_I, [_P, C.POINTER(_I)]),
+    "gnuais_batch_discard_frames": (_I, [_P, _P]),
     "gnuais_batch_counters": (_I, [_P, _P]),
     "gnuais_batch_total_received": (_I, [_P, C.POINTER(C.c_longlong)]),
     "gnuais_batch_maxval": (_I, [_P, _P]),

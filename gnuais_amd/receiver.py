@@ -118,6 +118,12 @@ class ReceiverBatch:
         check(self._lib.gnuais_batch_pending_frames(self._h, C.byref(n)))
         return n.value
 
+    def discard_frames(self, stream: Optional[int] = None):
+        if stream is None:
+            import torch
+            stream = torch.cuda.current_stream(self.device).cuda_stream
+        check(self._lib.gnuais_batch_discard_frames(self._h, C.c_void_p(stream)))
+
     def drain_frames(self) -> np.ndarray:
         n = self.pending_frames()
         out = np.zeros(max(n, 1), dtype=FRAME_DTYPE)

@@ -104,6 +104,9 @@ int  gnuais_batch_last_bits(gnuais_batch *b, uint8_t *h_bits, int stride, int32_
  * drained span (channel 0..N-1, then time).  *n_out = frames written. */
 int  gnuais_batch_drain_frames(gnuais_batch *b, gnuais_frame *h_out, int max, int *n_out);
 int  gnuais_batch_pending_frames(gnuais_batch *b, int *n_out);
+/* stream-ordered: drop everything queued so far without copying it out (the
+ * counters keep counting); for consumers that only read counters */
+int  gnuais_batch_discard_frames(gnuais_batch *b, void *stream);
 int  gnuais_batch_counters(gnuais_batch *b, gnuais_counters *h_out /* [n_channels] */);
 int  gnuais_batch_total_received(gnuais_batch *b, long long *total);
 /* filter_run_buf()'s return value for the last run: peak positive sample per channel

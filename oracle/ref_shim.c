@@ -41,7 +41,7 @@ typedef struct {
 	uint16_t nbits;       /* bufferlen handed to protodec_getdata          */
 } ref_frame_t;
 
-#define MAX_RX 4096
+#define MAX_RX 65536
 
 static struct receiver *g_rx[MAX_RX];
 static uint32_t g_bits_seen[MAX_RX];
@@ -55,12 +55,19 @@ static ref_frame_t *g_frames = NULL;
 static size_t g_frames_n = 0, g_frames_cap = 0;
 
 
+static int g_fast = 0;                  /* bench mode: no bookkeeping in the wrap */
+static int g_last_idx = 0;
+
 static int rx_index_of_decoder(struct demod_state_t *d)
 {
 	int i;
+	if (g_last_idx < g_nrx && g_rx[g_last_idx] && g_rx[g_last_idx]->decoder == d)
+		return g_last_idx;
 	for (i = 0; i < g_nrx; i++)
-		if (g_rx[i] && g_rx[i]->decoder == d)
+		if (g_rx[i] && g_rx[i]->decoder == d) {
+			g_last_idx = i;
 			return i;
+		}
 	return -1;
 }
 
@@ -104,8 +111,12 @@ static void record_frame(int idx, int bufferlen, struct demod_state_t *d)
 
 void __wrap_protodec_decode(char *in, int count, struct demod_state_t *d)
 {
-	int idx = rx_index_of_decoder(d);
-	int i;
+	int idx, i;
+	if (g_fast) {                   /* timed runs: straight through */
+		__real_protodec_decode(in, count, d);
+		return;
+	}
+	idx = rx_index_of_decoder(d);
 	if (idx >= 0 && (g_bit_rx == idx || g_bit_rx == -2)) {
 		for (i = 0; i < count; i++) {
 			if (g_bits_n == g_bits_cap) {
@@ -295,7 +306,9 @@ long ref_bench_run(short *buf, int total_len, int chunk)
 {
 	int i;
 	long tot = 0;
+	g_fast = 1;
 	ref_run_stream(buf, total_len, chunk);
+	g_fast = 0;
 	for (i = 0; i < g_nrx; i++)
 		tot += g_rx[i]->decoder->receivedframes;
 	return tot;
