@@ -61,7 +61,9 @@ struct gnuais_batch {
     // device state
     int16_t *hist[2] = {nullptr, nullptr};
     int hist_cur = 0;
-    uint32_t *sgn = nullptr, *pll = nullptr, *bits = nullptr, *nbits = nullptr;
+    uint32_t *sgn = nullptr, *ovf = nullptr, *pll = nullptr, *lastbit = nullptr;
+    uint32_t *segbits = nullptr, *segcnt = nullptr;
+    int n_seg = 0, seg_words = 0;
     uint32_t *ctl = nullptr, *cand = nullptr, *cand_first = nullptr, *cand_count = nullptr;
     uint32_t *frame_count = nullptr;
     int cand_K = 64;
@@ -74,6 +76,7 @@ struct gnuais_batch {
     // options
     int fir_T = 512;
     int fir_variant = 0;            // 0 scalar VALU, 1 packed VALU
+    int hdlc_lpw = 8;               // channels per wave in K2b
     bool timing = false;
     hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
     bool timed_last = false;
@@ -106,7 +109,8 @@ void gnuais_batch_destroy(gnuais_batch *b)
 {
     if (!b) return;
     (void) hipSetDevice(b->device);
-    void *ptrs[] = {b->hist[0], b->hist[1], b->sgn, b->pll, b->bits, b->nbits, b->ctl, b->cand,
+    void *ptrs[] = {b->hist[0], b->hist[1], b->sgn, b->ovf, b->pll, b->lastbit, b->segbits,
+                    b->segcnt, b->ctl, b->cand,
                     b->cand_first, b->cand_count,
                     b->frame_count, b->counters, b->maxval, b->frames, b->d_taps, b->stage_x};
     for (void *p : ptrs)
@@ -166,10 +170,14 @@ int gnuais_batch_create(gnuais_batch **out, int device, int n_channels, const fl
     };
     alloc((void **) &b->hist[0], sizeof(int16_t) * N * b->NT);
     alloc((void **) &b->hist[1], sizeof(int16_t) * N * b->NT);
-    alloc((void **) &b->sgn, sizeof(uint32_t) * N * b->sgn_words);
+    b->n_seg = (b->sgn_words + SEG_WORDS - 1) / SEG_WORDS;
+    b->seg_words = (int) (((uint64_t) SEG_WORDS * 32 * step / 65536 + 2 + 31) / 32) + 1;
+    alloc((void **) &b->sgn, sizeof(uint32_t) * N * (b->sgn_words + 2 * PLL_PAD));
+    alloc((void **) &b->ovf, sizeof(uint32_t) * N * (b->sgn_words + 2 * PLL_PAD));
     alloc((void **) &b->pll, sizeof(uint32_t) * N);
-    alloc((void **) &b->bits, sizeof(uint32_t) * N * b->bits_words);
-    alloc((void **) &b->nbits, sizeof(uint32_t) * N);
+    alloc((void **) &b->lastbit, sizeof(uint32_t) * N);
+    alloc((void **) &b->segbits, sizeof(uint32_t) * N * (size_t) b->n_seg * b->seg_words);
+    alloc((void **) &b->segcnt, sizeof(uint32_t) * N * (size_t) b->n_seg);
     alloc((void **) &b->ctl, sizeof(uint32_t) * N * HDLC_CTL_WORDS);
     // candidate ring: a frame needs >= 32 bits of preamble+flag, typical load is one
     // frame per 256 bit times; 64 slots per channel and call cover max_len <= 2^16
@@ -211,7 +219,8 @@ int gnuais_batch_reset(gnuais_batch *b)
     HIP_TRY(hipMemset(b->hist[1], 0, sizeof(int16_t) * N * b->NT));
     b->hist_cur = 0;
     HIP_TRY(hipMemset(b->pll, 0, sizeof(uint32_t) * N));              // receiver.c:66-71
-    HIP_TRY(hipMemset(b->nbits, 0, sizeof(uint32_t) * N));
+    HIP_TRY(hipMemset(b->lastbit, 0, sizeof(uint32_t) * N));
+    HIP_TRY(hipMemset(b->segcnt, 0, sizeof(uint32_t) * N * (size_t) b->n_seg));
     HIP_TRY(hipMemset(b->counters, 0, sizeof(int32_t) * N * 3));      // protodec.c:62-64
     HIP_TRY(hipMemset(b->maxval, 0, sizeof(int) * N));
     HIP_TRY(hipMemset(b->frame_count, 0, sizeof(uint32_t) * 2));
@@ -230,6 +239,9 @@ int gnuais_batch_set_option(gnuais_batch *b, const char *name, int value)
     } else if (!strcmp(name, "fir_variant")) {
         if (value < 0 || value > 1) return fail(GNUAIS_E_ARG, "fir_variant must be 0 or 1");
         b->fir_variant = value;
+    } else if (!strcmp(name, "hdlc_lpw")) {
+        if (value < 1 || value > 64) return fail(GNUAIS_E_ARG, "hdlc_lpw must be 1..64");
+        b->hdlc_lpw = value;
     } else {
         return fail(GNUAIS_E_ARG, "set_option: unknown option");
     }
@@ -256,11 +268,12 @@ static void fill_fir(const gnuais_batch *b, FirLaunch &f, const int16_t *x, int 
 
 static void fill_hdlc(const gnuais_batch *b, HdlcLaunch &h)
 {
-    h.bits = b->bits; h.nbits = b->nbits; h.ctl = b->ctl; h.cand = b->cand;
+    h.segbits = b->segbits; h.segcnt = b->segcnt; h.ctl = b->ctl; h.cand = b->cand;
     h.cand_first = b->cand_first; h.cand_count = b->cand_count;
     h.counters = b->counters; h.frames = b->frames; h.frame_count = b->frame_count;
-    h.frame_cap = (uint32_t) b->frame_cap; h.N = b->N; h.bits_words = b->bits_words;
-    h.K = b->cand_K;
+    h.frame_cap = (uint32_t) b->frame_cap; h.N = b->N; h.n_seg = b->n_seg;
+    h.seg_words = b->seg_words; h.K = b->cand_K;
+    h.lanes_per_wave = b->hdlc_lpw;
 }
 
 static int run_fir(gnuais_batch *b, const int16_t *x, int len, float *dump, hipStream_t s)
@@ -297,8 +310,9 @@ int gnuais_batch_run(gnuais_batch *b, const int16_t *d_samples, int len, void *s
     if (tm) HIP_TRY(hipEventRecord(b->ev[1], s));
     if (int rc = run_history(b, d_samples, len, s)) return rc;
     PllLaunch p;
-    p.sgn = b->sgn; p.pll = b->pll; p.bits = b->bits; p.nbits = b->nbits;
-    p.N = b->N; p.L = len; p.bits_words = b->bits_words; p.pllinc = b->pllinc;
+    p.sgn = b->sgn; p.ovf = b->ovf; p.pll = b->pll; p.lastbit = b->lastbit;
+    p.segbits = b->segbits; p.segcnt = b->segcnt;
+    p.N = b->N; p.L = len; p.n_seg = b->n_seg; p.seg_words = b->seg_words; p.pllinc = b->pllinc;
     if (tm) HIP_TRY(hipEventRecord(b->ev[2], s));
     HIP_TRY(launch_pll_nrzi(p, s));
     if (tm) HIP_TRY(hipEventRecord(b->ev[3], s));
@@ -362,24 +376,30 @@ int gnuais_batch_decode_bits(gnuais_batch *b, const uint8_t *h_bits, int stride,
 {
     if (!b || !h_bits || !h_count || stride <= 0) return fail(GNUAIS_E_ARG, "decode_bits: argument");
     if (int rc = set_device(b)) return rc;
-    const int N = b->N, chunk = b->bits_words * 32;
+    const int N = b->N, segcap = b->seg_words * 32, chunk = segcap * b->n_seg;
     int maxc = 0;
     for (int c = 0; c < N; ++c) {
         if (h_count[c] < 0 || h_count[c] > stride) return fail(GNUAIS_E_ARG, "decode_bits: count");
         maxc = std::max(maxc, h_count[c]);
     }
-    std::vector<uint32_t> words((size_t) b->bits_words * N), nb(N);
+    const size_t rowlen = (size_t) b->n_seg * b->seg_words;
+    std::vector<uint32_t> words(rowlen * N), cnt((size_t) b->n_seg * N);
     for (int pos = 0; pos < maxc; pos += chunk) {
         std::fill(words.begin(), words.end(), 0u);
+        std::fill(cnt.begin(), cnt.end(), 0u);
         for (int c = 0; c < N; ++c) {
             const int n = std::max(0, std::min(chunk, h_count[c] - pos));
-            nb[c] = (uint32_t) n;
             const uint8_t *src = h_bits + (size_t) c * stride + pos;
-            for (int k = 0; k < n; ++k)
-                if (src[k] & 1) words[(size_t) (k >> 5) * N + c] |= 1u << (k & 31);
+            for (int k = 0; k < n; ++k) {
+                const int seg = k / segcap, kk = k % segcap;
+                if (src[k] & 1)
+                    words[(size_t) c * rowlen + (size_t) seg * b->seg_words + (kk >> 5)] |= 1u << (kk & 31);
+            }
+            for (int seg = 0; seg * segcap < n; ++seg)
+                cnt[(size_t) c * b->n_seg + seg] = (uint32_t) std::min(segcap, n - seg * segcap);
         }
-        HIP_TRY(hipMemcpy(b->bits, words.data(), words.size() * 4, hipMemcpyHostToDevice));
-        HIP_TRY(hipMemcpy(b->nbits, nb.data(), nb.size() * 4, hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(b->segbits, words.data(), words.size() * 4, hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(b->segcnt, cnt.data(), cnt.size() * 4, hipMemcpyHostToDevice));
         HdlcLaunch h;
         fill_hdlc(b, h);
         HIP_TRY(launch_hdlc_crc(h, nullptr));
@@ -394,15 +414,23 @@ int gnuais_batch_last_bits(gnuais_batch *b, uint8_t *h_bits, int stride, int32_t
     if (!b || !h_bits || !h_count || stride <= 0) return fail(GNUAIS_E_ARG, "last_bits: argument");
     if (int rc = gnuais_batch_sync(b)) return rc;
     const int N = b->N;
-    std::vector<uint32_t> words((size_t) b->bits_words * N), nb(N);
-    HIP_TRY(hipMemcpy(words.data(), b->bits, words.size() * 4, hipMemcpyDeviceToHost));
-    HIP_TRY(hipMemcpy(nb.data(), b->nbits, nb.size() * 4, hipMemcpyDeviceToHost));
+    const size_t rowlen = (size_t) b->n_seg * b->seg_words;
+    std::vector<uint32_t> words(rowlen * N), cnt((size_t) b->n_seg * N);
+    HIP_TRY(hipMemcpy(words.data(), b->segbits, words.size() * 4, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(cnt.data(), b->segcnt, cnt.size() * 4, hipMemcpyDeviceToHost));
+    const int nseg_used = ((b->last_len + 31) / 32 + SEG_WORDS - 1) / SEG_WORDS;
     for (int c = 0; c < N; ++c) {
-        const int n = (int) std::min<uint32_t>(nb[c], (uint32_t) b->bits_words * 32);
-        h_count[c] = n;
-        if (n > stride) return fail(GNUAIS_E_ARG, "last_bits: stride too small");
+        int n = 0;
         uint8_t *dst = h_bits + (size_t) c * stride;
-        for (int k = 0; k < n; ++k) dst[k] = (words[(size_t) (k >> 5) * N + c] >> (k & 31)) & 1u;
+        for (int seg = 0; seg < nseg_used; ++seg) {
+            const int m = (int) std::min<uint32_t>(cnt[(size_t) c * b->n_seg + seg],
+                                                   (uint32_t) b->seg_words * 32);
+            if (n + m > stride) return fail(GNUAIS_E_ARG, "last_bits: stride too small");
+            const uint32_t *w = &words[(size_t) c * rowlen + (size_t) seg * b->seg_words];
+            for (int k = 0; k < m; ++k) dst[n + k] = (w[k >> 5] >> (k & 31)) & 1u;
+            n += m;
+        }
+        h_count[c] = n;
     }
     return GNUAIS_OK;
 }
@@ -488,12 +516,13 @@ int gnuais_batch_pll_state(gnuais_batch *b, gnuais_pll_state *h_out)
 {
     if (!b || !h_out) return fail(GNUAIS_E_ARG, "pll_state: argument");
     if (int rc = gnuais_batch_sync(b)) return rc;
-    std::vector<uint32_t> v((size_t) b->N);
+    std::vector<uint32_t> v((size_t) b->N), lb((size_t) b->N);
     HIP_TRY(hipMemcpy(v.data(), b->pll, v.size() * 4, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(lb.data(), b->lastbit, lb.size() * 4, hipMemcpyDeviceToHost));
     for (int c = 0; c < b->N; ++c) {
         h_out[c].pll = v[c] & 0xffffu;
         h_out[c].prev = (v[c] >> 16) & 1;
-        h_out[c].lastbit = (v[c] >> 17) & 1;
+        h_out[c].lastbit = lb[c] & 1;
     }
     return GNUAIS_OK;
 }

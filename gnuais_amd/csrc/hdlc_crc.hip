@@ -6,9 +6,11 @@
 // protodec_sdlc_crc() (src/protodec.c:106-167), for a whole batch of channels.
 //
 // K2b -- one lane = one channel walking its own recovered bit stream (K2a's
-// output); one wave = 64 adjacent channels; the wave's bit streams are staged in
-// LDS ([word][lane], conflict-free) so that every lane can advance at its own
-// pace.  The five-state machine of the reference is reproduced exactly -- same
+// output, one contiguous row per channel) at its own pace.  The walk is a chain
+// of dependent steps, so it is latency- not throughput-bound: a wave carries
+// only a few channels (blockDim = 4..16), which gives thousands of waves to
+// interleave on every SIMD and keeps the divergence between the channels of one
+// wave small.  The five-state machine of the reference is reproduced exactly -- same
 // states, same counters, same quirks (`last`
 // rewritten after every state, `nstartsign++` even after a reset in
 // ST_STARTSIGN, reset at bufferpos >= 449) -- but not bit by bit: the two states
@@ -25,7 +27,7 @@
 // HBM (fire-and-forget stores, no read-back); a frame that is still open at the
 // end of a call simply continues in the same record at the next call.
 //
-// K3 -- one thread per candidate closed in this call: the reference's CRC over
+// K3 -- the candidates closed in this call, shared evenly over threads: the reference's CRC over
 // n/8 + 2 bytes (bits packed LSB first, protodec.c:138-143), good frame <=>
 // 0x0f47 after the final complement (protodec.c:166).  Taking the CRC out of the
 // sequential walk costs nothing in exactness and turns its 464 shift steps per
@@ -45,7 +47,6 @@ enum { ST_SKURR = 1, ST_PREAMBLE = 2, ST_STARTSIGN = 3, ST_DATA = 4, ST_STOPSIGN
 // ctl[1]: partially filled frame-buffer word
 // ctl[2]: bits fed since reset
 // ctl[3]: ST_DATA entries since reset (candidate slots handed out)
-constexpr int TW = 240;                 // LDS tile: 240 words x 64 lanes (+1 lookahead row), < 64 KB
 constexpr uint32_t CAND_VALID = 0x10000u;
 
 __global__ void hdlc_reset_kernel(uint32_t *__restrict__ ctl, int N)
@@ -72,15 +73,12 @@ __device__ __forceinline__ int clz32(uint32_t v)        // 32 for v == 0
 }
 
 __global__ __launch_bounds__(64) void hdlc_deframe_kernel(
-    const uint32_t *__restrict__ bits, const uint32_t *__restrict__ nbits,
+    const uint32_t *__restrict__ segbits, const uint32_t *__restrict__ segcnt,
     uint32_t *__restrict__ ctl, uint32_t *__restrict__ cand, uint32_t *__restrict__ cand_first,
     uint32_t *__restrict__ cand_count, int32_t *__restrict__ counters,
-    uint32_t *__restrict__ flags, int N, int bits_words, int K)
+    uint32_t *__restrict__ flags, int N, int n_seg, int seg_words, int K)
 {
-    __shared__ uint32_t tile[(TW + 1) * 64];
-
-    const int lane = threadIdx.x;
-    const int cg = blockIdx.x * 64 + lane;
+    const int cg = blockIdx.x * blockDim.x + threadIdx.x;
     const bool live = cg < N;
     const size_t c = (size_t) (live ? cg : N - 1), n_ = (size_t) N;
 
@@ -99,26 +97,23 @@ __global__ __launch_bounds__(64) void hdlc_deframe_kernel(
     uint32_t *rec = cand + ((size_t) c * K + (open0 ? (nstart - 1) % (uint32_t) K : 0u)) * CAND_WORDS;
     bool rec_ok = open0;
 
-    int total = live ? (int) nbits[c] : 0;
-    if (total > bits_words * 32) total = bits_words * 32;
-    int pos = 0;
+    uint32_t seenbase = seen0;          // bits fed before the current segment
 
 #define HDLC_RESET()                                                                    \
     do { state = ST_SKURR; nstartsign = 0; antallpreamble = 0; antallenner = 0;        \
          last = 0; bitstuff = 0; bufferpos = 0; } while (0)
 
-    for (int tile0 = 0; tile0 < bits_words; tile0 += TW) {
-        if (!__any(pos < total)) break;
-        // stage TW+1 words per channel (coalesced rows of 64 lanes)
-        for (int r = 0; r <= TW; ++r) {
-            const int w = tile0 + r;
-            tile[r * 64 + lane] = (w < bits_words) ? bits[(size_t) w * n_ + c] : 0u;
-        }
-        const int tile_end = (total < (tile0 + TW) * 32) ? total : (tile0 + TW) * 32;
-
+    // K2x hands over one bit pack per 2048-sample segment; the word-parallel steps
+    // accept any window length, so a pack boundary is just a short window
+    for (int seg = 0; seg < n_seg; ++seg) {
+        const uint32_t *__restrict__ row = segbits + (c * (size_t) n_seg + seg) * (size_t) seg_words;
+        int tile_end = live ? (int) segcnt[c * (size_t) n_seg + seg] : 0;
+        if (tile_end > seg_words * 32) tile_end = seg_words * 32;
+        int pos = 0;
         while (pos < tile_end) {
-            const int lw = (pos >> 5) - tile0, sh = pos & 31;
-            const uint32_t lo = tile[lw * 64 + lane], hi = tile[(lw + 1) * 64 + lane];
+            const int lw = pos >> 5, sh = pos & 31;
+            const uint32_t lo = row[lw];
+            const uint32_t hi = (lw + 1 < seg_words) ? row[lw + 1] : 0u;
             const uint32_t W = sh ? ((lo >> sh) | (hi << (32 - sh))) : lo;   // bit j = x[pos+j]
             const int nv = (tile_end - pos < 32) ? tile_end - pos : 32;
             const uint32_t vm = lowmask(nv);
@@ -239,7 +234,7 @@ __global__ __launch_bounds__(64) void hdlc_deframe_kernel(
                     if (x == 0 && nb > 0) {
                         if (rec_ok) {
                             rec[CAND_HDR + (bufferpos >> 5)] = cur;
-                            rec[1] = seen0 + (uint32_t) pos;
+                            rec[1] = seenbase + (uint32_t) pos;
                             rec[0] = (uint32_t) nb | CAND_VALID;
                         }
                     } else {
@@ -256,6 +251,7 @@ __global__ __launch_bounds__(64) void hdlc_deframe_kernel(
                 }
             }
         }
+        seenbase += (uint32_t) tile_end;
     }
 #undef HDLC_RESET
 
@@ -264,7 +260,7 @@ __global__ __launch_bounds__(64) void hdlc_deframe_kernel(
                  ((uint32_t) antallenner << 11) | ((uint32_t) bitstuff << 14) | (last << 15) |
                  ((uint32_t) bufferpos << 16);
         ctl[n_ + c] = cur;
-        ctl[2 * n_ + c] = seen0 + (uint32_t) total;
+        ctl[2 * n_ + c] = seenbase;
         ctl[3 * n_ + c] = nstart;
         const bool open1 = (state == ST_DATA || state == ST_STOPSIGN);
         const uint32_t limit = nstart - (open1 ? 1u : 0u);
@@ -275,76 +271,106 @@ __global__ __launch_bounds__(64) void hdlc_deframe_kernel(
     }
 }
 
-// K3: one thread per (channel, candidate slot closed in this call)
-__global__ void hdlc_crc_kernel(const uint32_t *__restrict__ cand,
-                                const uint32_t *__restrict__ cand_first,
-                                const uint32_t *__restrict__ cand_count,
-                                int32_t *__restrict__ counters, uint32_t *__restrict__ frames,
-                                uint32_t *__restrict__ flags, uint32_t frame_cap, int N, int K)
+// K3: CRC check + delivery of the candidates closed in this call.  One block owns
+// 256 adjacent channels: their candidate counts are prefix-summed in LDS and the
+// block's threads then share the candidates evenly (dense work, however the
+// frames are spread over the channels).  CRC-16/X-25 by bytes through a
+// 256-entry table built in LDS from the bitwise definition (protodec.c:106-118).
+__global__ __launch_bounds__(256) void hdlc_crc_kernel(
+    const uint32_t *__restrict__ cand, const uint32_t *__restrict__ cand_first,
+    const uint32_t *__restrict__ cand_count, int32_t *__restrict__ counters,
+    uint32_t *__restrict__ frames, uint32_t *__restrict__ flags, uint32_t frame_cap, int N, int K)
 {
-    const size_t id = (size_t) blockIdx.x * blockDim.x + threadIdx.x;
-    const int c = (int) (id / (size_t) K), j = (int) (id % (size_t) K);
-    if (c >= N || (uint32_t) j >= cand_count[c]) return;
-    const uint32_t slot = (cand_first[c] + (uint32_t) j) % (uint32_t) K;
-    const uint32_t *rec = cand + ((size_t) c * K + slot) * CAND_WORDS;
-    const uint32_t hdr = rec[0];
-    if (!(hdr & CAND_VALID)) return;                    // frame abandoned before its closing flag
-    const int n = (int) (hdr & 0xffffu);
-    const int nbytes = n >> 3, buflen = nbytes + 2;     // protodec.c:133-134
-    uint32_t w[HDLC_BUF_WORDS];
+    __shared__ uint32_t tab[256];
+    __shared__ uint32_t pre[257];
+    const int tid = threadIdx.x;
+    const int c_own = blockIdx.x * 256 + tid;
+
+    {   // table entry tid: eight LFSR steps on the byte value
+        uint32_t t = (uint32_t) tid;
 #pragma unroll
-    for (int q = 0; q < HDLC_BUF_WORDS; ++q) w[q] = rec[CAND_HDR + q];
-    // protodec.c:106-118 over buflen bytes = 8*buflen buffer bits, LSB first
-    uint32_t crc = 0xffffu;
+        for (int k = 0; k < 8; ++k) t = (t >> 1) ^ ((t & 1u) ? 0x8408u : 0u);
+        tab[tid] = t;
+    }
+    // inclusive scan of the per-channel candidate counts
+    const uint32_t mine = (c_own < N) ? cand_count[c_own] : 0u;
+    pre[tid + 1] = mine;
+    if (tid == 0) pre[0] = 0;
+    __syncthreads();
+    for (int off = 1; off < 256; off <<= 1) {
+        const uint32_t v = (tid + 1 > off) ? pre[tid + 1 - off] : 0u;
+        __syncthreads();
+        pre[tid + 1] += v;
+        __syncthreads();
+    }
+    const uint32_t total = pre[256];
+    const size_t n_ = (size_t) N;
+
+    for (uint32_t i = (uint32_t) tid; i < total; i += 256) {
+        // channel of candidate i: largest k with pre[k] <= i
+        int lo = 0, hi = 255;
+        while (lo < hi) {
+            const int mid = (lo + hi + 1) >> 1;
+            if (pre[mid] <= i) lo = mid; else hi = mid - 1;
+        }
+        const int c = blockIdx.x * 256 + lo;
+        const uint32_t j = i - pre[lo];
+        const uint32_t slot = (cand_first[c] + j) % (uint32_t) K;
+        const uint32_t *rec = cand + ((size_t) c * K + slot) * CAND_WORDS;
+        const uint32_t hdr = rec[0];
+        if (!(hdr & CAND_VALID)) continue;              // frame abandoned before its closing flag
+        const int n = (int) (hdr & 0xffffu);
+        const int nbytes = n >> 3, buflen = nbytes + 2; // protodec.c:133-134
+        uint32_t w[HDLC_BUF_WORDS];
 #pragma unroll
-    for (int q = 0; q < HDLC_BUF_WORDS; ++q) {
-        const int nbit = 8 * buflen - 32 * q;           // bits of this word inside the span
-        if (nbit > 0) {
-            uint32_t v = w[q];
-            const int lim = nbit < 32 ? nbit : 32;
-            for (int b = 0; b < lim; ++b) {
-                const uint32_t fb = (crc ^ v) & 1u;
-                crc = (crc >> 1) ^ (fb ? 0x8408u : 0u);
-                v >>= 1;
+        for (int q = 0; q < HDLC_BUF_WORDS; ++q) w[q] = rec[CAND_HDR + q];
+        uint32_t crc = 0xffffu;
+#pragma unroll
+        for (int q = 0; q < HDLC_BUF_WORDS; ++q) {
+#pragma unroll
+            for (int bq = 0; bq < 4; ++bq) {
+                if (q * 4 + bq < buflen) {
+                    const uint32_t byte = (w[q] >> (8 * bq)) & 0xffu;
+                    crc = (crc >> 8) ^ tab[(crc ^ byte) & 0xffu];
+                }
             }
         }
-    }
-    const size_t n_ = (size_t) N;
-    if (crc == 0xf0b8u) {                               // ~crc == 0x0f47, protodec.c:166
-        atomicAdd(&counters[c], 1);                     // protodec.c:1103
-        const uint32_t idx = atomicAdd(&flags[0], 1u);
-        if (idx < frame_cap) {
-            uint32_t *out = frames + (size_t) idx * 16;
-            out[0] = (uint32_t) c;
-            out[1] = rec[1];
+        if (crc == 0xf0b8u) {                           // ~crc == 0x0f47, protodec.c:166
+            atomicAdd(&counters[c], 1);                 // protodec.c:1103
+            const uint32_t idx = atomicAdd(&flags[0], 1u);
+            if (idx < frame_cap) {
+                uint32_t *out = frames + (size_t) idx * 16;
+                out[0] = (uint32_t) c;
+                out[1] = rec[1];
 #pragma unroll
-            for (int q = 0; q < 14; ++q) {
-                uint32_t v = 0;
-                if (q * 4 < nbytes) {
-                    v = w[q];
-                    const int keep = nbytes - q * 4;
-                    if (keep < 4) v &= (1u << (8 * keep)) - 1u;
+                for (int q = 0; q < 14; ++q) {
+                    uint32_t v = 0;
+                    if (q * 4 < nbytes) {
+                        v = w[q];
+                        const int keep = nbytes - q * 4;
+                        if (keep < 4) v &= (1u << (8 * keep)) - 1u;
+                    }
+                    if (q == 13) v = (v & 0xffu) | (1u << 8) | ((uint32_t) n << 16);
+                    out[2 + q] = v;
                 }
-                if (q == 13) v = (v & 0xffu) | (1u << 8) | ((uint32_t) n << 16);
-                out[2 + q] = v;
+            } else {
+                flags[1] = 1;                           // ring full: frame dropped, still counted
             }
         } else {
-            flags[1] = 1;                               // ring full: frame dropped, still counted
+            atomicAdd(&counters[n_ + c], 1);            // protodec.c:1107
         }
-    } else {
-        atomicAdd(&counters[n_ + c], 1);                // protodec.c:1107
     }
 }
 
 hipError_t launch_hdlc_crc(const HdlcLaunch &a, hipStream_t stream)
 {
-    hipLaunchKernelGGL(hdlc_deframe_kernel, dim3((a.N + 63) / 64), dim3(64), 0, stream, a.bits,
-                       a.nbits, a.ctl, a.cand, a.cand_first, a.cand_count, a.counters,
-                       a.frame_count, a.N, a.bits_words, a.K);
+    const int lpw = a.lanes_per_wave > 0 ? a.lanes_per_wave : 8;
+    hipLaunchKernelGGL(hdlc_deframe_kernel, dim3((a.N + lpw - 1) / lpw), dim3(lpw), 0, stream,
+                       a.segbits, a.segcnt, a.ctl, a.cand, a.cand_first, a.cand_count, a.counters,
+                       a.frame_count, a.N, a.n_seg, a.seg_words, a.K);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
-    const size_t threads = (size_t) a.N * (size_t) a.K;
-    hipLaunchKernelGGL(hdlc_crc_kernel, dim3((unsigned) ((threads + 255) / 256)), dim3(256), 0,
+    hipLaunchKernelGGL(hdlc_crc_kernel, dim3((unsigned) ((a.N + 255) / 256)), dim3(256), 0,
                        stream, a.cand, a.cand_first, a.cand_count, a.counters,
                        (uint32_t *) a.frames, a.frame_count, a.frame_cap, a.N, a.K);
     return hipGetLastError();

@@ -22,14 +22,17 @@ hipError_t launch_fir_generic(const FirLaunch &a, hipStream_t stream);
 hipError_t launch_fir_history(const int16_t *x, const int16_t *hist_in, int16_t *hist_out,
                               int N, int L, int NT, hipStream_t stream);
 
-// ---- K2a: PLL clock recovery + NRZI (pll_nrzi.hip) ------------------------
+// ---- K2a: PLL clock recovery, K2x: slice + NRZI (pll_nrzi.hip) --------------
+constexpr int PLL_PAD = 8;           // prefetch depth; sgn/ovf carry 2*PLL_PAD spare rows
+constexpr int SEG_WORDS = 64;        // K2x segment: 64 sign words = 2048 samples
 struct PllLaunch {
-    const uint32_t *sgn;   // [ceil(L/32)][N]
-    uint32_t *pll;         // [N] phase, prev sign (bit 16), lastbit (bit 17) packed
-    uint32_t *bits;        // [bits_words][N] recovered bits, bit k of a channel at
-                           //   word k/32, bit position k%32 (LSB first)
-    uint32_t *nbits;       // [N] bits recovered this call
-    int N, L, bits_words;
+    const uint32_t *sgn;   // [ceil(L/32) + 2*PLL_PAD][N]
+    uint32_t *ovf;         // same shape: slice marks (pll overflow), bit 31 = oldest sample
+    uint32_t *pll;         // [N] phase (bits 15:0), prev sign (bit 16)
+    uint32_t *lastbit;     // [N] level at the last slice (receiver.h:38)
+    uint32_t *segbits;     // [N][n_seg][seg_words] recovered bits per segment, LSB first
+    uint32_t *segcnt;      // [N][n_seg] bits in each pack
+    int N, L, n_seg, seg_words;
     uint32_t pllinc;
 };
 hipError_t launch_pll_nrzi(const PllLaunch &a, hipStream_t stream);
@@ -40,8 +43,8 @@ constexpr int HDLC_BUF_WORDS = 15;   // 449 bits max (protodec.c:1024)
 constexpr int CAND_HDR = 2;          // [0] nbits | valid flag, [1] end_bit
 constexpr int CAND_WORDS = 18;       // header + 15 buffer words, padded to 72 bytes
 struct HdlcLaunch {
-    const uint32_t *bits;  // as above
-    const uint32_t *nbits; // [N]
+    const uint32_t *segbits;  // as above
+    const uint32_t *segcnt;
     uint32_t *ctl;         // [HDLC_CTL_WORDS][N] control state
     uint32_t *cand;        // [N][K][CAND_WORDS] per-channel ring of candidate frames
     uint32_t *cand_first;  // [N] first slot closed in this call
@@ -50,7 +53,8 @@ struct HdlcLaunch {
     void *frames;          // gnuais_frame[frame_cap]
     uint32_t *frame_count; // [2]: frames appended, overflow flag
     uint32_t frame_cap;
-    int N, bits_words, K;
+    int N, n_seg, seg_words, K;
+    int lanes_per_wave;    // channels per wave in K2b (blockDim)
 };
 hipError_t launch_hdlc_crc(const HdlcLaunch &a, hipStream_t stream);
 hipError_t launch_hdlc_reset(uint32_t *ctl, int N, hipStream_t stream);

@@ -1,22 +1,37 @@
-// pll_nrzi.hip -- K2a: bit-clock recovery PLL + NRZI decode for gfx950.
+// pll_nrzi.hip -- K2a: bit-clock recovery PLL, and K2x: slice + NRZI decode,
+// for gfx950.
 //
-// Stands in for the per-sample loop of receiver_run(), gnuais
+// Together they stand in for the per-sample loop of receiver_run(), gnuais
 // src/receiver.c:109-135, for a whole batch of channels.
 //
-// The loop is a nonlinear recurrence in time (the nudge direction depends on
-// the current phase), so time stays sequential per channel; the batch axis is
-// the parallel one: one lane = one channel, one wave = 64 adjacent channels
-// reading K1's sign words sgn[w][c] (coalesced, 256 B per wave per 32 samples).
+// K2a (pll_core_kernel).  The phase update is a nonlinear recurrence in time
+// (the nudge direction depends on the current phase), so time stays sequential
+// per channel and the batch axis is the parallel one: one lane = one channel,
+// one wave = 64 adjacent channels reading K1's sign words sgn[w][c] (coalesced).
+// A wave that is alone on its SIMD issues roughly one instruction every ~5
+// cycles whatever it is, so the whole game is instructions per sample.  The
+// kernel therefore keeps ONLY the recurrence: 6 VALU instructions per sample,
+//   v_bfe_i32   tm = -(transition at this sample)          receiver.c:113
+//   v_ashrrev   um = -(pll >= 0x8000)                      receiver.c:114
+//   v_bfi       k  = um ? INC-Q : INC+Q                    receiver.c:115-117
+//   v_bfi       k  = tm ? k : INC
+//   v_add_co    P += k            (carry = `pll > 0xffff`)  receiver.c:122-124
+//   v_addc      O  = 2*O + carry  (slice marks of the word)
+// hand-scheduled (the carry is consumed two instructions later, which is the
+// gfx950 wait-state requirement for a VALU-written VCC).  The 16-bit phase of
+// the reference lives in the top half of a 32-bit register (P = pll << 16), so
+// `pll &= 0xffff` (receiver.c:133) is the natural wrap of the add and
+// `pll < 0x8000` is the sign bit.  The nudge never carries by itself (pll <
+// 0x8000 -> +q stays < 0x10000; pll >= 0x8000 -> -q stays > 0), so folding nudge
+// and increment into one add leaves the overflow test unchanged.
 //
-// The 16-bit phase of the reference lives in the top half of a 32-bit register
-// (P = pll << 16), so `pll > 0xffff; pll &= 0xffff` (receiver.c:124,133) is the
-// carry-out of one 32-bit add and `pll < 0x8000` (receiver.c:114) is the sign
-// bit.  The nudge never carries by itself (pll < 0x8000 -> +q stays < 0x10000,
-// pll >= 0x8000 -> -q stays > 0), so folding nudge and increment into one add
-// leaves the overflow test unchanged.
-//
-// Output: the recovered (NRZI-decoded) bits, packed LSB first per channel:
-// bit k of channel c = bits[k/32][c] >> (k%32) & 1; nbits[c] = count.
+// K2x (nrzi_extract_kernel).  Everything that is NOT a recurrence runs in
+// parallel over (channel, 2048-sample segment): at every slice mark take the
+// level (receiver.c:126), NRZI-decode against the previous slice's level
+// (receiver.c:128-132; for the first mark of a segment that level is found by
+// looking back through the preceding words) and pack the bits.  Output: one
+// pack of seg_words words + a bit count per (channel, segment); bit k of a
+// pack is at word k/32, bit k%32.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -24,10 +39,40 @@
 
 namespace gnuais {
 
-__global__ __launch_bounds__(64) void pll_nrzi_kernel(
-    const uint32_t *__restrict__ sgn, uint32_t *__restrict__ pllst,
-    uint32_t *__restrict__ bits, uint32_t *__restrict__ nbits,
-    int N, int L, int bits_words, uint32_t pllinc)
+#define PLL_HEAD(sh)                                                                      \
+    "v_bfe_i32 %[tm], %[D], " #sh ", 1\n\t"                                               \
+    "v_ashrrev_i32 %[um], 31, %[P]\n\t"
+#define PLL_TAIL                                                                          \
+    "v_bfi_b32 %[k], %[um], %[Km], %[Kp]\n\t"                                             \
+    "v_bfi_b32 %[k], %[tm], %[k], %[INC]\n\t"                                             \
+    "v_add_co_u32 %[P], vcc, %[P], %[k]\n\t"
+#define PLL_CARRY "v_addc_co_u32 %[O], vcc, %[O], %[O], vcc\n\t"
+#define PLL_STEP(sh) PLL_HEAD(sh) PLL_CARRY PLL_TAIL
+
+// one full word (32 samples), oldest sample = bit 31 of D
+__device__ __forceinline__ void pll_word(uint32_t D, uint32_t &P, uint32_t &O, uint32_t Kp,
+                                         uint32_t Km, uint32_t INC)
+{
+    uint32_t tm, um, k;
+    asm volatile(
+        PLL_HEAD(31) PLL_TAIL
+        PLL_STEP(30) PLL_STEP(29) PLL_STEP(28) PLL_STEP(27) PLL_STEP(26) PLL_STEP(25)
+        PLL_STEP(24) PLL_STEP(23) PLL_STEP(22) PLL_STEP(21) PLL_STEP(20) PLL_STEP(19)
+        PLL_STEP(18) PLL_STEP(17) PLL_STEP(16) PLL_STEP(15) PLL_STEP(14) PLL_STEP(13)
+        PLL_STEP(12) PLL_STEP(11) PLL_STEP(10) PLL_STEP(9) PLL_STEP(8) PLL_STEP(7)
+        PLL_STEP(6) PLL_STEP(5) PLL_STEP(4) PLL_STEP(3) PLL_STEP(2) PLL_STEP(1)
+        PLL_STEP(0)
+        "s_nop 1\n\t"
+        PLL_CARRY
+        : [P] "+v"(P), [O] "+v"(O), [tm] "=&v"(tm), [um] "=&v"(um), [k] "=&v"(k)
+        : [D] "v"(D), [Kp] "v"(Kp), [Km] "v"(Km), [INC] "v"(INC)
+        : "vcc");
+}
+
+// sgn and ovf have PLL_PAD extra (zero / scratch) rows so the prefetch needs no bounds test
+__global__ __launch_bounds__(64) void pll_core_kernel(
+    const uint32_t *__restrict__ sgn, uint32_t *__restrict__ ovf, uint32_t *__restrict__ pllst,
+    int N, int L, uint32_t pllinc)
 {
     const int cg = blockIdx.x * 64 + threadIdx.x;
     const int c = cg < N ? cg : N - 1;
@@ -36,95 +81,141 @@ __global__ __launch_bounds__(64) void pll_nrzi_kernel(
     const uint32_t st = pllst[c];
     uint32_t P = (st & 0xffffu) << 16;            // receiver.h:40 pll, scaled
     uint32_t prev = (st >> 16) & 1u;              // receiver.h:44
-    uint32_t last = (st >> 17) & 1u;              // receiver.h:38 lastbit
     const uint32_t INC = pllinc << 16;            // receiver.c:122
     const uint32_t Q = (pllinc / 16u) << 16;      // receiver.c:84,115,117
     const uint32_t Kp = INC + Q, Km = INC - Q;
-
-    uint32_t outw = 0, outn = 0, wr = 0;
     const int W = (L + 31) >> 5;
+    const int Wfull = L >> 5;                     // words with all 32 samples valid
 
-    // The sign words of a channel are N*4 bytes apart, so every lane's load is its
-    // own 4-byte gather; with one wave per SIMD nothing else hides the HBM latency.
-    // Keep PF words in flight: the group for step g+1 is requested before the
-    // group of step g is consumed.
-    constexpr int PF = 8;
+    constexpr int PF = PLL_PAD;
     uint32_t nxt[PF];
+    const uint32_t *__restrict__ src = sgn + c;
 #pragma unroll
-    for (int q = 0; q < PF; ++q) nxt[q] = (q < W) ? sgn[(size_t) q * (size_t) N + c] : 0u;
+    for (int q = 0; q < PF; ++q) nxt[q] = src[(size_t) q * (size_t) N];
 
-    for (int w0 = 0; w0 < W; w0 += PF) {
+    for (int w0 = 0; w0 < Wfull; w0 += PF) {
         uint32_t grp[PF];
 #pragma unroll
         for (int q = 0; q < PF; ++q) grp[q] = nxt[q];
 #pragma unroll
-        for (int q = 0; q < PF; ++q) {
-            const int wn = w0 + PF + q;
-            nxt[q] = (wn < W) ? sgn[(size_t) wn * (size_t) N + c] : 0u;
-        }
+        for (int q = 0; q < PF; ++q) nxt[q] = src[(size_t) (w0 + PF + q) * (size_t) N];
 #pragma unroll
         for (int q = 0; q < PF; ++q) {
-            const int w = w0 + q;
-            if (w >= W) break;
-            const uint32_t S = grp[q];                          // bit 31 = oldest
-            const int nv = (L - w * 32 < 32) ? L - w * 32 : 32;
-            // transition word: bit (31-i) = s_i ^ s_{i-1}   (receiver.c:113)
-            uint32_t D = S ^ ((S >> 1) | (prev << 31));
-            uint32_t O = 0;                                     // overflow (slice) marks
-            if (nv == 32) {
-#pragma unroll
-                for (int i = 0; i < 32; ++i) {
-                    const bool t = (int32_t) D < 0;
-                    D <<= 1;
-                    const uint32_t Kt = ((int32_t) P < 0) ? Km : Kp; // receiver.c:114-118
-                    const uint32_t K = t ? Kt : INC;
-                    const uint32_t Pn = P + K;                    // receiver.c:122
-                    O = (O << 1) | (Pn < P ? 1u : 0u);            // receiver.c:124
-                    P = Pn;
-                }
+            if (w0 + q < Wfull) {
+                const uint32_t S = grp[q];                          // bit 31 = oldest
+                const uint32_t D = S ^ ((S >> 1) | (prev << 31));   // receiver.c:113
                 prev = S & 1u;
-            } else {
-                for (int i = 0; i < nv; ++i) {
-                    const bool t = (int32_t) D < 0;
-                    D <<= 1;
-                    const uint32_t Kt = ((int32_t) P < 0) ? Km : Kp;
-                    const uint32_t K = t ? Kt : INC;
-                    const uint32_t Pn = P + K;
-                    O = (O << 1) | (Pn < P ? 1u : 0u);
-                    P = Pn;
-                }
-                O <<= (32 - nv);                                  // left-align like S
-                prev = (S >> (32 - nv)) & 1u;
-            }
-            // slice + NRZI at every overflow, oldest first (receiver.c:126-132)
-            while (O) {
-                const int pos = __clz((int) O);
-                const uint32_t level = (S >> (31 - pos)) & 1u;
-                O &= ~(0x80000000u >> pos);
-                const uint32_t b = (level ^ last) ^ 1u;
-                last = level;
-                outw |= b << outn;
-                if (++outn == 32) {
-                    if (live && (int) wr < bits_words) bits[(size_t) wr * (size_t) N + cg] = outw;
-                    ++wr;
-                    outw = 0;
-                    outn = 0;
-                }
+                uint32_t O = 0;
+                pll_word(D, P, O, Kp, Km, INC);
+                if (live) ovf[(size_t) (w0 + q) * (size_t) N + cg] = O;
             }
         }
     }
-    if (outn && live && (int) wr < bits_words) bits[(size_t) wr * (size_t) N + cg] = outw;
-    if (live) {
-        nbits[cg] = wr * 32 + outn;
-        pllst[cg] = (P >> 16) | (prev << 16) | (last << 17);
+    if (Wfull < W) {                              // last, partial word (L % 32 samples)
+        const int nv = L - Wfull * 32;
+        const uint32_t S = src[(size_t) Wfull * (size_t) N];
+        uint32_t D = S ^ ((S >> 1) | (prev << 31));
+        uint32_t O = 0;
+        for (int i = 0; i < nv; ++i) {
+            const bool t = (int32_t) D < 0;
+            D <<= 1;
+            const uint32_t Kt = ((int32_t) P < 0) ? Km : Kp;
+            const uint32_t K = t ? Kt : INC;
+            const uint32_t Pn = P + K;
+            O = (O << 1) | (Pn < P ? 1u : 0u);
+            P = Pn;
+        }
+        O <<= (32 - nv);                          // left-align like S
+        prev = (S >> (32 - nv)) & 1u;
+        if (live) ovf[(size_t) Wfull * (size_t) N + cg] = O;
+    }
+    if (live) pllst[cg] = (P >> 16) | (prev << 16);
+}
+
+// grid.x = channel group (64 channels), grid.y = segment of SEG_WORDS words
+__global__ __launch_bounds__(64) void nrzi_extract_kernel(
+    const uint32_t *__restrict__ sgn, const uint32_t *__restrict__ ovf,
+    const uint32_t *__restrict__ lastbit, uint32_t *__restrict__ segbits,
+    uint32_t *__restrict__ segcnt, int N, int L, int n_seg, int seg_words)
+{
+    const int cg = blockIdx.x * 64 + threadIdx.x;
+    const int c = cg < N ? cg : N - 1;
+    const bool live = cg < N;
+    const int seg = blockIdx.y;
+    const int W = (L + 31) >> 5;
+    const int w0 = seg * SEG_WORDS;
+    const int w1 = (w0 + SEG_WORDS < W) ? w0 + SEG_WORDS : W;
+    if (w0 >= W) {
+        if (live) segcnt[(size_t) cg * n_seg + seg] = 0;
+        return;
+    }
+    // level at the last slice before this segment (receiver.h:38 lastbit): the
+    // latest mark is the lowest set bit of the nearest earlier non-empty word
+    uint32_t last = lastbit[c];
+    for (int w = w0 - 1; w >= 0; --w) {
+        const uint32_t O = ovf[(size_t) w * (size_t) N + c];
+        if (O) {
+            const uint32_t S = sgn[(size_t) w * (size_t) N + c];
+            last = (S >> (__ffs((int) O) - 1)) & 1u;
+            break;
+        }
+    }
+    uint32_t *__restrict__ out = segbits + ((size_t) c * n_seg + seg) * (size_t) seg_words;
+    uint32_t outw = 0, outn = 0, wr = 0;
+    for (int w = w0; w < w1; ++w) {
+        const uint32_t S = sgn[(size_t) w * (size_t) N + c];
+        uint32_t O = ovf[(size_t) w * (size_t) N + c];
+        while (O) {                                             // oldest mark first
+            const int pos = __clz((int) O);
+            const uint32_t level = (S >> (31 - pos)) & 1u;      // receiver.c:126
+            O &= ~(0x80000000u >> pos);
+            const uint32_t b = (level ^ last) ^ 1u;             // receiver.c:128
+            last = level;                                       // receiver.c:132
+            outw |= b << outn;
+            if (++outn == 32) {
+                if (live && (int) wr < seg_words) out[wr] = outw;
+                ++wr;
+                outw = 0;
+                outn = 0;
+            }
+        }
+    }
+    if (outn && live && (int) wr < seg_words) out[wr] = outw;
+    if (live) segcnt[(size_t) cg * n_seg + seg] = wr * 32 + outn;
+}
+
+// after K2x: carry the level of the call's last slice into the next call.  Runs
+// after K2x in the same stream (K2x reads lastbit[]).
+__global__ void nrzi_lastbit_kernel(const uint32_t *__restrict__ sgn,
+                                    const uint32_t *__restrict__ ovf,
+                                    uint32_t *__restrict__ lastbit, int N, int L)
+{
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= N) return;
+    const int W = (L + 31) >> 5;
+    for (int w = W - 1; w >= 0; --w) {
+        const uint32_t O = ovf[(size_t) w * (size_t) N + c];
+        if (O) {
+            const uint32_t S = sgn[(size_t) w * (size_t) N + c];
+            lastbit[c] = (S >> (__ffs((int) O) - 1)) & 1u;
+            return;
+        }
     }
 }
 
 hipError_t launch_pll_nrzi(const PllLaunch &a, hipStream_t stream)
 {
-    dim3 grid((a.N + 63) / 64), block(64);
-    hipLaunchKernelGGL(pll_nrzi_kernel, grid, block, 0, stream, a.sgn, a.pll, a.bits, a.nbits,
-                       a.N, a.L, a.bits_words, a.pllinc);
+    const int groups = (a.N + 63) / 64;
+    hipLaunchKernelGGL(pll_core_kernel, dim3(groups), dim3(64), 0, stream, a.sgn, a.ovf, a.pll,
+                       a.N, a.L, a.pllinc);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(nrzi_extract_kernel, dim3(groups, a.n_seg), dim3(64), 0, stream, a.sgn,
+                       a.ovf, a.lastbit, a.segbits, a.segcnt, a.N, a.L, a.n_seg, a.seg_words);
+    e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(nrzi_lastbit_kernel, dim3((a.N + 255) / 256), dim3(256), 0, stream, a.sgn,
+                       a.ovf, a.lastbit, a.N, a.L);
     return hipGetLastError();
 }
 

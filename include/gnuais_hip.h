@@ -137,7 +137,8 @@ int  gnuais_tile_channels(const int16_t *d_base, int n_base, int len, int16_t *d
 int  gnuais_batch_set_timing(gnuais_batch *b, int on);
 int  gnuais_batch_last_timing(gnuais_batch *b, float *ms4);
 /* tunables: "fir_T" (outputs per wave in K1, multiple of 32), "fir_variant"
- * (0 = v_mul/v_add, 1 = v_pk_mul/v_pk_add build of K1) */
+ * (0 = v_mul/v_add, 1 = v_pk_mul/v_pk_add build of K1), "hdlc_lpw" (channels
+ * per wave in the deframer, 1..64) */
 int  gnuais_batch_set_option(gnuais_batch *b, const char *name, int value);
 const char *gnuais_last_error(void);
 const char *gnuais_version(void);

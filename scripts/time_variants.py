@@ -11,8 +11,8 @@ x = tile_channels(torch.from_numpy(base).cuda(), n_ch)
 torch.cuda.synchronize()
 b = ReceiverBatch(n_ch, max_len=total)
 b.set_timing(True)
-for variant in (0, 1):
-    for T in (256, 512, 1024, 2048):
+for variant in (0,):
+    for T in (512,):
         b.set_option("fir_variant", variant); b.set_option("fir_T", T)
         res = []
         for it in range(4):
@@ -20,4 +20,9 @@ for variant in (0, 1):
         r = res[-1]
         print(f"variant={variant} T={T}: fir {r['fir_slice']:.3f} ms  pll {r['pll_nrzi']:.3f} ms  hdlc {r['hdlc_crc']:.3f} ms  total {r['total']:.3f} ms  "
               f"-> fir {n_ch*total/r['fir_slice']/1e9:.3f} Tsample/s, chain {n_ch*total/r['total']/1e9:.3f} Tsample/s", flush=True)
+for lpw in (1, 2, 4, 8, 16, 32, 64):
+    b.set_option("hdlc_lpw", lpw)
+    for it in range(3):
+        b.run(x); r = b.last_timing(); b.drain_frames()
+    print(f"hdlc_lpw={lpw}: pll {r['pll_nrzi']:.3f} ms hdlc {r['hdlc_crc']:.3f} ms total {r['total']:.3f} ms", flush=True)
 print("received total", b.total_received())
