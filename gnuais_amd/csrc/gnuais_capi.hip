@@ -22,6 +22,7 @@ using namespace gnuais;
 namespace gnuais {
 namespace scalar { hipError_t launch_fir_slice(const FirLaunch &a, hipStream_t stream); }
 namespace packed { hipError_t launch_fir_slice(const FirLaunch &a, hipStream_t stream); }
+namespace mfma { hipError_t launch_fir_slice(const FirLaunch &a, hipStream_t stream); }
 }
 
 static thread_local std::string g_err;
@@ -61,9 +62,19 @@ struct gnuais_batch {
     // device state
     int16_t *hist[2] = {nullptr, nullptr};
     int hist_cur = 0;
-    uint32_t *sgn = nullptr, *ovf = nullptr, *pll = nullptr, *lastbit = nullptr;
-    uint32_t *segbits = nullptr, *segcnt = nullptr;
+    uint32_t *sgn[2] = {nullptr, nullptr};      // K1 -> K2a/K2x hand-off, alternating per call
+    uint32_t *ovf = nullptr, *pll = nullptr, *lastbit = nullptr;
+    uint32_t *segbits[2] = {nullptr, nullptr};  // K2x -> K2b hand-off, alternating per call
+    uint32_t *segcnt[2] = {nullptr, nullptr};
     int n_seg = 0, seg_words = 0;
+    // stage pipeline: K1 on the caller's stream, K2a+K2x on s_pll, K2b+K3 on s_hdlc, so
+    // that the sequential kernels of call i overlap the FIR of call i+1
+    hipStream_t s_pll = nullptr, s_hdlc = nullptr;
+    hipEvent_t e_fir[2] = {nullptr, nullptr};   // K1 of the call that filled sgn[k] is done
+    hipEvent_t e_pll[2] = {nullptr, nullptr};   // K2a/K2x that read sgn[k] / filled segbits[k] are done
+    hipEvent_t e_hdlc[2] = {nullptr, nullptr};  // K2b that read segbits[k] is done
+    unsigned long long calls = 0;
+    bool pipeline = true;
     uint32_t *ctl = nullptr, *cand = nullptr, *cand_first = nullptr, *cand_count = nullptr;
     uint32_t *frame_count = nullptr;
     int cand_K = 64;
@@ -78,7 +89,8 @@ struct gnuais_batch {
     int fir_variant = 0;            // 0 scalar VALU, 1 packed VALU
     int hdlc_lpw = 8;               // channels per wave in K2b
     bool timing = false;
-    hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    int last_k = 0;
     bool timed_last = false;
     hipStream_t last_stream = nullptr;
     int last_len = 0;
@@ -109,14 +121,21 @@ void gnuais_batch_destroy(gnuais_batch *b)
 {
     if (!b) return;
     (void) hipSetDevice(b->device);
-    void *ptrs[] = {b->hist[0], b->hist[1], b->sgn, b->ovf, b->pll, b->lastbit, b->segbits,
-                    b->segcnt, b->ctl, b->cand,
+    void *ptrs[] = {b->hist[0], b->hist[1], b->sgn[0], b->sgn[1], b->ovf, b->pll, b->lastbit,
+                    b->segbits[0], b->segbits[1], b->segcnt[0], b->segcnt[1], b->ctl, b->cand,
                     b->cand_first, b->cand_count,
                     b->frame_count, b->counters, b->maxval, b->frames, b->d_taps, b->stage_x};
     for (void *p : ptrs)
         if (p) (void) hipFree(p);
     for (auto &e : b->ev)
         if (e) (void) hipEventDestroy(e);
+    for (int k = 0; k < 2; ++k) {
+        if (b->e_fir[k]) (void) hipEventDestroy(b->e_fir[k]);
+        if (b->e_pll[k]) (void) hipEventDestroy(b->e_pll[k]);
+        if (b->e_hdlc[k]) (void) hipEventDestroy(b->e_hdlc[k]);
+    }
+    if (b->s_pll) (void) hipStreamDestroy(b->s_pll);
+    if (b->s_hdlc) (void) hipStreamDestroy(b->s_hdlc);
     delete b;
 }
 
@@ -172,12 +191,14 @@ int gnuais_batch_create(gnuais_batch **out, int device, int n_channels, const fl
     alloc((void **) &b->hist[1], sizeof(int16_t) * N * b->NT);
     b->n_seg = (b->sgn_words + SEG_WORDS - 1) / SEG_WORDS;
     b->seg_words = (int) (((uint64_t) SEG_WORDS * 32 * step / 65536 + 2 + 31) / 32) + 1;
-    alloc((void **) &b->sgn, sizeof(uint32_t) * N * (b->sgn_words + 2 * PLL_PAD));
+    for (int k = 0; k < 2; ++k) {
+        alloc((void **) &b->sgn[k], sizeof(uint32_t) * N * (b->sgn_words + 2 * PLL_PAD));
+        alloc((void **) &b->segbits[k], sizeof(uint32_t) * N * (size_t) b->n_seg * b->seg_words);
+        alloc((void **) &b->segcnt[k], sizeof(uint32_t) * N * (size_t) b->n_seg);
+    }
     alloc((void **) &b->ovf, sizeof(uint32_t) * N * (b->sgn_words + 2 * PLL_PAD));
     alloc((void **) &b->pll, sizeof(uint32_t) * N);
     alloc((void **) &b->lastbit, sizeof(uint32_t) * N);
-    alloc((void **) &b->segbits, sizeof(uint32_t) * N * (size_t) b->n_seg * b->seg_words);
-    alloc((void **) &b->segcnt, sizeof(uint32_t) * N * (size_t) b->n_seg);
     alloc((void **) &b->ctl, sizeof(uint32_t) * N * HDLC_CTL_WORDS);
     // candidate ring: a frame needs >= 32 bits of preamble+flag, typical load is one
     // frame per 256 bit times; 64 slots per channel and call cover max_len <= 2^16
@@ -194,6 +215,21 @@ int gnuais_batch_create(gnuais_batch **out, int device, int n_channels, const fl
         e = hipMemcpy(b->d_taps, b->taps.data(), sizeof(float) * b->NT, hipMemcpyHostToDevice);
     for (auto &ev : b->ev)
         if (e == hipSuccess) e = hipEventCreate(&ev);
+    for (int k = 0; k < 2; ++k) {
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&b->e_fir[k], hipEventDisableTiming);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&b->e_pll[k], hipEventDisableTiming);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&b->e_hdlc[k], hipEventDisableTiming);
+    }
+    {
+        // the sequential stages are short on parallelism, long on latency: give them
+        // dispatch priority over the FIR's tens of thousands of workgroups
+        int lo = 0, hi = 0;
+        if (e == hipSuccess) e = hipDeviceGetStreamPriorityRange(&lo, &hi);
+        if (e == hipSuccess) e = hipStreamCreateWithPriority(&b->s_pll, hipStreamNonBlocking, hi);
+        if (e == hipSuccess) e = hipStreamCreateWithPriority(&b->s_hdlc, hipStreamNonBlocking, hi);
+    }
+    if (const char *v = getenv("GNUAIS_PIPELINE")) b->pipeline = atoi(v) != 0;
+    if (const char *v = getenv("GNUAIS_HDLC_LPW")) b->hdlc_lpw = std::min(64, std::max(1, atoi(v)));
     if (e != hipSuccess) {
         gnuais_batch_destroy(b);
         return fail(GNUAIS_E_HIP, "create: device allocation", e);
@@ -220,7 +256,9 @@ int gnuais_batch_reset(gnuais_batch *b)
     b->hist_cur = 0;
     HIP_TRY(hipMemset(b->pll, 0, sizeof(uint32_t) * N));              // receiver.c:66-71
     HIP_TRY(hipMemset(b->lastbit, 0, sizeof(uint32_t) * N));
-    HIP_TRY(hipMemset(b->segcnt, 0, sizeof(uint32_t) * N * (size_t) b->n_seg));
+    for (int k = 0; k < 2; ++k)
+        HIP_TRY(hipMemset(b->segcnt[k], 0, sizeof(uint32_t) * N * (size_t) b->n_seg));
+    b->calls = 0;
     HIP_TRY(hipMemset(b->counters, 0, sizeof(int32_t) * N * 3));      // protodec.c:62-64
     HIP_TRY(hipMemset(b->maxval, 0, sizeof(int) * N));
     HIP_TRY(hipMemset(b->frame_count, 0, sizeof(uint32_t) * 2));
@@ -237,8 +275,10 @@ int gnuais_batch_set_option(gnuais_batch *b, const char *name, int value)
         if (value < 64 || value % 32) return fail(GNUAIS_E_ARG, "fir_T must be a multiple of 32, >= 64");
         b->fir_T = value;
     } else if (!strcmp(name, "fir_variant")) {
-        if (value < 0 || value > 1) return fail(GNUAIS_E_ARG, "fir_variant must be 0 or 1");
+        if (value < 0 || value > 2) return fail(GNUAIS_E_ARG, "fir_variant must be 0, 1 or 2");
         b->fir_variant = value;
+    } else if (!strcmp(name, "pipeline")) {
+        b->pipeline = value != 0;
     } else if (!strcmp(name, "hdlc_lpw")) {
         if (value < 1 || value > 64) return fail(GNUAIS_E_ARG, "hdlc_lpw must be 1..64");
         b->hdlc_lpw = value;
@@ -248,12 +288,13 @@ int gnuais_batch_set_option(gnuais_batch *b, const char *name, int value)
     return GNUAIS_OK;
 }
 
-static void fill_fir(const gnuais_batch *b, FirLaunch &f, const int16_t *x, int len, float *dump)
+static void fill_fir(const gnuais_batch *b, FirLaunch &f, const int16_t *x, int len, float *dump,
+                     int k)
 {
     memset(&f, 0, sizeof f);
     f.x = x;
     f.hist = b->hist[b->hist_cur];
-    f.sgn = b->sgn;
+    f.sgn = b->sgn[k];
     f.dump = dump;
     f.maxval = b->maxval;
     f.d_taps = b->d_taps;
@@ -266,9 +307,9 @@ static void fill_fir(const gnuais_batch *b, FirLaunch &f, const int16_t *x, int 
     f.d = b->d;
 }
 
-static void fill_hdlc(const gnuais_batch *b, HdlcLaunch &h)
+static void fill_hdlc(const gnuais_batch *b, HdlcLaunch &h, int k)
 {
-    h.segbits = b->segbits; h.segcnt = b->segcnt; h.ctl = b->ctl; h.cand = b->cand;
+    h.segbits = b->segbits[k]; h.segcnt = b->segcnt[k]; h.ctl = b->ctl; h.cand = b->cand;
     h.cand_first = b->cand_first; h.cand_count = b->cand_count;
     h.counters = b->counters; h.frames = b->frames; h.frame_count = b->frame_count;
     h.frame_cap = (uint32_t) b->frame_cap; h.N = b->N; h.n_seg = b->n_seg;
@@ -276,15 +317,17 @@ static void fill_hdlc(const gnuais_batch *b, HdlcLaunch &h)
     h.lanes_per_wave = b->hdlc_lpw;
 }
 
-static int run_fir(gnuais_batch *b, const int16_t *x, int len, float *dump, hipStream_t s)
+static int run_fir(gnuais_batch *b, const int16_t *x, int len, float *dump, hipStream_t s, int k)
 {
     FirLaunch f;
-    fill_fir(b, f, x, len, dump);
+    fill_fir(b, f, x, len, dump, k);
     HIP_TRY(hipMemsetAsync(b->maxval, 0, sizeof(int) * (size_t) b->N, s));
     if (b->NE != 32)
         HIP_TRY(launch_fir_generic(f, s));
     else if (b->fir_variant == 1)
         HIP_TRY(packed::launch_fir_slice(f, s));
+    else if (b->fir_variant == 2)
+        HIP_TRY(mfma::launch_fir_slice(f, s));
     else
         HIP_TRY(scalar::launch_fir_slice(f, s));
     return GNUAIS_OK;
@@ -303,26 +346,47 @@ int gnuais_batch_run(gnuais_batch *b, const int16_t *d_samples, int len, void *s
     if (!b || !d_samples) return fail(GNUAIS_E_ARG, "run: NULL argument");
     if (len <= 0 || len > b->max_len) return fail(GNUAIS_E_ARG, "run: len out of range (max_len)");
     if (int rc = set_device(b)) return rc;
-    hipStream_t s = (hipStream_t) stream;
+    hipStream_t s0 = (hipStream_t) stream;
+    hipStream_t s1 = b->pipeline ? b->s_pll : s0, s2 = b->pipeline ? b->s_hdlc : s0;
+    const int k = (int) (b->calls & 1);           // hand-off buffer pair of this call
     const bool tm = b->timing;
-    if (tm) HIP_TRY(hipEventRecord(b->ev[0], s));
-    if (int rc = run_fir(b, d_samples, len, nullptr, s)) return rc;
-    if (tm) HIP_TRY(hipEventRecord(b->ev[1], s));
-    if (int rc = run_history(b, d_samples, len, s)) return rc;
+
+    // K1: needs sgn[k] free again, i.e. the K2a/K2x of call i-2 finished
+    if (b->pipeline && b->calls >= 2) HIP_TRY(hipStreamWaitEvent(s0, b->e_pll[k], 0));
+    if (tm) HIP_TRY(hipEventRecord(b->ev[0], s0));
+    if (int rc = run_fir(b, d_samples, len, nullptr, s0, k)) return rc;
+    if (tm) HIP_TRY(hipEventRecord(b->ev[1], s0));
+    if (int rc = run_history(b, d_samples, len, s0)) return rc;
+    if (b->pipeline) HIP_TRY(hipEventRecord(b->e_fir[k], s0));
+
+    // K2a + K2x: need this call's sign words, and segbits[k] drained by the K2b of call i-2
+    if (b->pipeline) {
+        HIP_TRY(hipStreamWaitEvent(s1, b->e_fir[k], 0));
+        if (b->calls >= 2) HIP_TRY(hipStreamWaitEvent(s1, b->e_hdlc[k], 0));
+    }
     PllLaunch p;
-    p.sgn = b->sgn; p.ovf = b->ovf; p.pll = b->pll; p.lastbit = b->lastbit;
-    p.segbits = b->segbits; p.segcnt = b->segcnt;
+    p.sgn = b->sgn[k]; p.ovf = b->ovf; p.pll = b->pll; p.lastbit = b->lastbit;
+    p.segbits = b->segbits[k]; p.segcnt = b->segcnt[k];
     p.N = b->N; p.L = len; p.n_seg = b->n_seg; p.seg_words = b->seg_words; p.pllinc = b->pllinc;
-    if (tm) HIP_TRY(hipEventRecord(b->ev[2], s));
-    HIP_TRY(launch_pll_nrzi(p, s));
-    if (tm) HIP_TRY(hipEventRecord(b->ev[3], s));
+    if (tm) HIP_TRY(hipEventRecord(b->ev[2], s1));
+    HIP_TRY(launch_pll_nrzi(p, s1));
+    if (tm) HIP_TRY(hipEventRecord(b->ev[3], s1));
+    if (b->pipeline) HIP_TRY(hipEventRecord(b->e_pll[k], s1));
+
+    // K2b + K3
+    if (b->pipeline) HIP_TRY(hipStreamWaitEvent(s2, b->e_pll[k], 0));
     HdlcLaunch h;
-    fill_hdlc(b, h);
-    HIP_TRY(launch_hdlc_crc(h, s));
-    if (tm) HIP_TRY(hipEventRecord(b->ev[4], s));
+    fill_hdlc(b, h, k);
+    if (tm) HIP_TRY(hipEventRecord(b->ev[5], s2));
+    HIP_TRY(launch_hdlc_crc(h, s2));
+    if (tm) HIP_TRY(hipEventRecord(b->ev[4], s2));
+    if (b->pipeline) HIP_TRY(hipEventRecord(b->e_hdlc[k], s2));
+
     b->timed_last = tm;
-    b->last_stream = s;
+    b->last_stream = s0;
     b->last_len = len;
+    b->last_k = k;
+    b->calls++;
     return GNUAIS_OK;
 }
 
@@ -331,6 +395,8 @@ int gnuais_batch_sync(gnuais_batch *b)
     if (!b) return fail(GNUAIS_E_ARG, "sync: NULL batch");
     if (int rc = set_device(b)) return rc;
     HIP_TRY(hipStreamSynchronize(b->last_stream));
+    HIP_TRY(hipStreamSynchronize(b->s_pll));
+    HIP_TRY(hipStreamSynchronize(b->s_hdlc));
     return GNUAIS_OK;
 }
 
@@ -364,7 +430,8 @@ int gnuais_batch_filter(gnuais_batch *b, const int16_t *d_samples, int len, floa
     if (len <= 0 || len > b->max_len) return fail(GNUAIS_E_ARG, "filter: len out of range");
     if (int rc = set_device(b)) return rc;
     hipStream_t s = (hipStream_t) stream;
-    if (int rc = run_fir(b, d_samples, len, d_out, s)) return rc;
+    if (int rc = gnuais_batch_sync(b)) return rc;       // the sign-word scratch is shared
+    if (int rc = run_fir(b, d_samples, len, d_out, s, (int) (b->calls & 1))) return rc;
     if (int rc = run_history(b, d_samples, len, s)) return rc;
     b->last_stream = s;
     b->timed_last = false;
@@ -375,7 +442,7 @@ int gnuais_batch_decode_bits(gnuais_batch *b, const uint8_t *h_bits, int stride,
                              const int32_t *h_count)
 {
     if (!b || !h_bits || !h_count || stride <= 0) return fail(GNUAIS_E_ARG, "decode_bits: argument");
-    if (int rc = set_device(b)) return rc;
+    if (int rc = gnuais_batch_sync(b)) return rc;
     const int N = b->N, segcap = b->seg_words * 32, chunk = segcap * b->n_seg;
     int maxc = 0;
     for (int c = 0; c < N; ++c) {
@@ -398,10 +465,10 @@ int gnuais_batch_decode_bits(gnuais_batch *b, const uint8_t *h_bits, int stride,
             for (int seg = 0; seg * segcap < n; ++seg)
                 cnt[(size_t) c * b->n_seg + seg] = (uint32_t) std::min(segcap, n - seg * segcap);
         }
-        HIP_TRY(hipMemcpy(b->segbits, words.data(), words.size() * 4, hipMemcpyHostToDevice));
-        HIP_TRY(hipMemcpy(b->segcnt, cnt.data(), cnt.size() * 4, hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(b->segbits[0], words.data(), words.size() * 4, hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(b->segcnt[0], cnt.data(), cnt.size() * 4, hipMemcpyHostToDevice));
         HdlcLaunch h;
-        fill_hdlc(b, h);
+        fill_hdlc(b, h, 0);
         HIP_TRY(launch_hdlc_crc(h, nullptr));
         HIP_TRY(hipDeviceSynchronize());
     }
@@ -416,8 +483,8 @@ int gnuais_batch_last_bits(gnuais_batch *b, uint8_t *h_bits, int stride, int32_t
     const int N = b->N;
     const size_t rowlen = (size_t) b->n_seg * b->seg_words;
     std::vector<uint32_t> words(rowlen * N), cnt((size_t) b->n_seg * N);
-    HIP_TRY(hipMemcpy(words.data(), b->segbits, words.size() * 4, hipMemcpyDeviceToHost));
-    HIP_TRY(hipMemcpy(cnt.data(), b->segcnt, cnt.size() * 4, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(words.data(), b->segbits[b->last_k], words.size() * 4, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(cnt.data(), b->segcnt[b->last_k], cnt.size() * 4, hipMemcpyDeviceToHost));
     const int nseg_used = ((b->last_len + 31) / 32 + SEG_WORDS - 1) / SEG_WORDS;
     for (int c = 0; c < N; ++c) {
         int n = 0;
@@ -471,7 +538,8 @@ int gnuais_batch_discard_frames(gnuais_batch *b, void *stream)
 {
     if (!b) return fail(GNUAIS_E_ARG, "discard_frames: NULL batch");
     if (int rc = set_device(b)) return rc;
-    HIP_TRY(hipMemsetAsync(b->frame_count, 0, sizeof(uint32_t) * 2, (hipStream_t) stream));
+    hipStream_t s = b->pipeline ? b->s_hdlc : (hipStream_t) stream;   // behind the last K3
+    HIP_TRY(hipMemsetAsync(b->frame_count, 0, sizeof(uint32_t) * 2, s));
     return GNUAIS_OK;
 }
 
@@ -575,7 +643,7 @@ int gnuais_batch_last_timing(gnuais_batch *b, float *ms4)
     if (int rc = gnuais_batch_sync(b)) return rc;
     HIP_TRY(hipEventElapsedTime(&ms4[0], b->ev[0], b->ev[1]));
     HIP_TRY(hipEventElapsedTime(&ms4[1], b->ev[2], b->ev[3]));
-    HIP_TRY(hipEventElapsedTime(&ms4[2], b->ev[3], b->ev[4]));
+    HIP_TRY(hipEventElapsedTime(&ms4[2], b->ev[5], b->ev[4]));
     HIP_TRY(hipEventElapsedTime(&ms4[3], b->ev[0], b->ev[4]));
     return GNUAIS_OK;
 }

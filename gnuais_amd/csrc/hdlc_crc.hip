@@ -78,6 +78,7 @@ __global__ __launch_bounds__(64) void hdlc_deframe_kernel(
     uint32_t *__restrict__ cand_count, int32_t *__restrict__ counters,
     uint32_t *__restrict__ flags, int N, int n_seg, int seg_words, int K)
 {
+    __builtin_amdgcn_s_setprio(3);      // latency-bound chain: take every issue slot it can use
     const int cg = blockIdx.x * blockDim.x + threadIdx.x;
     const bool live = cg < N;
     const size_t c = (size_t) (live ? cg : N - 1), n_ = (size_t) N;

@@ -74,6 +74,9 @@ __global__ __launch_bounds__(64) void pll_core_kernel(
     const uint32_t *__restrict__ sgn, uint32_t *__restrict__ ovf, uint32_t *__restrict__ pllst,
     int N, int L, uint32_t pllinc)
 {
+    // this wave is a long dependent chain; when it shares a SIMD with FIR waves of
+    // the next call it must win every issue slot it can use
+    __builtin_amdgcn_s_setprio(3);
     const int cg = blockIdx.x * 64 + threadIdx.x;
     const int c = cg < N ? cg : N - 1;
     const bool live = cg < N;

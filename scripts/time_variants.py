@@ -11,8 +11,8 @@ x = tile_channels(torch.from_numpy(base).cuda(), n_ch)
 torch.cuda.synchronize()
 b = ReceiverBatch(n_ch, max_len=total)
 b.set_timing(True)
-for variant in (0,):
-    for T in (512,):
+for variant in (0, 2):
+    for T in (512, 1024):
         b.set_option("fir_variant", variant); b.set_option("fir_T", T)
         res = []
         for it in range(4):

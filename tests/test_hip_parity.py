@@ -52,7 +52,7 @@ def oracle_fsm_rows(o, n, saturate=True):
 
 # ---------------------------------------------------------------- FIR (K1)
 
-@pytest.mark.parametrize("variant", [0, 1])
+@pytest.mark.parametrize("variant", [0, 1, 2])
 def test_fir_known_answers_bit_exact(variant):
     g = load("fir_kat")
     for k in g.files:
@@ -76,7 +76,7 @@ def test_fir_192k_generic_taps_bit_exact():
     assert np.array_equal(y.view(np.uint32), g["y192_noise_full"])
 
 
-@pytest.mark.parametrize("variant", [0, 1])
+@pytest.mark.parametrize("variant", [0, 1, 2])
 def test_fir_many_channels_chunked_vs_oracle(variant):
     """N not a multiple of 64, chunk lengths not multiples of 32, state carried."""
     rng = np.random.default_rng(21)
@@ -99,6 +99,24 @@ def test_fir_many_channels_chunked_vs_oracle(variant):
     got = np.concatenate(got, axis=0)
     assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
     assert np.array_equal(b.history(), np.stack([o.history(c) for c in range(n_ch)]))
+
+
+def test_fir_asymmetric_and_negative_taps_vs_oracle():
+    """Non-symmetric tables take the unshared-product kernel; negative taps make
+    -0 products (x = 0), which must not change any sum; an odd-sized table takes
+    the generic kernel."""
+    rng = np.random.default_rng(23)
+    x = rng.integers(-32768, 32768, (3000, 66)).astype(np.int16)
+    x[100:400, 7] = 0
+    for taps in (np.concatenate([[0, 0], rng.normal(0, 0.3, 32), [0, 0]]).astype(np.float32),
+                 np.concatenate([[0, 0], -np.abs(rng.normal(0, 0.3, 32)), [0, 0]]).astype(np.float32),
+                 rng.normal(0, 0.3, 20).astype(np.float32)):
+        o = Oracle(66, taps=taps)
+        want = o.run(x, want_filtered=True)["filtered"]
+        b = batch(66, taps=taps, max_len=3000)
+        got = b.filter(dev(x)).cpu().numpy()
+        assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+        b.close()
 
 
 # ---------------------------------------------------------------- full chain
