@@ -191,6 +191,10 @@ int gnuais_batch_create(gnuais_batch **out, int device, int n_channels, const fl
     alloc((void **) &b->hist[1], sizeof(int16_t) * N * b->NT);
     b->n_seg = (b->sgn_words + SEG_WORDS - 1) / SEG_WORDS;
     b->seg_words = (int) (((uint64_t) SEG_WORDS * 32 * step / 65536 + 2 + 31) / 32) + 1;
+    if (b->seg_words > 16) {       // K2b keeps one segment pack (<= 16 words) in registers
+        delete b;
+        return fail(GNUAIS_E_ARG, "create: pllinc too large (more than one slice per ~4.6 samples)");
+    }
     for (int k = 0; k < 2; ++k) {
         alloc((void **) &b->sgn[k], sizeof(uint32_t) * N * (b->sgn_words + 2 * PLL_PAD));
         alloc((void **) &b->segbits[k], sizeof(uint32_t) * N * (size_t) b->n_seg * b->seg_words);

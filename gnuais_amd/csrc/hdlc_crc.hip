@@ -5,34 +5,34 @@
 // protodec_reset() (src/protodec.c:87-100) and for protodec_calculate_crc() /
 // protodec_sdlc_crc() (src/protodec.c:106-167), for a whole batch of channels.
 //
-// K2b -- one lane = one channel walking its own recovered bit stream (K2a's
-// output, one contiguous row per channel) at its own pace.  The walk is a chain
-// of dependent steps, so it is latency- not throughput-bound: a wave carries
-// only a few channels (blockDim = 4..16), which gives thousands of waves to
-// interleave on every SIMD and keeps the divergence between the channels of one
-// wave small.  The five-state machine of the reference is reproduced exactly -- same
-// states, same counters, same quirks (`last`
-// rewritten after every state, `nstartsign++` even after a reset in
-// ST_STARTSIGN, reset at bufferpos >= 449) -- but not bit by bit: the two states
-// a channel spends its life in are advanced up to 32 bits per step with word
-// logic,
-//   ST_SKURR : "15 alternations then a 0" is a run-length test on x ^ (x << 1);
-//   ST_DATA  : "five 1s" (stuffing / closing flag) likewise; the bits up to the
-//              event are appended to the frame buffer with one funnel shift;
-// and ST_PREAMBLE / ST_STARTSIGN / ST_STOPSIGN take one bit per step (they last
-// ~20 bits per frame).  Lanes are not in lock-step on the bit index, so a wave
-// needs max-over-lanes(steps) iterations, not sum.
+// K2b -- one lane = one channel walking its own recovered bit stream (K2x's
+// per-segment bit packs) at its own pace.  A wave that is alone on its SIMD issues
+// about one instruction per 5 cycles, so what counts is instructions per channel,
+// i.e. steps x instructions per step.  The five-state machine of the reference is
+// reproduced exactly -- same states, same counters, same quirks (SURVEY.md
+// appendix A.7-A.9: `last` rewritten after every state, `nstartsign++` even after
+// a reset in ST_STARTSIGN, reset at bufferpos >= 449) -- but not bit by bit:
+//   ST_SKURR : "15 alternations then a 0" is a run-length test on x ^ (x << 1),
+//              up to 32 bits per step;
+//   ST_DATA  : up to 32 RAW bits per step.  Only two things matter while a frame is
+//              open: where it ends (five 1s followed by a sixth) and how many bits
+//              have been stored (bufferpos, for the 449 limit and the frame
+//              length); stuffed 0s are counted with a popcount and left in place.
+//              The raw bits go straight into the frame's candidate record in HBM
+//              (fire-and-forget stores, no read-back); a frame that is still open
+//              at the end of a call continues in the same record at the next call;
+//   ST_PREAMBLE / ST_STARTSIGN / ST_STOPSIGN last ~20 bits per frame and run bit
+//              by bit, but inside one step.
+// Lanes are not in lock-step on the bit index, so a wave needs
+// max-over-lanes(steps) iterations, not the sum.
 //
-// The frame bits go straight into a per-channel ring of candidate records in
-// HBM (fire-and-forget stores, no read-back); a frame that is still open at the
-// end of a call simply continues in the same record at the next call.
-//
-// K3 -- the candidates closed in this call, shared evenly over threads: the reference's CRC over
+// K3 -- the candidates closed in this call, shared evenly over threads: remove the
+// stuffed 0s (the bit after every five 1s), then the reference's CRC over
 // n/8 + 2 bytes (bits packed LSB first, protodec.c:138-143), good frame <=>
-// 0x0f47 after the final complement (protodec.c:166).  Taking the CRC out of the
-// sequential walk costs nothing in exactness and turns its 464 shift steps per
-// frame into fully parallel work.  Good frames are appended to the frame ring as
-// 64-byte records and counted in receivedframes, bad ones in lostframes.
+// 0x0f47 after the final complement (protodec.c:166).  Taking both out of the
+// sequential walk costs nothing in exactness and turns per-bit work into fully
+// parallel work.  Good frames are appended to the frame ring as 64-byte records
+// and counted in receivedframes, bad ones in lostframes.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -44,10 +44,13 @@ enum { ST_SKURR = 1, ST_PREAMBLE = 2, ST_STARTSIGN = 3, ST_DATA = 4, ST_STOPSIGN
 
 // ctl[0]: state[2:0] nstartsign[6:3] antallpreamble[10:7] antallenner[13:11]
 //         bitstuff[14] last[15] bufferpos[24:16]
-// ctl[1]: partially filled frame-buffer word
+// ctl[1]: partially filled word of the raw frame record
 // ctl[2]: bits fed since reset
 // ctl[3]: ST_DATA entries since reset (candidate slots handed out)
+// ctl[4]: raw bits in the open frame record
 constexpr uint32_t CAND_VALID = 0x10000u;
+constexpr int K3_CH = 32;               // channels per K3 block
+constexpr int PACK_MAX = 16;            // words per segment pack held in registers/LDS
 
 __global__ void hdlc_reset_kernel(uint32_t *__restrict__ ctl, int N)
 {
@@ -57,6 +60,7 @@ __global__ void hdlc_reset_kernel(uint32_t *__restrict__ ctl, int N)
     ctl[(size_t) N + c] = 0;
     ctl[(size_t) 2 * N + c] = 0;
     ctl[(size_t) 3 * N + c] = 0;
+    ctl[(size_t) 4 * N + c] = 0;
 }
 
 __device__ __forceinline__ uint32_t lowmask(int k)      // k in [0, 32]
@@ -91,6 +95,7 @@ __global__ __launch_bounds__(64) void hdlc_deframe_kernel(
     uint32_t cur = ctl[n_ + c];
     const uint32_t seen0 = ctl[2 * n_ + c];
     uint32_t nstart = ctl[3 * n_ + c];
+    int rawpos = (int) ctl[4 * n_ + c];
     int lost2 = 0;
 
     const bool open0 = (state == ST_DATA || state == ST_STOPSIGN);
@@ -105,16 +110,34 @@ __global__ __launch_bounds__(64) void hdlc_deframe_kernel(
          last = 0; bitstuff = 0; bufferpos = 0; } while (0)
 
     // K2x hands over one bit pack per 2048-sample segment; the word-parallel steps
-    // accept any window length, so a pack boundary is just a short window
+    // accept any window length, so a pack boundary is just a short window.  A step's
+    // window must not wait on HBM/L2 (~1-2 us per dependent load, several hundred
+    // steps per channel): the pack of the NEXT segment is fetched into registers
+    // while the current one is walked out of LDS.
+    extern __shared__ uint32_t lds_pack[];                    // [PACK_MAX + 1][blockDim.x]
+    const int tpb = (int) blockDim.x, tx = (int) threadIdx.x;
+    const uint32_t *__restrict__ rows = segbits + c * (size_t) n_seg * (size_t) seg_words;
+    uint32_t pf[PACK_MAX];
+    int pf_cnt = live ? (int) segcnt[c * (size_t) n_seg] : 0;
+#pragma unroll
+    for (int q = 0; q < PACK_MAX; ++q) pf[q] = (q < seg_words) ? rows[q] : 0u;
+
     for (int seg = 0; seg < n_seg; ++seg) {
-        const uint32_t *__restrict__ row = segbits + (c * (size_t) n_seg + seg) * (size_t) seg_words;
-        int tile_end = live ? (int) segcnt[c * (size_t) n_seg + seg] : 0;
+        int tile_end = pf_cnt;
         if (tile_end > seg_words * 32) tile_end = seg_words * 32;
+#pragma unroll
+        for (int q = 0; q < PACK_MAX; ++q) lds_pack[q * tpb + tx] = pf[q];
+        lds_pack[PACK_MAX * tpb + tx] = 0;
+        if (seg + 1 < n_seg) {
+            const uint32_t *__restrict__ nrow = rows + (size_t) (seg + 1) * (size_t) seg_words;
+            pf_cnt = live ? (int) segcnt[c * (size_t) n_seg + seg + 1] : 0;
+#pragma unroll
+            for (int q = 0; q < PACK_MAX; ++q) pf[q] = (q < seg_words) ? nrow[q] : 0u;
+        }
         int pos = 0;
         while (pos < tile_end) {
             const int lw = pos >> 5, sh = pos & 31;
-            const uint32_t lo = row[lw];
-            const uint32_t hi = (lw + 1 < seg_words) ? row[lw + 1] : 0u;
+            const uint32_t lo = lds_pack[lw * tpb + tx], hi = lds_pack[(lw + 1) * tpb + tx];
             const uint32_t W = sh ? ((lo >> sh) | (hi << (32 - sh))) : lo;   // bit j = x[pos+j]
             const int nv = (tile_end - pos < 32) ? tile_end - pos : 32;
             const uint32_t vm = lowmask(nv);
@@ -142,66 +165,100 @@ __global__ __launch_bounds__(64) void hdlc_deframe_kernel(
             } else if (state == ST_DATA) {
                 if (bitstuff) {                                // protodec.c:996-1007
                     const uint32_t x = W & 1u;
-                    if (x) state = ST_STOPSIGN;                // sixth 1: closing flag (or abort)
+                    if (x) {
+                        state = ST_STOPSIGN;                   // sixth 1: closing flag (or abort)
+                    } else {                                   // stuffed 0: stays in the raw record
+                        if ((rawpos & 31) == 31) {
+                            if (rec_ok) rec[CAND_HDR + (rawpos >> 5)] = cur;
+                            cur = 0;
+                        }
+                        ++rawpos;
+                    }
                     bitstuff = 0;
                     last = x;
                     pos += 1;
                 } else {                                       // protodec.c:1008-1027
                     // m = run of 1s ending at the previous bit (antallenner = m-1 when last = 1)
                     const int m = last ? antallenner + 1 : 0;
-                    const uint32_t Z2 = W & (W << 1), Z4 = Z2 & (Z2 << 2);
-                    const uint32_t F = Z4 & (W << 4);          // bit j: x[j-4..j] all 1
-                    const int t1 = ctz32(~W);                  // 1s from the window start
-                    int e = ctz32(F);
-                    if (m + t1 >= 5 && 4 - m < e) e = 4 - m;   // run continues the carried count
-                    const int n_ev = e + 1;                    // bits up to the fifth 1, inclusive
                     const int room = 449 - bufferpos;          // protodec.c:1024
-                    int n = nv;
-                    if (n_ev < n) n = n_ev;
-                    if (room < n) n = room;
-                    // buffer[bufferpos .. bufferpos+n) = x[pos .. pos+n)
-                    const uint32_t sb = W & lowmask(n);
-                    const int bsh = bufferpos & 31;
-                    const uint64_t t64 = (uint64_t) sb << bsh;
-                    cur |= (uint32_t) t64;
-                    if (bsh + n >= 32) {
-                        if (rec_ok) rec[CAND_HDR + (bufferpos >> 5)] = cur;
-                        cur = (uint32_t) (t64 >> 32);
+                    int nw = nv;
+                    if (nw > 32 - m) nw = 32 - m;
+                    if (nw > room) nw = room;                  // bufferpos can reach 449 only at
+                                                               // the last bit of this step
+                    const int nvE = nw + m;
+                    const uint32_t vmE = lowmask(nvE);
+                    // E: the carried 1s, then the window; bit j = raw bit j-m
+                    const uint32_t E = ((W << m) | lowmask(m)) & vmE;
+                    const uint32_t X1 = E & (E >> 1), X2 = X1 & (X1 >> 2);
+                    const uint32_t R5 = X2 & (E >> 4);         // five 1s starting at bit j
+                    const uint32_t S5 = R5 & ~(E << 1);        // ... that begin a run
+                    const uint32_t P5 = S5 << 4;               // position of the run's fifth 1
+                    const uint32_t nx = E >> 1, kn = vmE >> 1; // next bit / next bit is inside
+                    const uint32_t END5 = P5 & nx & kn;        // followed by a sixth 1: closing flag
+                    const uint32_t STF5 = P5 & ~nx & kn;       // followed by a 0: stuffing, dropped
+                    const uint32_t PND5 = P5 & ~kn;            // fifth 1 is the last bit seen
+                    int nraw, stored;
+                    if (END5) {
+                        const int pe = ctz32(END5);
+                        nraw = pe + 1 - m;                     // raw bits up to the fifth 1
+                        stored = nraw - __popc(STF5 & lowmask(pe));
+                    } else {
+                        nraw = nw;
+                        stored = nw - __popc(STF5);
                     }
-                    bufferpos += n;
-                    pos += n;
-                    const uint32_t xl = (W >> (n - 1)) & 1u;
-                    if (n == room) {                           // bufferpos >= 449: give up the frame
-                        if (rec_ok) rec[0] = 0;
-                        HDLC_RESET();
-                        last = xl;
-                    } else if (n == n_ev) {                    // five 1s: next bit is stuffing or flag
-                        bitstuff = 1;
+                    // raw record [rawpos .. rawpos+nraw) = x[pos .. pos+nraw)
+                    {
+                        const uint32_t sb = W & lowmask(nraw);
+                        const int bsh = rawpos & 31;
+                        const uint64_t t64 = (uint64_t) sb << bsh;
+                        cur |= (uint32_t) t64;
+                        if (bsh + nraw >= 32) {
+                            if (rec_ok) rec[CAND_HDR + (rawpos >> 5)] = cur;
+                            cur = (uint32_t) (t64 >> 32);
+                        }
+                        rawpos += nraw;
+                    }
+                    bufferpos += stored;
+                    if (END5) {
+                        pos += nraw + 1;                       // ... and the sixth 1
+                        state = ST_STOPSIGN;
                         antallenner = 0;
                         last = 1;
                     } else {
-                        const int mm = (t1 >= n) ? m + n : clz32(~(W << (32 - n)));
-                        last = xl;
-                        antallenner = xl ? mm - 1 : 0;
+                        pos += nraw;
+                        const uint32_t xl = (W >> (nraw - 1)) & 1u;
+                        if (bufferpos >= 449) {                // give up the frame
+                            if (rec_ok) rec[0] = 0;
+                            HDLC_RESET();
+                            last = xl;
+                        } else if (PND5) {                     // next bit is stuffing or flag
+                            bitstuff = 1;
+                            antallenner = 0;
+                            last = 1;
+                        } else {
+                            const int r = clz32(~(E << (32 - nvE)));   // run of 1s at the end
+                            last = xl;
+                            antallenner = r > 0 ? r - 1 : 0;
+                        }
                     }
                 }
             } else {
-                const uint32_t x = W & 1u;
-                bool single = true;
-                if (state == ST_PREAMBLE) {                    // protodec.c:1045-1072
-                    if (nstartsign == 0) {
-                        // the alternating part of the training sequence, all at once
-                        const uint32_t A = W ^ ((W << 1) | last);
-                        int t = ctz32(~A);
-                        if (t > nv) t = nv;
-                        if (t > 0) {
-                            antallpreamble = antallpreamble + t > 15 ? 15 : antallpreamble + t;
-                            last = (W >> (t - 1)) & 1u;
-                            pos += t;
-                            single = false;
-                        }
+                // ST_PREAMBLE / ST_STARTSIGN / ST_STOPSIGN: bit by bit, in one step
+                int k = 0;
+                if (state == ST_PREAMBLE && nstartsign == 0) {
+                    // the alternating part of the training sequence, all at once
+                    const uint32_t A = W ^ ((W << 1) | last);
+                    int t = ctz32(~A);
+                    if (t > nv) t = nv;
+                    if (t > 0) {
+                        antallpreamble = antallpreamble + t > 15 ? 15 : antallpreamble + t;
+                        last = (W >> (t - 1)) & 1u;
+                        k = t;
                     }
-                    if (single) {
+                }
+                while (k < nv && state != ST_SKURR && state != ST_DATA) {
+                    const uint32_t x = (W >> k) & 1u;
+                    if (state == ST_PREAMBLE) {                // protodec.c:1045-1072
                         if (x != last && nstartsign == 0) {
                             if (antallpreamble < 15) ++antallpreamble;
                         } else if (x == 1) {
@@ -212,44 +269,43 @@ __global__ __launch_bounds__(64) void hdlc_deframe_kernel(
                             if (nstartsign == 0) nstartsign = 1;
                             else HDLC_RESET();
                         }
-                    }
-                } else if (state == ST_STARTSIGN) {            // protodec.c:1074-1093
-                    if (nstartsign >= 7) {
-                        if (x == 0) {
-                            state = ST_DATA; nstartsign = 0; antallenner = 0;
-                            bufferpos = 0; cur = 0;
-                            // open a candidate record for this frame
-                            rec_ok = (nstart - first) < (uint32_t) K;
-                            rec = cand + ((size_t) c * K + nstart % (uint32_t) K) * CAND_WORDS;
-                            if (rec_ok) rec[0] = 0; else flags[1] = 1;
-                            ++nstart;
-                        } else {
+                    } else if (state == ST_STARTSIGN) {        // protodec.c:1074-1093
+                        if (nstartsign >= 7) {
+                            if (x == 0) {
+                                state = ST_DATA; nstartsign = 0; antallenner = 0;
+                                bufferpos = 0; cur = 0; rawpos = 0;
+                                // open a candidate record for this frame
+                                rec_ok = (nstart - first) < (uint32_t) K;
+                                rec = cand + ((size_t) c * K + nstart % (uint32_t) K) * CAND_WORDS;
+                                if (rec_ok) rec[0] = 0; else flags[1] = 1;
+                                ++nstart;
+                            } else {
+                                HDLC_RESET();
+                            }
+                        } else if (x == 0) {
                             HDLC_RESET();
                         }
-                    } else if (x == 0) {
+                        ++nstartsign;                          // also after a reset
+                    } else if (state == ST_STOPSIGN) {         // protodec.c:1095-1115
+                        const int nb = bufferpos - 6 - 16;
+                        if (x == 0 && nb > 0) {
+                            if (rec_ok) {
+                                rec[CAND_HDR + (rawpos >> 5)] = cur;
+                                rec[1] = seenbase + (uint32_t) (pos + k);
+                                rec[0] = (uint32_t) nb | CAND_VALID | ((uint32_t) rawpos << 17);
+                            }
+                        } else {
+                            ++lost2;                           // protodec.c:1112
+                            if (rec_ok) rec[0] = 0;
+                        }
+                        HDLC_RESET();
+                    } else {
                         HDLC_RESET();
                     }
-                    ++nstartsign;                              // also after a reset
-                } else if (state == ST_STOPSIGN) {             // protodec.c:1095-1115
-                    const int nb = bufferpos - 6 - 16;
-                    if (x == 0 && nb > 0) {
-                        if (rec_ok) {
-                            rec[CAND_HDR + (bufferpos >> 5)] = cur;
-                            rec[1] = seenbase + (uint32_t) pos;
-                            rec[0] = (uint32_t) nb | CAND_VALID;
-                        }
-                    } else {
-                        ++lost2;                               // protodec.c:1112
-                        if (rec_ok) rec[0] = 0;
-                    }
-                    HDLC_RESET();
-                } else {
-                    HDLC_RESET();
-                }
-                if (single) {
                     last = x;                                  // protodec.c:1119
-                    pos += 1;
+                    ++k;
                 }
+                pos += k;
             }
         }
         seenbase += (uint32_t) tile_end;
@@ -263,6 +319,7 @@ __global__ __launch_bounds__(64) void hdlc_deframe_kernel(
         ctl[n_ + c] = cur;
         ctl[2 * n_ + c] = seenbase;
         ctl[3 * n_ + c] = nstart;
+        ctl[4 * n_ + c] = (uint32_t) rawpos;
         const bool open1 = (state == ST_DATA || state == ST_STOPSIGN);
         const uint32_t limit = nstart - (open1 ? 1u : 0u);
         cand_first[c] = first;
@@ -272,10 +329,10 @@ __global__ __launch_bounds__(64) void hdlc_deframe_kernel(
     }
 }
 
-// K3: CRC check + delivery of the candidates closed in this call.  One block owns
-// 256 adjacent channels: their candidate counts are prefix-summed in LDS and the
-// block's threads then share the candidates evenly (dense work, however the
-// frames are spread over the channels).  CRC-16/X-25 by bytes through a
+// K3: CRC check + delivery of the candidates closed in this call.  One block of 256
+// threads owns K3_CH adjacent channels: their candidate counts are prefix-summed
+// in LDS and the block's threads then share the candidates evenly (dense work,
+// however the frames are spread over the channels; ~2 candidates per thread).  CRC-16/X-25 by bytes through a
 // 256-entry table built in LDS from the bitwise definition (protodec.c:106-118).
 __global__ __launch_bounds__(256) void hdlc_crc_kernel(
     const uint32_t *__restrict__ cand, const uint32_t *__restrict__ cand_first,
@@ -283,9 +340,10 @@ __global__ __launch_bounds__(256) void hdlc_crc_kernel(
     uint32_t *__restrict__ frames, uint32_t *__restrict__ flags, uint32_t frame_cap, int N, int K)
 {
     __shared__ uint32_t tab[256];
-    __shared__ uint32_t pre[257];
+    __shared__ uint32_t pre[K3_CH + 1];
+    __shared__ uint32_t stage[256][HDLC_BUF_WORDS + 1];     // unstuffed frame bits per thread
     const int tid = threadIdx.x;
-    const int c_own = blockIdx.x * 256 + tid;
+    const int c_own = blockIdx.x * K3_CH + tid;
 
     {   // table entry tid: eight LFSR steps on the byte value
         uint32_t t = (uint32_t) tid;
@@ -293,38 +351,63 @@ __global__ __launch_bounds__(256) void hdlc_crc_kernel(
         for (int k = 0; k < 8; ++k) t = (t >> 1) ^ ((t & 1u) ? 0x8408u : 0u);
         tab[tid] = t;
     }
-    // inclusive scan of the per-channel candidate counts
-    const uint32_t mine = (c_own < N) ? cand_count[c_own] : 0u;
-    pre[tid + 1] = mine;
-    if (tid == 0) pre[0] = 0;
+    // prefix sums of the per-channel candidate counts (K3_CH is small: serial scan)
+    if (tid < K3_CH) pre[tid + 1] = (c_own < N) ? cand_count[c_own] : 0u;
     __syncthreads();
-    for (int off = 1; off < 256; off <<= 1) {
-        const uint32_t v = (tid + 1 > off) ? pre[tid + 1 - off] : 0u;
-        __syncthreads();
-        pre[tid + 1] += v;
-        __syncthreads();
+    if (tid == 0) {
+        uint32_t run = 0;
+        pre[0] = 0;
+        for (int q = 1; q <= K3_CH; ++q) { run += pre[q]; pre[q] = run; }
     }
-    const uint32_t total = pre[256];
+    __syncthreads();
+    const uint32_t total = pre[K3_CH];
     const size_t n_ = (size_t) N;
 
     for (uint32_t i = (uint32_t) tid; i < total; i += 256) {
         // channel of candidate i: largest k with pre[k] <= i
-        int lo = 0, hi = 255;
+        int lo = 0, hi = K3_CH - 1;
         while (lo < hi) {
             const int mid = (lo + hi + 1) >> 1;
             if (pre[mid] <= i) lo = mid; else hi = mid - 1;
         }
-        const int c = blockIdx.x * 256 + lo;
+        const int c = blockIdx.x * K3_CH + lo;
         const uint32_t j = i - pre[lo];
         const uint32_t slot = (cand_first[c] + j) % (uint32_t) K;
         const uint32_t *rec = cand + ((size_t) c * K + slot) * CAND_WORDS;
         const uint32_t hdr = rec[0];
         if (!(hdr & CAND_VALID)) continue;              // frame abandoned before its closing flag
         const int n = (int) (hdr & 0xffffu);
+        const int rawlen = (int) (hdr >> 17);
         const int nbytes = n >> 3, buflen = nbytes + 2; // protodec.c:133-134
+        // protodec.c:1008-1023 on the raw bits: store every bit except the one that
+        // follows five 1s (it is a stuffed 0 inside a frame)
+        {
+            uint32_t raw[CAND_WORDS - CAND_HDR];                // whole record first: one latency
+#pragma unroll
+            for (int q = 0; q < CAND_WORDS - CAND_HDR; ++q) raw[q] = rec[CAND_HDR + q];
+            uint32_t curw = 0;
+            int bp = 0, ones = 0;
+            bool drop = false;
+#pragma unroll
+            for (int q = 0; q < CAND_WORDS - CAND_HDR; ++q) {
+                uint32_t rw = raw[q];
+                const int lim = rawlen - 32 * q < 32 ? rawlen - 32 * q : 32;
+                for (int b = 0; b < lim; ++b) {
+                    const uint32_t x = rw & 1u;
+                    rw >>= 1;
+                    if (drop) { drop = false; continue; }
+                    curw |= x << (bp & 31);
+                    if ((bp & 31) == 31) { stage[tid][bp >> 5] = curw; curw = 0; }
+                    ++bp;
+                    ones = x ? ones + 1 : 0;
+                    if (ones == 5) { drop = true; ones = 0; }
+                }
+            }
+            if (bp < 32 * (HDLC_BUF_WORDS + 1)) stage[tid][bp >> 5] = curw;
+        }
         uint32_t w[HDLC_BUF_WORDS];
 #pragma unroll
-        for (int q = 0; q < HDLC_BUF_WORDS; ++q) w[q] = rec[CAND_HDR + q];
+        for (int q = 0; q < HDLC_BUF_WORDS; ++q) w[q] = stage[tid][q];
         uint32_t crc = 0xffffu;
 #pragma unroll
         for (int q = 0; q < HDLC_BUF_WORDS; ++q) {
@@ -366,12 +449,14 @@ __global__ __launch_bounds__(256) void hdlc_crc_kernel(
 hipError_t launch_hdlc_crc(const HdlcLaunch &a, hipStream_t stream)
 {
     const int lpw = a.lanes_per_wave > 0 ? a.lanes_per_wave : 8;
-    hipLaunchKernelGGL(hdlc_deframe_kernel, dim3((a.N + lpw - 1) / lpw), dim3(lpw), 0, stream,
+    if (a.seg_words > PACK_MAX) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(hdlc_deframe_kernel, dim3((a.N + lpw - 1) / lpw), dim3(lpw),
+                       (PACK_MAX + 1) * lpw * sizeof(uint32_t), stream,
                        a.segbits, a.segcnt, a.ctl, a.cand, a.cand_first, a.cand_count, a.counters,
                        a.frame_count, a.N, a.n_seg, a.seg_words, a.K);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(hdlc_crc_kernel, dim3((unsigned) ((a.N + 255) / 256)), dim3(256), 0,
+    hipLaunchKernelGGL(hdlc_crc_kernel, dim3((unsigned) ((a.N + K3_CH - 1) / K3_CH)), dim3(256), 0,
                        stream, a.cand, a.cand_first, a.cand_count, a.counters,
                        (uint32_t *) a.frames, a.frame_count, a.frame_cap, a.N, a.K);
     return hipGetLastError();

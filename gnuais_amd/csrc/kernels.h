@@ -38,10 +38,10 @@ struct PllLaunch {
 hipError_t launch_pll_nrzi(const PllLaunch &a, hipStream_t stream);
 
 // ---- K2b: HDLC deframer, K3: CRC-16 + frame delivery (hdlc_crc.hip) ---------
-constexpr int HDLC_CTL_WORDS = 4;
+constexpr int HDLC_CTL_WORDS = 5;
 constexpr int HDLC_BUF_WORDS = 15;   // 449 bits max (protodec.c:1024)
 constexpr int CAND_HDR = 2;          // [0] nbits | valid flag, [1] end_bit
-constexpr int CAND_WORDS = 18;       // header + 15 buffer words, padded to 72 bytes
+constexpr int CAND_WORDS = 20;       // header + 17 raw words (449 frame bits + stuffing) = 80 bytes
 struct HdlcLaunch {
     const uint32_t *segbits;  // as above
     const uint32_t *segcnt;

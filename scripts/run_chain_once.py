@@ -11,6 +11,6 @@ for k, v in os.environ.items():
     if k.startswith("OPT_"):
         b.set_option(k[4:], int(v))
 for it in range(int(os.environ.get("ITERS", 3))):
-    b.run(x, sync=False); b.discard_frames()
+    b.run(x, sync=(os.environ.get("SYNC","1")=="1")); b.discard_frames()
 torch.cuda.synchronize()
 print("received", b.total_received())

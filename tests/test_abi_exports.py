@@ -72,3 +72,34 @@ def test_product_never_touches_the_oracle():
                     if re.search(r"ais_oracle|oracle_lib|libgnuais_ref|oracle/", txt):
                         bad.append(os.path.join(d, f))
     assert not bad, bad
+
+
+def test_dropin_c_file_compiles_standalone_and_in_tree(tmp_path):
+    """gnuais_amd/csrc/receiver_hip.c is plain C against the public ABI header, and
+    (where the reference tree is present) against the reference's own headers."""
+    src = os.path.join(ROOT, "gnuais_amd", "csrc", "receiver_hip.c")
+    inc = os.path.join(ROOT, "include")
+    subprocess.check_call(["gcc", "-std=gnu11", "-Wall", "-Werror", "-I", inc, "-c", src, "-o",
+                           str(tmp_path / "a.o")])
+    ref = "/root/reference"
+    if os.path.isdir(os.path.join(ref, "src")):
+        subprocess.check_call(["cmake", f"-DREF={ref}", f"-DOUT={tmp_path}", "-P",
+                               os.path.join(ROOT, "oracle", "gen_config.cmake")],
+                              stdout=subprocess.DEVNULL)
+        subprocess.check_call(["gcc", "-std=gnu11", "-w", "-fcommon", "-DGNUAIS_TREE", "-I", inc,
+                               "-I", str(tmp_path), "-I", os.path.join(ref, "src"), "-c", src,
+                               "-o", str(tmp_path / "b.o")])
+
+
+def test_public_struct_layout_matches_reference_sizes():
+    """SURVEY section 4 probe: sizeof(struct receiver) = 56, demod_state_t = 144."""
+    import tempfile
+    code = ('#include <stdio.h>\n#include "gnuais_receiver_abi.h"\n'
+            'int main(void){printf("%zu %zu\\n", sizeof(struct receiver), '
+            'sizeof(struct demod_state_t));return 0;}\n')
+    with tempfile.TemporaryDirectory() as d:
+        open(os.path.join(d, "s.c"), "w").write(code)
+        subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), os.path.join(d, "s.c"),
+                               "-o", os.path.join(d, "s")])
+        out = subprocess.check_output([os.path.join(d, "s")]).decode().split()
+    assert out == ["56", "144"]

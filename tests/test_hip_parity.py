@@ -340,3 +340,25 @@ def test_reset_restores_initial_state():
     b.reset()
     b.run(dev(x))
     assert b.drain_frames().tobytes() == frames_of(g["frames"]).tobytes()
+
+
+def test_dropin_receiver_run_matches_golden(tmp_path):
+    """The C drop-in (init_receiver/receiver_run/free_receiver over the C ABI) driven
+    like src/ais.c drives the reference: stereo raw file, 1020-frame chunks."""
+    import subprocess
+    exe = os.path.join(os.path.dirname(G), "c", "dropin_main.bin")
+    assert os.path.exists(exe), "build it with __graft_entry__.build()"
+    g = load("chain_48k")
+    raw = tmp_path / "stereo.raw"
+    g["x"].astype("<i2").tofile(raw)
+    out = subprocess.check_output([exe, str(raw)]).decode().splitlines()
+    want = frames_of(g["frames"])
+    lines = [l for l in out if l.startswith("ch ")]
+    got = sorted((l.split()[1], int(l.split()[3]), l.split()[5]) for l in lines)
+    exp = sorted(("AB"[int(f["channel"])], int(f["nbits"]),
+                  bytes(f["payload"][: f["nbits"] // 8]).hex()) for f in want)
+    assert got == exp
+    # per-buffer order: receiver A's frames before receiver B's, each in time order
+    cnt = g["counters"]
+    assert out[-2] == f"A: received {cnt[0][0]} lost {cnt[0][1]} lost2 {cnt[0][2]}"
+    assert out[-1] == f"B: received {cnt[1][0]} lost {cnt[1][1]} lost2 {cnt[1][2]}"
