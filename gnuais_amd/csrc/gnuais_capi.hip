@@ -87,7 +87,7 @@ struct gnuais_batch {
     // options
     int fir_T = 512;
     int fir_variant = 0;            // 0 scalar VALU, 1 packed VALU
-    int hdlc_lpw = 8;               // channels per wave in K2b
+    int hdlc_lpw = 64;              // channels per wave in K2b
     bool timing = false;
     hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     int last_k = 0;

@@ -135,179 +135,208 @@ __global__ __launch_bounds__(64) void hdlc_deframe_kernel(
             for (int q = 0; q < PACK_MAX; ++q) pf[q] = (q < seg_words) ? nrow[q] : 0u;
         }
         int pos = 0;
-        while (pos < tile_end) {
-            const int lw = pos >> 5, sh = pos & 31;
-            const uint32_t lo = lds_pack[lw * tpb + tx], hi = lds_pack[(lw + 1) * tpb + tx];
-            const uint32_t W = sh ? ((lo >> sh) | (hi << (32 - sh))) : lo;   // bit j = x[pos+j]
-            const int nv = (tile_end - pos < 32) ? tile_end - pos : 32;
-            const uint32_t vm = lowmask(nv);
+        // A wave executes the union of what its lanes do, so the walk is batched by
+        // mode: all lanes hunting for a preamble advance together, then all lanes
+        // matching a flag, then all lanes inside a frame.  Every step is closed-form
+        // (no per-bit loop anywhere), and an iteration runs exactly one mode's code.
+#define FETCH_WINDOW()                                                                          \
+        const int lw = pos >> 5, sh = pos & 31;                                                 \
+        const uint32_t lo = lds_pack[lw * tpb + tx], hi = lds_pack[(lw + 1) * tpb + tx];        \
+        const uint32_t W = sh ? ((lo >> sh) | (hi << (32 - sh))) : lo; /* bit j = x[pos+j] */  \
+        const int nv = (tile_end - pos < 32) ? tile_end - pos : 32
 
-            if (state == ST_SKURR) {
-                // protodec.c:1030-1043, up to nv bits at once.  A bit j = x_j != x_{j-1}.
-                const uint32_t A = W ^ ((W << 1) | last);
-                const uint32_t B2 = A & (A << 1), B4 = B2 & (B2 << 2), B8 = B4 & (B4 << 4);
-                const uint32_t B15 = B8 & (B8 << 7);          // 15 alternations inside the window
-                const int t = ctz32(~A);                       // alternation run from the window start
-                const int need = 14 - antallpreamble;          // run continues the carried count
-                const uint32_t C = lowmask(t) & ~lowmask(need > 0 ? need : 0);
-                const uint32_t TR = (B15 | C) & ~W & vm;       // antallpreamble > 14 && x == 0
-                if (TR) {
-                    pos += ctz32(TR) + 1;
-                    state = ST_PREAMBLE;
-                    antallpreamble = 0;
-                    last = 0;
-                } else {
-                    pos += nv;
-                    last = (W >> (nv - 1)) & 1u;
-                    int ap = (t >= nv) ? antallpreamble + nv : clz32(~(A << (32 - nv)));
-                    antallpreamble = ap > 15 ? 15 : ap;
-                }
-            } else if (state == ST_DATA) {
-                if (bitstuff) {                                // protodec.c:996-1007
-                    const uint32_t x = W & 1u;
-                    if (x) {
-                        state = ST_STOPSIGN;                   // sixth 1: closing flag (or abort)
-                    } else {                                   // stuffed 0: stays in the raw record
-                        if ((rawpos & 31) == 31) {
-                            if (rec_ok) rec[CAND_HDR + (rawpos >> 5)] = cur;
-                            cur = 0;
-                        }
-                        ++rawpos;
-                    }
-                    bitstuff = 0;
-                    last = x;
-                    pos += 1;
-                } else {                                       // protodec.c:1008-1027
-                    // m = run of 1s ending at the previous bit (antallenner = m-1 when last = 1)
-                    const int m = last ? antallenner + 1 : 0;
-                    const int room = 449 - bufferpos;          // protodec.c:1024
-                    int nw = nv;
-                    if (nw > 32 - m) nw = 32 - m;
-                    if (nw > room) nw = room;                  // bufferpos can reach 449 only at
-                                                               // the last bit of this step
-                    const int nvE = nw + m;
-                    const uint32_t vmE = lowmask(nvE);
-                    // E: the carried 1s, then the window; bit j = raw bit j-m
-                    const uint32_t E = ((W << m) | lowmask(m)) & vmE;
-                    const uint32_t X1 = E & (E >> 1), X2 = X1 & (X1 >> 2);
-                    const uint32_t R5 = X2 & (E >> 4);         // five 1s starting at bit j
-                    const uint32_t S5 = R5 & ~(E << 1);        // ... that begin a run
-                    const uint32_t P5 = S5 << 4;               // position of the run's fifth 1
-                    const uint32_t nx = E >> 1, kn = vmE >> 1; // next bit / next bit is inside
-                    const uint32_t END5 = P5 & nx & kn;        // followed by a sixth 1: closing flag
-                    const uint32_t STF5 = P5 & ~nx & kn;       // followed by a 0: stuffing, dropped
-                    const uint32_t PND5 = P5 & ~kn;            // fifth 1 is the last bit seen
-                    int nraw, stored;
-                    if (END5) {
-                        const int pe = ctz32(END5);
-                        nraw = pe + 1 - m;                     // raw bits up to the fifth 1
-                        stored = nraw - __popc(STF5 & lowmask(pe));
+        while (__any(pos < tile_end)) {
+            // ---- ST_SKURR: protodec.c:1030-1043, up to 32 bits per step -------------
+            while (__any(pos < tile_end && state == ST_SKURR)) {
+                if (pos < tile_end && state == ST_SKURR) {
+                    FETCH_WINDOW();
+                    const uint32_t vm = lowmask(nv);
+                    const uint32_t A = W ^ ((W << 1) | last);      // bit j: x_j != x_{j-1}
+                    const uint32_t B2 = A & (A << 1), B4 = B2 & (B2 << 2), B8 = B4 & (B4 << 4);
+                    const uint32_t B15 = B8 & (B8 << 7);           // 15 alternations inside the window
+                    const int t = ctz32(~A);                        // alternation run from the window start
+                    const int need = 14 - antallpreamble;           // run continues the carried count
+                    const uint32_t C = lowmask(t) & ~lowmask(need > 0 ? need : 0);
+                    const uint32_t TR = (B15 | C) & ~W & vm;        // antallpreamble > 14 && x == 0
+                    if (TR) {
+                        pos += ctz32(TR) + 1;
+                        state = ST_PREAMBLE;
+                        antallpreamble = 0;
+                        last = 0;
                     } else {
-                        nraw = nw;
-                        stored = nw - __popc(STF5);
-                    }
-                    // raw record [rawpos .. rawpos+nraw) = x[pos .. pos+nraw)
-                    {
-                        const uint32_t sb = W & lowmask(nraw);
-                        const int bsh = rawpos & 31;
-                        const uint64_t t64 = (uint64_t) sb << bsh;
-                        cur |= (uint32_t) t64;
-                        if (bsh + nraw >= 32) {
-                            if (rec_ok) rec[CAND_HDR + (rawpos >> 5)] = cur;
-                            cur = (uint32_t) (t64 >> 32);
-                        }
-                        rawpos += nraw;
-                    }
-                    bufferpos += stored;
-                    if (END5) {
-                        pos += nraw + 1;                       // ... and the sixth 1
-                        state = ST_STOPSIGN;
-                        antallenner = 0;
-                        last = 1;
-                    } else {
-                        pos += nraw;
-                        const uint32_t xl = (W >> (nraw - 1)) & 1u;
-                        if (bufferpos >= 449) {                // give up the frame
-                            if (rec_ok) rec[0] = 0;
-                            HDLC_RESET();
-                            last = xl;
-                        } else if (PND5) {                     // next bit is stuffing or flag
-                            bitstuff = 1;
-                            antallenner = 0;
-                            last = 1;
-                        } else {
-                            const int r = clz32(~(E << (32 - nvE)));   // run of 1s at the end
-                            last = xl;
-                            antallenner = r > 0 ? r - 1 : 0;
-                        }
+                        pos += nv;
+                        last = (W >> (nv - 1)) & 1u;
+                        const int ap = (t >= nv) ? antallpreamble + nv : clz32(~(A << (32 - nv)));
+                        antallpreamble = ap > 15 ? 15 : ap;
                     }
                 }
-            } else {
-                // ST_PREAMBLE / ST_STARTSIGN / ST_STOPSIGN: bit by bit, in one step
-                int k = 0;
-                if (state == ST_PREAMBLE && nstartsign == 0) {
-                    // the alternating part of the training sequence, all at once
-                    const uint32_t A = W ^ ((W << 1) | last);
-                    int t = ctz32(~A);
-                    if (t > nv) t = nv;
-                    if (t > 0) {
-                        antallpreamble = antallpreamble + t > 15 ? 15 : antallpreamble + t;
-                        last = (W >> (t - 1)) & 1u;
-                        k = t;
-                    }
-                }
-                while (k < nv && state != ST_SKURR && state != ST_DATA) {
-                    const uint32_t x = (W >> k) & 1u;
-                    if (state == ST_PREAMBLE) {                // protodec.c:1045-1072
-                        if (x != last && nstartsign == 0) {
-                            if (antallpreamble < 15) ++antallpreamble;
-                        } else if (x == 1) {
-                            if (nstartsign == 0) nstartsign = 3;
-                            else if (nstartsign == 5) { nstartsign = 6; antallpreamble = 0; state = ST_STARTSIGN; }
-                            else ++nstartsign;
-                        } else {
-                            if (nstartsign == 0) nstartsign = 1;
-                            else HDLC_RESET();
-                        }
-                    } else if (state == ST_STARTSIGN) {        // protodec.c:1074-1093
-                        if (nstartsign >= 7) {
-                            if (x == 0) {
-                                state = ST_DATA; nstartsign = 0; antallenner = 0;
-                                bufferpos = 0; cur = 0; rawpos = 0;
-                                // open a candidate record for this frame
-                                rec_ok = (nstart - first) < (uint32_t) K;
-                                rec = cand + ((size_t) c * K + nstart % (uint32_t) K) * CAND_WORDS;
-                                if (rec_ok) rec[0] = 0; else flags[1] = 1;
-                                ++nstart;
-                            } else {
-                                HDLC_RESET();
-                            }
-                        } else if (x == 0) {
-                            HDLC_RESET();
-                        }
-                        ++nstartsign;                          // also after a reset
-                    } else if (state == ST_STOPSIGN) {         // protodec.c:1095-1115
+            }
+            // ---- ST_PREAMBLE / ST_STARTSIGN / ST_STOPSIGN ------------------------------
+            // protodec.c:1045-1115.  After the alternating training bits the machine only
+            // counts 1s: from PREAMBLE with nstartsign = k >= 1 (or STARTSIGN, k = 6, 7) it
+            // needs R = 7 - k more 1s and then a 0 to enter ST_DATA; a 0 among the first
+            // R-1 of them resets from PREAMBLE (nstartsign 0), a 0 at the R-th or a 1 after
+            // them resets from STARTSIGN (nstartsign 1 after its trailing ++).
+            while (__any(pos < tile_end && state != ST_SKURR && state != ST_DATA)) {
+                if (pos < tile_end && state != ST_SKURR && state != ST_DATA) {
+                    FETCH_WINDOW();
+                    int k = 0;
+                    if (state == ST_STOPSIGN) {                 // protodec.c:1095-1115
+                        const uint32_t x = W & 1u;
                         const int nb = bufferpos - 6 - 16;
                         if (x == 0 && nb > 0) {
                             if (rec_ok) {
                                 rec[CAND_HDR + (rawpos >> 5)] = cur;
-                                rec[1] = seenbase + (uint32_t) (pos + k);
+                                rec[1] = seenbase + (uint32_t) pos;
                                 rec[0] = (uint32_t) nb | CAND_VALID | ((uint32_t) rawpos << 17);
                             }
                         } else {
-                            ++lost2;                           // protodec.c:1112
+                            ++lost2;                            // protodec.c:1112
                             if (rec_ok) rec[0] = 0;
                         }
                         HDLC_RESET();
+                        last = x;                               // protodec.c:1119
+                        k = 1;
+                    } else if (state != ST_PREAMBLE && state != ST_STARTSIGN) {
+                        HDLC_RESET();                           // not a state: as the reference's
+                        last = W & 1u;                          // switch would fall through
+                        k = 1;
                     } else {
-                        HDLC_RESET();
+                        if (state == ST_PREAMBLE && nstartsign == 0) {
+                            // alternating part of the training sequence, all at once
+                            const uint32_t A = W ^ ((W << 1) | last);
+                            int t = ctz32(~A);
+                            if (t > nv) t = nv;
+                            if (t > 0) {
+                                antallpreamble = antallpreamble + t > 15 ? 15 : antallpreamble + t;
+                                last = (W >> (t - 1)) & 1u;
+                                k = t;
+                            }
+                            if (k < nv) {                       // first repeated bit
+                                const uint32_t x0 = (W >> k) & 1u;
+                                nstartsign = x0 ? 3 : 1;        // protodec.c:1052-1053 / 1065-1066
+                                last = x0;
+                                ++k;
+                            }
+                        }
+                        if (k < nv && nstartsign != 0) {
+                            const int R = 7 - nstartsign;       // 1s still needed, then a 0
+                            const int avail = nv - k;
+                            int L = ctz32(~(W >> k));           // run of 1s from bit k
+                            if (L > avail) L = avail;
+                            if (L >= R + 1) {                   // a 1 where the 0 had to be
+                                HDLC_RESET(); nstartsign = 1; last = 1; k += R + 1;
+                            } else if (L < avail) {             // the run ends on a visible 0
+                                if (L == R) {                   // protodec.c:1076-1082: ST_DATA
+                                    state = ST_DATA; nstartsign = 1; antallenner = 0; antallpreamble = 0;
+                                    bufferpos = 0; cur = 0; rawpos = 0; bitstuff = 0; last = 0;
+                                    rec_ok = (nstart - first) < (uint32_t) K;
+                                    rec = cand + ((size_t) c * K + nstart % (uint32_t) K) * CAND_WORDS;
+                                    if (rec_ok) rec[0] = 0; else flags[1] = 1;
+                                    ++nstart;
+                                } else if (L == R - 1) {        // 0 in ST_STARTSIGN (nstartsign 6)
+                                    HDLC_RESET(); nstartsign = 1; last = 0;
+                                } else {                        // 0 while still in ST_PREAMBLE
+                                    HDLC_RESET(); last = 0;
+                                }
+                                k += L + 1;
+                            } else {                            // only 1s left in this window
+                                nstartsign += L;
+                                if (nstartsign >= 6) { state = ST_STARTSIGN; antallpreamble = 0; }
+                                last = 1;
+                                k += L;
+                            }
+                        }
                     }
-                    last = x;                                  // protodec.c:1119
-                    ++k;
+                    pos += k;
                 }
-                pos += k;
+            }
+            // ---- ST_DATA: protodec.c:995-1028, up to 32 raw bits per step ----------------
+            while (__any(pos < tile_end && state == ST_DATA)) {
+                if (pos < tile_end && state == ST_DATA) {
+                    FETCH_WINDOW();
+                    if (bitstuff) {                             // protodec.c:996-1007
+                        const uint32_t x = W & 1u;
+                        if (x) {
+                            state = ST_STOPSIGN;                // sixth 1: closing flag (or abort)
+                        } else {                                // stuffed 0: stays in the raw record
+                            if ((rawpos & 31) == 31) {
+                                if (rec_ok) rec[CAND_HDR + (rawpos >> 5)] = cur;
+                                cur = 0;
+                            }
+                            ++rawpos;
+                        }
+                        bitstuff = 0;
+                        last = x;
+                        pos += 1;
+                    } else {                                    // protodec.c:1008-1027
+                        // m = run of 1s ending at the previous bit (antallenner = m-1 when last = 1)
+                        const int m = last ? antallenner + 1 : 0;
+                        const int room = 449 - bufferpos;       // protodec.c:1024
+                        int nw = nv;
+                        if (nw > 32 - m) nw = 32 - m;
+                        if (nw > room) nw = room;               // bufferpos can reach 449 only at
+                                                                // the last bit of this step
+                        const int nvE = nw + m;
+                        const uint32_t vmE = lowmask(nvE);
+                        // E: the carried 1s, then the window; bit j = raw bit j-m
+                        const uint32_t E = ((W << m) | lowmask(m)) & vmE;
+                        const uint32_t X1 = E & (E >> 1), X2 = X1 & (X1 >> 2);
+                        const uint32_t R5 = X2 & (E >> 4);      // five 1s starting at bit j
+                        const uint32_t S5 = R5 & ~(E << 1);     // ... that begin a run
+                        const uint32_t P5 = S5 << 4;            // position of the run's fifth 1
+                        const uint32_t nx = E >> 1, kn = vmE >> 1;
+                        const uint32_t END5 = P5 & nx & kn;     // followed by a sixth 1: closing flag
+                        const uint32_t STF5 = P5 & ~nx & kn;    // followed by a 0: stuffing, dropped
+                        const uint32_t PND5 = P5 & ~kn;         // fifth 1 is the last bit seen
+                        int nraw, stored;
+                        if (END5) {
+                            const int pe = ctz32(END5);
+                            nraw = pe + 1 - m;                  // raw bits up to the fifth 1
+                            stored = nraw - __popc(STF5 & lowmask(pe));
+                        } else {
+                            nraw = nw;
+                            stored = nw - __popc(STF5);
+                        }
+                        {   // raw record [rawpos .. rawpos+nraw) = x[pos .. pos+nraw)
+                            const uint32_t sb = W & lowmask(nraw);
+                            const int bsh = rawpos & 31;
+                            const uint64_t t64 = (uint64_t) sb << bsh;
+                            cur |= (uint32_t) t64;
+                            if (bsh + nraw >= 32) {
+                                if (rec_ok) rec[CAND_HDR + (rawpos >> 5)] = cur;
+                                cur = (uint32_t) (t64 >> 32);
+                            }
+                            rawpos += nraw;
+                        }
+                        bufferpos += stored;
+                        if (END5) {
+                            pos += nraw + 1;                    // ... and the sixth 1
+                            state = ST_STOPSIGN;
+                            antallenner = 0;
+                            last = 1;
+                        } else {
+                            pos += nraw;
+                            const uint32_t xl = (W >> (nraw - 1)) & 1u;
+                            if (bufferpos >= 449) {             // give up the frame
+                                if (rec_ok) rec[0] = 0;
+                                HDLC_RESET();
+                                last = xl;
+                            } else if (PND5) {                  // next bit is stuffing or flag
+                                bitstuff = 1;
+                                antallenner = 0;
+                                last = 1;
+                            } else {
+                                const int r = clz32(~(E << (32 - nvE)));   // run of 1s at the end
+                                last = xl;
+                                antallenner = r > 0 ? r - 1 : 0;
+                            }
+                        }
+                    }
+                }
             }
         }
+#undef FETCH_WINDOW
         seenbase += (uint32_t) tile_end;
     }
 #undef HDLC_RESET
@@ -448,7 +477,7 @@ __global__ __launch_bounds__(256) void hdlc_crc_kernel(
 
 hipError_t launch_hdlc_crc(const HdlcLaunch &a, hipStream_t stream)
 {
-    const int lpw = a.lanes_per_wave > 0 ? a.lanes_per_wave : 8;
+    const int lpw = a.lanes_per_wave > 0 ? a.lanes_per_wave : 64;
     if (a.seg_words > PACK_MAX) return hipErrorInvalidValue;
     hipLaunchKernelGGL(hdlc_deframe_kernel, dim3((a.N + lpw - 1) / lpw), dim3(lpw),
                        (PACK_MAX + 1) * lpw * sizeof(uint32_t), stream,
