@@ -25,7 +25,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.3 TB/s measured)
-VALU_PEAK_TOPS = 78.6          # 256 CU x 4 SIMD x 32 lanes/clk x 2.4 GHz, unfused fp32 ops
+VALU_PEAK_TOPS = 70.1          # measured on MI355X (scripts/ubench/valu_rate): 64 lanes per 0.935 ns
+                               # per SIMD x 1024 SIMDs, unfused v_mul_f32/v_add_f32
 
 
 def cpu_baseline(x_host, n_sample_ch, total):
@@ -96,19 +97,21 @@ def main():
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
-    rx0 = b.total_received()
 
-    # per-kernel durations from HIP events recorded by the library on this stream
+    # isolated kernel durations (one call at a time, nothing overlapping): context only
     b.set_timing(True)
-    kt = {"fir_slice": [], "pll_nrzi": [], "hdlc_crc": []}
+    iso = {k: [] for k in b.KERNELS}
     for _ in range(3):
         step()
         t = b.last_timing()
-        for k in kt:
-            kt[k].append(t[k])
-    b.set_timing(False)
-    rx_timing_steps = 3
+        for k in iso:
+            iso[k].append(t[k])
+    torch.cuda.synchronize()
+    rx0 = b.total_received()
 
+    # timed region: K steps, asynchronous; the library records HIP events around every
+    # kernel on the stream it is launched on (event ring), read back after the region
+    b.set_timing(True)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -120,26 +123,25 @@ def main():
         dist.barrier()
     dt = time.perf_counter() - t0
     rx1 = b.total_received()
+    live = b.mean_timing()
+    b.set_timing(False)
+    msgs = float(rx1 - rx0)
     if world > 1:
-        tt = torch.tensor([dt], device=device, dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
-        mm = torch.tensor([float(rx1 - rx0)], device=device, dtype=torch.float64)
-        dist.all_reduce(mm, op=dist.ReduceOp.SUM)
-        msgs = float(mm.item())
-    else:
-        msgs = float(rx1 - rx0)
-    msgs_per_step = msgs / (args.steps + rx_timing_steps)
+        from gnuais_amd.shard import reduce_bench
+        dt, msgs, _ = reduce_bench(dist, device, dt, msgs, float(n_ch * total * args.steps))
+    msgs_per_step = msgs / args.steps
 
     if rank == 0:
         samples = float(world) * n_ch * total * args.steps
         value = samples / dt / 1e6
-        kavg = {k: float(np.mean(v)) for k, v in kt.items()}
+        kavg = {k: float(live[k]) for k in b.KERNELS}
+        kiso = {k: float(np.mean(v)) for k, v in iso.items()}
         dom = max(kavg, key=kavg.get)
         # algorithmic bytes of one launch: every int16 sample read once
         # by K1; K2a/K2b consume K1's 1-bit/sample and ~0.2-bit/sample streams
-        alg = {"fir_slice": n_ch * total * 2.0, "pll_nrzi": n_ch * total / 8.0,
-               "hdlc_crc": n_ch * total * 0.2 / 8.0}
+        alg = {"fir_slice": n_ch * total * 2.0, "pll_core": n_ch * total / 8.0,
+               "nrzi_extract": n_ch * total / 4.0, "hdlc_deframe": n_ch * total * 0.2 / 8.0,
+               "hdlc_crc": msgs_per_step * 80.0}
         ach = alg[dom] / (kavg[dom] * 1e-3) / 1e9
         out = {
             "metric": "Msamples/s demodulated (full chain, N-channel 48 kHz batch)",
@@ -151,14 +153,16 @@ def main():
                                    "incl. HDLC/CRC-16",
                        "channels_per_gpu": n_ch, "samples_per_channel": total,
                        "parallelism": f"channels sharded over {world} GPU(s), no collectives"},
-            "valid_crc_msgs_per_s": msgs_per_step * args.steps / dt,
+            "valid_crc_msgs_per_s": msgs / dt,
             "x_realtime_channels": value / 0.048,
-            "kernel_ms": kavg,
+            "kernel_ms": kavg, "kernel_ms_isolated": kiso, "kernel_ms_calls": int(live["calls"]),
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None,
                          "algorithmic_bytes_per_launch": alg[dom],
-                         "fir_valu_frac": (n_ch * total * 64.0 / (kavg["fir_slice"] * 1e-3) / 1e12)
-                                          / VALU_PEAK_TOPS},
+                         "achieved_isolated": alg[dom] / (kiso[dom] * 1e-3) / 1e9,
+                         "valu_ops_per_sample": 48,
+                         "valu_frac_isolated": (n_ch * total * 48.0 / (kiso["fir_slice"] * 1e-3)
+                                                / 1e12) / VALU_PEAK_TOPS},
         }
         if world == 1 and not args.no_cpu:
             out["cpu_baseline"] = cpu_baseline(x[:, : args.cpu_channels].cpu().numpy(),

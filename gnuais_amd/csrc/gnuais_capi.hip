@@ -89,7 +89,11 @@ struct gnuais_batch {
     int fir_variant = 0;            // 0 scalar VALU, 1 packed VALU
     int hdlc_lpw = 64;              // channels per wave in K2b
     bool timing = false;
-    hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    // timing: a ring of per-call event sets so that kernel durations can be read back
+    // for every call of a timed region, not just the last one
+    static constexpr int TIMING_RING = 64;
+    hipEvent_t evr[TIMING_RING][8] = {};   // 0,1 K1 | 2,6,3 K2a,K2x | 5,7,4 K2b,K3
+    unsigned long long timed_calls = 0;
     int last_k = 0;
     bool timed_last = false;
     hipStream_t last_stream = nullptr;
@@ -127,8 +131,9 @@ void gnuais_batch_destroy(gnuais_batch *b)
                     b->frame_count, b->counters, b->maxval, b->frames, b->d_taps, b->stage_x};
     for (void *p : ptrs)
         if (p) (void) hipFree(p);
-    for (auto &e : b->ev)
-        if (e) (void) hipEventDestroy(e);
+    for (auto &set : b->evr)
+        for (auto &e : set)
+            if (e) (void) hipEventDestroy(e);
     for (int k = 0; k < 2; ++k) {
         if (b->e_fir[k]) (void) hipEventDestroy(b->e_fir[k]);
         if (b->e_pll[k]) (void) hipEventDestroy(b->e_pll[k]);
@@ -217,8 +222,9 @@ int gnuais_batch_create(gnuais_batch **out, int device, int n_channels, const fl
     alloc((void **) &b->d_taps, sizeof(float) * b->NT);
     if (e == hipSuccess)
         e = hipMemcpy(b->d_taps, b->taps.data(), sizeof(float) * b->NT, hipMemcpyHostToDevice);
-    for (auto &ev : b->ev)
-        if (e == hipSuccess) e = hipEventCreate(&ev);
+    for (auto &set : b->evr)
+        for (auto &ev : set)
+            if (e == hipSuccess) e = hipEventCreate(&ev);
     for (int k = 0; k < 2; ++k) {
         if (e == hipSuccess) e = hipEventCreateWithFlags(&b->e_fir[k], hipEventDisableTiming);
         if (e == hipSuccess) e = hipEventCreateWithFlags(&b->e_pll[k], hipEventDisableTiming);
@@ -319,6 +325,7 @@ static void fill_hdlc(const gnuais_batch *b, HdlcLaunch &h, int k)
     h.frame_cap = (uint32_t) b->frame_cap; h.N = b->N; h.n_seg = b->n_seg;
     h.seg_words = b->seg_words; h.K = b->cand_K;
     h.lanes_per_wave = b->hdlc_lpw;
+    h.ev_mid = nullptr;
 }
 
 static int run_fir(gnuais_batch *b, const int16_t *x, int len, float *dump, hipStream_t s, int k)
@@ -354,12 +361,13 @@ int gnuais_batch_run(gnuais_batch *b, const int16_t *d_samples, int len, void *s
     hipStream_t s1 = b->pipeline ? b->s_pll : s0, s2 = b->pipeline ? b->s_hdlc : s0;
     const int k = (int) (b->calls & 1);           // hand-off buffer pair of this call
     const bool tm = b->timing;
+    hipEvent_t *ev = b->evr[b->timed_calls % gnuais_batch::TIMING_RING];
 
     // K1: needs sgn[k] free again, i.e. the K2a/K2x of call i-2 finished
     if (b->pipeline && b->calls >= 2) HIP_TRY(hipStreamWaitEvent(s0, b->e_pll[k], 0));
-    if (tm) HIP_TRY(hipEventRecord(b->ev[0], s0));
+    if (tm) HIP_TRY(hipEventRecord(ev[0], s0));
     if (int rc = run_fir(b, d_samples, len, nullptr, s0, k)) return rc;
-    if (tm) HIP_TRY(hipEventRecord(b->ev[1], s0));
+    if (tm) HIP_TRY(hipEventRecord(ev[1], s0));
     if (int rc = run_history(b, d_samples, len, s0)) return rc;
     if (b->pipeline) HIP_TRY(hipEventRecord(b->e_fir[k], s0));
 
@@ -372,21 +380,24 @@ int gnuais_batch_run(gnuais_batch *b, const int16_t *d_samples, int len, void *s
     p.sgn = b->sgn[k]; p.ovf = b->ovf; p.pll = b->pll; p.lastbit = b->lastbit;
     p.segbits = b->segbits[k]; p.segcnt = b->segcnt[k];
     p.N = b->N; p.L = len; p.n_seg = b->n_seg; p.seg_words = b->seg_words; p.pllinc = b->pllinc;
-    if (tm) HIP_TRY(hipEventRecord(b->ev[2], s1));
+    p.ev_mid = tm ? ev[6] : nullptr;
+    if (tm) HIP_TRY(hipEventRecord(ev[2], s1));
     HIP_TRY(launch_pll_nrzi(p, s1));
-    if (tm) HIP_TRY(hipEventRecord(b->ev[3], s1));
+    if (tm) HIP_TRY(hipEventRecord(ev[3], s1));
     if (b->pipeline) HIP_TRY(hipEventRecord(b->e_pll[k], s1));
 
     // K2b + K3
     if (b->pipeline) HIP_TRY(hipStreamWaitEvent(s2, b->e_pll[k], 0));
     HdlcLaunch h;
     fill_hdlc(b, h, k);
-    if (tm) HIP_TRY(hipEventRecord(b->ev[5], s2));
+    h.ev_mid = tm ? ev[7] : nullptr;
+    if (tm) HIP_TRY(hipEventRecord(ev[5], s2));
     HIP_TRY(launch_hdlc_crc(h, s2));
-    if (tm) HIP_TRY(hipEventRecord(b->ev[4], s2));
+    if (tm) HIP_TRY(hipEventRecord(ev[4], s2));
     if (b->pipeline) HIP_TRY(hipEventRecord(b->e_hdlc[k], s2));
 
     b->timed_last = tm;
+    if (tm) b->timed_calls++;
     b->last_stream = s0;
     b->last_len = len;
     b->last_k = k;
@@ -637,18 +648,46 @@ int gnuais_batch_set_timing(gnuais_batch *b, int on)
 {
     if (!b) return fail(GNUAIS_E_ARG, "set_timing: NULL batch");
     b->timing = on != 0;
+    if (on) b->timed_calls = 0;
     return GNUAIS_OK;
 }
 
-int gnuais_batch_last_timing(gnuais_batch *b, float *ms4)
+// ms[0] K1 fir_slice  [1] K2a pll_core  [2] K2x nrzi_extract (+ lastbit)
+// [3] K2b hdlc_deframe  [4] K3 hdlc_crc  [5] first event to last event of the call
+static int timing_of(gnuais_batch *b, unsigned long long call, float *ms)
 {
-    if (!b || !ms4) return fail(GNUAIS_E_ARG, "last_timing: argument");
-    if (!b->timed_last) return fail(GNUAIS_E_STATE, "last_timing: timing was not enabled for the last run");
+    hipEvent_t *ev = b->evr[call % gnuais_batch::TIMING_RING];
+    HIP_TRY(hipEventElapsedTime(&ms[0], ev[0], ev[1]));
+    HIP_TRY(hipEventElapsedTime(&ms[1], ev[2], ev[6]));
+    HIP_TRY(hipEventElapsedTime(&ms[2], ev[6], ev[3]));
+    HIP_TRY(hipEventElapsedTime(&ms[3], ev[5], ev[7]));
+    HIP_TRY(hipEventElapsedTime(&ms[4], ev[7], ev[4]));
+    HIP_TRY(hipEventElapsedTime(&ms[5], ev[0], ev[4]));
+    return GNUAIS_OK;
+}
+
+int gnuais_batch_last_timing(gnuais_batch *b, float *ms6)
+{
+    if (!b || !ms6) return fail(GNUAIS_E_ARG, "last_timing: argument");
+    if (!b->timed_calls) return fail(GNUAIS_E_STATE, "last_timing: no timed run");
     if (int rc = gnuais_batch_sync(b)) return rc;
-    HIP_TRY(hipEventElapsedTime(&ms4[0], b->ev[0], b->ev[1]));
-    HIP_TRY(hipEventElapsedTime(&ms4[1], b->ev[2], b->ev[3]));
-    HIP_TRY(hipEventElapsedTime(&ms4[2], b->ev[5], b->ev[4]));
-    HIP_TRY(hipEventElapsedTime(&ms4[3], b->ev[0], b->ev[4]));
+    return timing_of(b, b->timed_calls - 1, ms6);
+}
+
+int gnuais_batch_mean_timing(gnuais_batch *b, float *ms4, int *n_calls)
+{
+    if (!b || !ms4 || !n_calls) return fail(GNUAIS_E_ARG, "mean_timing: argument");
+    if (!b->timed_calls) return fail(GNUAIS_E_STATE, "mean_timing: no timed run");
+    if (int rc = gnuais_batch_sync(b)) return rc;
+    const unsigned long long n = std::min<unsigned long long>(b->timed_calls, gnuais_batch::TIMING_RING);
+    double acc[6] = {0, 0, 0, 0, 0, 0};
+    for (unsigned long long i = 0; i < n; ++i) {
+        float t[6];
+        if (int rc = timing_of(b, b->timed_calls - 1 - i, t)) return rc;
+        for (int q = 0; q < 6; ++q) acc[q] += t[q];
+    }
+    for (int q = 0; q < 6; ++q) ms4[q] = (float) (acc[q] / (double) n);
+    *n_calls = (int) n;
     return GNUAIS_OK;
 }
 

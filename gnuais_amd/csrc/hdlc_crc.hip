@@ -485,6 +485,7 @@ hipError_t launch_hdlc_crc(const HdlcLaunch &a, hipStream_t stream)
                        a.frame_count, a.N, a.n_seg, a.seg_words, a.K);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
+    if (a.ev_mid) (void) hipEventRecord(a.ev_mid, stream);
     hipLaunchKernelGGL(hdlc_crc_kernel, dim3((unsigned) ((a.N + K3_CH - 1) / K3_CH)), dim3(256), 0,
                        stream, a.cand, a.cand_first, a.cand_count, a.counters,
                        (uint32_t *) a.frames, a.frame_count, a.frame_cap, a.N, a.K);

@@ -34,6 +34,7 @@ struct PllLaunch {
     uint32_t *segcnt;      // [N][n_seg] bits in each pack
     int N, L, n_seg, seg_words;
     uint32_t pllinc;
+    hipEvent_t ev_mid;     // optional: recorded between K2a and K2x
 };
 hipError_t launch_pll_nrzi(const PllLaunch &a, hipStream_t stream);
 
@@ -55,6 +56,7 @@ struct HdlcLaunch {
     uint32_t frame_cap;
     int N, n_seg, seg_words, K;
     int lanes_per_wave;    // channels per wave in K2b (blockDim)
+    hipEvent_t ev_mid;     // optional: recorded between K2b and K3
 };
 hipError_t launch_hdlc_crc(const HdlcLaunch &a, hipStream_t stream);
 hipError_t launch_hdlc_reset(uint32_t *ctl, int N, hipStream_t stream);

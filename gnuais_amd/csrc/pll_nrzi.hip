@@ -213,6 +213,7 @@ hipError_t launch_pll_nrzi(const PllLaunch &a, hipStream_t stream)
                        a.N, a.L, a.pllinc);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
+    if (a.ev_mid) (void) hipEventRecord(a.ev_mid, stream);
     hipLaunchKernelGGL(nrzi_extract_kernel, dim3(groups, a.n_seg), dim3(64), 0, stream, a.sgn,
                        a.ovf, a.lastbit, a.segbits, a.segcnt, a.N, a.L, a.n_seg, a.seg_words);
     e = hipGetLastError();

@@ -162,13 +162,23 @@ class ReceiverBatch:
         return out
 
     # -- timing ---------------------------------------------------------------
+    KERNELS = ("fir_slice", "pll_core", "nrzi_extract", "hdlc_deframe", "hdlc_crc")
+
     def set_timing(self, on: bool):
         check(self._lib.gnuais_batch_set_timing(self._h, int(on)))
 
+    def mean_timing(self):
+        ms = (C.c_float * 6)()
+        n = C.c_int()
+        check(self._lib.gnuais_batch_mean_timing(self._h, ms, C.byref(n)))
+        d = dict(zip(self.KERNELS + ("total",), ms))
+        d["calls"] = n.value
+        return d
+
     def last_timing(self):
-        ms = (C.c_float * 4)()
+        ms = (C.c_float * 6)()
         check(self._lib.gnuais_batch_last_timing(self._h, ms))
-        return {"fir_slice": ms[0], "pll_nrzi": ms[1], "hdlc_crc": ms[2], "total": ms[3]}
+        return dict(zip(self.KERNELS + ("total",), ms))
 
 
 def crc16_batch(messages, device: int = 0) -> np.ndarray:

@@ -131,11 +131,16 @@ int  gnuais_crc16_batch(int device, const uint8_t *h_data, int stride, const int
 /* benchmark input builder: d_out[l][c] = d_base[c % n_base][(l + (c * 7919) % len) % len] */
 int  gnuais_tile_channels(const int16_t *d_base, int n_base, int len, int16_t *d_out,
 			  int n_channels, void *stream);
-/* per-kernel timing of the last run (HIP events on the run's stream), ms:
- * [0] FIR+slice  [1] PLL+NRZI  [2] HDLC+CRC  [3] whole run.  Needs
- * gnuais_batch_set_timing(b, 1) before the run. */
+/* per-kernel timing of the last run (HIP events recorded on the stream each
+ * kernel is launched on), ms[6]: [0] K1 fir_slice  [1] K2a pll_core
+ * [2] K2x nrzi_extract  [3] K2b hdlc_deframe  [4] K3 hdlc_crc  [5] whole call.
+ * Needs gnuais_batch_set_timing(b, 1) before the run. */
 int  gnuais_batch_set_timing(gnuais_batch *b, int on);
-int  gnuais_batch_last_timing(gnuais_batch *b, float *ms4);
+int  gnuais_batch_last_timing(gnuais_batch *b, float *ms6);
+/* mean over the (up to 64) most recent timed runs since set_timing(b, 1); with the
+ * stage pipeline on, these are the durations WHILE the stages of neighbouring
+ * calls overlap */
+int  gnuais_batch_mean_timing(gnuais_batch *b, float *ms6, int *n_calls);
 /* tunables: "fir_T" (outputs per wave in K1, multiple of 32), "fir_variant"
  * (0 = v_mul/v_add, 1 = v_pk_mul/v_pk_add build of K1), "hdlc_lpw" (channels
  * per wave in the deframer, 1..64) */
