@@ -55,6 +55,18 @@ def cpu_baseline(x_host, n_sample_ch, total):
             "kind": kind, "sample": sample, "seconds": round(dt, 2), "msgs": int(got)}
 
 
+def pmc_traffic(kernel):
+    """HBM bytes per launch of `kernel` from the committed PMC passes
+    (profiles/r01_pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs of this
+    same command; FETCH_SIZE doubled per MI355X_MICROARCH.md's gfx950 correction)."""
+    path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+    try:
+        with open(path) as f:
+            return float(json.load(f)["bytes_per_launch"][kernel])
+    except Exception:
+        return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -157,7 +169,7 @@ def main():
             "x_realtime_channels": value / 0.048,
             "kernel_ms": kavg, "kernel_ms_isolated": kiso, "kernel_ms_calls": int(live["calls"]),
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None,
+                         "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": pmc_traffic(dom),
                          "algorithmic_bytes_per_launch": alg[dom],
                          "achieved_isolated": alg[dom] / (kiso[dom] * 1e-3) / 1e9,
                          "valu_ops_per_sample": 48,
