@@ -90,6 +90,7 @@ template <int NE, bool DUMP, bool SYM>
 __global__ __launch_bounds__(64) void fir_slice_kernel(
     const int16_t *__restrict__ x, const int16_t *__restrict__ hist,
     uint32_t *__restrict__ sgn, float *__restrict__ dump, int *__restrict__ maxval,
+    int16_t *__restrict__ hist_out, int *__restrict__ maxval_next,
     int N, int L, int T, int d, int NT, FirTaps<NE> taps)
 {
     static_assert(NE == 32, "rotating accumulator file is sized for 32 effective taps");
@@ -295,6 +296,19 @@ __global__ __launch_bounds__(64) void fir_slice_kernel(
         }
     }
     if (live && peak > 0) atomicMax(&maxval[cg], peak);
+
+    // The wave that owns the end of the call also leaves the carry for the next
+    // one (filter.c:129-134 restated: the last NT input samples, oldest first, into
+    // the other history buffer) and clears the peak buffer the next call will use,
+    // so that one call is exactly one kernel on the caller's stream.
+    if (t1 == L && live) {
+        for (int k = 0; k < NT; ++k) {
+            const int m = L - NT + k;
+            hist_out[(size_t) k * (size_t) N + cg] =
+                (m >= 0) ? x[(size_t) m * (size_t) N + cg] : hist[(size_t) (NT + m) * (size_t) N + cg];
+        }
+        maxval_next[cg] = 0;
+    }
 }
 
 } // namespace FIR_VARIANT
@@ -394,7 +408,7 @@ hipError_t launch_fir_slice(const FirLaunch &a, hipStream_t stream)
 #endif
 #define FIR_LAUNCH(D, S)                                                                     \
     hipLaunchKernelGGL((fir_slice_kernel<32, D, S>), grid, block, 0, stream, a.x, a.hist, a.sgn, \
-                       a.dump, a.maxval, a.N, a.L, a.T, a.d, a.NT, t)
+                       a.dump, a.maxval, a.hist_out, a.maxval_next, a.N, a.L, a.T, a.d, a.NT, t)
     if (a.dump) { if (sym) FIR_LAUNCH(true, true); else FIR_LAUNCH(true, false); }
     else        { if (sym) FIR_LAUNCH(false, true); else FIR_LAUNCH(false, false); }
 #undef FIR_LAUNCH

@@ -63,23 +63,26 @@ struct gnuais_batch {
     int16_t *hist[2] = {nullptr, nullptr};
     int hist_cur = 0;
     uint32_t *sgn[2] = {nullptr, nullptr};      // K1 -> K2a/K2x hand-off, alternating per call
-    uint32_t *ovf = nullptr, *pll = nullptr, *lastbit = nullptr;
+    uint32_t *ovf[2] = {nullptr, nullptr};      // K2a -> K2x hand-off
+    uint32_t *pll = nullptr, *lastbit = nullptr;
     uint32_t *segbits[2] = {nullptr, nullptr};  // K2x -> K2b hand-off, alternating per call
     uint32_t *segcnt[2] = {nullptr, nullptr};
     int n_seg = 0, seg_words = 0;
-    // stage pipeline: K1 on the caller's stream, K2a+K2x on s_pll, K2b+K3 on s_hdlc, so
-    // that the sequential kernels of call i overlap the FIR of call i+1
-    hipStream_t s_pll = nullptr, s_hdlc = nullptr;
-    hipEvent_t e_fir[2] = {nullptr, nullptr};   // K1 of the call that filled sgn[k] is done
-    hipEvent_t e_pll[2] = {nullptr, nullptr};   // K2a/K2x that read sgn[k] / filled segbits[k] are done
-    hipEvent_t e_hdlc[2] = {nullptr, nullptr};  // K2b that read segbits[k] is done
+    // stage pipeline: K1 on the caller's stream and one internal stream per later
+    // kernel, so that the short-on-parallelism stages of call i overlap the FIR of
+    // call i+1 (and each other).  Every hand-off buffer exists twice (index = call & 1).
+    hipStream_t s_k[4] = {nullptr, nullptr, nullptr, nullptr};   // K2a, K2x, K2b, K3
+    hipEvent_t e_done[5][2] = {};               // e_done[s][k]: stage s of the call using pair k is done
+                                                // (0 K1, 1 K2a, 2 K2x, 3 K2b, 4 K3)
     unsigned long long calls = 0;
     bool pipeline = true;
-    uint32_t *ctl = nullptr, *cand = nullptr, *cand_first = nullptr, *cand_count = nullptr;
+    uint32_t *ctl = nullptr, *cand = nullptr;
+    uint32_t *cand_first[2] = {nullptr, nullptr}, *cand_count[2] = {nullptr, nullptr};  // K2b -> K3
     uint32_t *frame_count = nullptr;
     int cand_K = 64;
     int32_t *counters = nullptr;
-    int *maxval = nullptr;
+    int *maxval[2] = {nullptr, nullptr};   // ping-pong with the history buffers
+    int max_cur = 0, max_last = 0;
     gnuais_frame *frames = nullptr;
     float *d_taps = nullptr;
     int16_t *stage_x = nullptr;
@@ -92,7 +95,7 @@ struct gnuais_batch {
     // timing: a ring of per-call event sets so that kernel durations can be read back
     // for every call of a timed region, not just the last one
     static constexpr int TIMING_RING = 64;
-    hipEvent_t evr[TIMING_RING][8] = {};   // 0,1 K1 | 2,6,3 K2a,K2x | 5,7,4 K2b,K3
+    hipEvent_t evr[TIMING_RING][10] = {};  // 0,1 K1 | 2,6 K2a | 8,3 K2x | 5,7 K2b | 9,4 K3
     unsigned long long timed_calls = 0;
     int last_k = 0;
     bool timed_last = false;
@@ -125,22 +128,21 @@ void gnuais_batch_destroy(gnuais_batch *b)
 {
     if (!b) return;
     (void) hipSetDevice(b->device);
-    void *ptrs[] = {b->hist[0], b->hist[1], b->sgn[0], b->sgn[1], b->ovf, b->pll, b->lastbit,
-                    b->segbits[0], b->segbits[1], b->segcnt[0], b->segcnt[1], b->ctl, b->cand,
-                    b->cand_first, b->cand_count,
-                    b->frame_count, b->counters, b->maxval, b->frames, b->d_taps, b->stage_x};
+    void *ptrs[] = {b->hist[0], b->hist[1], b->sgn[0], b->sgn[1], b->ovf[0], b->ovf[1], b->pll,
+                    b->lastbit, b->segbits[0], b->segbits[1], b->segcnt[0], b->segcnt[1], b->ctl,
+                    b->cand, b->cand_first[0], b->cand_first[1], b->cand_count[0], b->cand_count[1],
+                    b->frame_count, b->counters, b->maxval[0], b->maxval[1], b->frames, b->d_taps,
+                    b->stage_x};
     for (void *p : ptrs)
         if (p) (void) hipFree(p);
     for (auto &set : b->evr)
         for (auto &e : set)
             if (e) (void) hipEventDestroy(e);
-    for (int k = 0; k < 2; ++k) {
-        if (b->e_fir[k]) (void) hipEventDestroy(b->e_fir[k]);
-        if (b->e_pll[k]) (void) hipEventDestroy(b->e_pll[k]);
-        if (b->e_hdlc[k]) (void) hipEventDestroy(b->e_hdlc[k]);
-    }
-    if (b->s_pll) (void) hipStreamDestroy(b->s_pll);
-    if (b->s_hdlc) (void) hipStreamDestroy(b->s_hdlc);
+    for (auto &pair : b->e_done)
+        for (auto &e : pair)
+            if (e) (void) hipEventDestroy(e);
+    for (auto &st : b->s_k)
+        if (st) (void) hipStreamDestroy(st);
     delete b;
 }
 
@@ -205,7 +207,11 @@ int gnuais_batch_create(gnuais_batch **out, int device, int n_channels, const fl
         alloc((void **) &b->segbits[k], sizeof(uint32_t) * N * (size_t) b->n_seg * b->seg_words);
         alloc((void **) &b->segcnt[k], sizeof(uint32_t) * N * (size_t) b->n_seg);
     }
-    alloc((void **) &b->ovf, sizeof(uint32_t) * N * (b->sgn_words + 2 * PLL_PAD));
+    for (int k = 0; k < 2; ++k) {
+        alloc((void **) &b->ovf[k], sizeof(uint32_t) * N * (b->sgn_words + 2 * PLL_PAD));
+        alloc((void **) &b->cand_first[k], sizeof(uint32_t) * N);
+        alloc((void **) &b->cand_count[k], sizeof(uint32_t) * N);
+    }
     alloc((void **) &b->pll, sizeof(uint32_t) * N);
     alloc((void **) &b->lastbit, sizeof(uint32_t) * N);
     alloc((void **) &b->ctl, sizeof(uint32_t) * N * HDLC_CTL_WORDS);
@@ -213,11 +219,10 @@ int gnuais_batch_create(gnuais_batch **out, int device, int n_channels, const fl
     // frame per 256 bit times; 64 slots per channel and call cover max_len <= 2^16
     b->cand_K = std::max(64, b->bits_words / 4);
     alloc((void **) &b->cand, sizeof(uint32_t) * N * (size_t) b->cand_K * CAND_WORDS);
-    alloc((void **) &b->cand_first, sizeof(uint32_t) * N);
-    alloc((void **) &b->cand_count, sizeof(uint32_t) * N);
     alloc((void **) &b->frame_count, sizeof(uint32_t) * 2);
     alloc((void **) &b->counters, sizeof(int32_t) * N * 3);
-    alloc((void **) &b->maxval, sizeof(int) * N);
+    alloc((void **) &b->maxval[0], sizeof(int) * N);
+    alloc((void **) &b->maxval[1], sizeof(int) * N);
     alloc((void **) &b->frames, sizeof(gnuais_frame) * (size_t) b->frame_cap);
     alloc((void **) &b->d_taps, sizeof(float) * b->NT);
     if (e == hipSuccess)
@@ -225,18 +230,16 @@ int gnuais_batch_create(gnuais_batch **out, int device, int n_channels, const fl
     for (auto &set : b->evr)
         for (auto &ev : set)
             if (e == hipSuccess) e = hipEventCreate(&ev);
-    for (int k = 0; k < 2; ++k) {
-        if (e == hipSuccess) e = hipEventCreateWithFlags(&b->e_fir[k], hipEventDisableTiming);
-        if (e == hipSuccess) e = hipEventCreateWithFlags(&b->e_pll[k], hipEventDisableTiming);
-        if (e == hipSuccess) e = hipEventCreateWithFlags(&b->e_hdlc[k], hipEventDisableTiming);
-    }
+    for (auto &pair : b->e_done)
+        for (auto &ev : pair)
+            if (e == hipSuccess) e = hipEventCreateWithFlags(&ev, hipEventDisableTiming);
     {
         // the sequential stages are short on parallelism, long on latency: give them
         // dispatch priority over the FIR's tens of thousands of workgroups
         int lo = 0, hi = 0;
         if (e == hipSuccess) e = hipDeviceGetStreamPriorityRange(&lo, &hi);
-        if (e == hipSuccess) e = hipStreamCreateWithPriority(&b->s_pll, hipStreamNonBlocking, hi);
-        if (e == hipSuccess) e = hipStreamCreateWithPriority(&b->s_hdlc, hipStreamNonBlocking, hi);
+        for (auto &st : b->s_k)
+            if (e == hipSuccess) e = hipStreamCreateWithPriority(&st, hipStreamNonBlocking, hi);
     }
     if (const char *v = getenv("GNUAIS_PIPELINE")) b->pipeline = atoi(v) != 0;
     if (const char *v = getenv("GNUAIS_HDLC_LPW")) b->hdlc_lpw = std::min(64, std::max(1, atoi(v)));
@@ -270,7 +273,9 @@ int gnuais_batch_reset(gnuais_batch *b)
         HIP_TRY(hipMemset(b->segcnt[k], 0, sizeof(uint32_t) * N * (size_t) b->n_seg));
     b->calls = 0;
     HIP_TRY(hipMemset(b->counters, 0, sizeof(int32_t) * N * 3));      // protodec.c:62-64
-    HIP_TRY(hipMemset(b->maxval, 0, sizeof(int) * N));
+    HIP_TRY(hipMemset(b->maxval[0], 0, sizeof(int) * N));
+    HIP_TRY(hipMemset(b->maxval[1], 0, sizeof(int) * N));
+    b->max_cur = 0;
     HIP_TRY(hipMemset(b->frame_count, 0, sizeof(uint32_t) * 2));
     HIP_TRY(launch_hdlc_reset(b->ctl, b->N, nullptr));                // protodec.c:87-100
     HIP_TRY(hipDeviceSynchronize());
@@ -306,7 +311,9 @@ static void fill_fir(const gnuais_batch *b, FirLaunch &f, const int16_t *x, int 
     f.hist = b->hist[b->hist_cur];
     f.sgn = b->sgn[k];
     f.dump = dump;
-    f.maxval = b->maxval;
+    f.maxval = b->maxval[b->max_cur];
+    f.hist_out = b->hist[b->hist_cur ^ 1];
+    f.maxval_next = b->maxval[b->max_cur ^ 1];
     f.d_taps = b->d_taps;
     memcpy(f.te, b->te, sizeof f.te);
     f.N = b->N;
@@ -320,35 +327,34 @@ static void fill_fir(const gnuais_batch *b, FirLaunch &f, const int16_t *x, int 
 static void fill_hdlc(const gnuais_batch *b, HdlcLaunch &h, int k)
 {
     h.segbits = b->segbits[k]; h.segcnt = b->segcnt[k]; h.ctl = b->ctl; h.cand = b->cand;
-    h.cand_first = b->cand_first; h.cand_count = b->cand_count;
+    h.cand_first = b->cand_first[k]; h.cand_count = b->cand_count[k];
     h.counters = b->counters; h.frames = b->frames; h.frame_count = b->frame_count;
     h.frame_cap = (uint32_t) b->frame_cap; h.N = b->N; h.n_seg = b->n_seg;
     h.seg_words = b->seg_words; h.K = b->cand_K;
     h.lanes_per_wave = b->hdlc_lpw;
-    h.ev_mid = nullptr;
 }
 
+// K1 + carry.  The specialised kernel updates the history and clears the next peak
+// buffer itself; the generic fallback needs the two helper launches.
 static int run_fir(gnuais_batch *b, const int16_t *x, int len, float *dump, hipStream_t s, int k)
 {
     FirLaunch f;
     fill_fir(b, f, x, len, dump, k);
-    HIP_TRY(hipMemsetAsync(b->maxval, 0, sizeof(int) * (size_t) b->N, s));
-    if (b->NE != 32)
+    if (b->NE != 32) {
+        HIP_TRY(hipMemsetAsync(b->maxval[b->max_cur ^ 1], 0, sizeof(int) * (size_t) b->N, s));
         HIP_TRY(launch_fir_generic(f, s));
-    else if (b->fir_variant == 1)
+        HIP_TRY(launch_fir_history(x, b->hist[b->hist_cur], b->hist[b->hist_cur ^ 1], b->N, len,
+                                   b->NT, s));
+    } else if (b->fir_variant == 1) {
         HIP_TRY(packed::launch_fir_slice(f, s));
-    else if (b->fir_variant == 2)
+    } else if (b->fir_variant == 2) {
         HIP_TRY(mfma::launch_fir_slice(f, s));
-    else
+    } else {
         HIP_TRY(scalar::launch_fir_slice(f, s));
-    return GNUAIS_OK;
-}
-
-static int run_history(gnuais_batch *b, const int16_t *x, int len, hipStream_t s)
-{
-    HIP_TRY(launch_fir_history(x, b->hist[b->hist_cur], b->hist[b->hist_cur ^ 1], b->N, len,
-                               b->NT, s));
+    }
     b->hist_cur ^= 1;
+    b->max_last = b->max_cur;
+    b->max_cur ^= 1;
     return GNUAIS_OK;
 }
 
@@ -358,43 +364,64 @@ int gnuais_batch_run(gnuais_batch *b, const int16_t *d_samples, int len, void *s
     if (len <= 0 || len > b->max_len) return fail(GNUAIS_E_ARG, "run: len out of range (max_len)");
     if (int rc = set_device(b)) return rc;
     hipStream_t s0 = (hipStream_t) stream;
-    hipStream_t s1 = b->pipeline ? b->s_pll : s0, s2 = b->pipeline ? b->s_hdlc : s0;
+    const bool pl = b->pipeline;
+    hipStream_t sA = pl ? b->s_k[0] : s0, sB = pl ? b->s_k[1] : s0;
+    hipStream_t sC = pl ? b->s_k[2] : s0, sD = pl ? b->s_k[3] : s0;
     const int k = (int) (b->calls & 1);           // hand-off buffer pair of this call
+    const bool reuse = pl && b->calls >= 2;       // pair k was last used by call i-2
     const bool tm = b->timing;
     hipEvent_t *ev = b->evr[b->timed_calls % gnuais_batch::TIMING_RING];
 
-    // K1: needs sgn[k] free again, i.e. the K2a/K2x of call i-2 finished
-    if (b->pipeline && b->calls >= 2) HIP_TRY(hipStreamWaitEvent(s0, b->e_pll[k], 0));
+    // K1 fills sgn[k]: its readers of call i-2 (K2a, K2x) must be done
+    if (reuse) {
+        HIP_TRY(hipStreamWaitEvent(s0, b->e_done[1][k], 0));
+        HIP_TRY(hipStreamWaitEvent(s0, b->e_done[2][k], 0));
+    }
     if (tm) HIP_TRY(hipEventRecord(ev[0], s0));
     if (int rc = run_fir(b, d_samples, len, nullptr, s0, k)) return rc;
     if (tm) HIP_TRY(hipEventRecord(ev[1], s0));
-    if (int rc = run_history(b, d_samples, len, s0)) return rc;
-    if (b->pipeline) HIP_TRY(hipEventRecord(b->e_fir[k], s0));
+    if (pl) HIP_TRY(hipEventRecord(b->e_done[0][k], s0));
 
-    // K2a + K2x: need this call's sign words, and segbits[k] drained by the K2b of call i-2
-    if (b->pipeline) {
-        HIP_TRY(hipStreamWaitEvent(s1, b->e_fir[k], 0));
-        if (b->calls >= 2) HIP_TRY(hipStreamWaitEvent(s1, b->e_hdlc[k], 0));
-    }
     PllLaunch p;
-    p.sgn = b->sgn[k]; p.ovf = b->ovf; p.pll = b->pll; p.lastbit = b->lastbit;
+    p.sgn = b->sgn[k]; p.ovf = b->ovf[k]; p.pll = b->pll; p.lastbit = b->lastbit;
     p.segbits = b->segbits[k]; p.segcnt = b->segcnt[k];
     p.N = b->N; p.L = len; p.n_seg = b->n_seg; p.seg_words = b->seg_words; p.pllinc = b->pllinc;
-    p.ev_mid = tm ? ev[6] : nullptr;
-    if (tm) HIP_TRY(hipEventRecord(ev[2], s1));
-    HIP_TRY(launch_pll_nrzi(p, s1));
-    if (tm) HIP_TRY(hipEventRecord(ev[3], s1));
-    if (b->pipeline) HIP_TRY(hipEventRecord(b->e_pll[k], s1));
+    // K2a: needs this call's sign words; fills ovf[k] (read by K2x of call i-2)
+    if (pl) {
+        HIP_TRY(hipStreamWaitEvent(sA, b->e_done[0][k], 0));
+        if (reuse) HIP_TRY(hipStreamWaitEvent(sA, b->e_done[2][k], 0));
+    }
+    if (tm) HIP_TRY(hipEventRecord(ev[2], sA));
+    HIP_TRY(launch_pll_core(p, sA));
+    if (tm) HIP_TRY(hipEventRecord(ev[6], sA));
+    if (pl) HIP_TRY(hipEventRecord(b->e_done[1][k], sA));
+    // K2x: needs ovf[k]; fills segbits[k] (read by K2b of call i-2)
+    if (pl) {
+        HIP_TRY(hipStreamWaitEvent(sB, b->e_done[1][k], 0));
+        if (reuse) HIP_TRY(hipStreamWaitEvent(sB, b->e_done[3][k], 0));
+    }
+    if (tm) HIP_TRY(hipEventRecord(ev[8], sB));
+    HIP_TRY(launch_nrzi_extract(p, sB));
+    if (tm) HIP_TRY(hipEventRecord(ev[3], sB));
+    if (pl) HIP_TRY(hipEventRecord(b->e_done[2][k], sB));
 
-    // K2b + K3
-    if (b->pipeline) HIP_TRY(hipStreamWaitEvent(s2, b->e_pll[k], 0));
     HdlcLaunch h;
     fill_hdlc(b, h, k);
-    h.ev_mid = tm ? ev[7] : nullptr;
-    if (tm) HIP_TRY(hipEventRecord(ev[5], s2));
-    HIP_TRY(launch_hdlc_crc(h, s2));
-    if (tm) HIP_TRY(hipEventRecord(ev[4], s2));
-    if (b->pipeline) HIP_TRY(hipEventRecord(b->e_hdlc[k], s2));
+    // K2b: needs segbits[k]; fills cand_first/count[k] (read by K3 of call i-2)
+    if (pl) {
+        HIP_TRY(hipStreamWaitEvent(sC, b->e_done[2][k], 0));
+        if (reuse) HIP_TRY(hipStreamWaitEvent(sC, b->e_done[4][k], 0));
+    }
+    if (tm) HIP_TRY(hipEventRecord(ev[5], sC));
+    HIP_TRY(launch_hdlc_deframe(h, sC));
+    if (tm) HIP_TRY(hipEventRecord(ev[7], sC));
+    if (pl) HIP_TRY(hipEventRecord(b->e_done[3][k], sC));
+    // K3
+    if (pl) HIP_TRY(hipStreamWaitEvent(sD, b->e_done[3][k], 0));
+    if (tm) HIP_TRY(hipEventRecord(ev[9], sD));
+    HIP_TRY(launch_hdlc_crc(h, sD));
+    if (tm) HIP_TRY(hipEventRecord(ev[4], sD));
+    if (pl) HIP_TRY(hipEventRecord(b->e_done[4][k], sD));
 
     b->timed_last = tm;
     if (tm) b->timed_calls++;
@@ -410,8 +437,7 @@ int gnuais_batch_sync(gnuais_batch *b)
     if (!b) return fail(GNUAIS_E_ARG, "sync: NULL batch");
     if (int rc = set_device(b)) return rc;
     HIP_TRY(hipStreamSynchronize(b->last_stream));
-    HIP_TRY(hipStreamSynchronize(b->s_pll));
-    HIP_TRY(hipStreamSynchronize(b->s_hdlc));
+    for (auto &st : b->s_k) HIP_TRY(hipStreamSynchronize(st));
     return GNUAIS_OK;
 }
 
@@ -447,7 +473,6 @@ int gnuais_batch_filter(gnuais_batch *b, const int16_t *d_samples, int len, floa
     hipStream_t s = (hipStream_t) stream;
     if (int rc = gnuais_batch_sync(b)) return rc;       // the sign-word scratch is shared
     if (int rc = run_fir(b, d_samples, len, d_out, s, (int) (b->calls & 1))) return rc;
-    if (int rc = run_history(b, d_samples, len, s)) return rc;
     b->last_stream = s;
     b->timed_last = false;
     return GNUAIS_OK;
@@ -484,6 +509,7 @@ int gnuais_batch_decode_bits(gnuais_batch *b, const uint8_t *h_bits, int stride,
         HIP_TRY(hipMemcpy(b->segcnt[0], cnt.data(), cnt.size() * 4, hipMemcpyHostToDevice));
         HdlcLaunch h;
         fill_hdlc(b, h, 0);
+        HIP_TRY(launch_hdlc_deframe(h, nullptr));
         HIP_TRY(launch_hdlc_crc(h, nullptr));
         HIP_TRY(hipDeviceSynchronize());
     }
@@ -553,7 +579,7 @@ int gnuais_batch_discard_frames(gnuais_batch *b, void *stream)
 {
     if (!b) return fail(GNUAIS_E_ARG, "discard_frames: NULL batch");
     if (int rc = set_device(b)) return rc;
-    hipStream_t s = b->pipeline ? b->s_hdlc : (hipStream_t) stream;   // behind the last K3
+    hipStream_t s = b->pipeline ? b->s_k[3] : (hipStream_t) stream;   // behind the last K3
     HIP_TRY(hipMemsetAsync(b->frame_count, 0, sizeof(uint32_t) * 2, s));
     return GNUAIS_OK;
 }
@@ -590,7 +616,7 @@ int gnuais_batch_maxval(gnuais_batch *b, int16_t *h_out)
     if (!b || !h_out) return fail(GNUAIS_E_ARG, "maxval: argument");
     if (int rc = gnuais_batch_sync(b)) return rc;
     std::vector<int> v((size_t) b->N);
-    HIP_TRY(hipMemcpy(v.data(), b->maxval, v.size() * 4, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(v.data(), b->maxval[b->max_last], v.size() * 4, hipMemcpyDeviceToHost));
     for (int c = 0; c < b->N; ++c) h_out[c] = (int16_t) v[c];
     return GNUAIS_OK;
 }
@@ -659,9 +685,9 @@ static int timing_of(gnuais_batch *b, unsigned long long call, float *ms)
     hipEvent_t *ev = b->evr[call % gnuais_batch::TIMING_RING];
     HIP_TRY(hipEventElapsedTime(&ms[0], ev[0], ev[1]));
     HIP_TRY(hipEventElapsedTime(&ms[1], ev[2], ev[6]));
-    HIP_TRY(hipEventElapsedTime(&ms[2], ev[6], ev[3]));
+    HIP_TRY(hipEventElapsedTime(&ms[2], ev[8], ev[3]));
     HIP_TRY(hipEventElapsedTime(&ms[3], ev[5], ev[7]));
-    HIP_TRY(hipEventElapsedTime(&ms[4], ev[7], ev[4]));
+    HIP_TRY(hipEventElapsedTime(&ms[4], ev[9], ev[4]));
     HIP_TRY(hipEventElapsedTime(&ms[5], ev[0], ev[4]));
     return GNUAIS_OK;
 }

@@ -475,7 +475,7 @@ __global__ __launch_bounds__(256) void hdlc_crc_kernel(
     }
 }
 
-hipError_t launch_hdlc_crc(const HdlcLaunch &a, hipStream_t stream)
+hipError_t launch_hdlc_deframe(const HdlcLaunch &a, hipStream_t stream)
 {
     const int lpw = a.lanes_per_wave > 0 ? a.lanes_per_wave : 64;
     if (a.seg_words > PACK_MAX) return hipErrorInvalidValue;
@@ -483,9 +483,11 @@ hipError_t launch_hdlc_crc(const HdlcLaunch &a, hipStream_t stream)
                        (PACK_MAX + 1) * lpw * sizeof(uint32_t), stream,
                        a.segbits, a.segcnt, a.ctl, a.cand, a.cand_first, a.cand_count, a.counters,
                        a.frame_count, a.N, a.n_seg, a.seg_words, a.K);
-    hipError_t e = hipGetLastError();
-    if (e != hipSuccess) return e;
-    if (a.ev_mid) (void) hipEventRecord(a.ev_mid, stream);
+    return hipGetLastError();
+}
+
+hipError_t launch_hdlc_crc(const HdlcLaunch &a, hipStream_t stream)
+{
     hipLaunchKernelGGL(hdlc_crc_kernel, dim3((unsigned) ((a.N + K3_CH - 1) / K3_CH)), dim3(256), 0,
                        stream, a.cand, a.cand_first, a.cand_count, a.counters,
                        (uint32_t *) a.frames, a.frame_count, a.frame_cap, a.N, a.K);

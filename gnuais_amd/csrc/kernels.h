@@ -12,7 +12,9 @@ struct FirLaunch {
     const int16_t *hist;   // [NT][N] previous call's last NT samples, oldest first
     uint32_t *sgn;         // [ceil(L/32)][N] sign words, bit 31 = oldest sample
     float *dump;           // optional [L][N] filter output
-    int *maxval;           // [N] peak positive sample (atomicMax; zeroed by the caller)
+    int *maxval;           // [N] peak positive sample (atomicMax into a zeroed buffer)
+    int16_t *hist_out;     // [NT][N] the other history buffer: written by the specialised kernel
+    int *maxval_next;      // [N] the other peak buffer: cleared by the specialised kernel
     const float *d_taps;   // device copy of all NT taps (generic kernel)
     float te[64];          // trimmed taps (specialised kernel)
     int N, L, T;           // T: outputs per wave, multiple of 32
@@ -34,9 +36,9 @@ struct PllLaunch {
     uint32_t *segcnt;      // [N][n_seg] bits in each pack
     int N, L, n_seg, seg_words;
     uint32_t pllinc;
-    hipEvent_t ev_mid;     // optional: recorded between K2a and K2x
 };
-hipError_t launch_pll_nrzi(const PllLaunch &a, hipStream_t stream);
+hipError_t launch_pll_core(const PllLaunch &a, hipStream_t stream);      // K2a
+hipError_t launch_nrzi_extract(const PllLaunch &a, hipStream_t stream);  // K2x + lastbit carry
 
 // ---- K2b: HDLC deframer, K3: CRC-16 + frame delivery (hdlc_crc.hip) ---------
 constexpr int HDLC_CTL_WORDS = 5;
@@ -56,9 +58,9 @@ struct HdlcLaunch {
     uint32_t frame_cap;
     int N, n_seg, seg_words, K;
     int lanes_per_wave;    // channels per wave in K2b (blockDim)
-    hipEvent_t ev_mid;     // optional: recorded between K2b and K3
 };
-hipError_t launch_hdlc_crc(const HdlcLaunch &a, hipStream_t stream);
+hipError_t launch_hdlc_deframe(const HdlcLaunch &a, hipStream_t stream); // K2b
+hipError_t launch_hdlc_crc(const HdlcLaunch &a, hipStream_t stream);     // K3
 hipError_t launch_hdlc_reset(uint32_t *ctl, int N, hipStream_t stream);
 
 // ---- utilities (util.hip) ---------------------------------------------------

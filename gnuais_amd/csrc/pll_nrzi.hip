@@ -206,17 +206,18 @@ __global__ void nrzi_lastbit_kernel(const uint32_t *__restrict__ sgn,
     }
 }
 
-hipError_t launch_pll_nrzi(const PllLaunch &a, hipStream_t stream)
+hipError_t launch_pll_core(const PllLaunch &a, hipStream_t stream)
 {
-    const int groups = (a.N + 63) / 64;
-    hipLaunchKernelGGL(pll_core_kernel, dim3(groups), dim3(64), 0, stream, a.sgn, a.ovf, a.pll,
-                       a.N, a.L, a.pllinc);
+    hipLaunchKernelGGL(pll_core_kernel, dim3((a.N + 63) / 64), dim3(64), 0, stream, a.sgn, a.ovf,
+                       a.pll, a.N, a.L, a.pllinc);
+    return hipGetLastError();
+}
+
+hipError_t launch_nrzi_extract(const PllLaunch &a, hipStream_t stream)
+{
+    hipLaunchKernelGGL(nrzi_extract_kernel, dim3((a.N + 63) / 64, a.n_seg), dim3(64), 0, stream,
+                       a.sgn, a.ovf, a.lastbit, a.segbits, a.segcnt, a.N, a.L, a.n_seg, a.seg_words);
     hipError_t e = hipGetLastError();
-    if (e != hipSuccess) return e;
-    if (a.ev_mid) (void) hipEventRecord(a.ev_mid, stream);
-    hipLaunchKernelGGL(nrzi_extract_kernel, dim3(groups, a.n_seg), dim3(64), 0, stream, a.sgn,
-                       a.ovf, a.lastbit, a.segbits, a.segcnt, a.N, a.L, a.n_seg, a.seg_words);
-    e = hipGetLastError();
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(nrzi_lastbit_kernel, dim3((a.N + 255) / 256), dim3(256), 0, stream, a.sgn,
                        a.ovf, a.lastbit, a.N, a.L);
