@@ -85,8 +85,12 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
+    # under torch.distributed.run (even with one rank) go through RCCL for the barrier
+    # and the reductions; a bare `python bench.py` needs no process group
+    use_dist = "RANK" in os.environ and "WORLD_SIZE" in os.environ
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
         dist.init_process_group("nccl", rank=rank, world_size=world)
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
@@ -124,21 +128,21 @@ def main():
     # timed region: K steps, asynchronous; the library records HIP events around every
     # kernel on the stream it is launched on (event ring), read back after the region
     b.set_timing(True)
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     dt = time.perf_counter() - t0
     rx1 = b.total_received()
     live = b.mean_timing()
     b.set_timing(False)
     msgs = float(rx1 - rx0)
-    if world > 1:
+    if use_dist:
         from gnuais_amd.shard import reduce_bench
         dt, msgs, _ = reduce_bench(dist, device, dt, msgs, float(n_ch * total * args.steps))
     msgs_per_step = msgs / args.steps
@@ -180,7 +184,7 @@ def main():
             out["cpu_baseline"] = cpu_baseline(x[:, : args.cpu_channels].cpu().numpy(),
                                                args.cpu_channels, total)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 
