@@ -74,17 +74,20 @@ struct gnuais_batch {
     hipStream_t s_k[4] = {nullptr, nullptr, nullptr, nullptr};   // K2a, K2x, K2b, K3
     hipEvent_t e_done[5][2] = {};               // e_done[s][k]: stage s of the call using pair k is done
                                                 // (0 K1, 1 K2a, 2 K2x, 3 K2b, 4 K3)
-    unsigned long long calls = 0;
+    unsigned long long calls = 0, hdlc_calls = 0;   // run calls / K3 launches since the last drain
     bool pipeline = true;
     uint32_t *ctl = nullptr, *cand = nullptr;
     uint32_t *cand_first[2] = {nullptr, nullptr}, *cand_count[2] = {nullptr, nullptr};  // K2b -> K3
-    uint32_t *frame_count = nullptr;
+    uint32_t *frame_count = nullptr, *chunks = nullptr;
+    int chunk_cap = 0;
     int cand_K = 64;
     int32_t *counters = nullptr;
     int *maxval[2] = {nullptr, nullptr};   // ping-pong with the history buffers
     int max_cur = 0, max_last = 0;
     gnuais_frame *frames = nullptr;
     float *d_taps = nullptr;
+    std::vector<gnuais_frame> drain_tmp;
+    std::vector<uint32_t> drain_chunks;
     int16_t *stage_x = nullptr;
     size_t stage_bytes = 0;
     // options
@@ -131,7 +134,7 @@ void gnuais_batch_destroy(gnuais_batch *b)
     void *ptrs[] = {b->hist[0], b->hist[1], b->sgn[0], b->sgn[1], b->ovf[0], b->ovf[1], b->pll,
                     b->lastbit, b->segbits[0], b->segbits[1], b->segcnt[0], b->segcnt[1], b->ctl,
                     b->cand, b->cand_first[0], b->cand_first[1], b->cand_count[0], b->cand_count[1],
-                    b->frame_count, b->counters, b->maxval[0], b->maxval[1], b->frames, b->d_taps,
+                    b->frame_count, b->chunks, b->counters, b->maxval[0], b->maxval[1], b->frames, b->d_taps,
                     b->stage_x};
     for (void *p : ptrs)
         if (p) (void) hipFree(p);
@@ -219,7 +222,9 @@ int gnuais_batch_create(gnuais_batch **out, int device, int n_channels, const fl
     // frame per 256 bit times; 64 slots per channel and call cover max_len <= 2^16
     b->cand_K = std::max(64, b->bits_words / 4);
     alloc((void **) &b->cand, sizeof(uint32_t) * N * (size_t) b->cand_K * CAND_WORDS);
-    alloc((void **) &b->frame_count, sizeof(uint32_t) * 2);
+    alloc((void **) &b->frame_count, sizeof(uint32_t) * 4);
+    b->chunk_cap = std::max(65536, 16 * ((b->N + 31) / 32));
+    alloc((void **) &b->chunks, sizeof(uint32_t) * 4 * (size_t) b->chunk_cap);
     alloc((void **) &b->counters, sizeof(int32_t) * N * 3);
     alloc((void **) &b->maxval[0], sizeof(int) * N);
     alloc((void **) &b->maxval[1], sizeof(int) * N);
@@ -272,11 +277,12 @@ int gnuais_batch_reset(gnuais_batch *b)
     for (int k = 0; k < 2; ++k)
         HIP_TRY(hipMemset(b->segcnt[k], 0, sizeof(uint32_t) * N * (size_t) b->n_seg));
     b->calls = 0;
+    b->hdlc_calls = 0;
     HIP_TRY(hipMemset(b->counters, 0, sizeof(int32_t) * N * 3));      // protodec.c:62-64
     HIP_TRY(hipMemset(b->maxval[0], 0, sizeof(int) * N));
     HIP_TRY(hipMemset(b->maxval[1], 0, sizeof(int) * N));
     b->max_cur = 0;
-    HIP_TRY(hipMemset(b->frame_count, 0, sizeof(uint32_t) * 2));
+    HIP_TRY(hipMemset(b->frame_count, 0, sizeof(uint32_t) * 4));
     HIP_TRY(launch_hdlc_reset(b->ctl, b->N, nullptr));                // protodec.c:87-100
     HIP_TRY(hipDeviceSynchronize());
     b->last_len = 0;
@@ -329,6 +335,8 @@ static void fill_hdlc(const gnuais_batch *b, HdlcLaunch &h, int k)
     h.segbits = b->segbits[k]; h.segcnt = b->segcnt[k]; h.ctl = b->ctl; h.cand = b->cand;
     h.cand_first = b->cand_first[k]; h.cand_count = b->cand_count[k];
     h.counters = b->counters; h.frames = b->frames; h.frame_count = b->frame_count;
+    h.chunks = b->chunks; h.chunk_cap = (uint32_t) b->chunk_cap;
+    h.call_seq = (uint32_t) (b->hdlc_calls & 0xfffffu);
     h.frame_cap = (uint32_t) b->frame_cap; h.N = b->N; h.n_seg = b->n_seg;
     h.seg_words = b->seg_words; h.K = b->cand_K;
     h.lanes_per_wave = b->hdlc_lpw;
@@ -420,6 +428,7 @@ int gnuais_batch_run(gnuais_batch *b, const int16_t *d_samples, int len, void *s
     if (pl) HIP_TRY(hipStreamWaitEvent(sD, b->e_done[3][k], 0));
     if (tm) HIP_TRY(hipEventRecord(ev[9], sD));
     HIP_TRY(launch_hdlc_crc(h, sD));
+    b->hdlc_calls++;
     if (tm) HIP_TRY(hipEventRecord(ev[4], sD));
     if (pl) HIP_TRY(hipEventRecord(b->e_done[4][k], sD));
 
@@ -511,6 +520,7 @@ int gnuais_batch_decode_bits(gnuais_batch *b, const uint8_t *h_bits, int stride,
         fill_hdlc(b, h, 0);
         HIP_TRY(launch_hdlc_deframe(h, nullptr));
         HIP_TRY(launch_hdlc_crc(h, nullptr));
+        b->hdlc_calls++;
         HIP_TRY(hipDeviceSynchronize());
     }
     b->last_stream = nullptr;
@@ -548,19 +558,46 @@ int gnuais_batch_drain_frames(gnuais_batch *b, gnuais_frame *h_out, int max, int
     if (!b || !n_out || (max > 0 && !h_out)) return fail(GNUAIS_E_ARG, "drain_frames: argument");
     *n_out = 0;
     if (int rc = gnuais_batch_sync(b)) return rc;
-    uint32_t cnt[2] = {0, 0};
+    uint32_t cnt[4] = {0, 0, 0, 0};
     HIP_TRY(hipMemcpy(cnt, b->frame_count, sizeof cnt, hipMemcpyDeviceToHost));
     const uint32_t have = std::min<uint32_t>(cnt[0], (uint32_t) b->frame_cap);
+    const uint32_t nchunks = std::min<uint32_t>(cnt[2], (uint32_t) b->chunk_cap);
     if ((uint32_t) max < have) return fail(GNUAIS_E_ARG, "drain_frames: output buffer too small");
-    if (have)
-        HIP_TRY(hipMemcpy(h_out, b->frames, sizeof(gnuais_frame) * have, hipMemcpyDeviceToHost));
+    bool overflow = cnt[1] || cnt[0] > (uint32_t) b->frame_cap || cnt[2] > (uint32_t) b->chunk_cap;
+    if (have) {
+        // K3 leaves the frames in chunks that are internally in the reference's print
+        // order (channel, then time); chunks are keyed by (channel block, call, pass)
+        b->drain_tmp.resize(have);
+        b->drain_chunks.resize((size_t) nchunks * 4);
+        HIP_TRY(hipMemcpy(b->drain_tmp.data(), b->frames, sizeof(gnuais_frame) * have,
+                          hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(b->drain_chunks.data(), b->chunks, sizeof(uint32_t) * 4 * nchunks,
+                          hipMemcpyDeviceToHost));
+        std::vector<uint32_t> order(nchunks);
+        for (uint32_t i = 0; i < nchunks; ++i) order[i] = i;
+        const uint32_t *ck = b->drain_chunks.data();
+        std::sort(order.begin(), order.end(), [ck](uint32_t x, uint32_t y) {
+            if (ck[4 * x] != ck[4 * y]) return ck[4 * x] < ck[4 * y];
+            return ck[4 * x + 1] < ck[4 * y + 1];
+        });
+        uint32_t w = 0;
+        for (uint32_t oi = 0; oi < nchunks; ++oi) {
+            const uint32_t *ch = ck + 4 * (size_t) order[oi];
+            uint32_t base = ch[2], n = ch[3];
+            if (base >= have) { overflow = true; continue; }
+            if (base + n > have) { n = have - base; overflow = true; }
+            memcpy(h_out + w, b->drain_tmp.data() + base, sizeof(gnuais_frame) * n);
+            w += n;
+        }
+        *n_out = (int) w;
+        if (b->hdlc_calls > 1)      // several calls in the span: interleave them per channel
+            std::stable_sort(h_out, h_out + w, [](const gnuais_frame &x, const gnuais_frame &y) {
+                return x.channel != y.channel ? x.channel < y.channel : x.end_bit < y.end_bit;
+            });
+    }
     HIP_TRY(hipMemset(b->frame_count, 0, sizeof cnt));
-    // reference order within the drained span: receiver (channel) 0..N-1, then time
-    std::sort(h_out, h_out + have, [](const gnuais_frame &x, const gnuais_frame &y) {
-        return x.channel != y.channel ? x.channel < y.channel : x.end_bit < y.end_bit;
-    });
-    *n_out = (int) have;
-    if (cnt[1] || cnt[0] > (uint32_t) b->frame_cap)
+    b->hdlc_calls = 0;
+    if (overflow)
         return fail(GNUAIS_E_OVERFLOW, "drain_frames: frame ring overflowed, frames were dropped");
     return GNUAIS_OK;
 }
@@ -569,7 +606,7 @@ int gnuais_batch_pending_frames(gnuais_batch *b, int *n_out)
 {
     if (!b || !n_out) return fail(GNUAIS_E_ARG, "pending_frames: argument");
     if (int rc = gnuais_batch_sync(b)) return rc;
-    uint32_t cnt[2] = {0, 0};
+    uint32_t cnt[4] = {0, 0, 0, 0};
     HIP_TRY(hipMemcpy(cnt, b->frame_count, sizeof cnt, hipMemcpyDeviceToHost));
     *n_out = (int) std::min<uint32_t>(cnt[0], (uint32_t) b->frame_cap);
     return GNUAIS_OK;
@@ -580,7 +617,8 @@ int gnuais_batch_discard_frames(gnuais_batch *b, void *stream)
     if (!b) return fail(GNUAIS_E_ARG, "discard_frames: NULL batch");
     if (int rc = set_device(b)) return rc;
     hipStream_t s = b->pipeline ? b->s_k[3] : (hipStream_t) stream;   // behind the last K3
-    HIP_TRY(hipMemsetAsync(b->frame_count, 0, sizeof(uint32_t) * 2, s));
+    HIP_TRY(hipMemsetAsync(b->frame_count, 0, sizeof(uint32_t) * 4, s));
+    b->hdlc_calls = 0;
     return GNUAIS_OK;
 }
 

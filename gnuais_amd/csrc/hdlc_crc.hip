@@ -359,18 +359,25 @@ __global__ __launch_bounds__(64) void hdlc_deframe_kernel(
 }
 
 // K3: CRC check + delivery of the candidates closed in this call.  One block of 256
-// threads owns K3_CH adjacent channels: their candidate counts are prefix-summed
-// in LDS and the block's threads then share the candidates evenly (dense work,
-// however the frames are spread over the channels; ~2 candidates per thread).  CRC-16/X-25 by bytes through a
-// 256-entry table built in LDS from the bitwise definition (protodec.c:106-118).
+// threads owns K3_CH adjacent channels: their candidate counts are prefix-summed in
+// LDS and the candidates, enumerated channel-major then in time, are taken 256 at
+// a time (one per thread).  CRC-16/X-25 by bytes through a 256-entry table built
+// in LDS from the bitwise definition (protodec.c:106-118).  The good frames of a
+// pass are compacted in order (ballot ranks), the block reserves one contiguous
+// piece of the frame ring for them and logs a chunk {key, base, count}: frames are
+// in the reference's print order inside every chunk, and chunks sort by key, so the
+// host reorders a few hundred chunks instead of sorting every frame.
 __global__ __launch_bounds__(256) void hdlc_crc_kernel(
     const uint32_t *__restrict__ cand, const uint32_t *__restrict__ cand_first,
     const uint32_t *__restrict__ cand_count, int32_t *__restrict__ counters,
-    uint32_t *__restrict__ frames, uint32_t *__restrict__ flags, uint32_t frame_cap, int N, int K)
+    uint32_t *__restrict__ frames, uint32_t *__restrict__ flags, uint32_t *__restrict__ chunks,
+    uint32_t frame_cap, uint32_t chunk_cap, uint32_t call_seq, int N, int K)
 {
     __shared__ uint32_t tab[256];
     __shared__ uint32_t pre[K3_CH + 1];
     __shared__ uint32_t stage[256][HDLC_BUF_WORDS + 1];     // unstuffed frame bits per thread
+    __shared__ uint32_t wave_cnt[4];
+    __shared__ uint32_t pass_base;
     const int tid = threadIdx.x;
     const int c_own = blockIdx.x * K3_CH + tid;
 
@@ -392,86 +399,129 @@ __global__ __launch_bounds__(256) void hdlc_crc_kernel(
     const uint32_t total = pre[K3_CH];
     const size_t n_ = (size_t) N;
 
-    for (uint32_t i = (uint32_t) tid; i < total; i += 256) {
-        // channel of candidate i: largest k with pre[k] <= i
-        int lo = 0, hi = K3_CH - 1;
-        while (lo < hi) {
-            const int mid = (lo + hi + 1) >> 1;
-            if (pre[mid] <= i) lo = mid; else hi = mid - 1;
-        }
-        const int c = blockIdx.x * K3_CH + lo;
-        const uint32_t j = i - pre[lo];
-        const uint32_t slot = (cand_first[c] + j) % (uint32_t) K;
-        const uint32_t *rec = cand + ((size_t) c * K + slot) * CAND_WORDS;
-        const uint32_t hdr = rec[0];
-        if (!(hdr & CAND_VALID)) continue;              // frame abandoned before its closing flag
-        const int n = (int) (hdr & 0xffffu);
-        const int rawlen = (int) (hdr >> 17);
-        const int nbytes = n >> 3, buflen = nbytes + 2; // protodec.c:133-134
-        // protodec.c:1008-1023 on the raw bits: store every bit except the one that
-        // follows five 1s (it is a stuffed 0 inside a frame)
-        {
-            uint32_t raw[CAND_WORDS - CAND_HDR];                // whole record first: one latency
+    for (uint32_t i0 = 0, pass = 0; i0 < total; i0 += 256, ++pass) {
+        const uint32_t i = i0 + (uint32_t) tid;
+        bool good = false;
+        uint32_t out[16];
 #pragma unroll
-            for (int q = 0; q < CAND_WORDS - CAND_HDR; ++q) raw[q] = rec[CAND_HDR + q];
-            uint32_t curw = 0;
-            int bp = 0, ones = 0;
-            bool drop = false;
-#pragma unroll
-            for (int q = 0; q < CAND_WORDS - CAND_HDR; ++q) {
-                uint32_t rw = raw[q];
-                const int lim = rawlen - 32 * q < 32 ? rawlen - 32 * q : 32;
-                for (int b = 0; b < lim; ++b) {
-                    const uint32_t x = rw & 1u;
-                    rw >>= 1;
-                    if (drop) { drop = false; continue; }
-                    curw |= x << (bp & 31);
-                    if ((bp & 31) == 31) { stage[tid][bp >> 5] = curw; curw = 0; }
-                    ++bp;
-                    ones = x ? ones + 1 : 0;
-                    if (ones == 5) { drop = true; ones = 0; }
-                }
+        for (int q = 0; q < 16; ++q) out[q] = 0;
+        if (i < total) {
+            // channel of candidate i: largest k with pre[k] <= i
+            int lo = 0, hi = K3_CH - 1;
+            while (lo < hi) {
+                const int mid = (lo + hi + 1) >> 1;
+                if (pre[mid] <= i) lo = mid; else hi = mid - 1;
             }
-            if (bp < 32 * (HDLC_BUF_WORDS + 1)) stage[tid][bp >> 5] = curw;
-        }
-        uint32_t w[HDLC_BUF_WORDS];
+            const int c = blockIdx.x * K3_CH + lo;
+            const uint32_t j = i - pre[lo];
+            const uint32_t slot = (cand_first[c] + j) % (uint32_t) K;
+            const uint32_t *rec = cand + ((size_t) c * K + slot) * CAND_WORDS;
+            const uint32_t hdr = rec[0];
+            if (hdr & CAND_VALID) {                     // else: abandoned before its closing flag
+                const int n = (int) (hdr & 0xffffu);
+                const int rawlen = (int) (hdr >> 17);
+                const int nbytes = n >> 3, buflen = nbytes + 2; // protodec.c:133-134
+                // protodec.c:1008-1023 on the raw bits: store every bit except the one
+                // that follows five 1s (it is a stuffed 0 inside a frame)
+                {
+                    uint32_t raw[CAND_WORDS - CAND_HDR];        // whole record first: one latency
 #pragma unroll
-        for (int q = 0; q < HDLC_BUF_WORDS; ++q) w[q] = stage[tid][q];
-        uint32_t crc = 0xffffu;
+                    for (int q = 0; q < CAND_WORDS - CAND_HDR; ++q) raw[q] = rec[CAND_HDR + q];
+                    uint32_t curw = 0;
+                    int bp = 0, ones = 0;
+                    bool drop = false;
 #pragma unroll
-        for (int q = 0; q < HDLC_BUF_WORDS; ++q) {
-#pragma unroll
-            for (int bq = 0; bq < 4; ++bq) {
-                if (q * 4 + bq < buflen) {
-                    const uint32_t byte = (w[q] >> (8 * bq)) & 0xffu;
-                    crc = (crc >> 8) ^ tab[(crc ^ byte) & 0xffu];
-                }
-            }
-        }
-        if (crc == 0xf0b8u) {                           // ~crc == 0x0f47, protodec.c:166
-            atomicAdd(&counters[c], 1);                 // protodec.c:1103
-            const uint32_t idx = atomicAdd(&flags[0], 1u);
-            if (idx < frame_cap) {
-                uint32_t *out = frames + (size_t) idx * 16;
-                out[0] = (uint32_t) c;
-                out[1] = rec[1];
-#pragma unroll
-                for (int q = 0; q < 14; ++q) {
-                    uint32_t v = 0;
-                    if (q * 4 < nbytes) {
-                        v = w[q];
-                        const int keep = nbytes - q * 4;
-                        if (keep < 4) v &= (1u << (8 * keep)) - 1u;
+                    for (int q = 0; q < CAND_WORDS - CAND_HDR; ++q) {
+                        uint32_t rw = raw[q];
+                        const int lim = rawlen - 32 * q < 32 ? rawlen - 32 * q : 32;
+                        for (int b = 0; b < lim; ++b) {
+                            const uint32_t x = rw & 1u;
+                            rw >>= 1;
+                            if (drop) { drop = false; continue; }
+                            curw |= x << (bp & 31);
+                            if ((bp & 31) == 31) { stage[tid][bp >> 5] = curw; curw = 0; }
+                            ++bp;
+                            ones = x ? ones + 1 : 0;
+                            if (ones == 5) { drop = true; ones = 0; }
+                        }
                     }
-                    if (q == 13) v = (v & 0xffu) | (1u << 8) | ((uint32_t) n << 16);
-                    out[2 + q] = v;
+                    if (bp < 32 * (HDLC_BUF_WORDS + 1)) stage[tid][bp >> 5] = curw;
                 }
+                uint32_t w[HDLC_BUF_WORDS];
+#pragma unroll
+                for (int q = 0; q < HDLC_BUF_WORDS; ++q) w[q] = stage[tid][q];
+                uint32_t crc = 0xffffu;
+#pragma unroll
+                for (int q = 0; q < HDLC_BUF_WORDS; ++q) {
+#pragma unroll
+                    for (int bq = 0; bq < 4; ++bq) {
+                        if (q * 4 + bq < buflen) {
+                            const uint32_t byte = (w[q] >> (8 * bq)) & 0xffu;
+                            crc = (crc >> 8) ^ tab[(crc ^ byte) & 0xffu];
+                        }
+                    }
+                }
+                if (crc == 0xf0b8u) {                   // ~crc == 0x0f47, protodec.c:166
+                    good = true;
+                    atomicAdd(&counters[c], 1);         // protodec.c:1103
+                    out[0] = (uint32_t) c;
+                    out[1] = rec[1];
+#pragma unroll
+                    for (int q = 0; q < 14; ++q) {
+                        uint32_t v = 0;
+                        if (q * 4 < nbytes) {
+                            v = w[q];
+                            const int keep = nbytes - q * 4;
+                            if (keep < 4) v &= (1u << (8 * keep)) - 1u;
+                        }
+                        if (q == 13) v = (v & 0xffu) | (1u << 8) | ((uint32_t) n << 16);
+                        out[2 + q] = v;
+                    }
+                } else {
+                    atomicAdd(&counters[n_ + c], 1);    // protodec.c:1107
+                }
+            }
+        }
+        // ordered compaction of this pass's good frames
+        const unsigned long long m = __ballot(good);
+        const int wave = tid >> 6, lane = tid & 63;
+        const uint32_t below = (uint32_t) __popcll(m & ((1ull << lane) - 1ull));
+        if (lane == 0) wave_cnt[wave] = (uint32_t) __popcll(m);
+        __syncthreads();
+        uint32_t woff = 0, npass = 0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            if (q < wave) woff += wave_cnt[q];
+            npass += wave_cnt[q];
+        }
+        if (tid == 0 && npass) {
+            const uint32_t base = atomicAdd(&flags[0], npass);
+            pass_base = base;
+            const uint32_t ci = atomicAdd(&flags[2], 1u);
+            if (ci < chunk_cap) {
+                uint32_t *ch = chunks + (size_t) ci * 4;
+                ch[0] = (uint32_t) blockIdx.x;          // key, major: channel block
+                ch[1] = (call_seq << 12) | pass;        // key, minor: call, then pass
+                ch[2] = base;
+                ch[3] = npass;
+            } else {
+                flags[1] = 1;
+            }
+        }
+        __syncthreads();
+        if (good) {
+            const uint32_t idx = pass_base + woff + below;
+            if (idx < frame_cap) {
+                uint4 *dst = reinterpret_cast<uint4 *>(frames + (size_t) idx * 16);
+                dst[0] = make_uint4(out[0], out[1], out[2], out[3]);
+                dst[1] = make_uint4(out[4], out[5], out[6], out[7]);
+                dst[2] = make_uint4(out[8], out[9], out[10], out[11]);
+                dst[3] = make_uint4(out[12], out[13], out[14], out[15]);
             } else {
                 flags[1] = 1;                           // ring full: frame dropped, still counted
             }
-        } else {
-            atomicAdd(&counters[n_ + c], 1);            // protodec.c:1107
         }
+        __syncthreads();
     }
 }
 
@@ -490,7 +540,8 @@ hipError_t launch_hdlc_crc(const HdlcLaunch &a, hipStream_t stream)
 {
     hipLaunchKernelGGL(hdlc_crc_kernel, dim3((unsigned) ((a.N + K3_CH - 1) / K3_CH)), dim3(256), 0,
                        stream, a.cand, a.cand_first, a.cand_count, a.counters,
-                       (uint32_t *) a.frames, a.frame_count, a.frame_cap, a.N, a.K);
+                       (uint32_t *) a.frames, a.frame_count, a.chunks, a.frame_cap, a.chunk_cap,
+                       a.call_seq, a.N, a.K);
     return hipGetLastError();
 }
 
