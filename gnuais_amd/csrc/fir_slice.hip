@@ -314,6 +314,179 @@ __global__ __launch_bounds__(64) void fir_slice_kernel(
 } // namespace FIR_VARIANT
 
 #ifdef FIR_PRIMARY
+// ---------------------------------------------------------------------------
+// K1s -- sign-exact slicer (the default on the receive path).
+//
+// receiver_run() only ever looks at `out > 0` (receiver.c:111,126).  The sign of
+// the reference's 32-term ordered fp32 sum y_ref can be decided from a much
+// cheaper quantity whenever that quantity is far enough from zero:
+//   y_c = the NC = 12 central taps only (te[10..21]; the 20 outer taps sum to
+//         5.4e-8), evaluated in fp32 in transposed form, 6 shared products + 12
+//         additions per sample;
+//   |y_ref - S|   <= ((1+u)^33 - 1) * X * sum|te|      (32 rounded products, 31 adds)
+//   |y_c   - S_c| <= ((1+u)^13 - 1) * X * sum|tc|      (12 rounded products, 11 adds)
+//   |S - S_c|     <=                  X * sum|te outside the centre|
+// with u = 2^-24, X = 32768 (int16 input), S / S_c the exact real sums; subnormal
+// products add at most 32 * 2^-150.  The host adds the three terms in double
+// precision from the actual table (0.2265 for the reference table) and passes
+// eps = that * 1.1.  If |y_c| > eps then y_ref has the sign of y_c and is not
+// zero; otherwise (about 1.5e-4 of the samples of a noisy channel, all of them in
+// a silent one) the sample is re-evaluated with the exact ordered 32-tap sum from
+// the input (L1/L2 hits).  The emitted sign words are therefore bit-identical to
+// K1's; the fp32 filter output itself is only available from the exact kernel
+// (gnuais_batch_filter).
+//
+// Same mapping as K1 (lane = channel, wave = 64 channels x one time segment), but
+// 12 accumulators rotate, so 96 phases (three sign words) are unrolled.
+template <int NE, int NC>
+__global__ __launch_bounds__(64) void fir_sign_kernel(
+    const int16_t *__restrict__ x, const int16_t *__restrict__ hist,
+    uint32_t *__restrict__ sgn, int *__restrict__ maxval,
+    int16_t *__restrict__ hist_out, int *__restrict__ maxval_next,
+    int N, int L, int T, int d, int NT, float eps, FirTaps<NE> taps)
+{
+    static_assert(NE == 32 && NC == 12, "sized for the reference table");
+    constexpr int J0 = (NE - NC) / 2;           // first central tap (10)
+    const int lane = threadIdx.x;
+    const int cg = blockIdx.x * 64 + lane;
+    const int c = cg < N ? cg : N - 1;
+    const bool live = cg < N;
+    const int t0 = blockIdx.y * T;              // T is a multiple of 96
+    const int t1 = (t0 + T < L) ? t0 + T : L;
+    if (t0 >= L) return;
+    const int dc = d - J0;                      // y_c[n] = sum_q tc[q] * x[n - dc + q]
+
+    float acc[NC];
+#pragma unroll
+    for (int q = 0; q < NC; ++q) acc[q] = 0.0f;
+    int peak = 0;
+    const int m0 = t0 - dc;                     // local sample i <-> m = m0 + i, feeds output o = i - q
+
+    // exact value of output n: filter.h:40-49 order, samples re-read from memory
+    auto exact_positive = [&](int n) -> bool {
+        float sum = 0.0f;
+#pragma unroll
+        for (int j = 0; j < NE; ++j) {
+            const float xs = (float) load_sample(x, hist, n - d + j, N, NT, c);
+            sum = sum + taps.te[j] * xs;
+        }
+        return sum > 0.0f;
+    };
+
+    // warm-up: samples i = 0 .. NC-2
+    {
+        int xw[NC - 1];
+#pragma unroll
+        for (int i = 0; i < NC - 1; ++i) xw[i] = load_sample(x, hist, m0 + i, N, NT, c);
+#pragma unroll
+        for (int i = 0; i < NC - 1; ++i) {
+            const float xs = (float) xw[i];
+#pragma unroll
+            for (int q = 0; q <= i; ++q) {
+                const int qm = q >= NC / 2 ? NC - 1 - q : q;
+                acc[(i - q) % NC] = (q == 0 ? 0.0f : acc[(i - q) % NC]) + taps.te[J0 + qm] * xs;
+            }
+        }
+    }
+
+    const int nblk = (t1 - t0 + 95) / 96;
+    for (int b = 0; b < nblk; ++b) {
+#pragma unroll
+        for (int w3 = 0; w3 < 3; ++w3) {
+            const int obase = b * 96 + w3 * 32;             // outputs obase .. obase+31
+            if (t0 + obase >= t1) break;
+            int xi[32];
+            const int mb = m0 + NC - 1 + obase;             // sample of phase 0
+            const bool interior = (mb >= 0) && (mb + 31 < L);
+            if (interior) {
+                const int16_t *row = x + (size_t) mb * (size_t) N + c;
+#pragma unroll
+                for (int p = 0; p < 32; ++p) xi[p] = (int) row[(size_t) p * (size_t) N];
+            } else {
+#pragma unroll
+                for (int p = 0; p < 32; ++p) {
+                    int m = mb + p;
+                    m = (m < L) ? m : L - 1;
+                    xi[p] = load_sample(x, hist, m, N, NT, c);
+                }
+            }
+            {   // filter.c:118-119 peak (same bookkeeping as K1, shift = dc - NC + 1)
+                int bp = 0;
+                if (interior) {
+#pragma unroll
+                    for (int p = 0; p < 32; ++p) bp = xi[p] > bp ? xi[p] : bp;
+                } else {
+#pragma unroll
+                    for (int p = 0; p < 32; ++p) {
+                        const int m = mb + p;
+                        const int v = (m >= 0 && m < L) ? xi[p] : 0;
+                        bp = v > bp ? v : bp;
+                    }
+                }
+                peak = bp > peak ? bp : peak;
+            }
+            uint32_t w = 0, amb = 0;
+#pragma unroll
+            for (int p = 0; p < 32; ++p) {
+                const int P = w3 * 32 + p;                  // phase 0..95, P % 12 static
+                const float xs = (float) xi[p];
+#pragma unroll
+                for (int q = 0; q < NC / 2; ++q) {
+                    const float pr = taps.te[J0 + q] * xs;  // == te[J0 + NC-1-q] * xs bit for bit
+                    const int s0 = (P + NC - 1 - q) % NC;
+                    const int s1 = (P + q) % NC;
+                    if (q == 0) acc[s0] = pr; else acc[s0] = acc[s0] + pr;
+                    acc[s1] = acc[s1] + pr;
+                }
+                const float y = acc[P % NC];                // y_c of output obase + p
+                w = (w << 1) | (y > 0.0f ? 1u : 0u);
+                amb = (amb << 1) | (__builtin_fabsf(y) <= eps ? 1u : 0u);
+            }
+            const int valid = t1 - (t0 + obase);
+            if (valid < 32) {
+                w &= ~0u << (32 - valid);
+                amb &= ~0u << (32 - valid);
+            }
+            // the samples whose sign y_c cannot certify: exact ordered sum
+            while (amb) {
+                const int pos = __clz((int) amb);
+                const uint32_t bit = 0x80000000u >> pos;
+                amb &= ~bit;
+                if (exact_positive(t0 + obase + pos)) w |= bit; else w &= ~bit;
+            }
+            if (live) sgn[(size_t) ((t0 + obase) >> 5) * (size_t) N + cg] = w;
+        }
+    }
+
+    if (t1 == L) {                              // the last dc-NC+1 samples of the call
+        const int shift = dc - NC + 1;
+        for (int n = (L - shift > 0 ? L - shift : 0); n < L; ++n) {
+            const int v = (int) x[(size_t) n * (size_t) N + c];
+            peak = v > peak ? v : peak;
+        }
+    }
+    if (live && peak > 0) atomicMax(&maxval[cg], peak);
+    if (t1 == L && live) {                      // carry for the next call, as in K1
+        for (int k = 0; k < NT; ++k) {
+            const int m = L - NT + k;
+            hist_out[(size_t) k * (size_t) N + cg] =
+                (m >= 0) ? x[(size_t) m * (size_t) N + cg] : hist[(size_t) (NT + m) * (size_t) N + cg];
+        }
+        maxval_next[cg] = 0;
+    }
+}
+
+hipError_t launch_fir_sign(const FirLaunch &a, hipStream_t stream)
+{
+    if (a.NE != 32 || a.dump || a.T % 96) return hipErrorInvalidValue;
+    dim3 grid((a.N + 63) / 64, (a.L + a.T - 1) / a.T), block(64);
+    FirTaps<32> t;
+    for (int j = 0; j < 32; ++j) t.te[j] = a.te[j];
+    hipLaunchKernelGGL((fir_sign_kernel<32, 12>), grid, block, 0, stream, a.x, a.hist, a.sgn,
+                       a.maxval, a.hist_out, a.maxval_next, a.N, a.L, a.T, a.d, a.NT, a.eps, t);
+    return hipGetLastError();
+}
+
 // Fallback for any other tap count (e.g. the 144-tap 192 kHz table): direct
 // form, window re-read from L1/L2 per output.  Correct, not fast; bit-identical
 // summation order.  One lane = one channel, grid.y = time segments.

@@ -8,6 +8,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -92,7 +93,10 @@ struct gnuais_batch {
     size_t stage_bytes = 0;
     // options
     int fir_T = 512;
-    int fir_variant = 0;            // 0 scalar VALU, 1 packed VALU
+    int fir_variant = 3;            // 3 sign-exact slicer (default when the table allows);
+                                    // 0 exact scalar VALU, 1 exact packed, 2 exact MFMA products
+    bool sign_ok = false;           // table is 32 symmetric effective taps: K1s applicable
+    float sign_eps = 0.0f;
     int hdlc_lpw = 64;              // channels per wave in K2b
     bool timing = false;
     // timing: a ring of per-call event sets so that kernel durations can be read back
@@ -186,6 +190,25 @@ int gnuais_batch_create(gnuais_batch **out, int device, int n_channels, const fl
     if (b->NE <= 64)
         for (int j = 0; j < b->NE; ++j) b->te[j] = b->taps[k0 + j];
 
+    {
+        // sign-exact slicer (fir_slice.hip K1s): error budget of the 12 central taps
+        // against the reference's ordered 32-term fp32 sum, for |x| <= 32768
+        bool sym = b->NE == 32;
+        for (int j = 0; sym && j < 32; ++j) sym = memcmp(&b->te[j], &b->te[31 - j], 4) == 0;
+        if (sym) {
+            const double u = 5.9604644775390625e-8, X = 32768.0;
+            double sum_all = 0, sum_c = 0, sum_out = 0;
+            for (int j = 0; j < 32; ++j) {
+                const double a = std::fabs((double) b->te[j]);
+                sum_all += a;
+                if (j >= 10 && j <= 21) sum_c += a; else sum_out += a;
+            }
+            const double bound = (std::pow(1 + u, 33) - 1) * X * sum_all +
+                                 (std::pow(1 + u, 13) - 1) * X * sum_c + X * sum_out + 1e-30;
+            b->sign_eps = (float) (bound * 1.1);
+            b->sign_ok = std::isfinite(bound) && b->sign_eps < 1e30f;
+        }
+    }
     b->sgn_words = (max_len + 31) / 32;
     // at most one slice per sample step of (pllinc + pllinc/16)/65536
     const uint64_t step = (uint64_t) b->pllinc + b->pllinc / 16;
@@ -296,7 +319,7 @@ int gnuais_batch_set_option(gnuais_batch *b, const char *name, int value)
         if (value < 64 || value % 32) return fail(GNUAIS_E_ARG, "fir_T must be a multiple of 32, >= 64");
         b->fir_T = value;
     } else if (!strcmp(name, "fir_variant")) {
-        if (value < 0 || value > 2) return fail(GNUAIS_E_ARG, "fir_variant must be 0, 1 or 2");
+        if (value < 0 || value > 3) return fail(GNUAIS_E_ARG, "fir_variant must be 0..3");
         b->fir_variant = value;
     } else if (!strcmp(name, "pipeline")) {
         b->pipeline = value != 0;
@@ -328,6 +351,7 @@ static void fill_fir(const gnuais_batch *b, FirLaunch &f, const int16_t *x, int 
     f.NT = b->NT;
     f.NE = b->NE;
     f.d = b->d;
+    f.eps = b->sign_eps;
 }
 
 static void fill_hdlc(const gnuais_batch *b, HdlcLaunch &h, int k)
@@ -353,6 +377,9 @@ static int run_fir(gnuais_batch *b, const int16_t *x, int len, float *dump, hipS
         HIP_TRY(launch_fir_generic(f, s));
         HIP_TRY(launch_fir_history(x, b->hist[b->hist_cur], b->hist[b->hist_cur ^ 1], b->N, len,
                                    b->NT, s));
+    } else if (b->fir_variant == 3 && b->sign_ok && !dump) {
+        f.T = (f.T + 95) / 96 * 96;
+        HIP_TRY(launch_fir_sign(f, s));
     } else if (b->fir_variant == 1) {
         HIP_TRY(packed::launch_fir_slice(f, s));
     } else if (b->fir_variant == 2) {

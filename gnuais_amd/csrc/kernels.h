@@ -19,7 +19,9 @@ struct FirLaunch {
     float te[64];          // trimmed taps (specialised kernel)
     int N, L, T;           // T: outputs per wave, multiple of 32
     int NT, NE, d;         // out[n] = sum_j te[j] * x[n - d + j], j < NE
+    float eps;             // sign-exact slicer: |central sum| > eps certifies the sign
 };
+hipError_t launch_fir_sign(const FirLaunch &a, hipStream_t stream);
 hipError_t launch_fir_generic(const FirLaunch &a, hipStream_t stream);
 hipError_t launch_fir_history(const int16_t *x, const int16_t *hist_in, int16_t *hist_out,
                               int N, int L, int NT, hipStream_t stream);

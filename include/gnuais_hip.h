@@ -142,7 +142,8 @@ int  gnuais_batch_last_timing(gnuais_batch *b, float *ms6);
  * calls overlap */
 int  gnuais_batch_mean_timing(gnuais_batch *b, float *ms6, int *n_calls);
 /* tunables: "fir_T" (outputs per wave in K1, multiple of 32), "fir_variant"
- * (0 = v_mul/v_add, 1 = v_pk_mul/v_pk_add build of K1), "hdlc_lpw" (channels
+ * (3 = sign-exact slicer, the default on the receive path; 0 = exact v_mul/v_add K1,
+ * 1 = its v_pk build, 2 = its MFMA-product build), "pipeline", "hdlc_lpw" (channels
  * per wave in the deframer, 1..64) */
 int  gnuais_batch_set_option(gnuais_batch *b, const char *name, int value);
 const char *gnuais_last_error(void);
