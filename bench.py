@@ -25,7 +25,11 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.3 TB/s measured)
-VALU_PEAK_TOPS = 70.1          # measured on MI355X (scripts/ubench/valu_rate): 64 lanes per 0.935 ns
+N_SIMD = 1024                  # 256 CUs x 4
+# SIMD time one 64-channel wave of the sign-exact slicer needs per sample, from the measured
+# per-instruction issue costs (scripts/ubench/valu_rate): 18 x 1.04 ns + 7.5 x 1.9 ns
+K1S_NS_PER_WAVE_SAMPLE = 33.0
+TIMING_STRIDE = 4              # per-kernel events on every 4th call of the timed region
                                # per SIMD x 1024 SIMDs, unfused v_mul_f32/v_add_f32
 
 
@@ -128,6 +132,7 @@ def main():
     # timed region: K steps, asynchronous; the library records HIP events around every
     # kernel on the stream it is launched on (event ring), read back after the region
     b.set_timing(True)
+    b.set_option("timing_stride", TIMING_STRIDE)    # the event records themselves cost stream time
     if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
@@ -141,6 +146,7 @@ def main():
     rx1 = b.total_received()
     live = b.mean_timing()
     b.set_timing(False)
+    b.set_option("timing_stride", 1)
     msgs = float(rx1 - rx0)
     if use_dist:
         from gnuais_amd.shard import reduce_bench
@@ -176,9 +182,12 @@ def main():
                          "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": pmc_traffic(dom),
                          "algorithmic_bytes_per_launch": alg[dom],
                          "achieved_isolated": alg[dom] / (kiso[dom] * 1e-3) / 1e9,
-                         "valu_ops_per_sample": 48,
-                         "valu_frac_isolated": (n_ch * total * 48.0 / (kiso["fir_slice"] * 1e-3)
-                                                / 1e12) / VALU_PEAK_TOPS},
+                         # K1s is VALU-issue bound, not HBM bound: per sample and wave 18 plain
+                         # fp32 ops (1.04 ns each at saturation, scripts/ubench) + 7.5 VOP3/VOPC
+                         # class ops (1.9 ns each) = 33 ns of SIMD time
+                         "valu_floor_ms": K1S_NS_PER_WAVE_SAMPLE * 1e-6 * (n_ch / 64.0) * total / N_SIMD,
+                         "valu_frac_isolated": (K1S_NS_PER_WAVE_SAMPLE * 1e-6 * (n_ch / 64.0) * total
+                                                / N_SIMD) / kiso["fir_slice"]},
         }
         if world == 1 and not args.no_cpu:
             out["cpu_baseline"] = cpu_baseline(x[:, : args.cpu_channels].cpu().numpy(),

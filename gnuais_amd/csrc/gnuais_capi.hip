@@ -63,22 +63,25 @@ struct gnuais_batch {
     // device state
     int16_t *hist[2] = {nullptr, nullptr};
     int hist_cur = 0;
-    uint32_t *sgn[2] = {nullptr, nullptr};      // K1 -> K2a/K2x hand-off, alternating per call
-    uint32_t *ovf[2] = {nullptr, nullptr};      // K2a -> K2x hand-off
+    // every hand-off buffer exists NBUF times (index = call % NBUF), so K1 can run up
+    // to NBUF-1 calls ahead of the sequential stages
+    static constexpr int NBUF = 4;
+    uint32_t *sgn[NBUF] = {};                   // K1 -> K2a/K2x
+    uint32_t *ovf[NBUF] = {};                   // K2a -> K2x
     uint32_t *pll = nullptr, *lastbit = nullptr;
-    uint32_t *segbits[2] = {nullptr, nullptr};  // K2x -> K2b hand-off, alternating per call
-    uint32_t *segcnt[2] = {nullptr, nullptr};
+    uint32_t *segbits[NBUF] = {};               // K2x -> K2b
+    uint32_t *segcnt[NBUF] = {};
     int n_seg = 0, seg_words = 0;
     // stage pipeline: K1 on the caller's stream and one internal stream per later
     // kernel, so that the short-on-parallelism stages of call i overlap the FIR of
     // call i+1 (and each other).  Every hand-off buffer exists twice (index = call & 1).
     hipStream_t s_k[4] = {nullptr, nullptr, nullptr, nullptr};   // K2a, K2x, K2b, K3
-    hipEvent_t e_done[5][2] = {};               // e_done[s][k]: stage s of the call using pair k is done
+    hipEvent_t e_done[5][NBUF] = {};            // e_done[s][k]: stage s of the call using set k is done
                                                 // (0 K1, 1 K2a, 2 K2x, 3 K2b, 4 K3)
     unsigned long long calls = 0, hdlc_calls = 0;   // run calls / K3 launches since the last drain
     bool pipeline = true;
     uint32_t *ctl = nullptr, *cand = nullptr;
-    uint32_t *cand_first[2] = {nullptr, nullptr}, *cand_count[2] = {nullptr, nullptr};  // K2b -> K3
+    uint32_t *cand_first[NBUF] = {}, *cand_count[NBUF] = {};   // K2b -> K3
     uint32_t *frame_count = nullptr, *chunks = nullptr;
     int chunk_cap = 0;
     int cand_K = 64;
@@ -93,12 +96,14 @@ struct gnuais_batch {
     size_t stage_bytes = 0;
     // options
     int fir_T = 512;
+    int stage_mask = 0x1f;                      // experiments only: bit s = launch stage s
     int fir_variant = 3;            // 3 sign-exact slicer (default when the table allows);
                                     // 0 exact scalar VALU, 1 exact packed, 2 exact MFMA products
     bool sign_ok = false;           // table is 32 symmetric effective taps: K1s applicable
     float sign_eps = 0.0f;
     int hdlc_lpw = 64;              // channels per wave in K2b
     bool timing = false;
+    int timing_stride = 1;          // time every n-th call only: ten event records a call are not free
     // timing: a ring of per-call event sets so that kernel durations can be read back
     // for every call of a timed region, not just the last one
     static constexpr int TIMING_RING = 64;
@@ -135,9 +140,13 @@ void gnuais_batch_destroy(gnuais_batch *b)
 {
     if (!b) return;
     (void) hipSetDevice(b->device);
-    void *ptrs[] = {b->hist[0], b->hist[1], b->sgn[0], b->sgn[1], b->ovf[0], b->ovf[1], b->pll,
-                    b->lastbit, b->segbits[0], b->segbits[1], b->segcnt[0], b->segcnt[1], b->ctl,
-                    b->cand, b->cand_first[0], b->cand_first[1], b->cand_count[0], b->cand_count[1],
+    for (int q = 0; q < gnuais_batch::NBUF; ++q) {
+        void *set[] = {b->sgn[q], b->ovf[q], b->segbits[q], b->segcnt[q], b->cand_first[q],
+                       b->cand_count[q]};
+        for (void *p : set)
+            if (p) (void) hipFree(p);
+    }
+    void *ptrs[] = {b->hist[0], b->hist[1], b->pll, b->lastbit, b->ctl, b->cand,
                     b->frame_count, b->chunks, b->counters, b->maxval[0], b->maxval[1], b->frames, b->d_taps,
                     b->stage_x};
     for (void *p : ptrs)
@@ -228,13 +237,13 @@ int gnuais_batch_create(gnuais_batch **out, int device, int n_channels, const fl
         delete b;
         return fail(GNUAIS_E_ARG, "create: pllinc too large (more than one slice per ~4.6 samples)");
     }
-    for (int k = 0; k < 2; ++k) {
-        alloc((void **) &b->sgn[k], sizeof(uint32_t) * N * (b->sgn_words + 2 * PLL_PAD));
+    for (int k = 0; k < gnuais_batch::NBUF; ++k) {
+        alloc((void **) &b->sgn[k], sizeof(uint32_t) * N * (b->sgn_words + PLL_PAD_ROWS));
         alloc((void **) &b->segbits[k], sizeof(uint32_t) * N * (size_t) b->n_seg * b->seg_words);
         alloc((void **) &b->segcnt[k], sizeof(uint32_t) * N * (size_t) b->n_seg);
     }
-    for (int k = 0; k < 2; ++k) {
-        alloc((void **) &b->ovf[k], sizeof(uint32_t) * N * (b->sgn_words + 2 * PLL_PAD));
+    for (int k = 0; k < gnuais_batch::NBUF; ++k) {
+        alloc((void **) &b->ovf[k], sizeof(uint32_t) * N * (b->sgn_words + PLL_PAD_ROWS));
         alloc((void **) &b->cand_first[k], sizeof(uint32_t) * N);
         alloc((void **) &b->cand_count[k], sizeof(uint32_t) * N);
     }
@@ -297,7 +306,7 @@ int gnuais_batch_reset(gnuais_batch *b)
     b->hist_cur = 0;
     HIP_TRY(hipMemset(b->pll, 0, sizeof(uint32_t) * N));              // receiver.c:66-71
     HIP_TRY(hipMemset(b->lastbit, 0, sizeof(uint32_t) * N));
-    for (int k = 0; k < 2; ++k)
+    for (int k = 0; k < gnuais_batch::NBUF; ++k)
         HIP_TRY(hipMemset(b->segcnt[k], 0, sizeof(uint32_t) * N * (size_t) b->n_seg));
     b->calls = 0;
     b->hdlc_calls = 0;
@@ -315,12 +324,19 @@ int gnuais_batch_reset(gnuais_batch *b)
 int gnuais_batch_set_option(gnuais_batch *b, const char *name, int value)
 {
     if (!b || !name) return fail(GNUAIS_E_ARG, "set_option: NULL");
+    if (!strcmp(name, "stage_mask")) {          // timing experiments; results are invalid if != 0x1f
+        b->stage_mask = value & 0x1f;
+        return GNUAIS_OK;
+    }
     if (!strcmp(name, "fir_T")) {
         if (value < 64 || value % 32) return fail(GNUAIS_E_ARG, "fir_T must be a multiple of 32, >= 64");
         b->fir_T = value;
     } else if (!strcmp(name, "fir_variant")) {
         if (value < 0 || value > 3) return fail(GNUAIS_E_ARG, "fir_variant must be 0..3");
         b->fir_variant = value;
+    } else if (!strcmp(name, "timing_stride")) {
+        if (value < 1) return fail(GNUAIS_E_ARG, "timing_stride must be >= 1");
+        b->timing_stride = value;
     } else if (!strcmp(name, "pipeline")) {
         b->pipeline = value != 0;
     } else if (!strcmp(name, "hdlc_lpw")) {
@@ -393,6 +409,59 @@ static int run_fir(gnuais_batch *b, const int16_t *x, int len, float *dump, hipS
     return GNUAIS_OK;
 }
 
+static void fill_pll(const gnuais_batch *b, PllLaunch &p, int k, int len)
+{
+    p.sgn = b->sgn[k]; p.ovf = b->ovf[k]; p.pll = b->pll; p.lastbit = b->lastbit;
+    p.segbits = b->segbits[k]; p.segcnt = b->segcnt[k];
+    p.N = b->N; p.L = len; p.n_seg = b->n_seg; p.seg_words = b->seg_words; p.pllinc = b->pllinc;
+}
+
+static hipError_t wait_on(const gnuais_batch *, hipStream_t st, hipEvent_t evt)
+{
+    return hipStreamWaitEvent(st, evt, 0);
+}
+
+// K2x, K2b, K3 of one call, each on its own stream (pipeline) or all on s0, after `after`
+// (the event that says this call's PLL stage is done; null = stream order on s0).
+static int run_tail(gnuais_batch *b, int k, int len, unsigned long long call, bool tm, hipEvent_t *ev,
+                    hipStream_t s0, hipEvent_t after)
+{
+    const bool pl = b->pipeline;
+    hipStream_t sB = pl ? b->s_k[1] : s0, sC = pl ? b->s_k[2] : s0, sD = pl ? b->s_k[3] : s0;
+    const bool reuse = pl && call >= (unsigned) gnuais_batch::NBUF;   // set k last used by call - NBUF
+    PllLaunch p;
+    fill_pll(b, p, k, len);
+    // K2x: needs ovf[k]; fills segbits[k] (read by K2b of call - NBUF)
+    if (pl) {
+        if (after) HIP_TRY(hipStreamWaitEvent(sB, after, 0));
+        if (reuse) HIP_TRY(wait_on(b, sB, b->e_done[3][k]));
+    }
+    if (tm) HIP_TRY(hipEventRecord(ev[8], sB));
+    if (b->stage_mask & 4) HIP_TRY(launch_nrzi_extract(p, sB));
+    if (tm) HIP_TRY(hipEventRecord(ev[3], sB));
+    if (pl) HIP_TRY(hipEventRecord(b->e_done[2][k], sB));
+
+    HdlcLaunch h;
+    fill_hdlc(b, h, k);
+    // K2b: needs segbits[k]; fills cand_first/count[k] (read by K3 of call - NBUF)
+    if (pl) {
+        HIP_TRY(hipStreamWaitEvent(sC, b->e_done[2][k], 0));
+        if (reuse) HIP_TRY(wait_on(b, sC, b->e_done[4][k]));
+    }
+    if (tm) HIP_TRY(hipEventRecord(ev[5], sC));
+    if (b->stage_mask & 8) HIP_TRY(launch_hdlc_deframe(h, sC));
+    if (tm) HIP_TRY(hipEventRecord(ev[7], sC));
+    if (pl) HIP_TRY(hipEventRecord(b->e_done[3][k], sC));
+    // K3
+    if (pl) HIP_TRY(hipStreamWaitEvent(sD, b->e_done[3][k], 0));
+    if (tm) HIP_TRY(hipEventRecord(ev[9], sD));
+    if (b->stage_mask & 16) HIP_TRY(launch_hdlc_crc(h, sD));
+    b->hdlc_calls++;
+    if (tm) HIP_TRY(hipEventRecord(ev[4], sD));
+    if (pl) HIP_TRY(hipEventRecord(b->e_done[4][k], sD));
+    return GNUAIS_OK;
+}
+
 int gnuais_batch_run(gnuais_batch *b, const int16_t *d_samples, int len, void *stream)
 {
     if (!b || !d_samples) return fail(GNUAIS_E_ARG, "run: NULL argument");
@@ -400,64 +469,36 @@ int gnuais_batch_run(gnuais_batch *b, const int16_t *d_samples, int len, void *s
     if (int rc = set_device(b)) return rc;
     hipStream_t s0 = (hipStream_t) stream;
     const bool pl = b->pipeline;
-    hipStream_t sA = pl ? b->s_k[0] : s0, sB = pl ? b->s_k[1] : s0;
-    hipStream_t sC = pl ? b->s_k[2] : s0, sD = pl ? b->s_k[3] : s0;
-    const int k = (int) (b->calls & 1);           // hand-off buffer pair of this call
-    const bool reuse = pl && b->calls >= 2;       // pair k was last used by call i-2
-    const bool tm = b->timing;
+    const int k = (int) (b->calls % gnuais_batch::NBUF);      // hand-off buffer set of this call
+    const bool reuse = pl && b->calls >= (unsigned) gnuais_batch::NBUF;   // set k last used by call i-NBUF
+    const bool tm = b->timing && (b->calls % (unsigned) b->timing_stride) == 0;
     hipEvent_t *ev = b->evr[b->timed_calls % gnuais_batch::TIMING_RING];
 
-    // K1 fills sgn[k]: its readers of call i-2 (K2a, K2x) must be done
-    if (reuse) {
-        HIP_TRY(hipStreamWaitEvent(s0, b->e_done[1][k], 0));
-        HIP_TRY(hipStreamWaitEvent(s0, b->e_done[2][k], 0));
+    {
+        hipStream_t sA = pl ? b->s_k[0] : s0;
+        // K1 fills sgn[k]: its readers of call i-NBUF (K2a, K2x) must be done
+        if (reuse) {
+            HIP_TRY(wait_on(b, s0, b->e_done[1][k]));
+            HIP_TRY(wait_on(b, s0, b->e_done[2][k]));
+        }
+        if (tm) HIP_TRY(hipEventRecord(ev[0], s0));
+        if (b->stage_mask & 1)
+            if (int rc = run_fir(b, d_samples, len, nullptr, s0, k)) return rc;
+        if (tm) HIP_TRY(hipEventRecord(ev[1], s0));
+        if (pl) HIP_TRY(hipEventRecord(b->e_done[0][k], s0));
+        // K2a: needs this call's sign words; fills ovf[k] (read by K2x of call i-NBUF)
+        PllLaunch p;
+        fill_pll(b, p, k, len);
+        if (pl) {
+            HIP_TRY(hipStreamWaitEvent(sA, b->e_done[0][k], 0));
+            if (reuse) HIP_TRY(wait_on(b, sA, b->e_done[2][k]));
+        }
+        if (tm) HIP_TRY(hipEventRecord(ev[2], sA));
+        if (b->stage_mask & 2) HIP_TRY(launch_pll_core(p, sA));
+        if (tm) HIP_TRY(hipEventRecord(ev[6], sA));
+        if (pl) HIP_TRY(hipEventRecord(b->e_done[1][k], sA));
+        if (int rc = run_tail(b, k, len, b->calls, tm, ev, s0, pl ? b->e_done[1][k] : nullptr)) return rc;
     }
-    if (tm) HIP_TRY(hipEventRecord(ev[0], s0));
-    if (int rc = run_fir(b, d_samples, len, nullptr, s0, k)) return rc;
-    if (tm) HIP_TRY(hipEventRecord(ev[1], s0));
-    if (pl) HIP_TRY(hipEventRecord(b->e_done[0][k], s0));
-
-    PllLaunch p;
-    p.sgn = b->sgn[k]; p.ovf = b->ovf[k]; p.pll = b->pll; p.lastbit = b->lastbit;
-    p.segbits = b->segbits[k]; p.segcnt = b->segcnt[k];
-    p.N = b->N; p.L = len; p.n_seg = b->n_seg; p.seg_words = b->seg_words; p.pllinc = b->pllinc;
-    // K2a: needs this call's sign words; fills ovf[k] (read by K2x of call i-2)
-    if (pl) {
-        HIP_TRY(hipStreamWaitEvent(sA, b->e_done[0][k], 0));
-        if (reuse) HIP_TRY(hipStreamWaitEvent(sA, b->e_done[2][k], 0));
-    }
-    if (tm) HIP_TRY(hipEventRecord(ev[2], sA));
-    HIP_TRY(launch_pll_core(p, sA));
-    if (tm) HIP_TRY(hipEventRecord(ev[6], sA));
-    if (pl) HIP_TRY(hipEventRecord(b->e_done[1][k], sA));
-    // K2x: needs ovf[k]; fills segbits[k] (read by K2b of call i-2)
-    if (pl) {
-        HIP_TRY(hipStreamWaitEvent(sB, b->e_done[1][k], 0));
-        if (reuse) HIP_TRY(hipStreamWaitEvent(sB, b->e_done[3][k], 0));
-    }
-    if (tm) HIP_TRY(hipEventRecord(ev[8], sB));
-    HIP_TRY(launch_nrzi_extract(p, sB));
-    if (tm) HIP_TRY(hipEventRecord(ev[3], sB));
-    if (pl) HIP_TRY(hipEventRecord(b->e_done[2][k], sB));
-
-    HdlcLaunch h;
-    fill_hdlc(b, h, k);
-    // K2b: needs segbits[k]; fills cand_first/count[k] (read by K3 of call i-2)
-    if (pl) {
-        HIP_TRY(hipStreamWaitEvent(sC, b->e_done[2][k], 0));
-        if (reuse) HIP_TRY(hipStreamWaitEvent(sC, b->e_done[4][k], 0));
-    }
-    if (tm) HIP_TRY(hipEventRecord(ev[5], sC));
-    HIP_TRY(launch_hdlc_deframe(h, sC));
-    if (tm) HIP_TRY(hipEventRecord(ev[7], sC));
-    if (pl) HIP_TRY(hipEventRecord(b->e_done[3][k], sC));
-    // K3
-    if (pl) HIP_TRY(hipStreamWaitEvent(sD, b->e_done[3][k], 0));
-    if (tm) HIP_TRY(hipEventRecord(ev[9], sD));
-    HIP_TRY(launch_hdlc_crc(h, sD));
-    b->hdlc_calls++;
-    if (tm) HIP_TRY(hipEventRecord(ev[4], sD));
-    if (pl) HIP_TRY(hipEventRecord(b->e_done[4][k], sD));
 
     b->timed_last = tm;
     if (tm) b->timed_calls++;
@@ -508,7 +549,7 @@ int gnuais_batch_filter(gnuais_batch *b, const int16_t *d_samples, int len, floa
     if (int rc = set_device(b)) return rc;
     hipStream_t s = (hipStream_t) stream;
     if (int rc = gnuais_batch_sync(b)) return rc;       // the sign-word scratch is shared
-    if (int rc = run_fir(b, d_samples, len, d_out, s, (int) (b->calls & 1))) return rc;
+    if (int rc = run_fir(b, d_samples, len, d_out, s, (int) (b->calls % gnuais_batch::NBUF))) return rc;
     b->last_stream = s;
     b->timed_last = false;
     return GNUAIS_OK;

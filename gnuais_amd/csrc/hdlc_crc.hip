@@ -376,6 +376,7 @@ __global__ __launch_bounds__(256) void hdlc_crc_kernel(
     __shared__ uint32_t tab[256];
     __shared__ uint32_t pre[K3_CH + 1];
     __shared__ uint32_t stage[256][HDLC_BUF_WORDS + 1];     // unstuffed frame bits per thread
+    __shared__ uint32_t rawlds[256][CAND_WORDS - CAND_HDR + 1];   // raw record per thread
     __shared__ uint32_t wave_cnt[4];
     __shared__ uint32_t pass_base;
     const int tid = threadIdx.x;
@@ -424,26 +425,28 @@ __global__ __launch_bounds__(256) void hdlc_crc_kernel(
                 // protodec.c:1008-1023 on the raw bits: store every bit except the one
                 // that follows five 1s (it is a stuffed 0 inside a frame)
                 {
-                    uint32_t raw[CAND_WORDS - CAND_HDR];        // whole record first: one latency
+                    // whole record first (one latency), parked in LDS so that the bit
+                    // loop below can stay rolled (small code: this kernel shares the
+                    // instruction cache with the FIR and the sequential kernels)
+                    uint32_t raw[CAND_WORDS - CAND_HDR];
 #pragma unroll
                     for (int q = 0; q < CAND_WORDS - CAND_HDR; ++q) raw[q] = rec[CAND_HDR + q];
-                    uint32_t curw = 0;
+#pragma unroll
+                    for (int q = 0; q < CAND_WORDS - CAND_HDR; ++q) rawlds[tid][q] = raw[q];
+                    uint32_t curw = 0, rw = 0;
                     int bp = 0, ones = 0;
                     bool drop = false;
-#pragma unroll
-                    for (int q = 0; q < CAND_WORDS - CAND_HDR; ++q) {
-                        uint32_t rw = raw[q];
-                        const int lim = rawlen - 32 * q < 32 ? rawlen - 32 * q : 32;
-                        for (int b = 0; b < lim; ++b) {
-                            const uint32_t x = rw & 1u;
-                            rw >>= 1;
-                            if (drop) { drop = false; continue; }
-                            curw |= x << (bp & 31);
-                            if ((bp & 31) == 31) { stage[tid][bp >> 5] = curw; curw = 0; }
-                            ++bp;
-                            ones = x ? ones + 1 : 0;
-                            if (ones == 5) { drop = true; ones = 0; }
-                        }
+#pragma unroll 1
+                    for (int r = 0; r < rawlen; ++r) {
+                        if ((r & 31) == 0) rw = rawlds[tid][r >> 5];
+                        const uint32_t x = rw & 1u;
+                        rw >>= 1;
+                        if (drop) { drop = false; continue; }
+                        curw |= x << (bp & 31);
+                        if ((bp & 31) == 31) { stage[tid][bp >> 5] = curw; curw = 0; }
+                        ++bp;
+                        ones = x ? ones + 1 : 0;
+                        if (ones == 5) { drop = true; ones = 0; }
                     }
                     if (bp < 32 * (HDLC_BUF_WORDS + 1)) stage[tid][bp >> 5] = curw;
                 }

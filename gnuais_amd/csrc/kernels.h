@@ -27,10 +27,12 @@ hipError_t launch_fir_history(const int16_t *x, const int16_t *hist_in, int16_t 
                               int N, int L, int NT, hipStream_t stream);
 
 // ---- K2a: PLL clock recovery, K2x: slice + NRZI (pll_nrzi.hip) --------------
-constexpr int PLL_PAD = 8;           // prefetch depth; sgn/ovf carry 2*PLL_PAD spare rows
+constexpr int PLL_PAD = 8;           // words per prefetch group (= unroll of the PLL loop body)
+constexpr int PLL_PAD_ROWS = 32;     // spare rows sgn/ovf carry so that batched reads need no bounds test
+constexpr int PLL_LDS_BYTES = 81 * 1024;   // > half of a CU's LDS: one PLL wave per CU
 constexpr int SEG_WORDS = 64;        // K2x segment: 64 sign words = 2048 samples
 struct PllLaunch {
-    const uint32_t *sgn;   // [ceil(L/32) + 2*PLL_PAD][N]
+    const uint32_t *sgn;   // [ceil(L/32) + PLL_PAD_ROWS][N]
     uint32_t *ovf;         // same shape: slice marks (pll overflow), bit 31 = oldest sample
     uint32_t *pll;         // [N] phase (bits 15:0), prev sign (bit 16)
     uint32_t *lastbit;     // [N] level at the last slice (receiver.h:38)

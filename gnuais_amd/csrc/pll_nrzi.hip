@@ -35,6 +35,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <algorithm>
 #include "kernels.h"
 
 namespace gnuais {
@@ -69,54 +70,132 @@ __device__ __forceinline__ void pll_word(uint32_t D, uint32_t &P, uint32_t &O, u
         : "vcc");
 }
 
-// sgn and ovf have PLL_PAD extra (zero / scratch) rows so the prefetch needs no bounds test
-__global__ __launch_bounds__(64) void pll_core_kernel(
+// One workgroup = 64 channels (group blockIdx.x) through the whole call, as TWO waves:
+//   wave 0  the recurrence.  It touches only LDS: beside a FIR that keeps the CU's vector
+//           memory pipeline full, every global load / store this wave issued cost it
+//           microseconds at ISSUE (measured: 0.60 ms without memory instructions, 1.3 ms
+//           with loads or stores, whatever the prefetch distance);
+//   wave 1  the mover.  Streams the sign words into an LDS ring PLL_RING words ahead
+//           (~50 us of lead) and drains the slice-mark words from a second ring, in
+//           batches.  Its own stalls are absorbed by the rings.
+// The rings are handed over through three monotonic LDS counters (words loaded, words
+// computed, words stored); the LDS unit serves DS instructions in order, so a counter
+// written after the data (release) is seen after the data (acquire).
+// The launch asks for PLL_LDS_BYTES of LDS, more than half a CU's 160 KB, so the dispatcher
+// places at most ONE of these workgroups per CU and two chains never share a SIMD (that
+// doubles both; seen when the FIR's grid grew, scripts/ubench/overlap.hip).
+constexpr int PLL_RING = 128;        // words per ring (in and out): 2 x 32 KB
+constexpr int PLL_BATCH = 16;        // words the mover handles per touch of the memory pipeline
+static_assert(2 * PLL_RING * 64 * 4 + 64 <= PLL_LDS_BYTES, "rings must fit the LDS we reserve");
+static_assert(PLL_BATCH <= PLL_PAD_ROWS, "the mover reads whole batches past the last word");
+
+__global__ __launch_bounds__(128) void pll_core_kernel(
     const uint32_t *__restrict__ sgn, uint32_t *__restrict__ ovf, uint32_t *__restrict__ pllst,
     int N, int L, uint32_t pllinc)
 {
-    // this wave is a long dependent chain; when it shares a SIMD with FIR waves of
-    // the next call it must win every issue slot it can use
-    __builtin_amdgcn_s_setprio(3);
-    const int cg = blockIdx.x * 64 + threadIdx.x;
+    extern __shared__ uint32_t lds[];
+    uint32_t *rin = lds, *rout = lds + PLL_RING * 64, *flag = lds + 2 * PLL_RING * 64;
+    const int lane = threadIdx.x & 63, role = threadIdx.x >> 6;
+    const int cg = blockIdx.x * 64 + lane;
     const int c = cg < N ? cg : N - 1;
     const bool live = cg < N;
+    const int W = (L + 31) >> 5;
+    const int Wfull = L >> 5;                     // words with all 32 samples valid
+    if (threadIdx.x < 3) flag[threadIdx.x] = 0;   // 0 loaded, 1 computed, 2 stored
+    __syncthreads();
+    const unsigned long long t_start = wall_clock64();
+    // nothing here may spin forever: a wave that waits longer than this gives up
+    auto expired = [&]() { return wall_clock64() - t_start > 20000000ull; };   // 200 ms
 
+    if (role == 1) {                              // ---- the mover ----
+        // Loads are software-pipelined: batch k+1 is in flight while batch k is written to the
+        // ring, so one memory round trip (several microseconds beside the FIR) is paid per
+        // batch of PLL_BATCH words only once, not in series with the LDS writes and the stores.
+        const uint32_t *__restrict__ src = sgn + c;
+        int w_issue = 0, w_in = 0, w_out = 0;     // words: loads issued / in the ring / stored
+        uint32_t va[PLL_BATCH], vb[PLL_BATCH];
+        bool a_pending = false;
+        while (w_out < W && !expired()) {
+            bool moved = false;
+            const int done = (int) __hip_atomic_load(flag + 1, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
+            const bool can_b = w_issue < W && w_issue + PLL_BATCH - done <= PLL_RING;
+            if (can_b) {
+#pragma unroll
+                for (int q = 0; q < PLL_BATCH; ++q) vb[q] = src[(size_t) (w_issue + q) * (size_t) N];
+            }
+            if (a_pending) {
+#pragma unroll
+                for (int q = 0; q < PLL_BATCH; ++q) rin[((w_in + q) % PLL_RING) * 64 + lane] = va[q];
+                w_in = w_in + PLL_BATCH < W ? w_in + PLL_BATCH : W;
+                __hip_atomic_store(flag + 0, (uint32_t) w_in, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                a_pending = false;
+                moved = true;
+            }
+            if (can_b) {
+#pragma unroll
+                for (int q = 0; q < PLL_BATCH; ++q) va[q] = vb[q];
+                a_pending = true;
+                w_issue += PLL_BATCH;
+                moved = true;
+            }
+            if (done - w_out >= PLL_BATCH || (done == W && done > w_out)) {
+                const int n = done - w_out < PLL_BATCH ? done - w_out : PLL_BATCH;
+#pragma unroll
+                for (int q = 0; q < PLL_BATCH; ++q)
+                    if (q < n) {
+                        const uint32_t O = rout[((w_out + q) % PLL_RING) * 64 + lane];
+                        if (live) ovf[(size_t) (w_out + q) * (size_t) N + cg] = O;
+                    }
+                w_out += n;
+                __hip_atomic_store(flag + 2, (uint32_t) w_out, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                moved = true;
+            }
+            if (!moved) __builtin_amdgcn_s_sleep(16);
+        }
+        return;
+    }
+
+    // ---- the recurrence ----
+    // a long dependent chain: when it shares a SIMD with other waves it must win every
+    // issue slot it can use
+    __builtin_amdgcn_s_setprio(3);
     const uint32_t st = pllst[c];
     uint32_t P = (st & 0xffffu) << 16;            // receiver.h:40 pll, scaled
     uint32_t prev = (st >> 16) & 1u;              // receiver.h:44
     const uint32_t INC = pllinc << 16;            // receiver.c:122
     const uint32_t Q = (pllinc / 16u) << 16;      // receiver.c:84,115,117
     const uint32_t Kp = INC + Q, Km = INC - Q;
-    const int W = (L + 31) >> 5;
-    const int Wfull = L >> 5;                     // words with all 32 samples valid
-
     constexpr int PF = PLL_PAD;
-    uint32_t nxt[PF];
-    const uint32_t *__restrict__ src = sgn + c;
-#pragma unroll
-    for (int q = 0; q < PF; ++q) nxt[q] = src[(size_t) q * (size_t) N];
 
     for (int w0 = 0; w0 < Wfull; w0 += PF) {
-        uint32_t grp[PF];
+        const int w1 = w0 + PF < Wfull ? w0 + PF : Wfull;
+        while ((int) __hip_atomic_load(flag + 0, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < w1 && !expired())
+            __builtin_amdgcn_s_sleep(1);
+        while (w1 - (int) __hip_atomic_load(flag + 2, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) > PLL_RING && !expired())
+            __builtin_amdgcn_s_sleep(1);
+        uint32_t cur[PF];
 #pragma unroll
-        for (int q = 0; q < PF; ++q) grp[q] = nxt[q];
-#pragma unroll
-        for (int q = 0; q < PF; ++q) nxt[q] = src[(size_t) (w0 + PF + q) * (size_t) N];
+        for (int q = 0; q < PF; ++q) cur[q] = rin[((w0 + q) % PLL_RING) * 64 + lane];
 #pragma unroll
         for (int q = 0; q < PF; ++q) {
             if (w0 + q < Wfull) {
-                const uint32_t S = grp[q];                          // bit 31 = oldest
+                const uint32_t S = cur[q];                          // bit 31 = oldest
                 const uint32_t D = S ^ ((S >> 1) | (prev << 31));   // receiver.c:113
                 prev = S & 1u;
                 uint32_t O = 0;
                 pll_word(D, P, O, Kp, Km, INC);
-                if (live) ovf[(size_t) (w0 + q) * (size_t) N + cg] = O;
+                rout[((w0 + q) % PLL_RING) * 64 + lane] = O;
             }
         }
+        __hip_atomic_store(flag + 1, (uint32_t) w1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
     if (Wfull < W) {                              // last, partial word (L % 32 samples)
         const int nv = L - Wfull * 32;
-        const uint32_t S = src[(size_t) Wfull * (size_t) N];
+        while ((int) __hip_atomic_load(flag + 0, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < W && !expired())
+            __builtin_amdgcn_s_sleep(1);
+        while (W - (int) __hip_atomic_load(flag + 2, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) > PLL_RING && !expired())
+            __builtin_amdgcn_s_sleep(1);
+        const uint32_t S = rin[(Wfull % PLL_RING) * 64 + lane];
         uint32_t D = S ^ ((S >> 1) | (prev << 31));
         uint32_t O = 0;
         for (int i = 0; i < nv; ++i) {
@@ -130,7 +209,8 @@ __global__ __launch_bounds__(64) void pll_core_kernel(
         }
         O <<= (32 - nv);                          // left-align like S
         prev = (S >> (32 - nv)) & 1u;
-        if (live) ovf[(size_t) Wfull * (size_t) N + cg] = O;
+        rout[(Wfull % PLL_RING) * 64 + lane] = O;
+        __hip_atomic_store(flag + 1, (uint32_t) W, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
     if (live) pllst[cg] = (P >> 16) | (prev << 16);
 }
@@ -208,7 +288,21 @@ __global__ void nrzi_lastbit_kernel(const uint32_t *__restrict__ sgn,
 
 hipError_t launch_pll_core(const PllLaunch &a, hipStream_t stream)
 {
-    hipLaunchKernelGGL(pll_core_kernel, dim3((a.N + 63) / 64), dim3(64), 0, stream, a.sgn, a.ovf,
+    // one wave per CU while the channel groups fit one round; beyond that share the CUs evenly
+    static int n_cu = 0;
+    if (!n_cu) {
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess ||
+            hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n_cu <= 0)
+            n_cu = 256;
+        hipError_t e = hipFuncSetAttribute((const void *) pll_core_kernel,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, PLL_LDS_BYTES);
+        if (e != hipSuccess) return e;
+    }
+    const int groups = (a.N + 63) / 64, per_cu = (groups + n_cu - 1) / n_cu;
+    const int need = 2 * PLL_RING * 64 * 4 + 64;
+    const int lds = per_cu <= 1 ? PLL_LDS_BYTES : std::max(need, (160 * 1024 / per_cu) & ~1023);
+    hipLaunchKernelGGL(pll_core_kernel, dim3(groups), dim3(128), lds, stream, a.sgn, a.ovf,
                        a.pll, a.N, a.L, a.pllinc);
     return hipGetLastError();
 }

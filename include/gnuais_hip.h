@@ -144,7 +144,9 @@ int  gnuais_batch_mean_timing(gnuais_batch *b, float *ms6, int *n_calls);
 /* tunables: "fir_T" (outputs per wave in K1, multiple of 32), "fir_variant"
  * (3 = sign-exact slicer, the default on the receive path; 0 = exact v_mul/v_add K1,
  * 1 = its v_pk build, 2 = its MFMA-product build), "pipeline", "hdlc_lpw" (channels
- * per wave in the deframer, 1..64) */
+ * per wave in the deframer, 1..64), "timing_stride" (with set_timing on, time every n-th
+ * call only: the ten event records of a timed call cost ~0.05 ms of stream time),
+ * "stage_mask" (experiments: bit s = launch stage s; results are wrong unless 0x1f) */
 int  gnuais_batch_set_option(gnuais_batch *b, const char *name, int value);
 const char *gnuais_last_error(void);
 const char *gnuais_version(void);

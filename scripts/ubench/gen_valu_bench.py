@@ -28,29 +28,66 @@ modes["iadd32"] = [f"v_add_u32 v{100+i}, v{100+i}, %0" for i in range(32)]
 modes["fma32"] = [f"v_fma_f32 v{100+i}, v{100+i}, %0, %0" for i in range(32)]
 # H: 32 x v_pk_fma
 modes["pk_fma32"] = [f"v_pk_fma_f32 v[{100+2*i}:{101+2*i}], v[{100+2*i}:{101+2*i}], %1, %1" for i in range(32)]
+
+# integer / bit ops used by the PLL core
+modes["bfi32"] = [f"v_bfi_b32 v{100+i}, v{100+i}, %0, %0" for i in range(32)]
+modes["bfe32"] = [f"v_bfe_i32 v{100+i}, v{100+i}, 3, 1" for i in range(32)]
+modes["ashr32"] = [f"v_ashrrev_i32 v{100+i}, 31, v{100+i}" for i in range(32)]
+modes["addco32"] = [f"v_add_co_u32 v{100+i}, vcc, v{100+i}, %0" for i in range(32)]
+modes["xor32"] = [f"v_xor_b32 v{100+i}, v{100+i}, %0" for i in range(32)]
+modes["cndmask32"] = [f"v_cndmask_b32 v{100+i}, v{100+i}, %0, vcc" for i in range(32)]
+modes["cmp32"] = [f"v_cmp_gt_f32 vcc, v{100+i}, %0" for i in range(32)]
+# the PLL recurrence itself: one dependent chain, 6 instr / sample, 8 samples
+pl = []
+for i in range(8):
+    pl += [f"v_bfe_i32 v101, v100, {i}, 1", "v_ashrrev_i32 v102, 31, v103",
+           "v_addc_co_u32 v104, vcc, v104, v104, vcc",
+           "v_bfi_b32 v105, v102, %0, %0", "v_bfi_b32 v105, v101, v105, %0",
+           "v_add_co_u32 v103, vcc, v103, v105"]
+modes["pll_chain"] = pl
+
+modes["cndmask_e64_s"] = ["s_mov_b64 s[20:21], -1"] + [f"v_cndmask_b32_e64 v{100+i}, v{100+i}, %0, s[20:21]" for i in range(32)]
+modes["cndmask_01_vcc"] = [f"v_cndmask_b32_e64 v{100+i}, 0, 1, vcc" for i in range(32)]
+modes["lshl_or32"] = [f"v_lshl_or_b32 v{100+i}, v{100+i}, 1, %0" for i in range(32)]
+modes["lshl_add_u64"] = [f"v_lshl_add_u64 v[{100+2*i}:{101+2*i}], v[{100+2*i}:{101+2*i}], 1, v[{100+2*i}:{101+2*i}]" for i in range(16)]
+modes["cvt32"] = [f"v_cvt_f32_i32 v{100+i}, v{100+i}" for i in range(32)]
+modes["max3_32"] = [f"v_max3_i32 v{100+i}, v{100+i}, %0, %0" for i in range(32)]
+f1 = []; f2 = []; f3 = []
+for i in range(16):
+    f1 += [f"v_cmp_lt_f32 vcc, 0, v{100+i}", "v_cndmask_b32_e64 v140, 0, 1, vcc", "v_lshl_or_b32 v141, v141, 1, v140",
+           f"v_cmp_le_f32 s[20:21], |v{100+i}|, %0", "v_cndmask_b32_e64 v142, 0, 1, s[20:21]", "v_lshl_or_b32 v143, v143, 1, v142"]
+    f2 += [f"v_cmp_lt_f32 vcc, 0, v{100+i}", "s_nop 0", "v_addc_co_u32 v141, vcc, v141, v141, vcc",
+           f"v_cmp_le_f32 vcc, |v{100+i}|, %0", "s_nop 0", "v_addc_co_u32 v143, vcc, v143, v143, vcc"]
+    # interleaved: cmp A ; cmp B(sgpr) ; addc A ; addc B
+    f3 += [f"v_cmp_lt_f32 vcc, 0, v{100+i}", f"v_cmp_le_f32 s[20:21], |v{100+i}|, %0",
+           "v_addc_co_u32 v141, vcc, v141, v141, vcc", "v_addc_co_u32 v143, s[22:23], v143, v143, s[20:21]"]
+modes["flags_cur"] = f1
+modes["flags_addc"] = f2
+modes["flags_addc_il"] = f3
 src = ['#include <hip/hip_runtime.h>', '#include <cstdio>', 'typedef float f32x2 __attribute__((ext_vector_type(2)));']
 names = list(modes)
 for k, (name, ins) in enumerate(modes.items()):
     body = "\\n\\t".join(ins)
-    src.append(f'''__global__ __launch_bounds__(256) void k{k}(float *out, int iters, float b) {{
+    src.append(f'''__global__ __launch_bounds__(256) void k{k}(float *out, int iters, float b, int lim) {{
   f32x2 bb = {{b, b}};
+  if ((int) (threadIdx.x & 63) >= lim) return;
   for (int it = 0; it < iters; ++it)
-    asm volatile("{body}" :: "v"(b), "v"(bb) : {clob(100, 180)});
+    asm volatile("{body}" :: "v"(b), "v"(bb) : {clob(100, 180)}, "vcc", "s20", "s21", "s22", "s23");
   out[blockIdx.x * blockDim.x + threadIdx.x] = b;
 }}''')
-src.append('typedef void (*kern_t)(float*, int, float);')
+src.append('typedef void (*kern_t)(float*, int, float, int);')
 src.append('int main() { float *d; (void) hipMalloc(&d, 8192 * 256 * 4); const int iters = 20000;')
 src.append('  kern_t ks[] = {' + ",".join(f"k{k}" for k in range(len(names))) + '};')
 src.append('  const char *nm[] = {' + ",".join(f'"{n}"' for n in names) + '};')
 src.append('  const int ninstr[] = {' + ",".join(str(len(modes[n])) for n in names) + '};')
-src.append('''  for (int wps = 1; wps <= 8; wps *= 2) for (int m = 0; m < (int)(sizeof(ks)/sizeof(ks[0])); ++m) {
+src.append('''  for (int lim = 64; lim >= 16; lim /= 2) for (int wps = 1; wps <= 4; wps *= 4) for (int m = 0; m < (int)(sizeof(ks)/sizeof(ks[0])); ++m) {
     hipEvent_t e0, e1; (void) hipEventCreate(&e0); (void) hipEventCreate(&e1);
-    hipLaunchKernelGGL(ks[m], dim3(256 * wps), dim3(256), 0, 0, d, 10, 1.0f);
+    hipLaunchKernelGGL(ks[m], dim3(256 * wps), dim3(256), 0, 0, d, 10, 1.0f, lim);
     (void) hipEventRecord(e0);
-    hipLaunchKernelGGL(ks[m], dim3(256 * wps), dim3(256), 0, 0, d, iters, 1.0f);
+    hipLaunchKernelGGL(ks[m], dim3(256 * wps), dim3(256), 0, 0, d, iters, 1.0f, lim);
     (void) hipEventRecord(e1); (void) hipEventSynchronize(e1);
     float ms; (void) hipEventElapsedTime(&ms, e0, e1);
-    printf("waves/SIMD=%d %-14s %8.3f ms  %.3f ns per wave-instruction per SIMD\\n", wps, nm[m], ms, ms * 1e6 / iters / wps / ninstr[m]);
+    printf("lanes=%d waves/SIMD=%d %-14s %8.3f ms  %.3f ns per wave-instruction per SIMD\\n", lim, wps, nm[m], ms, ms * 1e6 / iters / wps / ninstr[m]);
   }
   return 0; }''')
 open("valu_rate.hip", "w").write("\n".join(src))
