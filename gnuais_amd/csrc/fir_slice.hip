@@ -28,6 +28,7 @@
 #include <stdint.h>
 #include <string.h>
 
+#include <math.h>
 #include "kernels.h"
 
 #ifndef FIR_VARIANT
@@ -338,13 +339,32 @@ __global__ __launch_bounds__(64) void fir_slice_kernel(
 //
 // Same mapping as K1 (lane = channel, wave = 64 channels x one time segment), but
 // 12 accumulators rotate, so 96 phases (three sign words) are unrolled.
+#ifndef FIR_SIGN_FENCE
+#define FIR_SIGN_FENCE 4
+#endif
+// zero-instruction fence (see touch16): bounds how many samples the scheduler interleaves,
+// i.e. how many products are alive at once; without it the kernel needs 98 VGPRs (4 waves per
+// SIMD) instead of <= 88 (5 waves)
+__device__ __forceinline__ void touch12(float *a)
+{
+    asm volatile("" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]),
+                      "+v"(a[6]), "+v"(a[7]), "+v"(a[8]), "+v"(a[9]), "+v"(a[10]), "+v"(a[11]));
+}
+
 template <int NE, int NC>
 __global__ __launch_bounds__(64) void fir_sign_kernel(
     const int16_t *__restrict__ x, const int16_t *__restrict__ hist,
     uint32_t *__restrict__ sgn, int *__restrict__ maxval,
     int16_t *__restrict__ hist_out, int *__restrict__ maxval_next,
-    int N, int L, int T, int d, int NT, float eps, FirTaps<NE> taps)
+    int N, int L, int T, int d, int NT, float eps_up, FirTaps<NE> taps)
 {
+#if FIR_SIGN_FENCE > 0
+    // Claim 88 VGPRs although the fenced code needs 68: five waves per SIMD then leave 72
+    // registers for a wave of each of the stages that run beside us (K2a needs 56).  At seven
+    // waves per SIMD this kernel would fill the register file and they would wait for FIR
+    // waves to retire before they could even be placed.
+    asm volatile("" ::: "v87");
+#endif
     static_assert(NE == 32 && NC == 12, "sized for the reference table");
     constexpr int J0 = (NE - NC) / 2;           // first central tap (10)
     const int lane = threadIdx.x;
@@ -425,7 +445,13 @@ __global__ __launch_bounds__(64) void fir_sign_kernel(
                 }
                 peak = bp > peak ? bp : peak;
             }
-            uint32_t w = 0, amb = 0;
+            // Two flag bits per sample, each gathered with ONE v_alignbit_b32 (shift the word
+            // left, take the new bit from another register's bit 31) instead of compare +
+            // select + shift/or, which was a third of this kernel's issue time:
+            //   neg  collects the sign bit of y_c: 0 for y_c > 0 and for +0.0 (ambiguous anyway);
+            //   amb  collects the sign bit of |y_c| - eps_up, eps_up = nextafter(eps): set
+            //        exactly when |y_c| <= eps (a - b is negative or -0 iff a < b).
+            uint32_t neg = 0, amb = 0;
 #pragma unroll
             for (int p = 0; p < 32; ++p) {
                 const int P = w3 * 32 + p;                  // phase 0..95, P % 12 static
@@ -439,9 +465,13 @@ __global__ __launch_bounds__(64) void fir_sign_kernel(
                     acc[s1] = acc[s1] + pr;
                 }
                 const float y = acc[P % NC];                // y_c of output obase + p
-                w = (w << 1) | (y > 0.0f ? 1u : 0u);
-                amb = (amb << 1) | (__builtin_fabsf(y) <= eps ? 1u : 0u);
+                neg = __builtin_amdgcn_alignbit(neg, __float_as_uint(y), 31);
+                amb = __builtin_amdgcn_alignbit(amb, __float_as_uint(__builtin_fabsf(y) - eps_up), 31);
+#if FIR_SIGN_FENCE > 0
+                if (p % FIR_SIGN_FENCE == FIR_SIGN_FENCE - 1) touch12(acc);
+#endif
             }
+            uint32_t w = ~neg;
             const int valid = t1 - (t0 + obase);
             if (valid < 32) {
                 w &= ~0u << (32 - valid);
@@ -483,7 +513,8 @@ hipError_t launch_fir_sign(const FirLaunch &a, hipStream_t stream)
     FirTaps<32> t;
     for (int j = 0; j < 32; ++j) t.te[j] = a.te[j];
     hipLaunchKernelGGL((fir_sign_kernel<32, 12>), grid, block, 0, stream, a.x, a.hist, a.sgn,
-                       a.maxval, a.hist_out, a.maxval_next, a.N, a.L, a.T, a.d, a.NT, a.eps, t);
+                       a.maxval, a.hist_out, a.maxval_next, a.N, a.L, a.T, a.d, a.NT,
+                       __builtin_nextafterf(a.eps, INFINITY), t);
     return hipGetLastError();
 }
 

@@ -416,26 +416,18 @@ static void fill_pll(const gnuais_batch *b, PllLaunch &p, int k, int len)
     p.N = b->N; p.L = len; p.n_seg = b->n_seg; p.seg_words = b->seg_words; p.pllinc = b->pllinc;
 }
 
-static hipError_t wait_on(const gnuais_batch *, hipStream_t st, hipEvent_t evt)
-{
-    return hipStreamWaitEvent(st, evt, 0);
-}
 
 // K2x, K2b, K3 of one call, each on its own stream (pipeline) or all on s0, after `after`
 // (the event that says this call's PLL stage is done; null = stream order on s0).
-static int run_tail(gnuais_batch *b, int k, int len, unsigned long long call, bool tm, hipEvent_t *ev,
+static int run_tail(gnuais_batch *b, int k, int len, bool tm, hipEvent_t *ev,
                     hipStream_t s0, hipEvent_t after)
 {
     const bool pl = b->pipeline;
     hipStream_t sB = pl ? b->s_k[1] : s0, sC = pl ? b->s_k[2] : s0, sD = pl ? b->s_k[3] : s0;
-    const bool reuse = pl && call >= (unsigned) gnuais_batch::NBUF;   // set k last used by call - NBUF
     PllLaunch p;
     fill_pll(b, p, k, len);
     // K2x: needs ovf[k]; fills segbits[k] (read by K2b of call - NBUF)
-    if (pl) {
-        if (after) HIP_TRY(hipStreamWaitEvent(sB, after, 0));
-        if (reuse) HIP_TRY(wait_on(b, sB, b->e_done[3][k]));
-    }
+    if (pl && after) HIP_TRY(hipStreamWaitEvent(sB, after, 0));
     if (tm) HIP_TRY(hipEventRecord(ev[8], sB));
     if (b->stage_mask & 4) HIP_TRY(launch_nrzi_extract(p, sB));
     if (tm) HIP_TRY(hipEventRecord(ev[3], sB));
@@ -444,10 +436,7 @@ static int run_tail(gnuais_batch *b, int k, int len, unsigned long long call, bo
     HdlcLaunch h;
     fill_hdlc(b, h, k);
     // K2b: needs segbits[k]; fills cand_first/count[k] (read by K3 of call - NBUF)
-    if (pl) {
-        HIP_TRY(hipStreamWaitEvent(sC, b->e_done[2][k], 0));
-        if (reuse) HIP_TRY(wait_on(b, sC, b->e_done[4][k]));
-    }
+    if (pl) HIP_TRY(hipStreamWaitEvent(sC, b->e_done[2][k], 0));
     if (tm) HIP_TRY(hipEventRecord(ev[5], sC));
     if (b->stage_mask & 8) HIP_TRY(launch_hdlc_deframe(h, sC));
     if (tm) HIP_TRY(hipEventRecord(ev[7], sC));
@@ -476,11 +465,11 @@ int gnuais_batch_run(gnuais_batch *b, const int16_t *d_samples, int len, void *s
 
     {
         hipStream_t sA = pl ? b->s_k[0] : s0;
-        // K1 fills sgn[k]: its readers of call i-NBUF (K2a, K2x) must be done
-        if (reuse) {
-            HIP_TRY(wait_on(b, s0, b->e_done[1][k]));
-            HIP_TRY(wait_on(b, s0, b->e_done[2][k]));
-        }
+        // Hand-off set k was last used by call i-NBUF.  Its last user is that call's K3; wait for
+        // it on the HOST (normally long done): five stream-wait packets per call, each ~20 us of
+        // queue time on the stream it sits in, for a condition that is practically always true.
+        // A caller that runs more than NBUF-1 calls ahead of the device blocks here.
+        if (reuse) HIP_TRY(hipEventSynchronize(b->e_done[4][k]));
         if (tm) HIP_TRY(hipEventRecord(ev[0], s0));
         if (b->stage_mask & 1)
             if (int rc = run_fir(b, d_samples, len, nullptr, s0, k)) return rc;
@@ -491,13 +480,12 @@ int gnuais_batch_run(gnuais_batch *b, const int16_t *d_samples, int len, void *s
         fill_pll(b, p, k, len);
         if (pl) {
             HIP_TRY(hipStreamWaitEvent(sA, b->e_done[0][k], 0));
-            if (reuse) HIP_TRY(wait_on(b, sA, b->e_done[2][k]));
         }
         if (tm) HIP_TRY(hipEventRecord(ev[2], sA));
         if (b->stage_mask & 2) HIP_TRY(launch_pll_core(p, sA));
         if (tm) HIP_TRY(hipEventRecord(ev[6], sA));
         if (pl) HIP_TRY(hipEventRecord(b->e_done[1][k], sA));
-        if (int rc = run_tail(b, k, len, b->calls, tm, ev, s0, pl ? b->e_done[1][k] : nullptr)) return rc;
+        if (int rc = run_tail(b, k, len, tm, ev, s0, pl ? b->e_done[1][k] : nullptr)) return rc;
     }
 
     b->timed_last = tm;
