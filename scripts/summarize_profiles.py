@@ -1,0 +1,78 @@
+"""Turn what scripts/collect_profiles.sh left under gpurun_out/r01 into the tracked summaries
+under profiles/ (per round: r01_*).
+
+  python scripts/summarize_profiles.py [gpurun_out/r01] [r01]
+
+PMC units / corrections as MI355X_MICROARCH.md's HBM section prescribes: FETCH_SIZE and
+WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE reports half the bytes of a coalesced stream, so
+it is doubled (cross-check: 2 x FETCH of the FIR = the 1.573 GB of samples + the segment halo).
+"""
+import csv, json, os, shutil, sys
+from collections import defaultdict
+
+src = sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/r01"
+tag = sys.argv[2] if len(sys.argv) > 2 else "r01"
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+out = os.path.join(root, "profiles")
+os.makedirs(out, exist_ok=True)
+
+SHORT = [("fir_sign_kernel", "fir_slice"), ("fir_slice_kernel", "fir_slice"), ("pll_core_kernel", "pll_core"),
+         ("nrzi_extract_kernel", "nrzi_extract"), ("hdlc_deframe_kernel", "hdlc_deframe"),
+         ("hdlc_crc_kernel", "hdlc_crc")]
+
+
+def short(name):
+    for pat, s in SHORT:
+        if pat in name:
+            return s
+    return None
+
+
+def per_launch(path, n_ch=16384):
+    """mean counter value per launch, bench-sized launches only (grid of the C3 workload)"""
+    acc = defaultdict(lambda: defaultdict(list))
+    with open(path) as f:
+        for r in csv.DictReader(f):
+            s = short(r["Kernel_Name"])
+            if s is None:
+                continue
+            acc[s][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    # the three isolated + warm-up launches are the same size as the timed ones: plain mean
+    return {k: {c: sum(v) / len(v) for c, v in d.items()} for k, d in acc.items()}
+
+
+for name, dst in (("stats/bench_kernel_stats.csv", f"{tag}_bench_kernel_stats_pipelined.csv"),
+                  ("stats_nopipe/bench_kernel_stats.csv", f"{tag}_bench_kernel_stats_sequential.csv"),
+                  ("bench.json", f"{tag}_bench.json"),
+                  ("bench_under_rocprof.json", f"{tag}_bench_under_rocprof.json"),
+                  ("bench_nopipe.json", f"{tag}_bench_sequential.json")):
+    p = os.path.join(src, name)
+    if os.path.exists(p):
+        shutil.copy(p, os.path.join(out, dst))
+
+fetch = per_launch(os.path.join(src, "pmc_fetch/pmc_counter_collection.csv"))
+write = per_launch(os.path.join(src, "pmc_write/pmc_counter_collection.csv"))
+traffic = {"command": "rocprofv3 --kernel-trace --pmc FETCH_SIZE|WRITE_SIZE (separate passes) -- "
+                      "python bench.py --no-cpu --steps 6 --warmup 1",
+           "units": "FETCH_SIZE/WRITE_SIZE are reported in KiB; FETCH_SIZE is doubled (gfx950 reports half the "
+                    "bytes of a coalesced stream, MI355X_MICROARCH.md HBM section)",
+           "raw_kib_per_launch": {}, "bytes_per_launch": {}}
+for k in fetch:
+    f = fetch[k].get("FETCH_SIZE", 0.0)
+    w = write.get(k, {}).get("WRITE_SIZE", 0.0)
+    traffic["raw_kib_per_launch"][k] = {"FETCH_SIZE": f, "WRITE_SIZE": w}
+    traffic["bytes_per_launch"][k] = (2.0 * f + w) * 1024.0
+with open(os.path.join(out, f"{tag}_pmc_traffic.json"), "w") as f:
+    json.dump(traffic, f, indent=1)
+
+sq_path = os.path.join(src, "pmc_sq/pmc_counter_collection.csv")
+if os.path.exists(sq_path):
+    sq = per_launch(sq_path)
+    for k, d in sq.items():
+        if d.get("SQ_WAVE_CYCLES"):
+            d["valu_issue_share_of_wave_cycles"] = d.get("SQ_ACTIVE_INST_VALU", 0.0) / d["SQ_WAVE_CYCLES"]
+    with open(os.path.join(out, f"{tag}_pmc_sq_counters.json"), "w") as f:
+        json.dump({"command": "rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD "
+                              "SQ_INSTS_VMEM_WR SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU -- python bench.py "
+                              "--no-cpu --steps 6 --warmup 1", "per_launch_mean": sq}, f, indent=1)
+print(json.dumps(traffic["bytes_per_launch"], indent=1))
