@@ -409,6 +409,23 @@ __global__ __launch_bounds__(64) void fir_sign_kernel(
         }
     }
 
+    // Digital silence.  With every sample of a window 0 the reference's sum is exactly +0 and
+    // `out > 0` is false, but y_c = 0 is "ambiguous", and 32 exact evaluations per word and
+    // lane, one after the other, would make a silent channel ~50x slower than a live one.
+    // When a word has many ambiguous samples the lane therefore checks whether all samples
+    // its 32 windows can touch ([first-34, last-3] = this word's 32 samples, the 32 before
+    // and the 10 after) are 0.  all_zero() re-reads from memory; it only runs in that case.
+    auto all_zero = [&](int m_first, int count) -> bool {
+        uint32_t o = 0;
+        for (int i = 0; i < count; ++i) {
+            int m = m_first + i;
+            m = m < -NT ? -NT : (m > L - 1 ? L - 1 : m);   // clamped samples are outside every window
+            o |= (uint32_t) load_sample(x, hist, m, N, NT, c);
+        }
+        return o == 0;
+    };
+    bool zprev_known = false, zprev = false;    // was the previous word's block of 32 samples all 0?
+
     const int nblk = (t1 - t0 + 95) / 96;
     for (int b = 0; b < nblk; ++b) {
 #pragma unroll
@@ -477,6 +494,20 @@ __global__ __launch_bounds__(64) void fir_sign_kernel(
                 w &= ~0u << (32 - valid);
                 amb &= ~0u << (32 - valid);
             }
+            bool zc_known = false, zc = false;
+            if (__popc(amb) >= 8) {                         // a silent stretch?
+                uint32_t o = 0;
+#pragma unroll
+                for (int p = 0; p < 32; ++p) o |= (uint32_t) xi[p];
+                zc = o == 0;
+                zc_known = true;
+                if (zc && (zprev_known ? zprev : all_zero(mb - 32, 32)) && all_zero(mb + 32, 10)) {
+                    w &= ~amb;                              // y_ref == +0 for every one of them
+                    amb = 0;
+                }
+            }
+            zprev_known = zc_known;
+            zprev = zc;
             // the samples whose sign y_c cannot certify: exact ordered sum
             while (amb) {
                 const int pos = __clz((int) amb);

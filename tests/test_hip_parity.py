@@ -198,6 +198,65 @@ def test_chain_vs_oracle_noise_only_and_extremes():
     run_both(x, [total], x.shape[1])
 
 
+def test_chain_vs_oracle_digital_silence_patterns():
+    """All-zero stretches take K1s's all-windows-zero shortcut; everything around its edges
+    (a lone nonzero sample 1..45 samples before / 1..30 after a silent word, silence that
+    starts or ends mid-word, silence across call boundaries, tiny signals that keep y_c inside
+    the ambiguity band) must still give the reference's bits."""
+    rng = np.random.default_rng(41)
+    total = 3 * 4096 + 777
+    cols = [np.zeros(total)]
+    for k in range(1, 48):                       # one nonzero sample, various alignments and signs
+        v = np.zeros(total)
+        v[1000 + 37 * k + k] = (1 if k % 2 else -1) * (1 + (k % 5) * 8000)
+        v[5000 + k] = -3
+        cols.append(v)
+    for k in range(8):                           # silence <-> noise transitions at odd offsets
+        v = rng.normal(0, 2000, total)
+        v[700 + 13 * k: 2500 + 29 * k] = 0
+        v[4096 - k: 4096 + 40 + k] = 0           # across the first call boundary
+        v[9000 + k:] = 0
+        cols.append(v)
+    for k in range(8):                           # +-1 / +-2 dither: y_c stays ambiguous, y_ref does not vanish
+        cols.append(rng.integers(-1 - k % 2, 2 + k % 2, total).astype(np.float64))
+    x = np.clip(np.rint(np.stack(cols, axis=1)), -32768, 32767).astype(np.int16)
+    run_both(x, [4096, 4096, 4096, 777], x.shape[1], fir_T=512)
+    run_both(x, [total], x.shape[1])
+
+
+def test_more_channel_groups_than_cus():
+    """N/64 > 256: the PLL stage then shares CUs between workgroups (its LDS reservation is
+    sized per CU); a sample of channels from the first, a middle and the last group is compared
+    with the oracle."""
+    n_ch, total = 259 * 64 + 17, 2 * 2048 + 100
+    base = np.stack([synth.make_stream(total, seed=43, channel=c, sigma=(800.0, 4000.0)[c % 2])[0]
+                     for c in range(48)], axis=1)
+    x = np.ascontiguousarray(np.tile(base, (1, (n_ch + 47) // 48))[:, :n_ch])
+    b = batch(n_ch, max_len=2048 + 100)
+    pick = np.r_[0:40, 8000:8040, n_ch - 40:n_ch]
+    o = Oracle(len(pick))
+    gb = [[] for _ in pick]
+    ob = [[] for _ in pick]
+    for seg in (x[:2048], x[2048:4096], x[4096:]):
+        r = o.run(np.ascontiguousarray(seg[:, pick]), want_bits=True)
+        b.run(dev(seg))
+        lb = b.last_bits()
+        for i, c in enumerate(pick):
+            gb[i].append(lb[c])
+            ob[i].append(r["bits"][i])
+    for i in range(len(pick)):
+        assert np.array_equal(np.concatenate(gb[i]), np.concatenate(ob[i])), pick[i]
+    p = b.pll_state()
+    assert [(int(p["pll"][c]), int(p["prev"][c]), int(p["lastbit"][c])) for c in pick] == \
+        [o.pll(i) for i in range(len(pick))]
+    fr = b.drain_frames()
+    sel = fr[np.isin(fr["channel"], pick)]
+    remap = {int(c): i for i, c in enumerate(pick)}
+    sel = sel.copy()
+    sel["channel"] = [remap[int(c)] for c in sel["channel"]]
+    assert sel.tobytes() == o.frames().tobytes()
+
+
 def test_chain_192k_vs_oracle():
     total = 6 * 5120
     x = np.stack([synth.make_stream(total, seed=35, channel=c, sps=20, sigma=1500.0,
