@@ -196,6 +196,22 @@ def crc16_batch(messages, device: int = 0) -> np.ndarray:
     return out
 
 
+def nmea_from_frames(frames: np.ndarray, seqnr: np.ndarray) -> bytes:
+    """The "!AIVDM,...*hh\\r\\n" sentences the reference emits for these frame records
+    (protodec_getdata / protodec_generate_nmea), concatenated.  `seqnr` (uint8 per channel)
+    is the rolling sequence digit state, updated in place."""
+    lib = _lib.load()
+    frames = np.ascontiguousarray(frames, dtype=FRAME_DTYPE)
+    assert seqnr.dtype == np.uint8 and seqnr.flags.c_contiguous
+    cap = 164 * max(1, len(frames))
+    out = np.zeros(cap, dtype=np.uint8)
+    need = C.c_size_t(0)
+    n_sent = C.c_int(0)
+    check(lib.gnuais_nmea_from_frames(frames.ctypes.data, len(frames), seqnr.ctypes.data, len(seqnr),
+                                      out.ctypes.data, cap, C.byref(need), C.byref(n_sent)))
+    return out[: need.value].tobytes()
+
+
 def tile_channels(base, n_channels: int):
     """Device-side benchmark input builder: base torch int16 [K][L] ->
     interleaved [L][n_channels]."""

@@ -128,6 +128,16 @@ int  gnuais_default_taps(float *out36);
  * h_data = n_msgs rows of `stride` bytes, h_len[n_msgs]; h_crc[n_msgs] */
 int  gnuais_crc16_batch(int device, const uint8_t *h_data, int stride, const int32_t *h_len,
 			int n_msgs, uint16_t *h_crc);
+/* Row f1, first part -- the NMEA 0183 sentences of CRC-valid frames, byte-identical to what the
+ * reference passes to serial_write() (protodec_getdata src/protodec.c:896-926 +
+ * protodec_generate_nmea src/protodec.c:780-894).  Host-side, like the reference's own
+ * post-stage.  frames[n_frames] in delivery order (gnuais_batch_drain_frames);
+ * seqnr[n_channels] is the per-receiver rolling sequence digit d->seqnr (in/out, start at 0).
+ * Sentences are written back to back, each "!AIVDM,...*hh\r\n".  *out_len = bytes needed;
+ * out == NULL only sizes (seqnr still advances); too small a buffer -> GNUAIS_E_OVERFLOW. */
+int  gnuais_nmea_from_frames(const gnuais_frame *frames, int n_frames, uint8_t *seqnr,
+			     int n_channels, char *out, size_t out_cap, size_t *out_len,
+			     int *n_sentences);
 /* benchmark input builder: d_out[l][c] = d_base[c % n_base][(l + (c * 7919) % len) % len] */
 int  gnuais_tile_channels(const int16_t *d_base, int n_base, int len, int16_t *d_out,
 			  int n_channels, void *stream);

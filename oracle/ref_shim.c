@@ -15,6 +15,8 @@
  *   floats : filter_run_buf()      reference src/filter.c:106-143
  *   bits   : --wrap=protodec_decode  (called from src/receiver.c:130)
  *   frames : observed from the same wrap (receivedframes moves, protodec.c:1103)
+ *   NMEA   : --wrap=serial_write   (every sentence protodec_generate_nmea emits,
+ *            protodec.c:883-885; the decoder gets a dummy non-NULL d->serial)
  *
  * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may
  * load the resulting library.
@@ -292,6 +294,50 @@ void ref_decode_bits(int idx, const uint8_t *bits, int n)
 		char b = (char) bits[i];
 		protodec_decode(&b, 1, g_rx[idx]->decoder);
 	}
+}
+
+/* ------------------------------------------------------------------ */
+/* message layer (row f1): NMEA sentences of CRC-valid frames          */
+
+static char *g_nmea = NULL;
+static size_t g_nmea_n = 0, g_nmea_cap = 0;
+static int g_nmea_sentences = 0;
+
+int __wrap_serial_write(struct serial_state_t *state, char *s, int len)
+{
+	(void) state;
+	if (g_nmea_n + (size_t) len > g_nmea_cap) {
+		g_nmea_cap = (g_nmea_n + (size_t) len) * 2 + 4096;
+		g_nmea = realloc(g_nmea, g_nmea_cap);
+	}
+	memcpy(g_nmea + g_nmea_n, s, (size_t) len);
+	g_nmea_n += (size_t) len;
+	g_nmea_sentences++;
+	return len;
+}
+
+void ref_nmea_clear(void) { g_nmea_n = 0; g_nmea_sentences = 0; }
+size_t ref_nmea_bytes(void) { return g_nmea_n; }
+int ref_nmea_sentences(void) { return g_nmea_sentences; }
+const char *ref_nmea_ptr(void) { return g_nmea; }
+int ref_get_seqnr(int idx) { return g_rx[idx]->decoder->seqnr; }
+void ref_set_seqnr(int idx, int v) { g_rx[idx]->decoder->seqnr = (unsigned char) v; }
+
+/* Hand one CRC-valid frame to the reference's message layer the way protodec_decode does
+ * (protodec.c:1104 after protodec_calculate_crc filled d->rbuffer, :150-162): payload bits
+ * MSB-first per byte, one bit per char, then protodec_getdata(bufferlen, d).  `payload`
+ * is the packed form of the frame records (bit 7-i of byte j = rbuffer[8j+i]). */
+void ref_getdata(int idx, const uint8_t *payload, int nbits)
+{
+	static struct serial_state_t *dummy = (struct serial_state_t *) 16;   /* never dereferenced: wrapped */
+	struct demod_state_t *d = g_rx[idx]->decoder;
+	int i;
+	memset(d->rbuffer, 0, DEMOD_BUFFER_LEN);
+	for (i = 0; i < nbits && i < DEMOD_BUFFER_LEN - 8; i++)
+		d->rbuffer[i] = (payload[i >> 3] >> (7 - (i & 7))) & 1;
+	d->serial = dummy;
+	protodec_getdata(nbits, d);
+	d->serial = NULL;
 }
 
 extern unsigned short protodec_sdlc_crc(const unsigned char *data, unsigned len);

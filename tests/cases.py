@@ -110,3 +110,30 @@ def crc_cases():
     c = [b"123456789", b"", b"\x00", b"\xff\xff", bytes(range(58))]
     c += [bytes(rng.integers(0, 256, int(n), dtype=np.uint8)) for n in rng.integers(1, 58, 20)]
     return c
+
+
+def nmea_frames(seed=51, n_channels=5, n_random=600):
+    """Frame records for the message-layer (row f1) tests: every payload length class around
+    the 6-bit padding and the 61-character split, AIS types inside and outside 1..24, several
+    channels interleaved so that the rolling sequence digit wraps."""
+    import numpy as np
+    from oracle_lib import FRAME_DTYPE
+    rng = np.random.default_rng(seed)
+    lens = [0, 6, 8, 16, 38, 40, 96, 160, 168, 200, 256, 312, 360, 366, 368, 372, 376, 408, 416, 424]
+    types = [0, 1, 2, 3, 4, 5, 6, 9, 18, 19, 21, 24, 25, 31, 63]
+    rows = []
+    for k in range(n_random):
+        nbits = lens[k % len(lens)] if k < 3 * len(lens) else int(rng.integers(0, 54)) * 8
+        bits = rng.integers(0, 2, 53 * 8).astype(np.uint8)
+        t = types[(k * 7) % len(types)] if k % 3 else int(rng.integers(0, 64))
+        for i in range(6):
+            bits[i] = (t >> (5 - i)) & 1
+        bits[nbits - nbits % 8:] = 0               # the record keeps whole bytes only (protodec.c:133)
+        f = np.zeros(1, dtype=FRAME_DTYPE)[0]
+        f["channel"] = int(rng.integers(0, n_channels))
+        f["end_bit"] = k
+        f["payload"] = np.packbits(bits)
+        f["flags"] = 1
+        f["nbits"] = nbits
+        rows.append(f)
+    return np.array(rows, dtype=FRAME_DTYPE), n_channels

@@ -54,7 +54,37 @@ def run_chain(x, taps=None, pllinc=0, chunk=1020):
     return out
 
 
+def make_nmea():
+    """Row f1: frame records -> the sentences the reference's protodec_getdata() emits."""
+    ref = reference()
+    out = {}
+    fr, n_ch = cases.nmea_frames()
+    text, seq = ref.nmea_of_frames(fr, n_ch)
+    out["synthetic_frames"] = frames_raw(fr)
+    out["synthetic_nch"] = np.array([n_ch])
+    out["synthetic_text"] = np.frombuffer(text, dtype=np.uint8)
+    out["synthetic_seqnr"] = seq
+    for name in ("chain_48k", "chain_long"):       # frames the reference itself decoded
+        g = np.load(os.path.join(HERE, name + ".npz"))
+        fr = np.frombuffer(np.ascontiguousarray(g["frames"]).tobytes(), dtype=cases_frame_dtype())
+        n_ch = int(fr["channel"].max()) + 1
+        text, seq = ref.nmea_of_frames(fr, n_ch)
+        out[name + "_text"] = np.frombuffer(text, dtype=np.uint8)
+        out[name + "_seqnr"] = seq
+    np.savez_compressed(os.path.join(HERE, "nmea.npz"), **out)
+    print("nmea.npz", os.path.getsize(os.path.join(HERE, "nmea.npz")),
+          {k: v.shape for k, v in out.items()})
+
+
+def cases_frame_dtype():
+    from oracle_lib import FRAME_DTYPE
+    return FRAME_DTYPE
+
+
 def main():
+    if sys.argv[1:] == ["nmea"]:
+        make_nmea()
+        return
     ref = reference()
     # 1. full chain, 48 kHz, 2 channels (config C1 shape)
     np.savez_compressed(os.path.join(HERE, "chain_48k.npz"), **run_chain(cases.chain_48k()))
@@ -98,6 +128,7 @@ def main():
         fsm["counters_" + name] = ref.counters()[0]
         fsm["fsm_" + name] = np.array(list(ref.fsm(0).values()), dtype=np.int32)
     np.savez_compressed(os.path.join(HERE, "deframer_bits.npz"), **fsm)
+    make_nmea()
     for f in sorted(os.listdir(HERE)):
         if f.endswith(".npz"):
             print(f, os.path.getsize(os.path.join(HERE, f)))

@@ -215,6 +215,9 @@ class Reference:
         lib.ref_decode_bits.argtypes = [C.c_int, C.c_void_p, C.c_int]
         lib.ref_sdlc_crc.restype = C.c_uint
         lib.ref_sdlc_crc.argtypes = [C.c_void_p, C.c_uint]
+        lib.ref_getdata.argtypes = [C.c_int, C.c_void_p, C.c_int]
+        lib.ref_nmea_bytes.restype = C.c_size_t
+        lib.ref_nmea_ptr.restype = C.c_void_p
         lib.ref_bench_run.restype = C.c_long
         lib.ref_bench_run.argtypes = [C.c_void_p, C.c_int, C.c_int]
         assert lib.ref_frame_size() == 64
@@ -236,6 +239,20 @@ class Reference:
                 t = None if taps is None else np.ascontiguousarray(taps, dtype=np.float32)
                 self.lib.ref_receiver_set_params(idx, None if t is None else t.ctypes.data,
                                                  0 if t is None else int(t.size), pllinc)
+
+    def nmea_of_frames(self, frames: np.ndarray, n_channels: int):
+        """Hand frame records to the reference's own protodec_getdata(), one fresh receiver per
+        channel; returns (every sentence serial_write() received, concatenated; final seqnr[])."""
+        self.reset()
+        self.add_receivers(n_channels)
+        self.lib.ref_nmea_clear()
+        for f in frames:
+            pay = np.ascontiguousarray(f["payload"])
+            self.lib.ref_getdata(int(f["channel"]), pay.ctypes.data, int(f["nbits"]))
+        n = self.lib.ref_nmea_bytes()
+        text = C.string_at(self.lib.ref_nmea_ptr(), n) if n else b""
+        seq = np.array([self.lib.ref_get_seqnr(c) for c in range(n_channels)], dtype=np.uint8)
+        return text, seq
 
     def taps(self, idx: int = 0) -> np.ndarray:
         t = np.zeros(1024, dtype=np.float32)

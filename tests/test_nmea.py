@@ -1,0 +1,103 @@
+"""Row f1 (first part): gnuais_nmea_from_frames() against the reference's own
+protodec_getdata() / protodec_generate_nmea() -- byte for byte.
+
+CPU tests: committed golden text (tests/golden/nmea.npz, made by make_golden.py from
+oracle/_ref) and, where oracle/_ref is present, fresh random frames against the reference.
+The function is host code inside libgnuais_hip.so; no device call is made here."""
+import os
+
+import numpy as np
+import pytest
+
+import cases
+from oracle_lib import FRAME_DTYPE, have_reference, reference
+
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def nmea(frames, n_ch, seq=None):
+    from gnuais_amd import nmea_from_frames
+    seq = np.zeros(n_ch, dtype=np.uint8) if seq is None else seq
+    return nmea_from_frames(frames, seq), seq
+
+
+def test_nmea_golden_synthetic():
+    g = np.load(os.path.join(G, "nmea.npz"))
+    fr = np.frombuffer(np.ascontiguousarray(g["synthetic_frames"]).tobytes(), dtype=FRAME_DTYPE)
+    want = g["synthetic_text"].tobytes()
+    got, seq = nmea(fr, int(g["synthetic_nch"][0]))
+    assert got == want
+    assert np.array_equal(seq, g["synthetic_seqnr"])
+    # known shapes: a 168-bit type-1 message is one 28-character sentence on "channel A";
+    # anything above 366 bits splits, carries the sequence digit and an empty channel field
+    lines = want.split(b"\r\n")[:-1]
+    assert all(l.startswith(b"!AIVDM,") for l in lines)
+    assert any(l.startswith(b"!AIVDM,2,2,") and not l.endswith(b",0*" + l[-2:]) for l in lines)
+    for l in lines:                               # XOR checksum of the bytes between '!' and '*'
+        body, chk = l[1:].split(b"*")
+        x = 0
+        for ch in body:
+            x ^= ch
+        assert chk == b"%02X" % x
+
+
+@pytest.mark.parametrize("name", ["chain_48k", "chain_long"])
+def test_nmea_golden_decoded_frames(name):
+    g = np.load(os.path.join(G, "nmea.npz"))
+    c = np.load(os.path.join(G, name + ".npz"))
+    fr = np.frombuffer(np.ascontiguousarray(c["frames"]).tobytes(), dtype=FRAME_DTYPE)
+    got, seq = nmea(fr, int(fr["channel"].max()) + 1)
+    assert got == g[name + "_text"].tobytes()
+    assert np.array_equal(seq, g[name + "_seqnr"])
+
+
+def test_nmea_state_carries_and_sizes():
+    fr, n_ch = cases.nmea_frames(seed=52, n_random=200)
+    whole, seq_w = nmea(fr, n_ch)
+    seq = np.zeros(n_ch, dtype=np.uint8)
+    parts = b"".join(nmea(fr[i:i + 37], n_ch, seq)[0] for i in range(0, len(fr), 37))
+    assert parts == whole and np.array_equal(seq, seq_w)
+    # sizing call and loud failures
+    import ctypes as C
+    from gnuais_amd import lib as L
+    lib = L.load()
+    need, ns = C.c_size_t(0), C.c_int(0)
+    s0 = np.zeros(n_ch, dtype=np.uint8)
+    assert lib.gnuais_nmea_from_frames(fr.ctypes.data, len(fr), s0.ctypes.data, n_ch, None, 0,
+                                       C.byref(need), C.byref(ns)) == 0
+    assert need.value == len(whole) and ns.value == whole.count(b"\r\n")
+    small = np.zeros(10, dtype=np.uint8)
+    s0[:] = 0
+    assert lib.gnuais_nmea_from_frames(fr.ctypes.data, len(fr), s0.ctypes.data, n_ch, small.ctypes.data,
+                                       10, C.byref(need), C.byref(ns)) == -3   # GNUAIS_E_OVERFLOW
+    bad = fr.copy()
+    bad["channel"][3] = n_ch
+    assert lib.gnuais_nmea_from_frames(bad.ctypes.data, len(bad), s0.ctypes.data, n_ch, None, 0,
+                                       C.byref(need), C.byref(ns)) == -1   # GNUAIS_E_ARG
+
+
+@pytest.mark.skipif(not have_reference(), reason="oracle/_ref not built (reference tree absent)")
+@pytest.mark.parametrize("seed", [61, 62, 63])
+def test_nmea_random_frames_vs_reference(seed):
+    fr, n_ch = cases.nmea_frames(seed=seed, n_channels=7, n_random=900)
+    want, seq_want = reference().nmea_of_frames(fr, n_ch)
+    got, seq = nmea(fr, n_ch)
+    assert got == want
+    assert np.array_equal(seq, seq_want)
+
+
+@pytest.mark.gpu
+def test_nmea_of_device_chain_frames():
+    """Full chain on the GPU -> frame records -> sentences == the golden text the reference
+    produced from ITS frames for the same input."""
+    import torch
+    from gnuais_amd import ReceiverBatch
+    g = np.load(os.path.join(G, "nmea.npz"))
+    for name in ("chain_48k", "chain_long"):
+        c = np.load(os.path.join(G, name + ".npz"))
+        x = c["x"]
+        b = ReceiverBatch(x.shape[1], max_len=x.shape[0])
+        b.run(torch.from_numpy(np.ascontiguousarray(x)).cuda())
+        fr = b.drain_frames()
+        got, _ = nmea(fr, x.shape[1])
+        assert got == g[name + "_text"].tobytes()
