@@ -275,8 +275,23 @@ int gnuais_batch_create(gnuais_batch **out, int device, int n_channels, const fl
         // dispatch priority over the FIR's tens of thousands of workgroups
         int lo = 0, hi = 0;
         if (e == hipSuccess) e = hipDeviceGetStreamPriorityRange(&lo, &hi);
+        // Creation order matters (measured, scripts/alloc_experiment.py + scripts/queue_ids.py):
+        // HIP hands out hardware queues in creation order and the queues are spread over the
+        // compute pipes round-robin, so in a process with no other streams the 4th stream
+        // created here shares its pipe with the caller's (FIR) queue.  With the PLL stage or
+        // the deframer there a C3 call takes 0.81-0.83 ms, with K3 there 0.90-0.93 (K3 is the
+        // stage whose completion the host waits on before it reuses a hand-off set), with K2x
+        // 0.87.  Hence: K2x, K2b, K3, and the PLL stage last.  GNUAIS_STREAM_ORDER (four digits,
+        // stage indices 0 = K2a .. 3 = K3 in creation order) overrides, for processes that have
+        // created streams of their own before.
+        const char *order = getenv("GNUAIS_STREAM_ORDER");
+        if (!order || strlen(order) != 4) order = "1230";
+        for (int q = 0; q < 4; ++q) {
+            const int idx = (order[q] - '0') & 3;
+            if (e == hipSuccess && !b->s_k[idx]) e = hipStreamCreateWithPriority(&b->s_k[idx], hipStreamNonBlocking, hi);
+        }
         for (auto &st : b->s_k)
-            if (e == hipSuccess) e = hipStreamCreateWithPriority(&st, hipStreamNonBlocking, hi);
+            if (e == hipSuccess && !st) e = hipStreamCreateWithPriority(&st, hipStreamNonBlocking, hi);
     }
     if (const char *v = getenv("GNUAIS_PIPELINE")) b->pipeline = atoi(v) != 0;
     if (const char *v = getenv("GNUAIS_HDLC_LPW")) b->hdlc_lpw = std::min(64, std::max(1, atoi(v)));
