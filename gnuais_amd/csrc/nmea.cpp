@@ -1,72 +1,266 @@
-// nmea.cpp -- row f1 (first part): the NMEA 0183 sentences gnuais emits for a CRC-valid frame.
+// nmea.cpp -- row f1: what gnuais does with a CRC-valid frame after the hot path.
 //
-// Host-side restatement of protodec_getdata()'s sentence path, gnuais src/protodec.c:896-926,
-// and protodec_generate_nmea(), src/protodec.c:780-894, working from the 64-byte frame records
-// the device chain delivers (gnuais_batch_drain_frames) instead of from d->rbuffer.  This is
-// the reference's own post-stage (it runs once per valid frame, after the hot path) and, like
-// there, it runs on the host.  Output is byte-identical to what the reference hands to
-// serial_write() (src/protodec.c:883-885), including its quirks:
-//   * frames whose first 6 bits (the AIS type) are 0 or > 24 produce nothing and do not
-//     advance the sequence digit (:898-900);
-//   * the payload is padded with 0 bits to a multiple of 6 (:909-915), 61 characters per
-//     sentence (:793), 6-bit value v -> v + 48 if v < 40 else v + 56 (:810-815);
-//   * single-sentence messages carry channel 'A' and fill digit '0' whatever the padding was;
-//     multi-sentence messages carry the rolling sequence digit, an EMPTY channel field, and the
-//     fill digit only on the last part (:842-860);
-//   * the sequence digit advances 0,1,..,9,0 after EVERY accepted frame, single- or
-//     multi-sentence (:922-926);
-//   * checksum = XOR of everything between '!' and '*', upper-case hex, two digits (:864-881).
+// Host-side restatement of protodec_getdata(), gnuais src/protodec.c:896-986, working from the
+// 64-byte frame records the device chain delivers (gnuais_batch_drain_frames) instead of from
+// d->rbuffer.  This is the reference's own post-stage (once per valid frame) and, like there,
+// it runs on the host.  Two outputs, both byte-identical to the reference's:
+//
+//  * the NMEA 0183 sentences it hands to serial_write() / ipc_write() / myout_nmea()
+//    (protodec_generate_nmea, src/protodec.c:780-894), with its quirks:
+//      - frames whose first 6 bits (the AIS type) are 0 or > 24 produce nothing and do not
+//        advance the sequence digit (:898-900);
+//      - the payload is padded with 0 bits to a multiple of 6 (:909-915), 61 characters per
+//        sentence (:793), 6-bit value v -> v + 48 if v < 40 else v + 56 (:810-815);
+//      - single-sentence messages carry channel 'A' and fill digit '0' whatever the padding
+//        was; multi-sentence messages carry the rolling sequence digit, an EMPTY channel field,
+//        and the fill digit only on the last part (:842-860);
+//      - the sequence digit advances 0,1,..,9,0 after EVERY accepted frame (:922-926);
+//      - checksum = XOR of everything between '!' and '*', upper-case hex, two digits (:864-881);
+//
+//  * the line it prints on stdout (:934-985): "ch <id> type <t> mmsi <9 digits>:", the fields the
+//    per-type decoders print (src/protodec.c:357-776: types 1-3, 4, 5, 6, 7/13, 8, 18, 19, 20, 24
+//    and the two binary applications 1/11 and 1/40), and " (!<last sentence>)".  The field
+//    positions are the reference's, including the ones that differ from ITU-R M.1371 (a 2-bit
+//    navigation status at bit 38, the base-station date starting at bit 40, the weather report's
+//    wind speed overlapping its longitude); floats are formed and rounded exactly as there
+//    ((float) value / double constant, printed with %f).
 #include <stdint.h>
 #include <stddef.h>
+#include <stdarg.h>
+#include <stdio.h>
 #include <string.h>
+
+#include <string>
 
 #include "gnuais_hip.h"
 
 namespace {
 
-// `count` bits of the payload starting at bit `pos`, MSB first (protodec_henten, protodec.c:205-214);
-// bits at or beyond `nbits` read as 0
-inline unsigned take_bits(const gnuais_frame &f, int pos, int count, int nbits)
-{
-    unsigned v = 0;
-    for (int i = 0; i < count; ++i) {
-        const int b = pos + i;
-        const unsigned bit = (b < nbits && b < 8 * (int) sizeof f.payload) ? (f.payload[b >> 3] >> (7 - (b & 7))) & 1u : 0u;
-        v = (v << 1) | bit;
-    }
-    return v;
-}
-
 constexpr int CHARS_PER_SENTENCE = 61;      // protodec.c:793
 constexpr int MAX_TYPE = 24;                // cfg.h:48 MAX_AIS_PACKET_TYPE
 const char HEX[] = "0123456789ABCDEF";
 
+// the frame's payload as the reference's d->rbuffer: bit k, 0 beyond the frame
+struct Bits {
+    const gnuais_frame &f;
+    int nbits;
+    // `count` bits from `pos`, MSB first (protodec_henten, protodec.c:205-214)
+    unsigned long get(int pos, int count) const
+    {
+        unsigned long v = 0;
+        for (int i = 0; i < count; ++i) {
+            const int b = pos + i;
+            const unsigned bit =
+                (b < nbits && b < 8 * (int) sizeof f.payload) ? (f.payload[b >> 3] >> (7 - (b & 7))) & 1u : 0u;
+            v = (v << 1) | bit;
+        }
+        return v;
+    }
+    // two's complement field of `count` bits (the reference ORs the upper bits in by hand)
+    int sget(int pos, int count) const
+    {
+        unsigned long v = get(pos, count);
+        if ((v >> (count - 1)) & 1) v |= ~0ul << count;
+        return (int) v;
+    }
+    // `n` six-bit characters from `pos` (protodec_decode_sixbit_ascii :189-203), trailing
+    // blanks dropped (remove_trailing_spaces :173-184)
+    std::string text(int pos, int n) const
+    {
+        std::string s;
+        for (int k = 0; k < n; ++k) {
+            const int v = (int) get(pos + 6 * k, 6);
+            s.push_back(v >= 1 && v <= 31 ? (char) (v + 64) : (v >= 32 ? (char) v : ' '));
+        }
+        while (!s.empty() && s.back() == ' ') s.pop_back();
+        return s;
+    }
+};
+
+struct Out {
+    std::string s;
+    __attribute__((format(printf, 2, 3))) void add(const char *fmt, ...)
+    {
+        char tmp[512];
+        va_list ap;
+        va_start(ap, fmt);
+        const int n = vsnprintf(tmp, sizeof tmp, fmt, ap);
+        va_end(ap);
+        if (n > 0) s.append(tmp, (size_t) (n < (int) sizeof tmp ? n : (int) sizeof tmp - 1));
+    }
+};
+
+// International function identifiers of DAC 1 (appid_ifm, protodec.c:220-273)
+const char *ifm_name(int fi)
+{
+    static const struct { int fi; const char *name; } names[] = {
+        {0, "text-telegram"}, {1, "application-ack"}, {2, "iai-fi-capab-interrogation"},
+        {3, "iai-capabi-interrogation"}, {4, "capability-reply"}, {11, "tide-weather"},
+        {16, "vts-targets"}, {17, "ship-waypoints"}, {18, "advice-of-waypoints"},
+        {19, "extended-ship-data"}, {20, "berthing-data"}, {21, "weather-obs-report"},
+        {22, "area-notice-bc"}, {23, "area-notice-addr"}, {24, "extended-ship-static"},
+        {25, "dangerous-cargo-info"}, {26, "environmental"}, {27, "route-info-bc"},
+        {28, "route-info-addr"}, {29, "text-description-bc"}, {30, "text-description-addr"},
+        {40, "persons-on-board"}};
+    for (const auto &e : names)
+        if (e.fi == fi) return e.name;
+    return "unknown";
+}
+
+// binary applications of DAC 1 (protodec_msg_bin :338-350)
+void binary_payload(const Bits &b, int fi, int at, Out &o)
+{
+    if (fi == 40) {                              // protodec_msg_40 :279-285
+        o.add(" persons-on-board %d", (int) b.get(at, 13));
+    } else if (fi == 11) {                       // protodec_msg_11 :287-336, its offsets as they are
+        const int lat = (int) b.get(at, 24), lon = (int) b.get(at + 24, 25);
+        const int wind = (int) b.get(at + 40, 7), gust = (int) b.get(at + 47, 7);
+        const int wdir = (int) b.get(at + 54, 9), gdir = (int) b.get(at + 63, 9);
+        const int temp = (int) b.get(at + 72, 11), hum = (int) b.get(at + 83, 7);
+        const int dew = (int) b.get(at + 90, 10), pres = (int) b.get(at + 100, 9) + 800;
+        const int tend = (int) b.get(at + 109, 2), vis = (int) b.get(at + 111, 8);
+        const int level = (int) b.get(at + 119, 9), wave = (int) b.get(at + 124, 8);
+        const int wtemp = (int) b.get(at + 128, 10);
+        o.add(" lat %.6f lon %.6f wind_speed %dkt wind_gust %dkt wind_dir %d wind_gust_dir %d air_temp %.1fC"
+              " rel_humid %d%% dew_point %.1fC pressure %d pressure_tend %d visib %.1fNM water_level %.1fm"
+              " wave_height %.1fm water_temp %.1fC",
+              (float) lat / 60000.0, (float) lon / 60000.0, wind, gust, wdir, gdir, (float) temp / 10.0 - 60.0,
+              hum, (float) dew / 10.0 - 20.0, pres, tend, (float) vis / 10.0, (float) level / 10.0 - 10.0,
+              (float) wave / 10.0, (float) wtemp / 10.0 - 10.0);
+    }
+}
+
+void position_fields(int lat, int lon, unsigned course, unsigned sog, int rot, int navstat, unsigned heading, Out &o)
+{
+    o.add(" lat %.6f lon %.6f course %.0f speed %.1f rateofturn %d navstat %d heading %d",
+          (float) lat / 600000.0, (float) lon / 600000.0, (float) (unsigned short) course / 10.0,
+          (float) (unsigned short) sog / 10.0, rot, navstat, (int) (unsigned short) heading);
+}
+
+// the fields the reference prints for one frame (the switch at protodec.c:936-982)
+void describe(const Bits &b, unsigned type, int padded_len, Out &o)
+{
+    switch (type) {
+    case 1: case 2: case 3:                      // protodec_pos :357-402
+        position_fields(b.sget(89, 27), b.sget(61, 28), (unsigned) b.get(116, 12), (unsigned) b.get(50, 10),
+                        (int) (signed char) b.get(40, 8), (int) (signed char) b.get(38, 2),
+                        (unsigned) b.get(128, 9), o);
+        break;
+    case 4: {                                    // protodec_4 :404-441
+        const float lon = (float) ((float) b.sget(79, 28) / 10000.0 / 60.0);
+        const float lat = (float) ((float) b.sget(107, 27) / 10000.0 / 60.0);
+        o.add(" date %ld-%ld-%ld time %02ld:%02ld:%02ld lat %.6f lon %.6f", (long) b.get(40, 12),
+              (long) b.get(52, 4), (long) b.get(56, 5), (long) b.get(61, 5), (long) b.get(66, 6),
+              (long) b.get(72, 6), lat, lon);
+        break;
+    }
+    case 5: {                                    // protodec_5 :443-519
+        const unsigned A = (unsigned) b.get(240, 9), B = (unsigned) b.get(249, 9);
+        const unsigned char C = (unsigned char) b.get(258, 6), D = (unsigned char) b.get(264, 6);
+        const unsigned char draught = (unsigned char) b.get(294, 8);
+        o.add(" name \"%s\" destination \"%s\" type %d length %d width %d draught %.1f", b.text(112, 20).c_str(),
+              b.text(302, 20).c_str(), (int) b.get(232, 8), (int) (A + B), C + D, (float) draught / 10.0);
+        break;
+    }
+    case 6: {                                    // protodec_6 :525-542
+        const int dac = (int) b.get(72, 10), fi = (int) b.get(82, 6);
+        o.add(" dst_mmsi %09ld seq %d retransmitted %d appid %d app_dac %d app_fi %d", (long) b.get(40, 30),
+              (int) b.get(38, 2), (int) b.get(70, 1), (int) b.get(72, 16), dac, fi);
+        if (dac == 1) {
+            o.add("(%s)", ifm_name(fi));
+            binary_payload(b, fi, 88, o);
+        }
+        break;
+    }
+    case 7: case 13: {                           // protodec_7_13 :549-567
+        int pos = 40;
+        o.add(" buflen %d pos+32 %d", padded_len, pos + 32);
+        for (int i = 0; i < 4 && pos + 32 <= padded_len; pos += 32, ++i)
+            o.add(" ack %d (to %09ld seq %d)", i + 1, (long) b.get(pos, 30), (int) b.get(pos + 30, 2));
+        break;
+    }
+    case 8: {                                    // protodec_8 :573-584
+        const int dac = (int) b.get(40, 10), fi = (int) b.get(50, 6);
+        o.add(" appid %d app_dac %d app_fi %d", (int) b.get(40, 16), dac, fi);
+        if (dac == 1) {
+            o.add("(%s)", ifm_name(fi));
+            binary_payload(b, fi, 56, o);
+        }
+        break;
+    }
+    case 18:                                     // protodec_18 :586-635 (no turn rate / status in class B)
+        position_fields(b.sget(85, 27), b.sget(57, 28), (unsigned) b.get(112, 12), (unsigned) b.get(46, 10), 0, 15,
+                        (unsigned) b.get(124, 9), o);
+        break;
+    case 19: {                                   // protodec_19 :637-684
+        const unsigned A = (unsigned) b.get(271, 9), B = (unsigned) b.get(280, 9);
+        const unsigned char C = (unsigned char) b.get(289, 6), D = (unsigned char) b.get(295, 6);
+        o.add(" name \"%s\" type %d length %d  width %d", b.text(143, 20).c_str(), (int) b.get(263, 8),
+              (int) (A + B), C + D);
+        break;
+    }
+    case 20: {                                   // protodec_20 :686-705
+        int pos = 40;
+        for (int i = 0; i < 4 && pos + 30 < padded_len; pos += 30, ++i)
+            o.add(" reserve %d (ofs %d slots %d timeout %d incr %d)", i + 1, (int) b.get(pos, 12),
+                  (int) b.get(pos + 12, 4), (int) b.get(pos + 16, 3), (int) b.get(pos + 19, 11));
+        break;
+    }
+    case 24: {                                   // protodec_24 :707-776
+        const int part = (int) b.get(38, 2);
+        if (part == 0) o.add(" name \"%s\"", b.text(40, 20).c_str());
+        if (part == 1) {
+            const unsigned A = (unsigned) b.get(132, 9), B = (unsigned) b.get(141, 9);
+            const unsigned char C = (unsigned char) b.get(150, 6), D = (unsigned char) b.get(156, 6);
+            o.add(" callsign \"%s\" type %d length %d width %d", b.text(90, 6).c_str(), (int) b.get(40, 8),
+                  (int) (A + B), C + D);
+        }
+        break;
+    }
+    default:
+        break;
+    }
+}
+
+struct Sink {
+    char *p;
+    size_t cap, len;
+    bool fits;
+    void put(const char *s, size_t n)
+    {
+        if (p && len + n <= cap) memcpy(p + len, s, n);
+        else if (p) fits = false;
+        len += n;
+    }
+};
+
 } // namespace
 
-extern "C" int gnuais_nmea_from_frames(const gnuais_frame *frames, int n_frames, uint8_t *seqnr,
-                                       int n_channels, char *out, size_t out_cap, size_t *out_len,
-                                       int *n_sentences)
+extern "C" int gnuais_messages_from_frames(const gnuais_frame *frames, int n_frames, uint8_t *seqnr,
+                                           const char *chanid, int n_channels, char *nmea, size_t nmea_cap,
+                                           size_t *nmea_len, int *n_sentences, char *text, size_t text_cap,
+                                           size_t *text_len, int *n_lines)
 {
-    if (n_frames < 0 || (n_frames > 0 && !frames) || !seqnr || n_channels <= 0 || !out_len)
-        return GNUAIS_E_ARG;
-    size_t len = 0;
-    int total = 0;
-    bool fits = true;
+    if (n_frames < 0 || (n_frames > 0 && !frames) || !seqnr || n_channels <= 0) return GNUAIS_E_ARG;
+    Sink sn{nmea, nmea_cap, 0, true}, st{text, text_cap, 0, true};
+    const bool want_text = text_len != nullptr;
+    int sentences = 0, lines = 0;
     for (int k = 0; k < n_frames; ++k) {
         const gnuais_frame &f = frames[k];
         if (f.channel >= (uint32_t) n_channels) return GNUAIS_E_ARG;
         const int nbits = f.nbits;
         if (nbits > 8 * (int) sizeof f.payload) return GNUAIS_E_ARG;
-        const unsigned type = take_bits(f, 0, 6, nbits);
+        const Bits b{f, nbits};
+        const unsigned type = (unsigned) b.get(0, 6);
         if (type < 1 || type > MAX_TYPE) continue;
         const int fill = (6 - nbits % 6) % 6;
         const int nchars = (nbits + fill) / 6;
         const int parts = nchars <= CHARS_PER_SENTENCE ? 1 : (nchars + CHARS_PER_SENTENCE - 1) / CHARS_PER_SENTENCE;
         uint8_t &seq = seqnr[f.channel];
-        int done = 0;
+        char s[96];
+        int n = 0, done = 0;
         for (int part = 1; part <= parts; ++part) {
-            char s[96];
-            int n = 0;
+            n = 0;
             s[n++] = '!';
             memcpy(s + n, "AIVDM,", 6); n += 6;
             s[n++] = (char) ('0' + parts);
@@ -83,7 +277,7 @@ extern "C" int gnuais_nmea_from_frames(const gnuais_frame *frames, int n_frames,
                 s[n++] = ',';
             }
             for (int i = 0; i < CHARS_PER_SENTENCE && done < nchars; ++i, ++done) {
-                const unsigned v = take_bits(f, 6 * done, 6, nbits);
+                const unsigned v = (unsigned) b.get(6 * done, 6);
                 s[n++] = (char) (v < 40 ? v + 48 : v + 56);
             }
             s[n++] = ',';
@@ -93,16 +287,35 @@ extern "C" int gnuais_nmea_from_frames(const gnuais_frame *frames, int n_frames,
             s[n++] = '*';
             s[n++] = HEX[x >> 4];
             s[n++] = HEX[x & 15];
-            s[n++] = '\r';
-            s[n++] = '\n';
-            if (out && len + (size_t) n <= out_cap) memcpy(out + len, s, (size_t) n);
-            else fits = false;
-            len += (size_t) n;
-            ++total;
+            sn.put(s, (size_t) n);
+            sn.put("\r\n", 2);
+            ++sentences;
         }
         seq = (uint8_t) (seq >= 9 ? 0 : seq + 1);
+        if (want_text) {                         // protodec.c:934, 984: only the last sentence is shown
+            Out o;
+            o.add("ch %c type %d mmsi %09ld:", chanid ? chanid[f.channel] : (char) ('A' + f.channel % 26),
+                  (int) type, (long) b.get(8, 30));
+            describe(b, type, nbits + fill, o);
+            o.s.append(" (");
+            o.s.append(s, (size_t) n);
+            o.s.append(")\n");
+            st.put(o.s.data(), o.s.size());
+            ++lines;
+        }
     }
-    *out_len = len;
-    if (n_sentences) *n_sentences = total;
-    return (out && !fits) ? GNUAIS_E_OVERFLOW : GNUAIS_OK;
+    if (nmea_len) *nmea_len = sn.len;
+    if (n_sentences) *n_sentences = sentences;
+    if (text_len) *text_len = st.len;
+    if (n_lines) *n_lines = lines;
+    return (sn.fits && st.fits) ? GNUAIS_OK : GNUAIS_E_OVERFLOW;
+}
+
+extern "C" int gnuais_nmea_from_frames(const gnuais_frame *frames, int n_frames, uint8_t *seqnr,
+                                       int n_channels, char *out, size_t out_cap, size_t *out_len,
+                                       int *n_sentences)
+{
+    if (!out_len) return GNUAIS_E_ARG;
+    return gnuais_messages_from_frames(frames, n_frames, seqnr, nullptr, n_channels, out, out_cap, out_len,
+                                       n_sentences, nullptr, 0, nullptr, nullptr);
 }

@@ -212,6 +212,22 @@ def nmea_from_frames(frames: np.ndarray, seqnr: np.ndarray) -> bytes:
     return out[: need.value].tobytes()
 
 
+def messages_from_frames(frames: np.ndarray, seqnr: np.ndarray, chanid: Optional[bytes] = None):
+    """(NMEA sentences, stdout text) exactly as the reference's protodec_getdata() produces them
+    for these frame records.  `seqnr` as in nmea_from_frames; `chanid` one byte per channel."""
+    lib = _lib.load()
+    frames = np.ascontiguousarray(frames, dtype=FRAME_DTYPE)
+    assert seqnr.dtype == np.uint8 and seqnr.flags.c_contiguous
+    assert chanid is None or len(chanid) == len(seqnr)
+    nm = np.zeros(164 * max(1, len(frames)), dtype=np.uint8)
+    tx = np.zeros(1024 * max(1, len(frames)), dtype=np.uint8)
+    nm_len, tx_len = C.c_size_t(0), C.c_size_t(0)
+    check(lib.gnuais_messages_from_frames(frames.ctypes.data, len(frames), seqnr.ctypes.data, chanid,
+                                          len(seqnr), nm.ctypes.data, nm.size, C.byref(nm_len), None,
+                                          tx.ctypes.data, tx.size, C.byref(tx_len), None))
+    return nm[: nm_len.value].tobytes(), tx[: tx_len.value].tobytes()
+
+
 def tile_channels(base, n_channels: int):
     """Device-side benchmark input builder: base torch int16 [K][L] ->
     interleaved [L][n_channels]."""

@@ -138,6 +138,16 @@ int  gnuais_crc16_batch(int device, const uint8_t *h_data, int stride, const int
 int  gnuais_nmea_from_frames(const gnuais_frame *frames, int n_frames, uint8_t *seqnr,
 			     int n_channels, char *out, size_t out_cap, size_t *out_len,
 			     int *n_sentences);
+/* Row f1, complete -- everything protodec_getdata() (src/protodec.c:896-986) produces for CRC-valid
+ * frames: the NMEA sentences as above, and the line it prints on stdout for each accepted frame:
+ * "ch <id> type <t> mmsi <9 digits>:" + the fields of the per-type decoders (src/protodec.c:357-776)
+ * + " (!<last sentence>)\n".  chanid[n_channels] are the receivers' names (receiver.h name /
+ * d->chanid); NULL = 'A' + channel % 26.  Either output may be left out (nmea_len == NULL /
+ * text_len == NULL); a NULL buffer with a non-NULL length only sizes. */
+int  gnuais_messages_from_frames(const gnuais_frame *frames, int n_frames, uint8_t *seqnr,
+				 const char *chanid, int n_channels, char *nmea, size_t nmea_cap,
+				 size_t *nmea_len, int *n_sentences, char *text, size_t text_cap,
+				 size_t *text_len, int *n_lines);
 /* benchmark input builder: d_out[l][c] = d_base[c % n_base][(l + (c * 7919) % len) % len] */
 int  gnuais_tile_channels(const int16_t *d_base, int n_base, int len, int16_t *d_out,
 			  int n_channels, void *stream);

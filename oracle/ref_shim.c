@@ -340,6 +340,51 @@ void ref_getdata(int idx, const uint8_t *payload, int nbits)
 	d->serial = NULL;
 }
 
+/* the same, but also keeping what protodec_getdata() prints on stdout (protodec.c:934-985):
+ * fd 1 is pointed at a scratch file for the duration of the call */
+static char *g_text = NULL;
+static size_t g_text_n = 0, g_text_cap = 0;
+void ref_text_clear(void) { g_text_n = 0; }
+size_t ref_text_bytes(void) { return g_text_n; }
+const char *ref_text_ptr(void) { return g_text; }
+
+#include <unistd.h>
+void ref_getdata_text(int idx, const uint8_t *payload, int nbits)
+{
+	static FILE *scratch = NULL;
+	int saved, i;
+	long n;
+	if (!scratch)
+		scratch = tmpfile();
+	if (!scratch) {
+		ref_getdata(idx, payload, nbits);
+		return;
+	}
+	for (i = 0; i <= MAX_AIS_PACKET_TYPE; i++)
+		skip_type[i] = 0;
+	fflush(stdout);
+	rewind(scratch);
+	if (ftruncate(fileno(scratch), 0) != 0) { /* keep going: the read below is bounded by ftell */ }
+	saved = dup(1);
+	dup2(fileno(scratch), 1);
+	ref_getdata(idx, payload, nbits);
+	fflush(stdout);
+	dup2(saved, 1);
+	close(saved);
+	n = lseek(fileno(scratch), 0, SEEK_END);
+	if (n > 0) {
+		if (g_text_n + (size_t) n > g_text_cap) {
+			g_text_cap = (g_text_n + (size_t) n) * 2 + 4096;
+			g_text = realloc(g_text, g_text_cap);
+		}
+		lseek(fileno(scratch), 0, SEEK_SET);
+		if (read(fileno(scratch), g_text + g_text_n, (size_t) n) == n)
+			g_text_n += (size_t) n;
+	}
+	for (i = 0; i <= MAX_AIS_PACKET_TYPE; i++)
+		skip_type[i] = 1;
+}
+
 extern unsigned short protodec_sdlc_crc(const unsigned char *data, unsigned len);
 unsigned ref_sdlc_crc(const unsigned char *data, unsigned len)
 {

@@ -136,4 +136,25 @@ def nmea_frames(seed=51, n_channels=5, n_random=600):
         f["flags"] = 1
         f["nbits"] = nbits
         rows.append(f)
+    # binary messages of DAC 1 (types 6 and 8) with every function identifier the reference names,
+    # among them the two it decodes further (11 weather, 40 persons on board)
+    for k, fi in enumerate(list(range(0, 6)) + [11, 16, 17, 21, 24, 29, 30, 40, 41, 63] * 2):
+        t = 6 if k % 2 else 8
+        nbits = (360, 200, 168, 424)[k % 4]
+        bits = rng.integers(0, 2, 53 * 8).astype(np.uint8)
+        for i in range(6):
+            bits[i] = (t >> (5 - i)) & 1
+        at = 72 if t == 6 else 40
+        for i in range(10):
+            bits[at + i] = (1 >> (9 - i)) & 1          # DAC = 1
+        for i in range(6):
+            bits[at + 10 + i] = (fi >> (5 - i)) & 1
+        bits[nbits:] = 0
+        f = np.zeros(1, dtype=FRAME_DTYPE)[0]
+        f["channel"] = k % n_channels
+        f["end_bit"] = n_random + k
+        f["payload"] = np.packbits(bits)
+        f["flags"] = 1
+        f["nbits"] = nbits
+        rows.append(f)
     return np.array(rows, dtype=FRAME_DTYPE), n_channels

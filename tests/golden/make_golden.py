@@ -59,17 +59,19 @@ def make_nmea():
     ref = reference()
     out = {}
     fr, n_ch = cases.nmea_frames()
-    text, seq = ref.nmea_of_frames(fr, n_ch)
+    text, seq, printed = ref.nmea_of_frames(fr, n_ch, stdout=True)
     out["synthetic_frames"] = frames_raw(fr)
     out["synthetic_nch"] = np.array([n_ch])
     out["synthetic_text"] = np.frombuffer(text, dtype=np.uint8)
+    out["synthetic_stdout"] = np.frombuffer(printed, dtype=np.uint8)
     out["synthetic_seqnr"] = seq
     for name in ("chain_48k", "chain_long"):       # frames the reference itself decoded
         g = np.load(os.path.join(HERE, name + ".npz"))
         fr = np.frombuffer(np.ascontiguousarray(g["frames"]).tobytes(), dtype=cases_frame_dtype())
         n_ch = int(fr["channel"].max()) + 1
-        text, seq = ref.nmea_of_frames(fr, n_ch)
+        text, seq, printed = ref.nmea_of_frames(fr, n_ch, stdout=True)
         out[name + "_text"] = np.frombuffer(text, dtype=np.uint8)
+        out[name + "_stdout"] = np.frombuffer(printed, dtype=np.uint8)
         out[name + "_seqnr"] = seq
     np.savez_compressed(os.path.join(HERE, "nmea.npz"), **out)
     print("nmea.npz", os.path.getsize(os.path.join(HERE, "nmea.npz")),

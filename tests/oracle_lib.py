@@ -216,6 +216,9 @@ class Reference:
         lib.ref_sdlc_crc.restype = C.c_uint
         lib.ref_sdlc_crc.argtypes = [C.c_void_p, C.c_uint]
         lib.ref_getdata.argtypes = [C.c_int, C.c_void_p, C.c_int]
+        lib.ref_getdata_text.argtypes = [C.c_int, C.c_void_p, C.c_int]
+        lib.ref_text_bytes.restype = C.c_size_t
+        lib.ref_text_ptr.restype = C.c_void_p
         lib.ref_nmea_bytes.restype = C.c_size_t
         lib.ref_nmea_ptr.restype = C.c_void_p
         lib.ref_bench_run.restype = C.c_long
@@ -240,19 +243,25 @@ class Reference:
                 self.lib.ref_receiver_set_params(idx, None if t is None else t.ctypes.data,
                                                  0 if t is None else int(t.size), pllinc)
 
-    def nmea_of_frames(self, frames: np.ndarray, n_channels: int):
+    def nmea_of_frames(self, frames: np.ndarray, n_channels: int, stdout: bool = False):
         """Hand frame records to the reference's own protodec_getdata(), one fresh receiver per
-        channel; returns (every sentence serial_write() received, concatenated; final seqnr[])."""
+        channel; returns (every sentence serial_write() received, concatenated; final seqnr[])
+        and, with stdout=True, also what it printed on stdout."""
         self.reset()
         self.add_receivers(n_channels)
         self.lib.ref_nmea_clear()
+        self.lib.ref_text_clear()
+        call = self.lib.ref_getdata_text if stdout else self.lib.ref_getdata
         for f in frames:
             pay = np.ascontiguousarray(f["payload"])
-            self.lib.ref_getdata(int(f["channel"]), pay.ctypes.data, int(f["nbits"]))
+            call(int(f["channel"]), pay.ctypes.data, int(f["nbits"]))
         n = self.lib.ref_nmea_bytes()
         text = C.string_at(self.lib.ref_nmea_ptr(), n) if n else b""
         seq = np.array([self.lib.ref_get_seqnr(c) for c in range(n_channels)], dtype=np.uint8)
-        return text, seq
+        if not stdout:
+            return text, seq
+        m = self.lib.ref_text_bytes()
+        return text, seq, (C.string_at(self.lib.ref_text_ptr(), m) if m else b"")
 
     def taps(self, idx: int = 0) -> np.ndarray:
         t = np.zeros(1024, dtype=np.float32)

@@ -51,6 +51,45 @@ def test_nmea_golden_decoded_frames(name):
     assert np.array_equal(seq, g[name + "_seqnr"])
 
 
+def test_stdout_text_golden():
+    """The line protodec_getdata() prints for every accepted frame, all per-type decoders."""
+    from gnuais_amd import messages_from_frames
+    g = np.load(os.path.join(G, "nmea.npz"))
+    fr = np.frombuffer(np.ascontiguousarray(g["synthetic_frames"]).tobytes(), dtype=FRAME_DTYPE)
+    n_ch = int(g["synthetic_nch"][0])
+    nm, tx = messages_from_frames(fr, np.zeros(n_ch, dtype=np.uint8))
+    assert nm == g["synthetic_text"].tobytes()
+    want = g["synthetic_stdout"].tobytes()
+    if tx != want:                                # show the first differing line
+        for a, b in zip(tx.split(b"\n"), want.split(b"\n")):
+            assert a == b
+    assert tx == want
+    types = {l.split(b" type ")[1].split(b" ")[0] for l in want.split(b"\n") if b" type " in l}
+    assert types == {str(t).encode() for t in range(1, 25)}      # every accepted AIS type occurs
+    assert b"(tide-weather) lat" in want and b"(persons-on-board) persons-on-board" in want
+    for name in ("chain_48k", "chain_long"):
+        c = np.load(os.path.join(G, name + ".npz"))
+        fr = np.frombuffer(np.ascontiguousarray(c["frames"]).tobytes(), dtype=FRAME_DTYPE)
+        n_ch = int(fr["channel"].max()) + 1
+        nm, tx = messages_from_frames(fr, np.zeros(n_ch, dtype=np.uint8))
+        assert tx == g[name + "_stdout"].tobytes()
+
+
+@pytest.mark.skipif(not have_reference(), reason="oracle/_ref not built (reference tree absent)")
+@pytest.mark.parametrize("seed", [71, 72])
+def test_stdout_text_random_frames_vs_reference(seed):
+    from gnuais_amd import messages_from_frames
+    fr, n_ch = cases.nmea_frames(seed=seed, n_channels=4, n_random=1500)
+    want_nm, seq_want, want_tx = reference().nmea_of_frames(fr, n_ch, stdout=True)
+    seq = np.zeros(n_ch, dtype=np.uint8)
+    nm, tx = messages_from_frames(fr, seq)
+    assert nm == want_nm and np.array_equal(seq, seq_want)
+    if tx != want_tx:
+        for a, b in zip(tx.split(b"\n"), want_tx.split(b"\n")):
+            assert a == b
+    assert tx == want_tx
+
+
 def test_nmea_state_carries_and_sizes():
     fr, n_ch = cases.nmea_frames(seed=52, n_random=200)
     whole, seq_w = nmea(fr, n_ch)
