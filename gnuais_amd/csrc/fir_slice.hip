@@ -351,22 +351,28 @@ __device__ __forceinline__ void touch12(float *a)
                       "+v"(a[6]), "+v"(a[7]), "+v"(a[8]), "+v"(a[9]), "+v"(a[10]), "+v"(a[11]));
 }
 
-template <int NE, int NC>
+// NES > 0: the table has exactly NES effective taps and travels whole in SGPRs (`taps`, NT = NES);
+// NES == 0: only the NC central taps do, the exact re-evaluation reads the NE taps from memory.
+template <int NES, int NC, int NT>
 __global__ __launch_bounds__(64) void fir_sign_kernel(
     const int16_t *__restrict__ x, const int16_t *__restrict__ hist,
     uint32_t *__restrict__ sgn, int *__restrict__ maxval,
     int16_t *__restrict__ hist_out, int *__restrict__ maxval_next,
-    int N, int L, int T, int d, int NT, float eps_up, FirTaps<NE> taps)
+    const float *__restrict__ te_mem, int N, int L, int T, int d, int NTaps, int NE_rt, float eps_up,
+    FirTaps<NT> taps)
 {
+    const int NE = NES > 0 ? NES : NE_rt;
+    const int J0 = (NE - NC) / 2;               // first central tap (10 of 32 for the reference table)
+    auto ctap = [&](int q) -> float { return NES > 0 ? taps.te[(NES - NC) / 2 + q] : taps.te[q]; };
 #if FIR_SIGN_FENCE > 0
+    if constexpr (NC == 12)
     // Claim 88 VGPRs although the fenced code needs 68: five waves per SIMD then leave 72
     // registers for a wave of each of the stages that run beside us (K2a needs 56).  At seven
     // waves per SIMD this kernel would fill the register file and they would wait for FIR
     // waves to retire before they could even be placed.
     asm volatile("" ::: "v87");
 #endif
-    static_assert(NE == 32 && NC == 12, "sized for the reference table");
-    constexpr int J0 = (NE - NC) / 2;           // first central tap (10)
+    static_assert(96 % NC == 0 && NC % 2 == 0, "96 unrolled phases must hold whole turns of the accumulator ring");
     const int lane = threadIdx.x;
     const int cg = blockIdx.x * 64 + lane;
     const int c = cg < N ? cg : N - 1;
@@ -382,13 +388,28 @@ __global__ __launch_bounds__(64) void fir_sign_kernel(
     int peak = 0;
     const int m0 = t0 - dc;                     // local sample i <-> m = m0 + i, feeds output o = i - q
 
-    // exact value of output n: filter.h:40-49 order, samples re-read from memory
+    // exact value of output n: filter.h:40-49 order, samples re-read from memory 32 at a time
+    // (all loads of a chunk in flight together), taps from memory (uniform: scalar loads)
     auto exact_positive = [&](int n) -> bool {
         float sum = 0.0f;
+        if constexpr (NES > 0) {
 #pragma unroll
-        for (int j = 0; j < NE; ++j) {
-            const float xs = (float) load_sample(x, hist, n - d + j, N, NT, c);
-            sum = sum + taps.te[j] * xs;
+            for (int j = 0; j < NES; ++j) {
+                const float xs = (float) load_sample(x, hist, n - d + j, N, NTaps, c);
+                sum = sum + taps.te[j] * xs;
+            }
+            return sum > 0.0f;
+        }
+        for (int j0 = 0; j0 < NE; j0 += 32) {
+            int xs[32];
+#pragma unroll
+            for (int j = 0; j < 32; ++j) {
+                const int jj = j0 + j < NE ? j0 + j : NE - 1;
+                xs[j] = load_sample(x, hist, n - d + jj, N, NTaps, c);
+            }
+#pragma unroll
+            for (int j = 0; j < 32; ++j)
+                if (j0 + j < NE) sum = sum + te_mem[j0 + j] * (float) xs[j];
         }
         return sum > 0.0f;
     };
@@ -397,14 +418,14 @@ __global__ __launch_bounds__(64) void fir_sign_kernel(
     {
         int xw[NC - 1];
 #pragma unroll
-        for (int i = 0; i < NC - 1; ++i) xw[i] = load_sample(x, hist, m0 + i, N, NT, c);
+        for (int i = 0; i < NC - 1; ++i) xw[i] = load_sample(x, hist, m0 + i, N, NTaps, c);
 #pragma unroll
         for (int i = 0; i < NC - 1; ++i) {
             const float xs = (float) xw[i];
 #pragma unroll
             for (int q = 0; q <= i; ++q) {
                 const int qm = q >= NC / 2 ? NC - 1 - q : q;
-                acc[(i - q) % NC] = (q == 0 ? 0.0f : acc[(i - q) % NC]) + taps.te[J0 + qm] * xs;
+                acc[(i - q) % NC] = (q == 0 ? 0.0f : acc[(i - q) % NC]) + ctap(qm) * xs;
             }
         }
     }
@@ -413,14 +434,15 @@ __global__ __launch_bounds__(64) void fir_sign_kernel(
     // `out > 0` is false, but y_c = 0 is "ambiguous", and 32 exact evaluations per word and
     // lane, one after the other, would make a silent channel ~50x slower than a live one.
     // When a word has many ambiguous samples the lane therefore checks whether all samples
-    // its 32 windows can touch ([first-34, last-3] = this word's 32 samples, the 32 before
-    // and the 10 after) are 0.  all_zero() re-reads from memory; it only runs in that case.
+    // its 32 windows can touch are 0: this word's 32 samples, the J0 + NC - 1 before them and the
+    // J0 after them (21 and 10 for the reference table).  all_zero() re-reads from memory; it
+    // only runs in that case.
     auto all_zero = [&](int m_first, int count) -> bool {
         uint32_t o = 0;
         for (int i = 0; i < count; ++i) {
             int m = m_first + i;
-            m = m < -NT ? -NT : (m > L - 1 ? L - 1 : m);   // clamped samples are outside every window
-            o |= (uint32_t) load_sample(x, hist, m, N, NT, c);
+            m = m < -NTaps ? -NTaps : (m > L - 1 ? L - 1 : m);   // clamped samples are outside every window
+            o |= (uint32_t) load_sample(x, hist, m, N, NTaps, c);
         }
         return o == 0;
     };
@@ -444,7 +466,7 @@ __global__ __launch_bounds__(64) void fir_sign_kernel(
                 for (int p = 0; p < 32; ++p) {
                     int m = mb + p;
                     m = (m < L) ? m : L - 1;
-                    xi[p] = load_sample(x, hist, m, N, NT, c);
+                    xi[p] = load_sample(x, hist, m, N, NTaps, c);
                 }
             }
             {   // filter.c:118-119 peak (same bookkeeping as K1, shift = dc - NC + 1)
@@ -475,7 +497,7 @@ __global__ __launch_bounds__(64) void fir_sign_kernel(
                 const float xs = (float) xi[p];
 #pragma unroll
                 for (int q = 0; q < NC / 2; ++q) {
-                    const float pr = taps.te[J0 + q] * xs;  // == te[J0 + NC-1-q] * xs bit for bit
+                    const float pr = ctap(q) * xs;      // == central tap NC-1-q times xs, bit for bit
                     const int s0 = (P + NC - 1 - q) % NC;
                     const int s1 = (P + q) % NC;
                     if (q == 0) acc[s0] = pr; else acc[s0] = acc[s0] + pr;
@@ -485,7 +507,10 @@ __global__ __launch_bounds__(64) void fir_sign_kernel(
                 neg = __builtin_amdgcn_alignbit(neg, __float_as_uint(y), 31);
                 amb = __builtin_amdgcn_alignbit(amb, __float_as_uint(__builtin_fabsf(y) - eps_up), 31);
 #if FIR_SIGN_FENCE > 0
-                if (p % FIR_SIGN_FENCE == FIR_SIGN_FENCE - 1) touch12(acc);
+                if (p % FIR_SIGN_FENCE == FIR_SIGN_FENCE - 1) {
+#pragma unroll
+                    for (int g = 0; g < NC; g += 12) touch12(acc + g);
+                }
 #endif
             }
             uint32_t w = ~neg;
@@ -501,7 +526,9 @@ __global__ __launch_bounds__(64) void fir_sign_kernel(
                 for (int p = 0; p < 32; ++p) o |= (uint32_t) xi[p];
                 zc = o == 0;
                 zc_known = true;
-                if (zc && (zprev_known ? zprev : all_zero(mb - 32, 32)) && all_zero(mb + 32, 10)) {
+                const int before = J0 + NC - 1;
+                if (zc && ((before <= 32 && zprev_known) ? zprev : all_zero(mb - before, before)) &&
+                    all_zero(mb + 32, J0)) {
                     w &= ~amb;                              // y_ref == +0 for every one of them
                     amb = 0;
                 }
@@ -528,10 +555,10 @@ __global__ __launch_bounds__(64) void fir_sign_kernel(
     }
     if (live && peak > 0) atomicMax(&maxval[cg], peak);
     if (t1 == L && live) {                      // carry for the next call, as in K1
-        for (int k = 0; k < NT; ++k) {
-            const int m = L - NT + k;
+        for (int k = 0; k < NTaps; ++k) {
+            const int m = L - NTaps + k;
             hist_out[(size_t) k * (size_t) N + cg] =
-                (m >= 0) ? x[(size_t) m * (size_t) N + cg] : hist[(size_t) (NT + m) * (size_t) N + cg];
+                (m >= 0) ? x[(size_t) m * (size_t) N + cg] : hist[(size_t) (NTaps + m) * (size_t) N + cg];
         }
         maxval_next[cg] = 0;
     }
@@ -539,13 +566,26 @@ __global__ __launch_bounds__(64) void fir_sign_kernel(
 
 hipError_t launch_fir_sign(const FirLaunch &a, hipStream_t stream)
 {
-    if (a.NE != 32 || a.dump || a.T % 96) return hipErrorInvalidValue;
+    if (a.dump || a.T % 96 || !a.te_mem || (a.NC != 12 && a.NC != 48) || a.NE < a.NC || (a.NE - a.NC) % 2)
+        return hipErrorInvalidValue;
     dim3 grid((a.N + 63) / 64, (a.L + a.T - 1) / a.T), block(64);
-    FirTaps<32> t;
-    for (int j = 0; j < 32; ++j) t.te[j] = a.te[j];
-    hipLaunchKernelGGL((fir_sign_kernel<32, 12>), grid, block, 0, stream, a.x, a.hist, a.sgn,
-                       a.maxval, a.hist_out, a.maxval_next, a.N, a.L, a.T, a.d, a.NT,
-                       __builtin_nextafterf(a.eps, INFINITY), t);
+    const float eps_up = __builtin_nextafterf(a.eps, INFINITY);
+    if (a.NC == 12 && a.NE == 32) {
+        FirTaps<32> t;
+        for (int j = 0; j < 32; ++j) t.te[j] = a.te[j];
+        hipLaunchKernelGGL((fir_sign_kernel<32, 12, 32>), grid, block, 0, stream, a.x, a.hist, a.sgn, a.maxval,
+                           a.hist_out, a.maxval_next, a.te_mem, a.N, a.L, a.T, a.d, a.NT, a.NE, eps_up, t);
+    } else if (a.NC == 12) {
+        FirTaps<12> t;
+        for (int j = 0; j < 12; ++j) t.te[j] = a.ctaps[j];
+        hipLaunchKernelGGL((fir_sign_kernel<0, 12, 12>), grid, block, 0, stream, a.x, a.hist, a.sgn, a.maxval,
+                           a.hist_out, a.maxval_next, a.te_mem, a.N, a.L, a.T, a.d, a.NT, a.NE, eps_up, t);
+    } else {
+        FirTaps<48> t;
+        for (int j = 0; j < 48; ++j) t.te[j] = a.ctaps[j];
+        hipLaunchKernelGGL((fir_sign_kernel<0, 48, 48>), grid, block, 0, stream, a.x, a.hist, a.sgn, a.maxval,
+                           a.hist_out, a.maxval_next, a.te_mem, a.N, a.L, a.T, a.d, a.NT, a.NE, eps_up, t);
+    }
     return hipGetLastError();
 }
 

@@ -59,7 +59,7 @@ struct gnuais_batch {
     int max_len = 0, frame_cap = 0;
     int sgn_words = 0, bits_words = 0;
     std::vector<float> taps;
-    float te[64] = {0};
+    float te[128] = {0};
     // device state
     int16_t *hist[2] = {nullptr, nullptr};
     int hist_cur = 0;
@@ -101,6 +101,8 @@ struct gnuais_batch {
                                     // 0 exact scalar VALU, 1 exact packed, 2 exact MFMA products
     bool sign_ok = false;           // table is 32 symmetric effective taps: K1s applicable
     float sign_eps = 0.0f;
+    int sign_NC = 12;               // central taps K1s evaluates
+    int k0 = 0;                     // first effective tap
     int hdlc_lpw = 64;              // channels per wave in K2b
     bool timing = false;
     int timing_stride = 1;          // time every n-th call only: ten event records a call are not free
@@ -196,26 +198,35 @@ int gnuais_batch_create(gnuais_batch **out, int device, int n_channels, const fl
     while (k1 > k0 && b->taps[k1] == 0.0f) --k1;
     b->NE = k1 - k0 + 1;
     b->d = b->NT - k0;
-    if (b->NE <= 64)
+    b->k0 = k0;
+    if (b->NE <= 128)
         for (int j = 0; j < b->NE; ++j) b->te[j] = b->taps[k0 + j];
 
     {
-        // sign-exact slicer (fir_slice.hip K1s): error budget of the 12 central taps
-        // against the reference's ordered 32-term fp32 sum, for |x| <= 32768
-        bool sym = b->NE == 32;
-        for (int j = 0; sym && j < 32; ++j) sym = memcmp(&b->te[j], &b->te[31 - j], 4) == 0;
-        if (sym) {
+        // sign-exact slicer (fir_slice.hip K1s): error budget of the NC central taps against the
+        // reference's ordered NE-term fp32 sum, for |x| <= 32768.  The smallest NC the kernel is
+        // built for (12, 48) whose bound stays small enough is used: 12 for the reference table
+        // (32 effective taps, bound 0.23), 48 for the 192 kHz table (126 taps, bound 0.87).
+        const int NE = b->NE;
+        bool sym = NE <= 128;
+        for (int j = 0; sym && j < NE; ++j) sym = memcmp(&b->te[j], &b->te[NE - 1 - j], 4) == 0;
+        for (int NC : {12, 48}) {
+            if (!sym || b->sign_ok || NE < NC || (NE - NC) % 2) continue;
             const double u = 5.9604644775390625e-8, X = 32768.0;
+            const int J0 = (NE - NC) / 2;
             double sum_all = 0, sum_c = 0, sum_out = 0;
-            for (int j = 0; j < 32; ++j) {
+            for (int j = 0; j < NE; ++j) {
                 const double a = std::fabs((double) b->te[j]);
                 sum_all += a;
-                if (j >= 10 && j <= 21) sum_c += a; else sum_out += a;
+                if (j >= J0 && j < J0 + NC) sum_c += a; else sum_out += a;
             }
-            const double bound = (std::pow(1 + u, 33) - 1) * X * sum_all +
-                                 (std::pow(1 + u, 13) - 1) * X * sum_c + X * sum_out + 1e-30;
-            b->sign_eps = (float) (bound * 1.1);
-            b->sign_ok = std::isfinite(bound) && b->sign_eps < 1e30f;
+            const double bound = (std::pow(1 + u, NE + 1) - 1) * X * sum_all +
+                                 (std::pow(1 + u, NC + 1) - 1) * X * sum_c + X * sum_out + 1e-30;
+            if (std::isfinite(bound) && bound < 2.0) {
+                b->sign_eps = (float) (bound * 1.1);
+                b->sign_NC = NC;
+                b->sign_ok = true;
+            }
         }
     }
     b->sgn_words = (max_len + 31) / 32;
@@ -383,6 +394,10 @@ static void fill_fir(const gnuais_batch *b, FirLaunch &f, const int16_t *x, int 
     f.NE = b->NE;
     f.d = b->d;
     f.eps = b->sign_eps;
+    f.NC = b->sign_NC;
+    if (b->sign_ok)
+        for (int j = 0; j < b->sign_NC; ++j) f.ctaps[j] = b->te[(b->NE - b->sign_NC) / 2 + j];
+    f.te_mem = b->d_taps + b->k0;
 }
 
 static void fill_hdlc(const gnuais_batch *b, HdlcLaunch &h, int k)
@@ -403,14 +418,14 @@ static int run_fir(gnuais_batch *b, const int16_t *x, int len, float *dump, hipS
 {
     FirLaunch f;
     fill_fir(b, f, x, len, dump, k);
-    if (b->NE != 32) {
+    if (b->fir_variant == 3 && b->sign_ok && !dump) {
+        f.T = (f.T + 95) / 96 * 96;
+        HIP_TRY(launch_fir_sign(f, s));
+    } else if (b->NE != 32) {
         HIP_TRY(hipMemsetAsync(b->maxval[b->max_cur ^ 1], 0, sizeof(int) * (size_t) b->N, s));
         HIP_TRY(launch_fir_generic(f, s));
         HIP_TRY(launch_fir_history(x, b->hist[b->hist_cur], b->hist[b->hist_cur ^ 1], b->N, len,
                                    b->NT, s));
-    } else if (b->fir_variant == 3 && b->sign_ok && !dump) {
-        f.T = (f.T + 95) / 96 * 96;
-        HIP_TRY(launch_fir_sign(f, s));
     } else if (b->fir_variant == 1) {
         HIP_TRY(packed::launch_fir_slice(f, s));
     } else if (b->fir_variant == 2) {

@@ -20,6 +20,9 @@ struct FirLaunch {
     int N, L, T;           // T: outputs per wave, multiple of 32
     int NT, NE, d;         // out[n] = sum_j te[j] * x[n - d + j], j < NE
     float eps;             // sign-exact slicer: |central sum| > eps certifies the sign
+    int NC;                //   central taps used (12 or 48)
+    float ctaps[48];       //   te[(NE-NC)/2 .. +NC)
+    const float *te_mem;   //   the NE effective taps in device memory (exact re-evaluation)
 };
 hipError_t launch_fir_sign(const FirLaunch &a, hipStream_t stream);
 hipError_t launch_fir_generic(const FirLaunch &a, hipStream_t stream);

@@ -257,6 +257,30 @@ def test_more_channel_groups_than_cus():
     assert sel.tobytes() == o.frames().tobytes()
 
 
+@pytest.mark.parametrize("n_taps,shape", [(24, "tri"), (60, "gauss"), (37, "gauss"), (130, "gauss"), (36, "zero_edge")])
+def test_chain_vs_oracle_other_symmetric_tables(n_taps, shape):
+    """Tables other than the two the reference ships: the sign-exact slicer picks 12 or 48 central
+    taps from its error bound (or leaves the table to the generic kernel: odd length differences,
+    more than 128 effective taps), and the bits must not change."""
+    k = np.arange(n_taps, dtype=np.float64)
+    mid = (n_taps - 1) / 2.0
+    if shape == "tri":
+        t = 0.05 * (1.0 - np.abs(k - mid) / (mid + 1))
+    elif shape == "zero_edge":
+        t = 0.3 * np.exp(-((k - mid) ** 2) / (2 * 4.0 ** 2))
+        t[:3] = 0.0
+        t[-3:] = 0.0
+    else:
+        t = 0.25 * np.exp(-((k - mid) ** 2) / (2 * (n_taps / 9.0) ** 2))
+    taps = t.astype(np.float32)
+    assert np.array_equal(taps, taps[::-1])
+    total = 3 * 2048 + 300
+    x = np.stack([synth.make_stream(total, seed=37, channel=c, sigma=(600.0, 2500.0, 9000.0)[c % 3])[0]
+                  for c in range(9)], axis=1)
+    x[:, 8] = 0                                                  # and a silent channel
+    run_both(x, [2048, 2048, 2048, 300], 9, taps=taps)
+
+
 def test_chain_192k_vs_oracle():
     total = 6 * 5120
     x = np.stack([synth.make_stream(total, seed=35, channel=c, sps=20, sigma=1500.0,
