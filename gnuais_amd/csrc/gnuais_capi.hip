@@ -441,7 +441,7 @@ static int run_fir(gnuais_batch *b, const int16_t *x, int len, float *dump, hipS
 
 static void fill_pll(const gnuais_batch *b, PllLaunch &p, int k, int len)
 {
-    p.sgn = b->sgn[k]; p.ovf = b->ovf[k]; p.pll = b->pll; p.lastbit = b->lastbit;
+    p.sgn = b->sgn[k]; p.ovf = b->ovf[k]; p.pll = b->pll; p.watchdog = b->frame_count + 3; p.lastbit = b->lastbit;
     p.segbits = b->segbits[k]; p.segcnt = b->segcnt[k];
     p.N = b->N; p.L = len; p.n_seg = b->n_seg; p.seg_words = b->seg_words; p.pllinc = b->pllinc;
 }
@@ -650,6 +650,7 @@ int gnuais_batch_drain_frames(gnuais_batch *b, gnuais_frame *h_out, int max, int
     const uint32_t nchunks = std::min<uint32_t>(cnt[2], (uint32_t) b->chunk_cap);
     if ((uint32_t) max < have) return fail(GNUAIS_E_ARG, "drain_frames: output buffer too small");
     bool overflow = cnt[1] || cnt[0] > (uint32_t) b->frame_cap || cnt[2] > (uint32_t) b->chunk_cap;
+    const bool watchdog = cnt[3] != 0;          // a PLL-stage wave timed out waiting for its partner
     if (have) {
         // K3 leaves the frames in chunks that are internally in the reference's print
         // order (channel, then time); chunks are keyed by (channel block, call, pass)
@@ -683,6 +684,8 @@ int gnuais_batch_drain_frames(gnuais_batch *b, gnuais_frame *h_out, int max, int
     }
     HIP_TRY(hipMemset(b->frame_count, 0, sizeof cnt));
     b->hdlc_calls = 0;
+    if (watchdog)
+        return fail(GNUAIS_E_HIP, "drain_frames: the PLL stage's watchdog fired (device hung or badly oversubscribed); results are incomplete");
     if (overflow)
         return fail(GNUAIS_E_OVERFLOW, "drain_frames: frame ring overflowed, frames were dropped");
     return GNUAIS_OK;
@@ -703,7 +706,7 @@ int gnuais_batch_discard_frames(gnuais_batch *b, void *stream)
     if (!b) return fail(GNUAIS_E_ARG, "discard_frames: NULL batch");
     if (int rc = set_device(b)) return rc;
     hipStream_t s = b->pipeline ? b->s_k[3] : (hipStream_t) stream;   // behind the last K3
-    HIP_TRY(hipMemsetAsync(b->frame_count, 0, sizeof(uint32_t) * 4, s));
+    HIP_TRY(hipMemsetAsync(b->frame_count, 0, sizeof(uint32_t) * 3, s));
     b->hdlc_calls = 0;
     return GNUAIS_OK;
 }

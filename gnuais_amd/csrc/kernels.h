@@ -38,6 +38,7 @@ struct PllLaunch {
     const uint32_t *sgn;   // [ceil(L/32) + PLL_PAD_ROWS][N]
     uint32_t *ovf;         // same shape: slice marks (pll overflow), bit 31 = oldest sample
     uint32_t *pll;         // [N] phase (bits 15:0), prev sign (bit 16)
+    uint32_t *watchdog;    // one word: set to 1 if a wave of the launch gave up waiting for its partner
     uint32_t *lastbit;     // [N] level at the last slice (receiver.h:38)
     uint32_t *segbits;     // [N][n_seg][seg_words] recovered bits per segment, LSB first
     uint32_t *segcnt;      // [N][n_seg] bits in each pack

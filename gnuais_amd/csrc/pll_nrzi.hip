@@ -91,7 +91,7 @@ static_assert(PLL_BATCH <= PLL_PAD_ROWS, "the mover reads whole batches past the
 
 __global__ __launch_bounds__(128) void pll_core_kernel(
     const uint32_t *__restrict__ sgn, uint32_t *__restrict__ ovf, uint32_t *__restrict__ pllst,
-    int N, int L, uint32_t pllinc)
+    uint32_t *__restrict__ watchdog, int N, int L, uint32_t pllinc)
 {
     extern __shared__ uint32_t lds[];
     uint32_t *rin = lds, *rout = lds + PLL_RING * 64, *flag = lds + 2 * PLL_RING * 64;
@@ -105,7 +105,13 @@ __global__ __launch_bounds__(128) void pll_core_kernel(
     __syncthreads();
     const unsigned long long t_start = wall_clock64();
     // nothing here may spin forever: a wave that waits longer than this gives up
-    auto expired = [&]() { return wall_clock64() - t_start > 20000000ull; };   // 200 ms
+    // (200 ms; the two waves of a workgroup normally hand over every few microseconds) and says
+    // so in *watchdog, which the host turns into an error when the frames are drained
+    auto expired = [&]() {
+        if (wall_clock64() - t_start <= 20000000ull) return false;
+        if (lane == 0) atomicOr(watchdog, 1u);
+        return true;
+    };
 
     if (role == 1) {                              // ---- the mover ----
         // Loads are software-pipelined: batch k+1 is in flight while batch k is written to the
@@ -303,7 +309,7 @@ hipError_t launch_pll_core(const PllLaunch &a, hipStream_t stream)
     const int need = 2 * PLL_RING * 64 * 4 + 64;
     const int lds = per_cu <= 1 ? PLL_LDS_BYTES : std::max(need, (160 * 1024 / per_cu) & ~1023);
     hipLaunchKernelGGL(pll_core_kernel, dim3(groups), dim3(128), lds, stream, a.sgn, a.ovf,
-                       a.pll, a.N, a.L, a.pllinc);
+                       a.pll, a.watchdog, a.N, a.L, a.pllinc);
     return hipGetLastError();
 }
 
