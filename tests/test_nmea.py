@@ -90,6 +90,25 @@ def test_stdout_text_random_frames_vs_reference(seed):
     assert tx == want_tx
 
 
+def test_threaded_formatting_equals_serial():
+    """>= 16384 frames grouped by channel are formatted by several host threads (ranges cut at
+    channel boundaries); the bytes and the sequence state must equal the serial path's."""
+    from gnuais_amd import messages_from_frames
+    fr, n_ch = cases.nmea_frames(seed=53, n_channels=97, n_random=3000)
+    big = np.tile(fr, 12)
+    grouped = big[np.argsort(big["channel"], kind="stable")]
+    s1 = np.zeros(n_ch, dtype=np.uint8)
+    nm1, tx1 = messages_from_frames(grouped, s1)                       # threaded
+    s2 = np.zeros(n_ch, dtype=np.uint8)
+    parts = [messages_from_frames(grouped[i:i + 5000], s2) for i in range(0, len(grouped), 5000)]   # serial
+    assert nm1 == b"".join(p[0] for p in parts)
+    assert tx1 == b"".join(p[1] for p in parts)
+    assert np.array_equal(s1, s2)
+    s3 = np.zeros(n_ch, dtype=np.uint8)
+    nm3, tx3 = messages_from_frames(big, s3)                            # not grouped: serial, other order
+    assert len(nm3) == len(nm1) and len(tx3) == len(tx1)
+
+
 def test_nmea_state_carries_and_sizes():
     fr, n_ch = cases.nmea_frames(seed=52, n_random=200)
     whole, seq_w = nmea(fr, n_ch)
