@@ -13,6 +13,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <chrono>
 #include <vector>
 
 #include "../../include/gnuais_hip.h"
@@ -75,7 +76,9 @@ struct gnuais_batch {
     // stage pipeline: K1 on the caller's stream and one internal stream per later
     // kernel, so that the short-on-parallelism stages of call i overlap the FIR of
     // call i+1 (and each other).  Every hand-off buffer exists twice (index = call & 1).
-    hipStream_t s_k[4] = {nullptr, nullptr, nullptr, nullptr};   // K2a, K2x, K2b, K3
+    hipStream_t s_k[4] = {nullptr, nullptr, nullptr, nullptr};   // K2a, K2x, K2b, K3 (entries of pool[])
+    static constexpr int POOL = 8;
+    hipStream_t pool[POOL] = {};                // candidates for gnuais_batch_autotune(); pool[0..3] are the default
     hipEvent_t e_done[5][NBUF] = {};            // e_done[s][k]: stage s of the call using set k is done
                                                 // (0 K1, 1 K2a, 2 K2x, 3 K2b, 4 K3)
     unsigned long long calls = 0, hdlc_calls = 0;   // run calls / K3 launches since the last drain
@@ -123,6 +126,11 @@ static int set_device(const gnuais_batch *b)
     return GNUAIS_OK;
 }
 
+static double now_ms()
+{
+    return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
 extern "C" {
 
 const char *gnuais_last_error(void) { return g_err.c_str(); }
@@ -159,7 +167,7 @@ void gnuais_batch_destroy(gnuais_batch *b)
     for (auto &pair : b->e_done)
         for (auto &e : pair)
             if (e) (void) hipEventDestroy(e);
-    for (auto &st : b->s_k)
+    for (auto &st : b->pool)
         if (st) (void) hipStreamDestroy(st);
     delete b;
 }
@@ -297,12 +305,25 @@ int gnuais_batch_create(gnuais_batch **out, int device, int n_channels, const fl
         // created streams of their own before.
         const char *order = getenv("GNUAIS_STREAM_ORDER");
         if (!order || strlen(order) != 4) order = "1230";
+        int made = 0;
         for (int q = 0; q < 4; ++q) {
             const int idx = (order[q] - '0') & 3;
-            if (e == hipSuccess && !b->s_k[idx]) e = hipStreamCreateWithPriority(&b->s_k[idx], hipStreamNonBlocking, hi);
+            if (e == hipSuccess && !b->s_k[idx]) {
+                e = hipStreamCreateWithPriority(&b->pool[made], hipStreamNonBlocking, hi);
+                b->s_k[idx] = b->pool[made++];
+            }
         }
         for (auto &st : b->s_k)
-            if (e == hipSuccess && !st) e = hipStreamCreateWithPriority(&st, hipStreamNonBlocking, hi);
+            if (e == hipSuccess && !st) {
+                e = hipStreamCreateWithPriority(&b->pool[made], hipStreamNonBlocking, hi);
+                st = b->pool[made++];
+            }
+        // spare candidates for gnuais_batch_autotune(): in a process that has created streams of its
+        // own the default assignment can be 1.7x slower than the best one (0.86 vs 1.39-1.43 ms
+        // per C3 call with two application streams), and there is no API to ask which queue a
+        // stream got -- so the assignment can be measured instead
+        for (; made < gnuais_batch::POOL; ++made)
+            if (e == hipSuccess) e = hipStreamCreateWithPriority(&b->pool[made], hipStreamNonBlocking, hi);
     }
     if (const char *v = getenv("GNUAIS_PIPELINE")) b->pipeline = atoi(v) != 0;
     if (const char *v = getenv("GNUAIS_HDLC_LPW")) b->hdlc_lpw = std::min(64, std::max(1, atoi(v)));
@@ -525,6 +546,69 @@ int gnuais_batch_run(gnuais_batch *b, const int16_t *d_samples, int len, void *s
     b->last_k = k;
     b->calls++;
     return GNUAIS_OK;
+}
+
+int gnuais_batch_sync(gnuais_batch *b);
+int gnuais_batch_reset(gnuais_batch *b);
+int gnuais_batch_discard_frames(gnuais_batch *b, void *stream);
+
+// Try the stage -> stream assignments greedily (PLL stage first, then K3, K2b, K2x; each on every
+// free candidate stream), timing a few pipelined calls of the caller's own input each, and keep
+// the fastest.  Resets the batch afterwards (the calls advanced every receiver's state).
+int gnuais_batch_autotune(gnuais_batch *b, const int16_t *d_samples, int len, void *stream, float *ms_per_call)
+{
+    if (!b || !d_samples) return fail(GNUAIS_E_ARG, "autotune: NULL argument");
+    if (!b->pipeline) return fail(GNUAIS_E_STATE, "autotune: the stage pipeline is off");
+    if (int rc = gnuais_batch_sync(b)) return rc;
+    const bool timing = b->timing;
+    b->timing = false;
+    auto measure = [&](double &ms) -> int {
+        const int warm = 4, meas = 10;
+        for (int i = 0; i < warm + meas; ++i) {
+            if (i == warm) {
+                if (int rc = gnuais_batch_sync(b)) return rc;
+                ms = -now_ms();
+            }
+            if (int rc = gnuais_batch_run(b, d_samples, len, stream)) return rc;
+            if (int rc = gnuais_batch_discard_frames(b, stream)) return rc;
+        }
+        if (int rc = gnuais_batch_sync(b)) return rc;
+        ms = (ms + now_ms()) / meas;
+        return GNUAIS_OK;
+    };
+    const int order[4] = {0, 3, 2, 1};          // K2a, K3, K2b, K2x
+    int chosen[4] = {-1, -1, -1, -1};
+    double best_all = 0;
+    for (int r = 0; r < 4; ++r) {
+        const int role = order[r];
+        double best = 1e30;
+        int best_s = -1;
+        for (int cand = 0; cand < gnuais_batch::POOL; ++cand) {
+            bool used = false;
+            for (int q = 0; q < r; ++q) used |= chosen[order[q]] == cand;
+            if (used) continue;
+            int trial[4];
+            for (int q = 0; q < 4; ++q) trial[q] = chosen[q];
+            trial[role] = cand;
+            for (int q = r + 1; q < 4; ++q) {   // the roles not decided yet: any distinct free streams
+                for (int f = 0; f < gnuais_batch::POOL; ++f) {
+                    bool taken = false;
+                    for (int t = 0; t < 4; ++t) taken |= trial[t] == f;
+                    if (!taken) { trial[order[q]] = f; break; }
+                }
+            }
+            for (int q = 0; q < 4; ++q) b->s_k[q] = b->pool[trial[q]];
+            double ms = 0;
+            if (int rc = measure(ms)) return rc;
+            if (ms < best) { best = ms; best_s = cand; }
+        }
+        chosen[role] = best_s;
+        best_all = best;
+    }
+    for (int q = 0; q < 4; ++q) b->s_k[q] = b->pool[chosen[q]];
+    b->timing = timing;
+    if (ms_per_call) *ms_per_call = (float) best_all;
+    return gnuais_batch_reset(b);
 }
 
 int gnuais_batch_sync(gnuais_batch *b)

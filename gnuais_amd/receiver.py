@@ -77,6 +77,18 @@ class ReceiverBatch:
             assert x.ndim == 2 and x.shape[1] == self.n_channels
             check(self._lib.gnuais_batch_run_host(self._h, x.ctypes.data, int(x.shape[0])))
 
+    def autotune(self, samples, stream: Optional[int] = None) -> float:
+        """Measure the stage -> stream assignments on `samples` (CUDA/HIP int16 tensor) and keep the
+        fastest; resets the batch.  Returns the best ms per call seen."""
+        import torch
+        assert samples.is_cuda and samples.dtype == torch.int16 and samples.is_contiguous()
+        if stream is None:
+            stream = torch.cuda.current_stream(samples.device).cuda_stream
+        ms = C.c_float(0)
+        check(self._lib.gnuais_batch_autotune(self._h, samples.data_ptr(), int(samples.shape[0]),
+                                              C.c_void_p(stream), C.byref(ms)))
+        return ms.value
+
     def sync(self):
         check(self._lib.gnuais_batch_sync(self._h))
 

@@ -168,6 +168,11 @@ int  gnuais_batch_mean_timing(gnuais_batch *b, float *ms6, int *n_calls);
  * call only: the ten event records of a timed call cost ~0.05 ms of stream time),
  * "stage_mask" (experiments: bit s = launch stage s; results are wrong unless 0x1f) */
 int  gnuais_batch_set_option(gnuais_batch *b, const char *name, int value);
+/* Optional, once, before real work: time the stage -> stream assignments on `d_samples` (about 0.5 s
+ * of pipelined calls) and keep the fastest; RESETS the batch.  Which hardware queue a stream gets
+ * depends on what else the process created before, is not queryable, and matters by up to 1.7x. */
+int  gnuais_batch_autotune(gnuais_batch *b, const int16_t *d_samples, int len, void *stream,
+			   float *ms_per_call);
 const char *gnuais_last_error(void);
 const char *gnuais_version(void);
 

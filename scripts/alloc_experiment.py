@@ -15,8 +15,22 @@ def bench(b, steps=60):
         b.run(x, sync=False); b.discard_frames()
     b.sync(); torch.cuda.synchronize()
     return (time.perf_counter() - t) / steps * 1e3
+pre = int(os.environ.get("PRE_STREAMS", 0))      # streams the application created (and used) before us
+keep = []
+for i in range(pre):
+    st = torch.cuda.Stream(priority=-1 if i % 2 else 0)
+    with torch.cuda.stream(st):
+        keep.append(torch.zeros(16, device="cuda") + 1)
+torch.cuda.synchronize()
 mode = os.environ.get("MODE", "seq")
-if mode == "seq":
+if mode == "autotune":
+    b = ReceiverBatch(n_ch, max_len=total)
+    print("before autotune: ms/step %.3f" % bench(b), flush=True)
+    t = time.perf_counter(); best = b.autotune(x); dt = time.perf_counter() - t
+    print("autotune took %.2f s, best seen %.3f ms" % (dt, best), flush=True)
+    for i in range(2):
+        print("after autotune, round", i, "ms/step %.3f" % bench(b), flush=True)
+elif mode == "seq":
     for i in range(4):
         b = ReceiverBatch(n_ch, max_len=total)
         print("batch", i, "ms/step %.3f" % bench(b), flush=True)

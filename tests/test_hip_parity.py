@@ -403,6 +403,23 @@ def test_c3_full_size_properties():
 
 # ---------------------------------------------------------------- API behaviour
 
+def test_autotune_keeps_results_and_resets_state():
+    """gnuais_batch_autotune() re-binds stages to streams and resets the batch: what follows must
+    be what a fresh batch produces."""
+    g = load("chain_48k")
+    x = g["x"]
+    n_ch = x.shape[1]
+    big = np.ascontiguousarray(np.tile(x, (1, 64))[:, :128])      # enough channels to launch every stage
+    b = batch(128, max_len=x.shape[0])
+    ms = b.autotune(dev(big))
+    assert ms > 0
+    assert int(b.counters()["receivedframes"].sum()) == 0          # reset
+    b.run(dev(big))
+    fr = b.drain_frames()
+    first = fr[fr["channel"] < n_ch]
+    assert first.tobytes() == frames_of(g["frames"]).tobytes()
+
+
 def test_argument_errors_are_loud():
     from gnuais_amd import lib
     b = batch(4, max_len=100)
