@@ -75,7 +75,8 @@ struct gnuais_batch {
     int n_seg = 0, seg_words = 0;
     // stage pipeline: K1 on the caller's stream and one internal stream per later
     // kernel, so that the short-on-parallelism stages of call i overlap the FIR of
-    // call i+1 (and each other).  Every hand-off buffer exists twice (index = call & 1).
+    // call i+1 (and each other).  NBUF = 4 measured best: 3 starves the FIR (1.0 ms per C3 call),
+    // 5..8 let it run further ahead and the stages get in each other's way more (0.84).
     hipStream_t s_k[4] = {nullptr, nullptr, nullptr, nullptr};   // K2a, K2x, K2b, K3 (entries of pool[])
     static constexpr int POOL = 8;
     hipStream_t pool[POOL] = {};                // candidates for gnuais_batch_autotune(); pool[0..3] are the default
