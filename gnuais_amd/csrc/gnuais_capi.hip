@@ -78,8 +78,9 @@ struct gnuais_batch {
     // call i+1 (and each other).  NBUF = 4 measured best: 3 starves the FIR (1.0 ms per C3 call),
     // 5..8 let it run further ahead and the stages get in each other's way more (0.84).
     hipStream_t s_k[4] = {nullptr, nullptr, nullptr, nullptr};   // K2a, K2x, K2b, K3 (entries of pool[])
-    static constexpr int POOL = 8;
-    hipStream_t pool[POOL] = {};                // candidates for gnuais_batch_autotune(); pool[0..3] are the default
+    static constexpr int POOL = 12;
+    hipStream_t pool[POOL] = {};                // candidates for gnuais_batch_autotune(): [0..3] the default
+                                                // assignment, [0..7] high priority, [8..11] default priority
     hipEvent_t e_done[5][NBUF] = {};            // e_done[s][k]: stage s of the call using set k is done
                                                 // (0 K1, 1 K2a, 2 K2x, 3 K2b, 4 K3)
     unsigned long long calls = 0, hdlc_calls = 0;   // run calls / K3 launches since the last drain
@@ -324,7 +325,7 @@ int gnuais_batch_create(gnuais_batch **out, int device, int n_channels, const fl
         // per C3 call with two application streams), and there is no API to ask which queue a
         // stream got -- so the assignment can be measured instead
         for (; made < gnuais_batch::POOL; ++made)
-            if (e == hipSuccess) e = hipStreamCreateWithPriority(&b->pool[made], hipStreamNonBlocking, hi);
+            if (e == hipSuccess) e = hipStreamCreateWithPriority(&b->pool[made], hipStreamNonBlocking, made < 8 ? hi : 0);
     }
     if (const char *v = getenv("GNUAIS_PIPELINE")) b->pipeline = atoi(v) != 0;
     if (const char *v = getenv("GNUAIS_HDLC_LPW")) b->hdlc_lpw = std::min(64, std::max(1, atoi(v)));
