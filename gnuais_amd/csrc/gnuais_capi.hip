@@ -562,7 +562,10 @@ int gnuais_batch_discard_frames(gnuais_batch *b, void *stream);
 int gnuais_batch_autotune(gnuais_batch *b, const int16_t *d_samples, int len, void *stream, float *ms_per_call)
 {
     if (!b || !d_samples) return fail(GNUAIS_E_ARG, "autotune: NULL argument");
-    if (!b->pipeline) return fail(GNUAIS_E_STATE, "autotune: the stage pipeline is off");
+    if (!b->pipeline) {                         // one stream, nothing to assign
+        if (ms_per_call) *ms_per_call = 0.0f;
+        return GNUAIS_OK;
+    }
     if (int rc = gnuais_batch_sync(b)) return rc;
     const bool timing = b->timing;
     b->timing = false;
