@@ -159,3 +159,29 @@ def test_nmea_of_device_chain_frames():
         fr = b.drain_frames()
         got, _ = nmea(fr, x.shape[1])
         assert got == g[name + "_text"].tobytes()
+
+
+@pytest.mark.gpu
+def test_wav_file_to_sentences_end_to_end(tmp_path):
+    """f2 + hot path + f1: a stereo WAV of the golden input, read properly, decodes to the golden
+    sentences whatever the call size."""
+    import torch
+    from gnuais_amd import ReceiverBatch, io, messages_from_frames
+    g = np.load(os.path.join(G, "nmea.npz"))
+    c = np.load(os.path.join(G, "chain_48k.npz"))
+    p = tmp_path / "in.wav"
+    io.write_wav(str(p), 48000, c["x"])
+    rate, x = io.read_wav(str(p))
+    assert rate == 48000 and np.array_equal(x, c["x"])
+    for call in (1020, 7777, x.shape[0]):
+        b = ReceiverBatch(x.shape[1], max_len=call)
+        seq = np.zeros(x.shape[1], dtype=np.uint8)
+        frames = []
+        for part in io.chunks(x, call):
+            b.run(torch.from_numpy(np.array(part, dtype=np.int16)).cuda())
+            frames.append(b.drain_frames())
+        fr = np.concatenate(frames)
+        fr = fr[np.argsort(fr["channel"], kind="stable")]          # the golden text is per receiver, in time order
+        nm, tx = messages_from_frames(fr, seq)
+        assert nm == g["chain_48k_text"].tobytes()
+        assert tx == g["chain_48k_stdout"].tobytes()
