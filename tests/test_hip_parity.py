@@ -420,6 +420,31 @@ def test_autotune_keeps_results_and_resets_state():
     assert first.tobytes() == frames_of(g["frames"]).tobytes()
 
 
+def test_two_batches_interleaved_on_two_streams():
+    """Two independent batches in one process, calls interleaved asynchronously on two caller
+    streams: each must produce what it produces alone."""
+    import torch
+    total = 4 * 1280
+    xa = np.stack([synth.make_stream(total, seed=45, channel=c, sigma=1500.0)[0] for c in range(70)], axis=1)
+    xb = np.stack([synth.make_stream(total, seed=46, channel=c, sigma=4000.0)[0] for c in range(130)], axis=1)
+    oa, ob = Oracle(70), Oracle(130)
+    ba, bb = batch(70, max_len=1280), batch(130, max_len=1280)
+    sa, sb = torch.cuda.Stream(), torch.cuda.Stream()
+    da, db = dev(xa), dev(xb)
+    torch.cuda.synchronize()
+    for i in range(0, total, 1280):
+        oa.run(xa[i:i + 1280])
+        ob.run(xb[i:i + 1280])
+        ba.run(da[i:i + 1280], stream=sa.cuda_stream, sync=False)
+        bb.run(db[i:i + 1280], stream=sb.cuda_stream, sync=False)
+    assert ba.drain_frames().tobytes() == oa.frames().tobytes()
+    assert bb.drain_frames().tobytes() == ob.frames().tobytes()
+    for bt, o, n in ((ba, oa, 70), (bb, ob, 130)):
+        p = bt.pll_state()
+        assert [(int(a), int(b_), int(c_)) for a, b_, c_ in zip(p["pll"], p["prev"], p["lastbit"])] == \
+            [o.pll(c) for c in range(n)]
+
+
 def test_argument_errors_are_loud():
     from gnuais_amd import lib
     b = batch(4, max_len=100)
