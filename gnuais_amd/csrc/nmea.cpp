@@ -29,6 +29,7 @@
 #include <stdarg.h>
 #include <stdio.h>
 #include <string.h>
+#include <math.h>
 
 #include <algorithm>
 #include <string>
@@ -362,6 +363,50 @@ extern "C" int gnuais_messages_from_frames(const gnuais_frame *frames, int n_fra
     if (text_len) *text_len = st.len;
     if (n_lines) *n_lines = lines;
     return (sn.fits && st.fits) ? GNUAIS_OK : GNUAIS_E_OVERFLOW;
+}
+
+// ---- range statistics (range.c:18-53) ---------------------------------------------------------------
+// The float/double mix of every expression follows the reference: its doubles are the literals 0.5, 1.0,
+// 2.0 and M_PI inside otherwise-float arithmetic, each result rounded to float where the reference stores
+// or passes a float.  sinf/cosf/atan2f/sqrtf are the host libm's, as there.
+static float to_rad(float deg) { return (float) (deg * (M_PI / 180.0)); }             // lat2rad/lon2rad :8-16
+
+static float km_distance(float lat1, float lon1, float lat2, float lon2)              // :18-30
+{
+    const float sdlat = sinf((float) ((lat1 - lat2) * 0.5));
+    const float sdlon = sinf((float) ((lon1 - lon2) * 0.5));
+    const float c1 = cosf(lat1), c2 = cosf(lat2);
+    const float a = sdlat * sdlat + c1 * c2 * sdlon * sdlon;
+    const float c = (float) (2.0 * atan2f(sqrtf(a), sqrtf((float) (1.0 - a))));
+    return (float) ((111.2 * 180.0 / M_PI) * c);
+}
+
+extern "C" int gnuais_range_from_frames(const gnuais_frame *frames, int n_frames, int n_channels,
+                                        float my_lat_deg, float my_lon_deg, float *best_range_km)
+{
+    if (n_frames < 0 || (n_frames > 0 && !frames) || n_channels <= 0 || !best_range_km) return GNUAIS_E_ARG;
+    // cfg.c:364-368: a station position outside these bounds means "no location", and nothing is tracked
+    if (!(my_lat_deg > -90 && my_lat_deg < 90 && my_lon_deg > -180 && my_lon_deg < 180)) return GNUAIS_OK;
+    const float mylat = to_rad(my_lat_deg), mylng = to_rad(my_lon_deg);
+    for (int k = 0; k < n_frames; ++k) {
+        const gnuais_frame &f = frames[k];
+        if (f.channel >= (uint32_t) n_channels || f.nbits > 8 * sizeof f.payload) return GNUAIS_E_ARG;
+        const Bits b{f, (int) f.nbits};
+        long latitude, longitude;
+        switch ((unsigned) b.get(0, 6)) {
+        case 1: case 2: case 3: latitude = b.sget(89, 27); longitude = b.sget(61, 28); break;   // protodec.c:399
+        case 4: latitude = b.sget(107, 27); longitude = b.sget(79, 28); break;                  // :441
+        case 18: latitude = b.sget(85, 27); longitude = b.sget(57, 28); break;                  // :628
+        default: continue;
+        }
+        const float lat = (float) ((float) latitude / 600000.0), lon = (float) ((float) longitude / 600000.0);
+        // update_range :32-45: bad fixes and the 0/0 "no position" are ignored
+        if (lat > 89.0 || lat < -89.0 || lon > 180.01 || lon < -180.01) continue;
+        if (lat < 0.001 && lat > -0.001 && lon < 0.001 && lon > -0.001) continue;
+        const float d = km_distance(mylat, mylng, to_rad(lat), to_rad(lon));
+        if (d > best_range_km[f.channel]) best_range_km[f.channel] = d;
+    }
+    return GNUAIS_OK;
 }
 
 extern "C" int gnuais_nmea_from_frames(const gnuais_frame *frames, int n_frames, uint8_t *seqnr,

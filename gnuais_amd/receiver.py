@@ -240,6 +240,17 @@ def messages_from_frames(frames: np.ndarray, seqnr: np.ndarray, chanid: Optional
     return nm[: nm_len.value].tobytes(), tx[: tx_len.value].tobytes()
 
 
+def range_from_frames(frames: np.ndarray, best_range_km: np.ndarray, my_lat_deg: float, my_lon_deg: float):
+    """update_range() (range.c:32-45) over these frame records: best_range_km[channel] (float32,
+    updated in place) keeps the farthest plausible position of a type 1-3 / 4 / 18 report."""
+    frames = np.ascontiguousarray(frames, dtype=FRAME_DTYPE)
+    assert best_range_km.dtype == np.float32 and best_range_km.flags.c_contiguous
+    check(_lib.load().gnuais_range_from_frames(frames.ctypes.data, len(frames), len(best_range_km),
+                                               C.c_float(my_lat_deg), C.c_float(my_lon_deg),
+                                               best_range_km.ctypes.data))
+    return best_range_km
+
+
 def tile_channels(base, n_channels: int):
     """Device-side benchmark input builder: base torch int16 [K][L] ->
     interleaved [L][n_channels]."""

@@ -148,6 +148,14 @@ int  gnuais_messages_from_frames(const gnuais_frame *frames, int n_frames, uint8
 				 const char *chanid, int n_channels, char *nmea, size_t nmea_cap,
 				 size_t *nmea_len, int *n_sentences, char *text, size_t text_cap,
 				 size_t *text_len, int *n_lines);
+/* Range statistics (range.c:32-45, called from the position decoders protodec.c:399,441,628):
+ * best_range_km[channel] = max(itself, great-circle km from the station to every plausible
+ * position in frames of type 1-3, 4 and 18), the reference's float arithmetic step for step.
+ * A station position outside (-90,90) x (-180,180) degrees means "no location" as in
+ * cfg.c:364 and leaves the array untouched.  log_range() (range.c:47-53) is the caller's:
+ * print entries > 0.1 and zero them. */
+int  gnuais_range_from_frames(const gnuais_frame *frames, int n_frames, int n_channels,
+			      float my_lat_deg, float my_lon_deg, float *best_range_km);
 /* benchmark input builder: d_out[l][c] = d_base[c % n_base][(l + (c * 7919) % len) % len] */
 int  gnuais_tile_channels(const int16_t *d_base, int n_base, int len, int16_t *d_out,
 			  int n_channels, void *stream);

@@ -385,6 +385,24 @@ void ref_getdata_text(int idx, const uint8_t *payload, int nbits)
 		skip_type[i] = 1;
 }
 
+/* range statistics: the station position as cfg.c:364-368 stores it after parsing the config
+ * (degrees -> radians through the reference's own lat2rad/lon2rad), then the reference's
+ * update_range() runs inside protodec_getdata() for position reports (protodec.c:399,441,628) */
+extern float mylat, mylng;
+extern int have_my_loc;
+extern float lat2rad(float), lon2rad(float);
+void ref_set_location(float lat_deg, float lon_deg)
+{
+	mylat = lat_deg;
+	mylng = lon_deg;
+	have_my_loc = (mylat > -90 && mylat < 90 && mylng > -180 && mylng < 180);
+	if (have_my_loc) {
+		mylat = lat2rad(mylat);
+		mylng = lon2rad(mylng);
+	}
+}
+float ref_best_range(int idx) { return g_rx[idx]->decoder->best_range; }
+
 extern unsigned short protodec_sdlc_crc(const unsigned char *data, unsigned len);
 unsigned ref_sdlc_crc(const unsigned char *data, unsigned len)
 {

@@ -158,3 +158,51 @@ def nmea_frames(seed=51, n_channels=5, n_random=600):
         f["nbits"] = nbits
         rows.append(f)
     return np.array(rows, dtype=FRAME_DTYPE), n_channels
+
+
+def range_frames(seed=61, n_channels=6, n_random=1500, own_channel=False):
+    """Position reports (types 1-3, 4, 18) for the range statistics (row f4): crafted fixes at the
+    plausibility limits of update_range() (range.c:34-39), the 0/0 "no position", antipodes, and
+    random fields (about a third of which are implausible); other types in between.  With
+    own_channel every frame sits on a channel of its own, so best_range[] is the distance of
+    each single fix rather than a maximum."""
+    import numpy as np
+    from oracle_lib import FRAME_DTYPE
+    rng = np.random.default_rng(seed)
+    where = {1: (89, 61), 2: (89, 61), 3: (89, 61), 4: (107, 79), 18: (85, 57)}   # (lat, lon) bit offsets
+    crafted = [(0, 0), (599, 599), (600, 0), (-599, -600), (53400000, 0), (53400001, 0), (-53400000, 1),
+               (53399999, 108006000), (0, 108006001), (0, -108006001), (12345678, 108005999),
+               (35982000, 6186000), (-35982000, -101814000), (36000000, 6000000), (36000060, 6000060),
+               (67108863, 134217727), (-67108864, -134217728), (54600000, 108000000)]
+    rows = []
+    for k in range(n_random + 5 * len(crafted)):
+        if k < 5 * len(crafted):
+            t = (1, 2, 3, 4, 18)[k % 5]
+            lat, lon = crafted[k // 5]
+        else:
+            t = (1, 2, 3, 4, 18, 5, 8, 19)[int(rng.integers(0, 8))]
+            lat, lon = int(rng.integers(-2 ** 26, 2 ** 26)), int(rng.integers(-2 ** 27, 2 ** 27))
+            if k % 3 == 0:                                  # near the station: small distances
+                lat, lon = 36000000 + int(rng.integers(-3000, 3000)), 6000000 + int(rng.integers(-3000, 3000))
+        bits = rng.integers(0, 2, 53 * 8).astype(np.uint8)
+        for i in range(6):
+            bits[i] = (t >> (5 - i)) & 1
+        if t in where:
+            la, lo = where[t]
+            for i in range(27):
+                bits[la + i] = ((lat & (2 ** 27 - 1)) >> (26 - i)) & 1
+            for i in range(28):
+                bits[lo + i] = ((lon & (2 ** 28 - 1)) >> (27 - i)) & 1
+        nbits = 168 if k % 11 else 96                       # a short record: fields read past its end
+        bits[nbits:] = 0
+        f = np.zeros(1, dtype=FRAME_DTYPE)[0]
+        f["channel"] = k if own_channel else int(rng.integers(0, n_channels))
+        f["end_bit"] = k
+        f["payload"] = np.packbits(bits)
+        f["flags"] = 1
+        f["nbits"] = nbits
+        rows.append(f)
+    return np.array(rows, dtype=FRAME_DTYPE), (len(rows) if own_channel else n_channels)
+
+
+RANGE_STATIONS = [(60.0, 10.0), (-33.9, 151.2), (0.0, 0.0), (89.5, -179.5), (95.0, 10.0), (-200.0, -200.0)]

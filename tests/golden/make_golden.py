@@ -78,12 +78,29 @@ def make_nmea():
           {k: v.shape for k, v in out.items()})
 
 
+def make_range():
+    """Row f4: frame records -> best_range per channel for several station positions."""
+    ref = reference()
+    fr, n_ch = cases.range_frames()
+    out = {"frames": frames_raw(fr), "nch": np.array([n_ch]),
+           "stations": np.array(cases.RANGE_STATIONS, dtype=np.float32)}
+    out["best_range"] = np.stack([ref.range_of_frames(fr, n_ch, la, lo) for la, lo in cases.RANGE_STATIONS])
+    fr1, n1 = cases.range_frames(n_random=400, own_channel=True)       # one fix per channel: every distance
+    out["single_frames"] = frames_raw(fr1)
+    out["single_range"] = np.stack([ref.range_of_frames(fr1, n1, la, lo) for la, lo in cases.RANGE_STATIONS])
+    np.savez_compressed(os.path.join(HERE, "range.npz"), **out)
+    print("range.npz", os.path.getsize(os.path.join(HERE, "range.npz")), out["best_range"],
+          "distinct single distances", len(np.unique(out["single_range"])))
+
+
 def cases_frame_dtype():
     from oracle_lib import FRAME_DTYPE
     return FRAME_DTYPE
 
 
 def main():
+    if sys.argv[1:] == ["range"]:
+        return make_range()
     if sys.argv[1:] == ["nmea"]:
         make_nmea()
         return

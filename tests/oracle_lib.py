@@ -217,6 +217,9 @@ class Reference:
         lib.ref_sdlc_crc.argtypes = [C.c_void_p, C.c_uint]
         lib.ref_getdata.argtypes = [C.c_int, C.c_void_p, C.c_int]
         lib.ref_getdata_text.argtypes = [C.c_int, C.c_void_p, C.c_int]
+        lib.ref_set_location.argtypes = [C.c_float, C.c_float]
+        lib.ref_best_range.argtypes = [C.c_int]
+        lib.ref_best_range.restype = C.c_float
         lib.ref_text_bytes.restype = C.c_size_t
         lib.ref_text_ptr.restype = C.c_void_p
         lib.ref_nmea_bytes.restype = C.c_size_t
@@ -262,6 +265,16 @@ class Reference:
             return text, seq
         m = self.lib.ref_text_bytes()
         return text, seq, (C.string_at(self.lib.ref_text_ptr(), m) if m else b"")
+
+    def range_of_frames(self, frames: np.ndarray, n_channels: int, lat_deg: float, lon_deg: float) -> np.ndarray:
+        """best_range of every channel's decoder after the reference's protodec_getdata() saw these
+        frames with the station at (lat, lon) degrees (update_range, range.c:32-45)."""
+        self.lib.ref_set_location(lat_deg, lon_deg)
+        try:
+            self.nmea_of_frames(frames, n_channels, stdout=True)     # nothing is skipped on this path
+            return np.array([self.lib.ref_best_range(c) for c in range(n_channels)], dtype=np.float32)
+        finally:
+            self.lib.ref_set_location(-200.0, -200.0)
 
     def taps(self, idx: int = 0) -> np.ndarray:
         t = np.zeros(1024, dtype=np.float32)
