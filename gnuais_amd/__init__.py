@@ -12,7 +12,7 @@ __all__ = ["params", "synth", "ReceiverBatch"]
 
 
 def __getattr__(name):
-    if name in ("ReceiverBatch", "crc16_batch", "tile_channels", "nmea_from_frames", "messages_from_frames", "range_from_frames"):
+    if name in ("ReceiverBatch", "crc16_batch", "tile_channels", "nmea_from_frames", "messages_from_frames", "range_from_frames", "vessels_from_frames", "VESSEL_DTYPE"):
         from . import receiver
         return getattr(receiver, name)
     raise AttributeError(name)

@@ -46,19 +46,25 @@ const char HEX[] = "0123456789ABCDEF";
 
 // the frame's payload as the reference's d->rbuffer: bit k, 0 beyond the frame
 struct Bits {
-    const gnuais_frame &f;
+    // the frame's bits below `nbits`, zero beyond (as d->rbuffer is, protodec.c:150), padded so that
+    // any field can be fetched with one 8-byte load
+    uint8_t w[72];
     int nbits;
-    // `count` bits from `pos`, MSB first (protodec_henten, protodec.c:205-214)
+    Bits(const gnuais_frame &f, int n) : nbits(n)
+    {
+        memset(w, 0, sizeof w);
+        const int whole = std::min(n, 8 * (int) sizeof f.payload) >> 3, rest = n & 7;
+        memcpy(w, f.payload, (size_t) whole);
+        if (rest && whole < (int) sizeof f.payload) w[whole] = (uint8_t) (f.payload[whole] & (0xff00 >> rest));
+    }
+    // `count` (<= 32) bits from `pos`, MSB first (protodec_henten, protodec.c:205-214)
     unsigned long get(int pos, int count) const
     {
-        unsigned long v = 0;
-        for (int i = 0; i < count; ++i) {
-            const int b = pos + i;
-            const unsigned bit =
-                (b < nbits && b < 8 * (int) sizeof f.payload) ? (f.payload[b >> 3] >> (7 - (b & 7))) & 1u : 0u;
-            v = (v << 1) | bit;
-        }
-        return v;
+        if (pos >= 8 * 64) return 0;
+        uint64_t v;
+        memcpy(&v, w + (pos >> 3), 8);
+        v = __builtin_bswap64(v);
+        return (unsigned long) ((v << (pos & 7)) >> (64 - count));
     }
     // two's complement field of `count` bits (the reference ORs the upper bits in by hand)
     int sget(int pos, int count) const
@@ -250,7 +256,7 @@ static int format_range(const gnuais_frame *frames, int k0, int k1, uint8_t *seq
         if (f.channel >= (uint32_t) n_channels) return GNUAIS_E_ARG;
         const int nbits = f.nbits;
         if (nbits > 8 * (int) sizeof f.payload) return GNUAIS_E_ARG;
-        const Bits b{f, nbits};
+        const Bits b(f, nbits);
         const unsigned type = (unsigned) b.get(0, 6);
         if (type < 1 || type > MAX_TYPE) continue;
         const int fill = (6 - nbits % 6) % 6;
@@ -391,7 +397,7 @@ extern "C" int gnuais_range_from_frames(const gnuais_frame *frames, int n_frames
     for (int k = 0; k < n_frames; ++k) {
         const gnuais_frame &f = frames[k];
         if (f.channel >= (uint32_t) n_channels || f.nbits > 8 * sizeof f.payload) return GNUAIS_E_ARG;
-        const Bits b{f, (int) f.nbits};
+        const Bits b(f, (int) f.nbits);
         long latitude, longitude;
         switch ((unsigned) b.get(0, 6)) {
         case 1: case 2: case 3: latitude = b.sget(89, 27); longitude = b.sget(61, 28); break;   // protodec.c:399
@@ -406,6 +412,159 @@ extern "C" int gnuais_range_from_frames(const gnuais_frame *frames, int n_frames
         const float d = km_distance(mylat, mylng, to_rad(lat), to_rad(lon));
         if (d > best_range_km[f.channel]) best_range_km[f.channel] = d;
     }
+    return GNUAIS_OK;
+}
+
+// ---- vessel table: the reference's position cache, folded per batch (cache.c:163-384) ------------
+namespace {
+
+static_assert(sizeof(gnuais_vessel) == 120, "gnuais_vessel layout");
+
+gnuais_vessel fresh_vessel(int mmsi)                 // cache_get's new entry :175-196
+{
+    gnuais_vessel v;
+    memset(&v, 0, sizeof v);
+    v.mmsi = mmsi;
+    v.hdg = -1; v.course = -1; v.sog = -1; v.shiptype = -1; v.imo = -1; v.navstat = -1;
+    v.A = v.B = v.C = v.D = -1;
+    v.persons_on_board = -1;
+    return v;
+}
+
+void put(char *dst, size_t cap, const std::string &s)
+{
+    memset(dst, 0, cap);
+    memcpy(dst, s.data(), std::min(s.size(), cap - 1));
+}
+
+void set_position(gnuais_vessel &v, int navstat, long latitude, long longitude, int hdg, unsigned course,
+                  unsigned sog)                      // cache_position :204-229
+{
+    v.set |= GNUAIS_V_POSITION;
+    v.lat = (float) ((float) latitude / 600000.0);
+    v.lon = (float) ((float) longitude / 600000.0);
+    v.hdg = hdg;
+    v.course = (float) ((float) (unsigned short) course / 10.0);
+    v.sog = (float) ((float) (unsigned short) sog / 10.0);
+    v.navstat = navstat;
+}
+
+void set_static(gnuais_vessel &v, int imo, int shiptype, int A, int B, int C, int D, float draught)
+{
+    v.set |= GNUAIS_V_DATA | GNUAIS_V_STATIC;
+    v.imo = imo; v.shiptype = shiptype; v.A = A; v.B = B; v.C = C; v.D = D; v.draught = draught;
+}
+
+void set_name(gnuais_vessel &v, const std::string &name, const std::string &destination)   // :336-361
+{
+    v.set |= GNUAIS_V_DATA | GNUAIS_V_NAME;
+    put(v.name, sizeof v.name, name);
+    put(v.destination, sizeof v.destination, destination);
+}
+
+void set_callsign(gnuais_vessel &v, const std::string &cs)
+{
+    v.set |= GNUAIS_V_CALLSIGN;
+    put(v.callsign, sizeof v.callsign, cs);
+}
+
+// what one frame does to its vessel's entry: the cache_*() calls of the per-type decoders
+bool touches_cache(const Bits &b, unsigned type)
+{
+    switch (type) {
+    case 1: case 2: case 3: case 4: case 5: case 18: case 19: return true;
+    case 24: return b.get(38, 2) <= 1;
+    case 6: return b.get(72, 10) == 1 && b.get(82, 6) == 40;
+    case 8: return b.get(40, 10) == 1 && b.get(50, 6) == 40;
+    default: return false;
+    }
+}
+
+void fold(gnuais_vessel &v, const Bits &b, unsigned type)
+{
+    switch (type) {
+    case 1: case 2: case 3:                          // protodec_pos :390-397
+        set_position(v, (int) (signed char) b.get(38, 2), b.sget(89, 27), b.sget(61, 28), (int) b.get(128, 9),
+                     (unsigned) b.get(116, 12), (unsigned) b.get(50, 10));
+        break;
+    case 4:                                          // protodec_4 :435-439: a position, nothing else known
+        set_position(v, 0, b.sget(107, 27), b.sget(79, 28), 0, 0, 0);
+        break;
+    case 18:                                         // protodec_18 :619-626
+        set_position(v, 15, b.sget(85, 27), b.sget(57, 28), (int) b.get(124, 9), (unsigned) b.get(112, 12),
+                     (unsigned) b.get(46, 10));
+        break;
+    case 5: {                                        // protodec_5 :516-518 -> cache_vesseldata :235-275
+        const unsigned char draught = (unsigned char) b.get(294, 8);
+        set_callsign(v, b.text(70, 6));
+        set_name(v, b.text(112, 20), b.text(302, 20));
+        set_static(v, (int) b.get(40, 30), (int) b.get(232, 8), (int) b.get(240, 9), (int) b.get(249, 9),
+                   (unsigned char) b.get(258, 6), (unsigned char) b.get(264, 6), (float) (draught / 10.0));
+        break;
+    }
+    case 19:                                         // protodec_19 :676-678: class B has no destination
+        set_name(v, b.text(143, 20), "CLASS B");
+        set_static(v, 0, (int) b.get(263, 8), (int) b.get(271, 9), (int) b.get(280, 9),
+                   (unsigned char) b.get(289, 6), (unsigned char) b.get(295, 6), 0);
+        break;
+    case 24:                                         // protodec_24 :740-741, :772-774
+        if (b.get(38, 2) == 0) set_name(v, b.text(40, 20), "CLASS B");
+        if (b.get(38, 2) == 1) {
+            set_callsign(v, b.text(90, 6));
+            set_static(v, 0, (int) b.get(40, 8), (int) b.get(132, 9), (int) b.get(141, 9),
+                       (unsigned char) b.get(150, 6), (unsigned char) b.get(156, 6), 0);
+        }
+        break;
+    case 6: case 8:                                  // protodec_msg_40 :279-285
+        v.set |= GNUAIS_V_PERSONS;
+        v.persons_on_board = (int) b.get(type == 6 ? 88 : 56, 13);
+        break;
+    default: break;
+    }
+}
+
+} // namespace
+
+extern "C" int gnuais_vessels_from_frames(const gnuais_frame *frames, int n_frames, gnuais_vessel *vessels,
+                                          int cap, int *n_vessels)
+{
+    if (n_frames < 0 || (n_frames > 0 && !frames) || !vessels || cap < 0 || !n_vessels || *n_vessels < 0 ||
+        *n_vessels > cap)
+        return GNUAIS_E_ARG;
+    const int n_old = *n_vessels;
+    for (int i = 1; i < n_old; ++i)
+        if (vessels[i].mmsi <= vessels[i - 1].mmsi) return GNUAIS_E_ARG;
+    // (mmsi, arrival order) of every frame that reaches a cache_*() call; sorted, each vessel's
+    // updates are contiguous and still in arrival order
+    std::vector<std::pair<int, int>> upd;
+    upd.reserve((size_t) n_frames);
+    for (int k = 0; k < n_frames; ++k) {
+        const gnuais_frame &f = frames[k];
+        if (f.nbits > 8 * sizeof f.payload) return GNUAIS_E_ARG;
+        const Bits b(f, (int) f.nbits);
+        const unsigned type = (unsigned) b.get(0, 6);
+        if (type < 1 || type > MAX_TYPE || !touches_cache(b, type)) continue;
+        upd.emplace_back((int) b.get(8, 30), k);
+    }
+    std::sort(upd.begin(), upd.end());
+    std::vector<gnuais_vessel> out;
+    out.reserve((size_t) n_old + upd.size());
+    int o = 0;
+    for (size_t u = 0; u < upd.size();) {
+        const int mmsi = upd[u].first;
+        while (o < n_old && vessels[o].mmsi < mmsi) out.push_back(vessels[o++]);
+        gnuais_vessel v = (o < n_old && vessels[o].mmsi == mmsi) ? vessels[o++] : fresh_vessel(mmsi);
+        for (; u < upd.size() && upd[u].first == mmsi; ++u) {
+            const gnuais_frame &f = frames[upd[u].second];
+            const Bits b(f, (int) f.nbits);
+            fold(v, b, (unsigned) b.get(0, 6));
+        }
+        out.push_back(v);
+    }
+    while (o < n_old) out.push_back(vessels[o++]);
+    if ((int) out.size() > cap) return GNUAIS_E_OVERFLOW;
+    if (!out.empty()) memcpy(vessels, out.data(), out.size() * sizeof(gnuais_vessel));
+    *n_vessels = (int) out.size();
     return GNUAIS_OK;
 }
 

@@ -251,6 +251,29 @@ def range_from_frames(frames: np.ndarray, best_range_km: np.ndarray, my_lat_deg:
     return best_range_km
 
 
+# struct gnuais_vessel (include/gnuais_hip.h) = the reference's struct cache_ent, strings inline
+VESSEL_DTYPE = np.dtype([("mmsi", "<i4"), ("set", "<u4"), ("lat", "<f4"), ("lon", "<f4"), ("hdg", "<i4"),
+                         ("course", "<f4"), ("sog", "<f4"), ("navstat", "<i4"), ("imo", "<i4"),
+                         ("shiptype", "<i4"), ("A", "<i4"), ("B", "<i4"), ("C", "<i4"), ("D", "<i4"),
+                         ("draught", "<f4"), ("persons_on_board", "<i4"), ("callsign", "S8"),
+                         ("name", "S24"), ("destination", "S24")])
+assert VESSEL_DTYPE.itemsize == 120
+
+
+def vessels_from_frames(frames: np.ndarray, table: Optional[np.ndarray] = None) -> np.ndarray:
+    """Fold frame records into the vessel table the reference's position cache would hold
+    (cache.c:204-384), continuing from `table` (sorted by MMSI) or from an empty cache."""
+    frames = np.ascontiguousarray(frames, dtype=FRAME_DTYPE)
+    n_old = 0 if table is None else len(table)
+    out = np.zeros(n_old + len(frames), dtype=VESSEL_DTYPE)
+    if n_old:
+        out[:n_old] = table
+    n = C.c_int(n_old)
+    check(_lib.load().gnuais_vessels_from_frames(frames.ctypes.data, len(frames), out.ctypes.data, len(out),
+                                                 C.byref(n)))
+    return out[: n.value].copy()
+
+
 def tile_channels(base, n_channels: int):
     """Device-side benchmark input builder: base torch int16 [K][L] ->
     interleaved [L][n_channels]."""

@@ -42,6 +42,34 @@ typedef struct gnuais_frame {
 	uint16_t nbits;        /* bufferpos - 22, src/protodec.c:1096               */
 } gnuais_frame;
 
+/* One entry of the reference's position cache, struct cache_ent (src/cache.h:27-56), strings
+ * inline: what the cache holds for one MMSI after the per-type decoders called cache_position /
+ * cache_vesseldata / cache_vesseldatab / cache_vesseldatabb / cache_vesselname /
+ * cache_vessel_persons (src/cache.c:204-384).  Fields nobody has set keep cache_get()'s
+ * defaults (src/cache.c:181-196): 0 for lat/lon/draught, -1 for the other numbers, and the
+ * GNUAIS_V_* bit of an unset string is clear (the reference holds NULL there).  120 bytes. */
+#define GNUAIS_V_POSITION 1u    /* received_pos is set: a type 1-3 / 4 / 18 report            */
+#define GNUAIS_V_DATA     2u    /* received_data is set: type 5 / 19 / 24                     */
+#define GNUAIS_V_PERSONS  4u    /* received_persons_on_board is set: DAC 1 FI 40              */
+#define GNUAIS_V_NAME     8u    /* name and destination hold strings                          */
+#define GNUAIS_V_CALLSIGN 16u   /* callsign holds a string                                    */
+#define GNUAIS_V_STATIC   32u   /* imo, shiptype, A-D, draught were written                   */
+typedef struct gnuais_vessel {
+	int32_t  mmsi;
+	uint32_t set;              /* GNUAIS_V_* */
+	float    lat, lon;
+	int32_t  hdg;
+	float    course, sog;
+	int32_t  navstat;
+	int32_t  imo;
+	int32_t  shiptype, A, B, C, D;
+	float    draught;
+	int32_t  persons_on_board;
+	char     callsign[8];      /* <= 6 characters + NUL */
+	char     name[24];         /* <= 20 characters + NUL */
+	char     destination[24];
+} gnuais_vessel;
+
 /* per-channel counters: src/protodec.h:58-60, bumped at src/protodec.c:1103,1107,1112,
  * read by src/ais.c:296-310 */
 typedef struct gnuais_counters {
@@ -156,6 +184,14 @@ int  gnuais_messages_from_frames(const gnuais_frame *frames, int n_frames, uint8
  * print entries > 0.1 and zero them. */
 int  gnuais_range_from_frames(const gnuais_frame *frames, int n_frames, int n_channels,
 			      float my_lat_deg, float my_lon_deg, float *best_range_km);
+/* The batched front of the reference's position cache (row f3).  Folds the frames, in order,
+ * into `vessels` exactly as the reference's decoders fold them into its cache one
+ * cache_*() call at a time (protodec.c:282,390,435,516,619,676-678,740,772): on entry
+ * `*n_vessels` entries sorted by MMSI (0 = empty cache), on return the updated table, sorted.
+ * A consumer then makes one sink call per vessel and batch instead of one per message.
+ * GNUAIS_E_OVERFLOW when more than `cap` vessels are needed (table left as on entry). */
+int  gnuais_vessels_from_frames(const gnuais_frame *frames, int n_frames, gnuais_vessel *vessels,
+				int cap, int *n_vessels);
 /* benchmark input builder: d_out[l][c] = d_base[c % n_base][(l + (c * 7919) % len) % len] */
 int  gnuais_tile_channels(const int16_t *d_base, int n_base, int len, int16_t *d_out,
 			  int n_channels, void *stream);

@@ -303,9 +303,13 @@ static char *g_nmea = NULL;
 static size_t g_nmea_n = 0, g_nmea_cap = 0;
 static int g_nmea_sentences = 0;
 
+extern int __real_serial_write(struct serial_state_t *state, char *s, int len);
+static int g_serial_live = 0;   /* timing runs: let the reference's serial_write() do its write() */
+
 int __wrap_serial_write(struct serial_state_t *state, char *s, int len)
 {
-	(void) state;
+	if (g_serial_live)
+		return __real_serial_write(state, s, len);
 	if (g_nmea_n + (size_t) len > g_nmea_cap) {
 		g_nmea_cap = (g_nmea_n + (size_t) len) * 2 + 4096;
 		g_nmea = realloc(g_nmea, g_nmea_cap);
@@ -402,6 +406,84 @@ void ref_set_location(float lat_deg, float lon_deg)
 	}
 }
 float ref_best_range(int idx) { return g_rx[idx]->decoder->best_range; }
+
+/* position cache: switch the reference's own cache on (cache.c:59-77), let protodec_getdata()
+ * fill it, then take it out with cache_rotate() (cache.c:141-155) and flatten it the way
+ * out_json.c:241-262 walks it (sp_fhead/sp_fnext, key order).  Record = gnuais_vessel of
+ * include/gnuais_hip.h; timestamps are reported as "set or not" only. */
+#include "cache.h"
+struct flat_vessel {
+	int32_t mmsi; uint32_t set; float lat, lon; int32_t hdg; float course, sog; int32_t navstat;
+	int32_t imo, shiptype, A, B, C, D; float draught; int32_t persons_on_board;
+	char callsign[8], name[24], destination[24];
+};
+void ref_cache_enable(void)
+{
+	if (!cache_positions)
+		cache_init();
+}
+int ref_cache_take(struct flat_vessel *out, int cap)
+{
+	struct sptree *sp = cache_rotate();
+	struct spblk *x;
+	int n = 0;
+	for (x = sp_fhead(sp); x != NULL; x = sp_fnext(x)) {
+		struct cache_ent *e = (struct cache_ent *) x->data;
+		if (n < cap) {
+			struct flat_vessel *v = &out[n];
+			memset(v, 0, sizeof(*v));
+			v->mmsi = e->mmsi;
+			v->set = (e->received_pos ? 1u : 0) | (e->received_data ? 2u : 0) |
+				 (e->received_persons_on_board ? 4u : 0) | ((e->name && e->destination) ? 8u : 0) |
+				 (e->callsign ? 16u : 0) | (e->shiptype != -1 || e->imo != -1 ? 32u : 0);
+			v->lat = e->lat; v->lon = e->lon; v->hdg = e->hdg; v->course = e->course; v->sog = e->sog;
+			v->navstat = e->navstat; v->imo = e->imo; v->shiptype = e->shiptype;
+			v->A = e->A; v->B = e->B; v->C = e->C; v->D = e->D; v->draught = e->draught;
+			v->persons_on_board = e->persons_on_board;
+			if (e->callsign) strncpy(v->callsign, e->callsign, sizeof(v->callsign) - 1);
+			if (e->name) strncpy(v->name, e->name, sizeof(v->name) - 1);
+			if (e->destination) strncpy(v->destination, e->destination, sizeof(v->destination) - 1);
+		}
+		n++;
+	}
+	cache_free(sp);
+	hfree(sp);
+	return n;
+}
+
+/* timing (scripts/time_sinks.py): `n` frame records (gnuais_frame, 64 bytes: channel at 0, payload
+ * at 8, nbits at 62) through the reference's protodec_getdata() one by one, with its sinks live:
+ * serial_write() on `serial_fd` (>= 0), printf/fflush on whatever fd 1 is (with_text), the
+ * position cache when it was enabled.  Returns seconds. */
+#include <time.h>
+double ref_getdata_many(const uint8_t *records, int n, int serial_fd, int with_text)
+{
+	struct serial_state_t port;
+	struct timespec t0, t1;
+	int i, k;
+	port.fd = serial_fd;
+	for (i = 0; i <= MAX_AIS_PACKET_TYPE; i++)
+		skip_type[i] = with_text ? 0 : 1;
+	g_serial_live = 1;
+	clock_gettime(CLOCK_MONOTONIC, &t0);
+	for (k = 0; k < n; k++) {
+		const uint8_t *r = records + (size_t) k * 64;
+		struct demod_state_t *d = g_rx[*(const uint32_t *) r]->decoder;
+		const int nbits = *(const uint16_t *) (r + 62);
+		memset(d->rbuffer, 0, DEMOD_BUFFER_LEN);
+		for (i = 0; i < nbits && i < DEMOD_BUFFER_LEN - 8; i++)
+			d->rbuffer[i] = (r[8 + (i >> 3)] >> (7 - (i & 7))) & 1;
+		d->serial = serial_fd >= 0 ? &port : NULL;
+		protodec_getdata(nbits, d);
+		d->serial = NULL;
+	}
+	fflush(stdout);
+	clock_gettime(CLOCK_MONOTONIC, &t1);
+	g_serial_live = 0;
+	for (i = 0; i <= MAX_AIS_PACKET_TYPE; i++)
+		skip_type[i] = 1;
+	return (double) (t1.tv_sec - t0.tv_sec) + 1e-9 * (double) (t1.tv_nsec - t0.tv_nsec);
+}
 
 extern unsigned short protodec_sdlc_crc(const unsigned char *data, unsigned len);
 unsigned ref_sdlc_crc(const unsigned char *data, unsigned len)

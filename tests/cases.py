@@ -206,3 +206,43 @@ def range_frames(seed=61, n_channels=6, n_random=1500, own_channel=False):
 
 
 RANGE_STATIONS = [(60.0, 10.0), (-33.9, 151.2), (0.0, 0.0), (89.5, -179.5), (95.0, 10.0), (-200.0, -200.0)]
+
+
+def vessel_frames(seed=71, n_channels=4, n=1500, n_mmsi=500):
+    """Frames of every type that reaches the position cache (1-5, 18, 19, 24 parts A/B and the
+    unused part numbers, binary messages with and without DAC 1 / FI 40), drawn over a small
+    pool of MMSIs so that entries are overwritten field group by field group in every order;
+    names with trailing blanks, '@' and short records among them."""
+    import numpy as np
+    from oracle_lib import FRAME_DTYPE
+    rng = np.random.default_rng(seed)
+    pool = [int(v) for v in rng.integers(1, 2 ** 30, n_mmsi)] + [0, 2 ** 30 - 1, 1]
+    types = [1, 2, 3, 4, 5, 18, 19, 24, 24, 6, 8, 9, 21]
+    rows = []
+    for k in range(n):
+        t = types[int(rng.integers(0, len(types)))]
+        bits = rng.integers(0, 2, 53 * 8).astype(np.uint8)
+
+        def put(at, width, value):
+            for i in range(width):
+                bits[at + i] = (value >> (width - 1 - i)) & 1
+        put(0, 6, t)
+        put(8, 30, pool[int(rng.integers(0, len(pool)))])
+        if t in (6, 8):
+            at = 72 if t == 6 else 40
+            put(at, 10, 1 if k % 4 else int(rng.integers(0, 1024)))
+            put(at + 10, 6, 40 if k % 3 else int(rng.integers(0, 64)))
+        if t in (5, 19, 24) and k % 5 == 0:            # text that ends in blanks / '@' (both decode to ' ')
+            at = {5: 112, 19: 143, 24: 40}[t]
+            for c in range(int(rng.integers(0, 21)), 20):
+                put(at + 6 * c, 6, 32 if c % 2 else 0)
+        nbits = (424 if t == 5 else 312 if t == 19 else 168) if k % 9 else int(rng.integers(5, 53)) * 8
+        bits[nbits:] = 0
+        f = np.zeros(1, dtype=FRAME_DTYPE)[0]
+        f["channel"] = int(rng.integers(0, n_channels))
+        f["end_bit"] = k
+        f["payload"] = np.packbits(bits)
+        f["flags"] = 1
+        f["nbits"] = nbits
+        rows.append(f)
+    return np.array(rows, dtype=FRAME_DTYPE), n_channels

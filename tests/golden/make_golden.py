@@ -93,12 +93,26 @@ def make_range():
           "distinct single distances", len(np.unique(out["single_range"])))
 
 
+def make_vessels():
+    """Row f3: frame records -> the reference's position cache, flattened."""
+    ref = reference()
+    fr, n_ch = cases.vessel_frames()
+    tab = ref.cache_of_frames(fr, n_ch)
+    out = {"frames": frames_raw(fr), "nch": np.array([n_ch]),
+           "vessels": np.frombuffer(tab.tobytes(), dtype=np.uint8)}
+    np.savez_compressed(os.path.join(HERE, "vessels.npz"), **out)
+    print("vessels.npz", os.path.getsize(os.path.join(HERE, "vessels.npz")), len(tab), "vessels; set bits",
+          {int(b): int((tab["set"] == b).sum()) for b in np.unique(tab["set"])})
+
+
 def cases_frame_dtype():
     from oracle_lib import FRAME_DTYPE
     return FRAME_DTYPE
 
 
 def main():
+    if sys.argv[1:] == ["vessels"]:
+        return make_vessels()
     if sys.argv[1:] == ["range"]:
         return make_range()
     if sys.argv[1:] == ["nmea"]:

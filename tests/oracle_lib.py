@@ -220,6 +220,7 @@ class Reference:
         lib.ref_set_location.argtypes = [C.c_float, C.c_float]
         lib.ref_best_range.argtypes = [C.c_int]
         lib.ref_best_range.restype = C.c_float
+        lib.ref_cache_take.argtypes = [C.c_void_p, C.c_int]
         lib.ref_text_bytes.restype = C.c_size_t
         lib.ref_text_ptr.restype = C.c_void_p
         lib.ref_nmea_bytes.restype = C.c_size_t
@@ -275,6 +276,24 @@ class Reference:
             return np.array([self.lib.ref_best_range(c) for c in range(n_channels)], dtype=np.float32)
         finally:
             self.lib.ref_set_location(-200.0, -200.0)
+
+    def cache_of_frames(self, frames: np.ndarray, n_channels: int, pieces=None) -> np.ndarray:
+        """The reference's own position cache (cache.c) after its protodec_getdata() saw these
+        frames, flattened in key order into gnuais_vessel records.  `pieces` (split points)
+        only proves that the cache carries across calls -- it is taken out once, at the end."""
+        from gnuais_amd.receiver import VESSEL_DTYPE
+        self.lib.ref_cache_enable()
+        out = np.zeros(max(1, len(frames)), dtype=VESSEL_DTYPE)
+        self.lib.ref_cache_take(out.ctypes.data_as(C.c_void_p), 0)          # start from an empty cache
+        self.reset()
+        self.add_receivers(n_channels)
+        for lo, hi in zip([0] + list(pieces or []), list(pieces or []) + [len(frames)]):
+            for f in frames[lo:hi]:
+                pay = np.ascontiguousarray(f["payload"])
+                self.lib.ref_getdata_text(int(f["channel"]), pay.ctypes.data, int(f["nbits"]))
+        n = self.lib.ref_cache_take(out.ctypes.data_as(C.c_void_p), len(out))
+        assert n <= len(out)
+        return out[:n].copy()
 
     def taps(self, idx: int = 0) -> np.ndarray:
         t = np.zeros(1024, dtype=np.float32)

@@ -74,10 +74,12 @@ def test_product_never_touches_the_oracle():
     assert not bad, bad
 
 
-def test_dropin_c_file_compiles_standalone_and_in_tree(tmp_path):
-    """gnuais_amd/csrc/receiver_hip.c is plain C against the public ABI header, and
-    (where the reference tree is present) against the reference's own headers."""
-    src = os.path.join(ROOT, "gnuais_amd", "csrc", "receiver_hip.c")
+@pytest.mark.parametrize("name", ["receiver_hip.c", "sinks_batch.c"])
+def test_dropin_c_file_compiles_standalone_and_in_tree(tmp_path, name):
+    """The host-side C files that a gnuais tree adds (the receiver drop-in, the batched sink
+    adapter) are plain C against the public headers, and (where the reference tree is present)
+    against the reference's own headers."""
+    src = os.path.join(ROOT, "gnuais_amd", "csrc", name)
     inc = os.path.join(ROOT, "include")
     subprocess.check_call(["gcc", "-std=gnu11", "-Wall", "-Werror", "-I", inc, "-c", src, "-o",
                            str(tmp_path / "a.o")])

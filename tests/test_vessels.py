@@ -1,0 +1,76 @@
+"""Row f3 (cache side): gnuais_vessels_from_frames() against the reference's own position cache
+(cache.c:163-384) as its per-type decoders fill it one cache_*() call per message
+(protodec.c:282,390,435,516,619,676-678,740,772) -- field for field, floats bit for bit.
+
+CPU tests: committed golden (tests/golden/vessels.npz, made by make_golden.py from oracle/_ref)
+and, where oracle/_ref is present, fresh random traffic.  Host code inside libgnuais_hip.so."""
+import os
+
+import numpy as np
+import pytest
+
+import cases
+from oracle_lib import FRAME_DTYPE, have_reference, reference
+
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def as_frames(a):
+    return np.frombuffer(np.ascontiguousarray(a).tobytes(), dtype=FRAME_DTYPE)
+
+
+def test_vessels_golden():
+    from gnuais_amd import VESSEL_DTYPE, vessels_from_frames
+    g = np.load(os.path.join(G, "vessels.npz"))
+    fr = as_frames(g["frames"])
+    want = np.frombuffer(g["vessels"].tobytes(), dtype=VESSEL_DTYPE)
+    got = vessels_from_frames(fr)
+    assert len(got) == len(want)
+    for name in VESSEL_DTYPE.names:               # a readable failure before the byte compare
+        assert np.array_equal(got[name], want[name]), name
+    assert got.tobytes() == want.tobytes()
+    # the table is the cache in key order, and the traffic leaves entries in every state
+    assert np.all(np.diff(got["mmsi"].astype(np.int64)) > 0)
+    assert len(np.unique(got["set"])) >= 8
+    only_pos = got[got["set"] == 1]
+    assert len(only_pos) and np.all(only_pos["shiptype"] == -1) and np.all(only_pos["persons_on_board"] == -1)
+    class_b = got[(got["destination"] == b"CLASS B")]
+    assert len(class_b)
+
+
+def test_vessels_fold_continues_across_batches():
+    """Draining in pieces and carrying the table gives the table of the whole: the fold is the
+    cache's own, entry by entry."""
+    from gnuais_amd import vessels_from_frames
+    g = np.load(os.path.join(G, "vessels.npz"))
+    fr = as_frames(g["frames"])
+    whole = vessels_from_frames(fr)
+    tab = None
+    for i in range(0, len(fr), 131):
+        tab = vessels_from_frames(fr[i:i + 131], tab)
+    assert tab.tobytes() == whole.tobytes()
+    assert vessels_from_frames(fr[:0], whole).tobytes() == whole.tobytes()
+
+
+def test_vessels_argument_errors():
+    import ctypes as C
+    from gnuais_amd import VESSEL_DTYPE, lib
+    g = np.load(os.path.join(G, "vessels.npz"))
+    fr = as_frames(g["frames"])
+    L = lib.load()
+    small = np.zeros(3, dtype=VESSEL_DTYPE)
+    n = C.c_int(0)
+    assert L.gnuais_vessels_from_frames(fr.ctypes.data, len(fr), small.ctypes.data, 3, C.byref(n)) == -3
+    assert n.value == 0 and not small["mmsi"].any()               # left as on entry
+    small["mmsi"] = [5, 5, 9]                                      # not strictly ascending
+    n = C.c_int(3)
+    assert L.gnuais_vessels_from_frames(fr.ctypes.data, 0, small.ctypes.data, 3, C.byref(n)) == -1
+
+
+@pytest.mark.skipif(not have_reference(), reason="oracle/_ref not built")
+@pytest.mark.parametrize("seed,n_mmsi", [(7, 40), (8, 900)])
+def test_vessels_random_against_reference(seed, n_mmsi):
+    from gnuais_amd import vessels_from_frames
+    fr, n_ch = cases.vessel_frames(seed=200 + seed, n=900, n_mmsi=n_mmsi)
+    want = reference().cache_of_frames(fr, n_ch, pieces=[300, 301])
+    assert vessels_from_frames(fr).tobytes() == want.tobytes()
