@@ -448,71 +448,125 @@ __global__ __launch_bounds__(64) void fir_sign_kernel(
     };
     bool zprev_known = false, zprev = false;    // was the previous word's block of 32 samples all 0?
 
-    const int nblk = (t1 - t0 + 95) / 96;
-    for (int b = 0; b < nblk; ++b) {
-#pragma unroll
-        for (int w3 = 0; w3 < 3; ++w3) {
-            const int obase = b * 96 + w3 * 32;             // outputs obase .. obase+31
-            if (t0 + obase >= t1) break;
-            int xi[32];
-            const int mb = m0 + NC - 1 + obase;             // sample of phase 0
-            const bool interior = (mb >= 0) && (mb + 31 < L);
-            if (interior) {
-                const int16_t *row = x + (size_t) mb * (size_t) N + c;
-#pragma unroll
-                for (int p = 0; p < 32; ++p) xi[p] = (int) row[(size_t) p * (size_t) N];
-            } else {
-#pragma unroll
-                for (int p = 0; p < 32; ++p) {
-                    int m = mb + p;
-                    m = (m < L) ? m : L - 1;
-                    xi[p] = load_sample(x, hist, m, N, NTaps, c);
-                }
-            }
-            {   // filter.c:118-119 peak (same bookkeeping as K1, shift = dc - NC + 1)
-                int bp = 0;
+  if constexpr (NC % 32 != 16) {
+        const int nblk = (t1 - t0 + 95) / 96;
+        for (int b = 0; b < nblk; ++b) {
+    #pragma unroll
+            for (int w3 = 0; w3 < 3; ++w3) {
+                const int obase = b * 96 + w3 * 32;             // outputs obase .. obase+31
+                if (t0 + obase >= t1) break;
+                int xi[32];
+                const int mb = m0 + NC - 1 + obase;             // sample of phase 0
+                const bool interior = (mb >= 0) && (mb + 31 < L);
                 if (interior) {
-#pragma unroll
-                    for (int p = 0; p < 32; ++p) bp = xi[p] > bp ? xi[p] : bp;
+                    const int16_t *row = x + (size_t) mb * (size_t) N + c;
+    #pragma unroll
+                    for (int p = 0; p < 32; ++p) xi[p] = (int) row[(size_t) p * (size_t) N];
                 } else {
-#pragma unroll
+    #pragma unroll
                     for (int p = 0; p < 32; ++p) {
-                        const int m = mb + p;
-                        const int v = (m >= 0 && m < L) ? xi[p] : 0;
-                        bp = v > bp ? v : bp;
+                        int m = mb + p;
+                        m = (m < L) ? m : L - 1;
+                        xi[p] = load_sample(x, hist, m, N, NTaps, c);
                     }
                 }
-                peak = bp > peak ? bp : peak;
-            }
-            // Two flag bits per sample, each gathered with ONE v_alignbit_b32 (shift the word
-            // left, take the new bit from another register's bit 31) instead of compare +
-            // select + shift/or, which was a third of this kernel's issue time:
-            //   neg  collects the sign bit of y_c: 0 for y_c > 0 and for +0.0 (ambiguous anyway);
-            //   amb  collects the sign bit of |y_c| - eps_up, eps_up = nextafter(eps): set
-            //        exactly when |y_c| <= eps (a - b is negative or -0 iff a < b).
-            uint32_t neg = 0, amb = 0;
-#pragma unroll
-            for (int p = 0; p < 32; ++p) {
-                const int P = w3 * 32 + p;                  // phase 0..95, P % 12 static
-                const float xs = (float) xi[p];
-#pragma unroll
-                for (int q = 0; q < NC / 2; ++q) {
-                    const float pr = ctap(q) * xs;      // == central tap NC-1-q times xs, bit for bit
-                    const int s0 = (P + NC - 1 - q) % NC;
-                    const int s1 = (P + q) % NC;
-                    if (q == 0) acc[s0] = pr; else acc[s0] = acc[s0] + pr;
-                    acc[s1] = acc[s1] + pr;
+                {   // filter.c:118-119 peak (same bookkeeping as K1, shift = dc - NC + 1)
+                    int bp = 0;
+                    if (interior) {
+    #pragma unroll
+                        for (int p = 0; p < 32; ++p) bp = xi[p] > bp ? xi[p] : bp;
+                    } else {
+    #pragma unroll
+                        for (int p = 0; p < 32; ++p) {
+                            const int m = mb + p;
+                            const int v = (m >= 0 && m < L) ? xi[p] : 0;
+                            bp = v > bp ? v : bp;
+                        }
+                    }
+                    peak = bp > peak ? bp : peak;
                 }
-                const float y = acc[P % NC];                // y_c of output obase + p
-                neg = __builtin_amdgcn_alignbit(neg, __float_as_uint(y), 31);
-                amb = __builtin_amdgcn_alignbit(amb, __float_as_uint(__builtin_fabsf(y) - eps_up), 31);
-#if FIR_SIGN_FENCE > 0
-                if (p % FIR_SIGN_FENCE == FIR_SIGN_FENCE - 1) {
-#pragma unroll
-                    for (int g = 0; g < NC; g += 12) touch12(acc + g);
+                // Two flag bits per sample, each gathered with ONE v_alignbit_b32 (shift the word
+                // left, take the new bit from another register's bit 31) instead of compare +
+                // select + shift/or, which was a third of this kernel's issue time:
+                //   neg  collects the sign bit of y_c: 0 for y_c > 0 and for +0.0 (ambiguous anyway);
+                //   amb  collects the sign bit of |y_c| - eps_up, eps_up = nextafter(eps): set
+                //        exactly when |y_c| <= eps (a - b is negative or -0 iff a < b).
+                uint32_t neg = 0, amb = 0;
+    #pragma unroll
+                for (int p = 0; p < 32; ++p) {
+                    const int P = w3 * 32 + p;                  // phase 0..95, P % 12 static
+                    const float xs = (float) xi[p];
+    #pragma unroll
+                    for (int q = 0; q < NC / 2; ++q) {
+                        const float pr = ctap(q) * xs;      // == central tap NC-1-q times xs, bit for bit
+                        const int s0 = (P + NC - 1 - q) % NC;
+                        const int s1 = (P + q) % NC;
+                        if (q == 0) acc[s0] = pr; else acc[s0] = acc[s0] + pr;
+                        acc[s1] = acc[s1] + pr;
+                    }
+                    const float y = acc[P % NC];                // y_c of output obase + p
+                    neg = __builtin_amdgcn_alignbit(neg, __float_as_uint(y), 31);
+                    amb = __builtin_amdgcn_alignbit(amb, __float_as_uint(__builtin_fabsf(y) - eps_up), 31);
+    #if FIR_SIGN_FENCE > 0
+                    if (p % FIR_SIGN_FENCE == FIR_SIGN_FENCE - 1) {
+    #pragma unroll
+                        for (int g = 0; g < NC; g += 12) touch12(acc + g);
+                    }
+    #endif
                 }
-#endif
+                uint32_t w = ~neg;
+                const int valid = t1 - (t0 + obase);
+                if (valid < 32) {
+                    w &= ~0u << (32 - valid);
+                    amb &= ~0u << (32 - valid);
+                }
+                bool zc_known = false, zc = false;
+                if (__popc(amb) >= 8) {                         // a silent stretch?
+                    uint32_t o = 0;
+    #pragma unroll
+                    for (int p = 0; p < 32; ++p) o |= (uint32_t) xi[p];
+                    zc = o == 0;
+                    zc_known = true;
+                    const int before = J0 + NC - 1;
+                    if (zc && ((before <= 32 && zprev_known) ? zprev : all_zero(mb - before, before)) &&
+                        all_zero(mb + 32, J0)) {
+                        w &= ~amb;                              // y_ref == +0 for every one of them
+                        amb = 0;
+                    }
+                }
+                zprev_known = zc_known;
+                zprev = zc;
+                // the samples whose sign y_c cannot certify: exact ordered sum
+                while (amb) {
+                    const int pos = __clz((int) amb);
+                    const uint32_t bit = 0x80000000u >> pos;
+                    amb &= ~bit;
+                    if (exact_positive(t0 + obase + pos)) w |= bit; else w &= ~bit;
+                }
+                if (live) sgn[(size_t) ((t0 + obase) >> 5) * (size_t) N + cg] = w;
             }
+        }
+  } else {
+        // Unrolled phases must hold whole turns of the accumulator ring (the ring index of every
+        // phase is static).  NC = 12: 96 phases = three sign words, one group of 32 samples per word.
+        // NC = 48: 96 phases would be 80 KB of code, more than the 64 KB instruction cache two CUs
+        // share (measured: the kernel then runs at half its issue rate); 48 phases = three groups of
+        // 16 samples are 31 KB, and a word is flushed after every second group.
+        constexpr int GROUP = 16;
+        constexpr int UNROLL = NC;
+        constexpr int NG = UNROLL / GROUP;
+        static_assert(UNROLL % NC == 0 && UNROLL % GROUP == 0, "whole ring turns, whole groups");
+        // Two flag bits per sample, each gathered with ONE v_alignbit_b32 (shift the word
+        // left, take the new bit from another register's bit 31) instead of compare +
+        // select + shift/or, which was a third of this kernel's issue time:
+        //   neg  collects the sign bit of y_c: 0 for y_c > 0 and for +0.0 (ambiguous anyway);
+        //   amb  collects the sign bit of |y_c| - eps_up, eps_up = nextafter(eps): set
+        //        exactly when |y_c| <= eps (a - b is negative or -0 iff a < b).
+        uint32_t neg = 0, amb = 0, zor = 0;
+
+        // one finished sign word: outputs obase .. obase+31 (the flags of the newest 32 samples)
+        auto flush = [&](int obase) {
+            const int mb = m0 + NC - 1 + obase;                 // sample of the word's first phase
             uint32_t w = ~neg;
             const int valid = t1 - (t0 + obase);
             if (valid < 32) {
@@ -520,16 +574,13 @@ __global__ __launch_bounds__(64) void fir_sign_kernel(
                 amb &= ~0u << (32 - valid);
             }
             bool zc_known = false, zc = false;
-            if (__popc(amb) >= 8) {                         // a silent stretch?
-                uint32_t o = 0;
-#pragma unroll
-                for (int p = 0; p < 32; ++p) o |= (uint32_t) xi[p];
-                zc = o == 0;
+            if (__popc(amb) >= 8) {                             // a silent stretch?
+                zc = zor == 0;
                 zc_known = true;
                 const int before = J0 + NC - 1;
                 if (zc && ((before <= 32 && zprev_known) ? zprev : all_zero(mb - before, before)) &&
                     all_zero(mb + 32, J0)) {
-                    w &= ~amb;                              // y_ref == +0 for every one of them
+                    w &= ~amb;                                  // y_ref == +0 for every one of them
                     amb = 0;
                 }
             }
@@ -543,8 +594,86 @@ __global__ __launch_bounds__(64) void fir_sign_kernel(
                 if (exact_positive(t0 + obase + pos)) w |= bit; else w &= ~bit;
             }
             if (live) sgn[(size_t) ((t0 + obase) >> 5) * (size_t) N + cg] = w;
+            zor = 0;
+        };
+
+        const int ngroups = (t1 - t0 + GROUP - 1) / GROUP;
+        for (int b = 0; b * NG < ngroups; ++b) {
+    #pragma unroll
+            for (int g = 0; g < NG; ++g) {
+                const int gi = b * NG + g;                      // group index within the segment
+                const int gbase = gi * GROUP;                   // outputs gbase .. gbase+GROUP-1
+                if (gi >= ngroups) break;
+                int xi[GROUP];
+                const int mb = m0 + NC - 1 + gbase;             // sample of the group's first phase
+                const bool interior = (mb >= 0) && (mb + GROUP - 1 < L);
+                if (interior) {
+                    const int16_t *row = x + (size_t) mb * (size_t) N + c;
+    #pragma unroll
+                    for (int p = 0; p < GROUP; ++p) xi[p] = (int) row[(size_t) p * (size_t) N];
+                } else {
+    #pragma unroll
+                    for (int p = 0; p < GROUP; ++p) {
+                        int m = mb + p;
+                        m = (m < L) ? m : L - 1;
+                        xi[p] = load_sample(x, hist, m, N, NTaps, c);
+                    }
+                }
+                {   // filter.c:118-119 peak (same bookkeeping as K1, shift = dc - NC + 1)
+                    int bp = 0;
+                    if (interior) {
+    #pragma unroll
+                        for (int p = 0; p < GROUP; ++p) bp = xi[p] > bp ? xi[p] : bp;
+                    } else {
+    #pragma unroll
+                        for (int p = 0; p < GROUP; ++p) {
+                            const int m = mb + p;
+                            const int v = (m >= 0 && m < L) ? xi[p] : 0;
+                            bp = v > bp ? v : bp;
+                        }
+                    }
+                    peak = bp > peak ? bp : peak;
+                }
+    #pragma unroll
+                for (int p = 0; p < GROUP; ++p) {
+                    const int P = g * GROUP + p;                // phase within the unrolled block, P % NC static
+                    const float xs = (float) xi[p];
+    #pragma unroll
+                    for (int q = 0; q < NC / 2; ++q) {
+                        const float pr = ctap(q) * xs;      // == central tap NC-1-q times xs, bit for bit
+                        const int s0 = (P + NC - 1 - q) % NC;
+                        const int s1 = (P + q) % NC;
+                        if (q == 0) acc[s0] = pr; else acc[s0] = acc[s0] + pr;
+                        acc[s1] = acc[s1] + pr;
+                    }
+                    const float y = acc[P % NC];                // y_c of output gbase + p
+                    neg = __builtin_amdgcn_alignbit(neg, __float_as_uint(y), 31);
+                    amb = __builtin_amdgcn_alignbit(amb, __float_as_uint(__builtin_fabsf(y) - eps_up), 31);
+    #if FIR_SIGN_FENCE > 0
+                    if (p % FIR_SIGN_FENCE == FIR_SIGN_FENCE - 1) {
+    #pragma unroll
+                        for (int gg = 0; gg < NC; gg += 12) touch12(acc + gg);
+                    }
+    #endif
+                }
+                // zor = OR of the word's samples, for the silence test in flush(), which only looks at
+                // it when the word has >= 8 ambiguous samples.  A first half without any cannot belong
+                // to a silent word, whatever its samples are.
+                if (amb != 0) {
+    #pragma unroll
+                    for (int p = 0; p < GROUP; ++p) zor |= (uint32_t) xi[p];
+                } else {
+                    zor |= 1u;
+                }
+                if (gi & 1) flush(gbase - 16);
+            }
         }
-    }
+        if (ngroups & 1) {                     // a last word with only its first half
+            neg <<= 16;
+            amb <<= 16;
+            flush((ngroups - 1) * 16);
+        }
+  }
 
     if (t1 == L) {                              // the last dc-NC+1 samples of the call
         const int shift = dc - NC + 1;

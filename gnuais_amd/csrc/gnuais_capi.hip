@@ -225,14 +225,25 @@ int gnuais_batch_create(gnuais_batch **out, int device, int n_channels, const fl
             if (!sym || b->sign_ok || NE < NC || (NE - NC) % 2) continue;
             const double u = 5.9604644775390625e-8, X = 32768.0;
             const int J0 = (NE - NC) / 2;
-            double sum_all = 0, sum_c = 0, sum_out = 0;
-            for (int j = 0; j < NE; ++j) {
-                const double a = std::fabs((double) b->te[j]);
-                sum_all += a;
-                if (j >= J0 && j < J0 + NC) sum_c += a; else sum_out += a;
-            }
-            const double bound = (std::pow(1 + u, NE + 1) - 1) * X * sum_all +
-                                 (std::pow(1 + u, NC + 1) - 1) * X * sum_c + X * sum_out + 1e-30;
+            // An ordered fp32 sum s_1 = fl(p_1), s_j = fl(s_{j-1} + fl(p_j)) of n products carries
+            // product i with the factor (1+d_i) * prod_{j=max(i,2)..n} (1+e_j), |d|,|e| <= u: k_i = n
+            // rounding factors for i = 1, n-i+2 for i >= 2 (Higham, Accuracy and Stability, sec. 4.2).
+            // So |s_n - S| <= X * sum_i |t_i| * ((1+u)^k_i - 1): the late terms of the sum, and for a
+            // bell-shaped table the big central ones are late enough, pass through few additions.
+            // The reference adds in tap order (filter.h:40-49); K1s's accumulators take their NC
+            // products in sample order, which is tap order from one edge of the centre to the other
+            // (either edge: the table is symmetric).
+            auto ordered = [&](int first, int n) {
+                double e = 0;
+                for (int i = 1; i <= n; ++i)
+                    e += std::fabs((double) b->te[first + i - 1]) * (std::pow(1 + u, i == 1 ? n : n - i + 2) - 1);
+                return e;
+            };
+            double sum_out = 0;
+            for (int j = 0; j < NE; ++j)
+                if (j < J0 || j >= J0 + NC) sum_out += std::fabs((double) b->te[j]);
+            // + NE subnormal products, each off by at most 2^-150 (absolute)
+            const double bound = X * (ordered(0, NE) + ordered(J0, NC) + sum_out) + 1e-30;
             if (std::isfinite(bound) && bound < 2.0) {
                 b->sign_eps = (float) (bound * 1.1);
                 b->sign_NC = NC;
