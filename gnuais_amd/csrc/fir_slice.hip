@@ -324,14 +324,14 @@ __global__ __launch_bounds__(64) void fir_slice_kernel(
 //   y_c = the NC = 12 central taps only (te[10..21]; the 20 outer taps sum to
 //         5.4e-8), evaluated in fp32 in transposed form, 6 shared products + 12
 //         additions per sample;
-//   |y_ref - S|   <= ((1+u)^33 - 1) * X * sum|te|      (32 rounded products, 31 adds)
-//   |y_c   - S_c| <= ((1+u)^13 - 1) * X * sum|tc|      (12 rounded products, 11 adds)
-//   |S - S_c|     <=                  X * sum|te outside the centre|
+//   |y_ref - S|   <= X * sum_i |te_i| * ((1+u)^k_i - 1)   k_i = roundings product i passes
+//   |y_c   - S_c| <= X * sum_i |tc_i| * ((1+u)^k_i - 1)   through: n for i = 1, n-i+2 after
+//   |S - S_c|     <= X * sum|te outside the centre|
 // with u = 2^-24, X = 32768 (int16 input), S / S_c the exact real sums; subnormal
 // products add at most 32 * 2^-150.  The host adds the three terms in double
-// precision from the actual table (0.2265 for the reference table) and passes
-// eps = that * 1.1.  If |y_c| > eps then y_ref has the sign of y_c and is not
-// zero; otherwise (about 1.5e-4 of the samples of a noisy channel, all of them in
+// precision from the actual table (gnuais_capi.hip; 0.124 for the reference table) and
+// passes eps = that * 1.1.  If |y_c| > eps then y_ref has the sign of y_c and is not
+// zero; otherwise (about 1e-4 of the samples of a noisy channel, all of them in
 // a silent one) the sample is re-evaluated with the exact ordered 32-tap sum from
 // the input (L1/L2 hits).  The emitted sign words are therefore bit-identical to
 // K1's; the fp32 filter output itself is only available from the exact kernel
