@@ -597,7 +597,9 @@ __global__ __launch_bounds__(64) void fir_sign_kernel(
             zor = 0;
         };
 
-        const int ngroups = (t1 - t0 + GROUP - 1) / GROUP;
+        // whole words, also for a last word that ends inside its first half: flush()'s silence test
+        // needs all 32 samples of the word in zor (the phases past t1 are masked out)
+        const int ngroups = (t1 - t0 + 31) / 32 * 2;
         for (int b = 0; b * NG < ngroups; ++b) {
     #pragma unroll
             for (int g = 0; g < NG; ++g) {
@@ -667,11 +669,6 @@ __global__ __launch_bounds__(64) void fir_sign_kernel(
                 }
                 if (gi & 1) flush(gbase - 16);
             }
-        }
-        if (ngroups & 1) {                     // a last word with only its first half
-            neg <<= 16;
-            amb <<= 16;
-            flush((ngroups - 1) * 16);
         }
   }
 

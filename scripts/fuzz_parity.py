@@ -1,0 +1,137 @@
+"""Randomised parity soak: the HIP chain against the C oracle on random configurations for a given
+number of seconds -- channel counts, call lengths (down to 1 sample), tables (the reference's, the
+192 kHz one, random symmetric and asymmetric ones), pllinc, signal levels from near-silence to
+clipping, and inputs built to sit on the slicer's decision threshold (tiny amplitudes, long runs of
+0 / +-1, sparse impulses), where the sign-exact slicer has to fall back to the exact sum.
+    python scripts/fuzz_parity.py [seconds] [first_seed]
+Prints one line per case; exits non-zero at the first mismatch, naming the seed."""
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import torch                                                        # noqa: E402
+from gnuais_amd import ReceiverBatch, params, synth                 # noqa: E402
+from oracle_lib import Oracle                                       # noqa: E402
+
+FSM_KEYS = ("state", "nstartsign", "antallpreamble", "antallenner", "bitstuff", "last", "bufferpos")
+
+
+def table(rng):
+    kind = rng.integers(0, 10)
+    if kind < 5:
+        return None, 0, "ref"
+    if kind == 5:
+        return params.taps_192k(), params.PLLINC_192K, "192k"
+    n = int(rng.integers(8, 140))
+    k = np.arange(n, dtype=np.float64)
+    mid = (n - 1) / 2.0
+    t = rng.uniform(0.05, 0.9) * np.exp(-((k - mid) ** 2) / (2 * rng.uniform(0.8, n / 6.0 + 1) ** 2))
+    if kind == 6:
+        t *= rng.choice([-1.0, 1.0], n)                          # sign changes, still symmetric or not
+        t = (t + t[::-1]) / 2 if rng.integers(0, 2) else t
+    if kind == 7:
+        t = t + rng.normal(0, 0.01, n)                           # asymmetric: exact kernels only
+    if kind == 8:
+        t[: int(rng.integers(0, 4))] = 0.0
+        t[n - int(rng.integers(0, 4)):] = 0.0
+    pllinc = int(rng.choice([0, 0x10000 // 5, 13500, 0x10000 // 7, 0x10000 // 20, 9000]))
+    return t.astype(np.float32), pllinc, f"rand{kind}/{n}"
+
+
+def column(rng, total, sps):
+    kind = rng.integers(0, 9)
+    if kind <= 3:
+        sigma = float(rng.choice([0.0, 1.0, 30.0, 500.0, 1000.0, 3000.0, 9000.0, 25000.0]))
+        return synth.make_stream(total, seed=int(rng.integers(1, 1 << 30)), channel=int(rng.integers(0, 999)),
+                                 sps=sps, sigma=sigma, occupancy=float(rng.uniform(0.1, 1.0)),
+                                 amplitude=float(rng.choice([3.0, 40.0, 1200.0, 12000.0, 30000.0])))[0]
+    if kind == 4:
+        return np.zeros(total, dtype=np.int16)
+    if kind == 5:                                                 # tiny values: y hovers around 0
+        return rng.integers(-2, 3, total).astype(np.int16)
+    if kind == 6:                                                 # sparse impulses in silence
+        x = np.zeros(total, dtype=np.int16)
+        at = rng.integers(0, total, max(1, total // 97))
+        x[at] = rng.integers(-32768, 32768, len(at))
+        return x
+    if kind == 7:                                                 # silence / signal / silence
+        x = rng.normal(0, 800, total)
+        a, b = sorted(rng.integers(0, total, 2))
+        x[a:b] = 0
+        return np.clip(np.rint(x), -32768, 32767).astype(np.int16)
+    return rng.integers(-32768, 32768, total).astype(np.int16)   # full-scale noise
+
+
+def one_case(seed):
+    rng = np.random.default_rng(seed)
+    taps, pllinc, tname = table(rng)
+    sps = 20 if tname == "192k" else 5
+    n_ch = int(rng.choice([1, 2, 3, 63, 64, 65, 130, 257]))
+    total = int(rng.integers(1, 30000))
+    x = np.stack([column(rng, total, sps) for _ in range(n_ch)], axis=1)
+    chunks = []
+    left = total
+    while left:
+        n = int(min(left, rng.choice([1, 2, 35, 36, 37, 95, 96, 97, 1020, 4096, 9999, 30000])))
+        chunks.append(n)
+        left -= n
+    o = Oracle(n_ch, taps=taps, pllinc=pllinc)
+    b = ReceiverBatch(n_ch, taps=taps, pllinc=pllinc, max_len=max(chunks))
+    if os.environ.get("FIR_VARIANT"):
+        b.set_option("fir_variant", int(os.environ["FIR_VARIANT"]))
+    if rng.integers(0, 3) == 0:
+        b.set_option("fir_T", int(rng.choice([96, 128, 256, 512, 2048])))
+    pos = 0
+    for n in chunks:
+        seg = np.ascontiguousarray(x[pos:pos + n])
+        pos += n
+        r = o.run(seg, want_bits=True)
+        b.run(torch.from_numpy(seg).cuda())
+        lb = b.last_bits()
+        if not np.array_equal(b.maxval(), r["maxval"]):
+            return f"maxval differs, call of {n} at {pos - n}"
+        for c in range(n_ch):
+            if not np.array_equal(lb[c], r["bits"][c]):
+                return f"bits differ, channel {c}, call of {n} at {pos - n}"
+    if b.drain_frames().tobytes() != o.frames().tobytes():
+        return "frames differ"
+    cnt = b.counters()
+    if not np.array_equal(np.stack([cnt["receivedframes"], cnt["lostframes"], cnt["lostframes2"]], axis=1),
+                          o.counters()):
+        return "counters differ"
+    p = b.pll_state()
+    if [(int(a), int(bb), int(cc)) for a, bb, cc in zip(p["pll"], p["prev"], p["lastbit"])] != \
+            [o.pll(c) for c in range(n_ch)]:
+        return "pll state differs"
+    f = b.fsm_state()
+    for c in range(n_ch):
+        h = o.hdlc(c)
+        want = [h[k] for k in FSM_KEYS]
+        want[2] = min(want[2], 15)
+        if [int(f[c][k]) for k in FSM_KEYS] != want:
+            return f"fsm state differs, channel {c}"
+    return f"ok   {tname:10s} n_ch {n_ch:3d} total {total:5d} calls {len(chunks):4d} frames {int(o.counters()[:, 0].sum())}"
+
+
+def main():
+    seconds = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
+    seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+    t0 = time.time()
+    n = 0
+    while time.time() - t0 < seconds:
+        res = one_case(seed)
+        print(f"seed {seed}: {res}", flush=True)
+        if not res.startswith("ok"):
+            sys.exit(1)
+        seed += 1
+        n += 1
+    print(f"{n} cases, all bit-exact, {time.time() - t0:.0f} s")
+
+
+if __name__ == "__main__":
+    main()

@@ -288,6 +288,24 @@ def test_chain_192k_vs_oracle():
     run_both(x, [4096, total - 4096], 5, taps=params.taps_192k(), pllinc=params.PLLINC_192K)
 
 
+def test_chain_192k_sparse_impulses_and_ragged_ends():
+    """Impulses in digital silence under the 144-tap table: nearly every sample is undecidable from
+    the central taps, the silence shortcut must see every sample a window touches -- also in a last
+    word that ends in its first half (found by scripts/fuzz_parity.py, seed 218)."""
+    rng = np.random.default_rng(218)
+    total = 96 + 1020 + 9999 + 1020 + 3000
+    cols = []
+    for c in range(6):
+        x = np.zeros(total, dtype=np.int16)
+        at = rng.integers(0, total, total // (40, 97, 300)[c % 3])
+        x[at] = rng.integers(-32768, 32768, len(at))
+        cols.append(x)
+    cols.append(np.zeros(total, dtype=np.int16))
+    x = np.stack(cols, axis=1)
+    for chunks in ([96, 1020, 9999, 1020, 3000], [4111, 4113, 4127, total - 12351]):   # lengths = 15, 17, 31 mod 32
+        run_both(x, chunks, x.shape[1], taps=params.taps_192k(), pllinc=params.PLLINC_192K)
+
+
 def test_shards_equal_whole():
     """channels are independent -- two half batches == one batch."""
     n_ch, total = 128, 8 * 1280
