@@ -118,13 +118,61 @@ def one_case(seed):
     return f"ok   {tname:10s} n_ch {n_ch:3d} total {total:5d} calls {len(chunks):4d} frames {int(o.counters()[:, 0].sum())}"
 
 
+def pipelined_case(seed):
+    """Many channels, calls queued asynchronously (several in flight on the stage streams, hand-off
+    buffers reused), optional stream autotune / deframer width / timing events; compared at the end."""
+    rng = np.random.default_rng(seed)
+    taps, pllinc, tname = (None, 0, "ref") if rng.integers(0, 4) else (params.taps_192k(), params.PLLINC_192K, "192k")
+    sps = 20 if tname == "192k" else 5
+    n_ch = int(rng.choice([64, 300, 1024, 2500, 4096]))
+    n_calls = int(rng.integers(2, 14))
+    lens = [int(rng.choice([1020, 4096, 20000, 7777, 333, 48000 // 4])) for _ in range(n_calls)]
+    total = sum(lens)
+    k = 48
+    base = np.stack([column(rng, total, sps) for _ in range(k)], axis=0)
+    x = synth.tile_channels(base, n_ch)
+    xd = torch.from_numpy(x).cuda()
+    o = Oracle(n_ch, taps=taps, pllinc=pllinc)
+    b = ReceiverBatch(n_ch, taps=taps, pllinc=pllinc, max_len=max(lens))
+    opts = []
+    if rng.integers(0, 3) == 0:
+        b.autotune(xd[: max(lens)].contiguous(), torch.cuda.current_stream().cuda_stream)
+        opts.append("autotune")
+    if rng.integers(0, 3) == 0:
+        lpw = int(rng.choice([1, 4, 16, 64]))
+        b.set_option("hdlc_lpw", lpw)
+        opts.append(f"lpw{lpw}")
+    if rng.integers(0, 3) == 0:
+        b.set_timing(True)
+        b.set_option("timing_stride", int(rng.choice([1, 3])))
+        opts.append("timing")
+    stream = torch.cuda.current_stream().cuda_stream
+    pos = 0
+    for n in lens:
+        b.run(xd[pos:pos + n], stream=stream, sync=False)
+        pos += n
+    o.run(x, threads=32)
+    got = b.drain_frames()
+    if got.tobytes() != o.frames().tobytes():
+        return f"frames differ ({len(got)} vs {len(o.frames())}) {opts}"
+    cnt = b.counters()
+    if not np.array_equal(np.stack([cnt["receivedframes"], cnt["lostframes"], cnt["lostframes2"]], axis=1),
+                          o.counters()):
+        return f"counters differ {opts}"
+    p = b.pll_state()
+    if [(int(a), int(bb), int(cc)) for a, bb, cc in zip(p["pll"], p["prev"], p["lastbit"])] != \
+            [o.pll(c) for c in range(n_ch)]:
+        return f"pll state differs {opts}"
+    return f"ok   {tname:5s} n_ch {n_ch:4d} calls {lens} frames {len(got)} {' '.join(opts)}"
+
+
 def main():
     seconds = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
     t0 = time.time()
     n = 0
     while time.time() - t0 < seconds:
-        res = one_case(seed)
+        res = pipelined_case(seed) if os.environ.get("PIPE") else one_case(seed)
         print(f"seed {seed}: {res}", flush=True)
         if not res.startswith("ok"):
             sys.exit(1)

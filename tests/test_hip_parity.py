@@ -419,6 +419,23 @@ def test_c3_full_size_properties():
                                     cnt["lostframes2"]], axis=1)[pick], o.counters())
 
 
+# ---------------------------------------------------------------- randomised soak (short form)
+
+def test_randomised_soak_short():
+    """scripts/fuzz_parity.py for a few dozen seeds: random tables, channel counts, call lengths down
+    to one sample, inputs on the slicer's threshold; then a few pipelined cases (calls queued
+    asynchronously, hand-off buffers reused).  The script itself runs for as long as it is given."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(G), "..", "scripts"))
+    import fuzz_parity
+    for seed in list(range(1000, 1030)) + [218, 219]:
+        res = fuzz_parity.one_case(seed)
+        assert res.startswith("ok"), (seed, res)
+    for seed in (3, 4, 5):
+        res = fuzz_parity.pipelined_case(seed)
+        assert res.startswith("ok"), (seed, res)
+
+
 # ---------------------------------------------------------------- API behaviour
 
 def test_autotune_keeps_results_and_resets_state():
