@@ -166,13 +166,77 @@ def pipelined_case(seed):
     return f"ok   {tname:5s} n_ch {n_ch:4d} calls {lens} frames {len(got)} {' '.join(opts)}"
 
 
+def deframer_case(seed):
+    """protodec_decode() alone: adversarial bit streams (flags back to back, endless training, frames
+    of every length up to and beyond the 449-bit buffer, bit errors, stuffing at the edges, runs of
+    ones), fed in several calls of random size so that every state crosses a call boundary."""
+    rng = np.random.default_rng(seed)
+    n_ch = int(rng.choice([1, 5, 64, 96, 200]))
+    flag = np.array([0, 1, 1, 1, 1, 1, 1, 0], dtype=np.uint8)
+    streams = []
+    for c in range(n_ch):
+        parts = []
+        for _ in range(int(rng.integers(1, 40))):
+            kind = rng.integers(0, 9)
+            if kind == 0:
+                parts.append((rng.random(int(rng.integers(0, 300))) < rng.random()).astype(np.uint8))
+            elif kind == 1:
+                parts.append(np.tile(flag, int(rng.integers(1, 6))))
+            elif kind == 2:
+                parts.append((np.arange(int(rng.integers(0, 80))) & 1).astype(np.uint8))
+            elif kind == 3:
+                parts.append(np.ones(int(rng.integers(0, 40)), dtype=np.uint8))
+            elif kind == 4:
+                parts.append(np.zeros(int(rng.integers(0, 40)), dtype=np.uint8))
+            else:
+                n = int(rng.choice([0, 1, 2, 3, 11, 20, 21, 22, 40, 52, 53, 54, 55, 60, 80]))
+                body = bytes(rng.integers(0, 256, n, dtype=np.uint8)) if rng.integers(0, 4) else bytes([0xff] * n)
+                fb = synth.hdlc_frame_bits(body, training_bits=int(rng.integers(0, 40)),
+                                           stuff=bool(rng.integers(0, 8)))
+                if rng.integers(0, 5) == 0:
+                    fb[int(rng.integers(0, fb.size))] ^= 1
+                if rng.integers(0, 6) == 0:
+                    fb = fb[: int(rng.integers(0, fb.size))]               # cut off
+                parts.append(fb)
+        streams.append(np.concatenate(parts).astype(np.uint8) if parts else np.zeros(0, dtype=np.uint8))
+    o = Oracle(n_ch)
+    b = ReceiverBatch(n_ch, max_len=48000)
+    if rng.integers(0, 2):
+        b.set_option("hdlc_lpw", int(rng.choice([1, 2, 8, 32, 64])))
+    pos = [0] * n_ch
+    while any(pos[c] < len(streams[c]) for c in range(n_ch)):
+        piece = []
+        for c in range(n_ch):
+            n = int(rng.choice([0, 1, 7, 8, 9, 31, 32, 33, 100, 449, 1000, 5000]))
+            piece.append(streams[c][pos[c]:pos[c] + n])
+            pos[c] += n
+        for c in range(n_ch):
+            o.decode_bits(c, piece[c])
+        b.decode_bits(piece)
+    if b.drain_frames().tobytes() != o.frames().tobytes():
+        return "frames differ"
+    cnt = b.counters()
+    if not np.array_equal(np.stack([cnt["receivedframes"], cnt["lostframes"], cnt["lostframes2"]], axis=1),
+                          o.counters()):
+        return "counters differ"
+    f = b.fsm_state()
+    for c in range(n_ch):
+        h = o.hdlc(c)
+        want = [h[k] for k in FSM_KEYS]
+        want[2] = min(want[2], 15)
+        if [int(f[c][k]) for k in FSM_KEYS] != want:
+            return f"fsm state differs, channel {c}: {[int(f[c][k]) for k in FSM_KEYS]} vs {want}"
+    return f"ok   deframer n_ch {n_ch:3d} bits {sum(len(s_) for s_ in streams)} frames {int(o.counters()[:, 0].sum())}"
+
+
 def main():
     seconds = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
     t0 = time.time()
     n = 0
     while time.time() - t0 < seconds:
-        res = pipelined_case(seed) if os.environ.get("PIPE") else one_case(seed)
+        res = (pipelined_case(seed) if os.environ.get("PIPE") else deframer_case(seed) if os.environ.get("DEFRAMER")
+               else one_case(seed))
         print(f"seed {seed}: {res}", flush=True)
         if not res.startswith("ok"):
             sys.exit(1)

@@ -434,6 +434,9 @@ def test_randomised_soak_short():
     for seed in (3, 4, 5):
         res = fuzz_parity.pipelined_case(seed)
         assert res.startswith("ok"), (seed, res)
+    for seed in range(2000, 2012):
+        res = fuzz_parity.deframer_case(seed)
+        assert res.startswith("ok"), (seed, res)
 
 
 # ---------------------------------------------------------------- API behaviour
