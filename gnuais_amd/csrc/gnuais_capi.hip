@@ -2,9 +2,12 @@
 //
 // Owns the per-batch device state (FIR history, PLL phase, deframer state,
 // frame ring) and sequences the kernels of one receiver_run() pass:
-//   K1 fir_slice -> history update -> K2a pll_nrzi -> K2b hdlc_crc
-// all on the caller's stream.  No CPU implementation of the chain exists here:
-// without a usable HIP device every entry point fails with GNUAIS_E_HIP.
+//   K1 fir_slice (+ history carry) -> K2a pll_core -> K2x nrzi_extract -> K2b hdlc_deframe -> K3 hdlc_crc
+// K1 on the caller's stream, every later stage on an internal stream of its own, chained by
+// events over four sets of hand-off buffers, so that the stages of consecutive calls overlap
+// (DESIGN.md 4.6); `pipeline` = 0 runs them back to back on the caller's stream instead.
+// No CPU implementation of the chain exists here: without a usable HIP device every entry
+// point fails with GNUAIS_E_HIP.
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -267,7 +270,7 @@ int gnuais_batch_create(gnuais_batch **out, int device, int n_channels, const fl
     b->n_seg = (b->sgn_words + SEG_WORDS - 1) / SEG_WORDS;
     b->seg_words = (int) (((uint64_t) SEG_WORDS * 32 * step / 65536 + 2 + 31) / 32) + 1;
     if (b->seg_words > 16) {       // K2b keeps one segment pack (<= 16 words) in registers
-        delete b;
+        gnuais_batch_destroy(b);
         return fail(GNUAIS_E_ARG, "create: pllinc too large (more than one slice per ~4.6 samples)");
     }
     for (int k = 0; k < gnuais_batch::NBUF; ++k) {
