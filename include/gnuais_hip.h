@@ -94,7 +94,7 @@ typedef struct gnuais_batch gnuais_batch;
 /* ---- lifetime: init_receiver()/free_receiver(), src/receiver.c:52-82 --------
  * taps/n_taps: filter_init(len, taps) arguments (src/filter.c:57); NULL/0 =
  *   the reference table (src/receiver.c:39-50).
- * pllinc: rx->pllinc (src/receiver.c:69); 0 = 0x10000/5.  Values above 14 200 (fewer than
+ * pllinc: rx->pllinc (src/receiver.c:69); 0 = 0x10000/5.  Values above 14 426 (fewer than
  * ~4.6 samples per bit; AIS at 48 kHz has 5) are refused with GNUAIS_E_ARG: the deframer's
  * per-segment bit pack is sized for at most 16 words.
  * max_len: largest `len` a run call will be given.
