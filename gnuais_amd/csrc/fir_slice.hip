@@ -564,6 +564,34 @@ __global__ __launch_bounds__(64) void fir_sign_kernel(
         //        exactly when |y_c| <= eps (a - b is negative or -0 iff a < b).
         uint32_t neg = 0, amb = 0, zor = 0;
 
+        // The error bound behind eps is linear in the largest |x| a window holds and was taken for
+        // 32768.  With 126 taps a third of this kernel's time went into exact re-evaluations
+        // (126 taps each, ~5e-4 of the samples, most of them in the noise between messages where
+        // |x| stays small), so this instantiation first takes the largest |x| of every sample its
+        // segment's windows can touch and scales eps with it: eps_w = eps * M / 32768 (+ the absolute
+        // slack for subnormal products).  One more pass over the segment's input (second read
+        // mostly from L2 / Infinity Cache), 1 % more VALU work.
+        float eps_w;
+        {
+            const int mlo = t0 - d;                             // oldest sample of output t0's window
+            const int mhi = t1 - 1 - d + NE - 1;                // newest sample of output t1-1's window
+            int M = 0;
+            for (int mbase = mlo; mbase <= mhi; mbase += 16) {
+                int v[16];
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const int m = mbase + i <= mhi ? mbase + i : mhi;
+                    v[i] = load_sample(x, hist, m, N, NTaps, c);
+                }
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const int a = v[i] < 0 ? -v[i] : v[i];
+                    M = a > M ? a : M;
+                }
+            }
+            eps_w = eps_up * ((float) M * (1.0f / 32768.0f)) + 1e-30f;
+        }
+
         // one finished sign word: outputs obase .. obase+31 (the flags of the newest 32 samples)
         auto flush = [&](int obase) {
             const int mb = m0 + NC - 1 + obase;                 // sample of the word's first phase
@@ -650,7 +678,7 @@ __global__ __launch_bounds__(64) void fir_sign_kernel(
                     }
                     const float y = acc[P % NC];                // y_c of output gbase + p
                     neg = __builtin_amdgcn_alignbit(neg, __float_as_uint(y), 31);
-                    amb = __builtin_amdgcn_alignbit(amb, __float_as_uint(__builtin_fabsf(y) - eps_up), 31);
+                    amb = __builtin_amdgcn_alignbit(amb, __float_as_uint(__builtin_fabsf(y) - eps_w), 31);
     #if FIR_SIGN_FENCE > 0
                     if (p % FIR_SIGN_FENCE == FIR_SIGN_FENCE - 1) {
     #pragma unroll
