@@ -483,6 +483,37 @@ def test_two_batches_interleaved_on_two_streams():
             [o.pll(c) for c in range(n)]
 
 
+def test_frame_ring_overflow_is_loud_and_recoverable():
+    """More CRC-valid frames between two drains than `frame_capacity`: the drain says so
+    (GNUAIS_E_OVERFLOW), what it does deliver are real frames, the per-channel counters (kept on the
+    device, protodec.c:1103) stay exact, and the next span is whole again."""
+    import ctypes as C
+    from gnuais_amd import lib
+    total = 10 * 1280
+    x = np.stack([synth.make_stream(2 * total, seed=47, channel=c, occupancy=1.0)[0] for c in range(40)], axis=1)
+    o = Oracle(40)
+    b = batch(40, max_len=total, frame_capacity=64)
+    o.run(x[:total])
+    b.run(dev(x[:total]))
+    want = o.frames()
+    assert len(want) > 200
+    out = np.zeros(4096, dtype=FRAME_DTYPE)
+    got = C.c_int()
+    rc = b._lib.gnuais_batch_drain_frames(b._h, out.ctypes.data, int(out.size), C.byref(got))
+    assert rc == lib.E_OVERFLOW and b"overflow" in b._lib.gnuais_last_error()
+    assert 0 < got.value <= 64
+    have = {bytes(f.tobytes()) for f in want}
+    assert all(bytes(f.tobytes()) in have for f in out[: got.value])
+    cnt = b.counters()
+    assert np.array_equal(np.stack([cnt["receivedframes"], cnt["lostframes"], cnt["lostframes2"]], axis=1),
+                          o.counters())
+    # a span that fits is delivered whole and in order
+    o.clear_frames()
+    o.run(x[total:total + 1280])
+    b.run(dev(x[total:total + 1280]))
+    assert b.drain_frames().tobytes() == o.frames().tobytes()
+
+
 def test_argument_errors_are_loud():
     from gnuais_amd import lib
     b = batch(4, max_len=100)
