@@ -286,9 +286,11 @@ int gnuais_batch_create(gnuais_batch **out, int device, int n_channels, const fl
     alloc((void **) &b->pll, sizeof(uint32_t) * N);
     alloc((void **) &b->lastbit, sizeof(uint32_t) * N);
     alloc((void **) &b->ctl, sizeof(uint32_t) * N * HDLC_CTL_WORDS);
-    // candidate ring: a frame needs >= 32 bits of preamble+flag, typical load is one
-    // frame per 256 bit times; 64 slots per channel and call cover max_len <= 2^16
-    b->cand_K = std::max(64, b->bits_words / 4);
+    // candidate ring, per channel and call.  The deframer cannot open frames faster than one per
+    // 30 bits (16 alternating bits to leave ST_SKURR, protodec.c:1030-1043, six ones each for the
+    // opening and the closing flag, a bit in ST_STOPSIGN), so this many slots hold whatever a call
+    // can produce, adversarial bit streams included (real traffic: <= 38 frames per second)
+    b->cand_K = std::max(64, b->bits_words * 32 / 30 + 2);
     alloc((void **) &b->cand, sizeof(uint32_t) * N * (size_t) b->cand_K * CAND_WORDS);
     alloc((void **) &b->frame_count, sizeof(uint32_t) * 4);
     b->chunk_cap = std::max(65536, 16 * ((b->N + 31) / 32));

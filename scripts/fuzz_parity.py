@@ -191,6 +191,10 @@ def deframer_case(seed):
                 parts.append(np.ones(int(rng.integers(0, 40)), dtype=np.uint8))
             elif kind == 4:
                 parts.append(np.zeros(int(rng.integers(0, 40)), dtype=np.uint8))
+            elif kind == 5 and rng.integers(0, 3) == 0:                   # frames as dense as they get
+                data = (rng.random(int(rng.integers(0, 60))) < 0.4).astype(np.uint8)
+                cyc = np.concatenate([(np.arange(16) & 1).astype(np.uint8), flag, data, flag])
+                parts.append(np.tile(cyc, int(rng.integers(1, 120))))
             else:
                 n = int(rng.choice([0, 1, 2, 3, 11, 20, 21, 22, 40, 52, 53, 54, 55, 60, 80]))
                 body = bytes(rng.integers(0, 256, n, dtype=np.uint8)) if rng.integers(0, 4) else bytes([0xff] * n)

@@ -369,6 +369,32 @@ def test_deframer_random_vs_oracle_many_channels():
     assert fsm_rows(b) == oracle_fsm_rows(o, n_ch)
 
 
+def test_deframer_densest_possible_frames():
+    """Frames opened as fast as the state machine allows (16 alternating bits, flag, a few data bits,
+    flag: one candidate per ~32-70 bits, ten times real traffic): every one of them is checked and
+    counted, none is dropped for lack of candidate slots."""
+    flag = np.array([0, 1, 1, 1, 1, 1, 1, 0], dtype=np.uint8)
+    alt = (np.arange(16) & 1).astype(np.uint8)
+    rng = np.random.default_rng(44)
+    streams = []
+    for reps, datalen in ((300, 0), (300, 30), (250, 40), (150, 64)):
+        data = rng.integers(0, 2, datalen).astype(np.uint8)
+        for i in range(4, datalen):
+            if data[i - 4:i].all():
+                data[i] = 0
+        streams.append(np.tile(np.concatenate([alt, flag, data, flag]), reps).astype(np.uint8))
+    o = Oracle(len(streams))
+    for c, st in enumerate(streams):
+        o.decode_bits(c, st)
+    b = batch(len(streams), max_len=48000)
+    b.decode_bits(streams)
+    assert b.drain_frames().tobytes() == o.frames().tobytes()
+    cnt = b.counters()
+    got = np.stack([cnt["receivedframes"], cnt["lostframes"], cnt["lostframes2"]], axis=1)
+    assert np.array_equal(got, o.counters())
+    assert got[0, 2] == 300 and got[1, 1] == 300
+
+
 def test_crc16_device_known_answers():
     from gnuais_amd import crc16_batch
     g = load("crc16")
