@@ -89,12 +89,19 @@ def one_case(seed):
         b.set_option("fir_variant", int(os.environ["FIR_VARIANT"]))
     if rng.integers(0, 3) == 0:
         b.set_option("fir_T", int(rng.choice([96, 128, 256, 512, 2048])))
+    host_input = rng.integers(0, 4) == 0          # gnuais_batch_run_host: the drop-in's entry point
+    reset_at = int(rng.integers(0, len(chunks))) if rng.integers(0, 6) == 0 else -1
     pos = 0
-    for n in chunks:
+    for i, n in enumerate(chunks):
+        if i == reset_at:                         # init_receiver() again: everything back to zero
+            b.drain_frames()
+            b.reset()
+            o.reset()
+            o.clear_frames()
         seg = np.ascontiguousarray(x[pos:pos + n])
         pos += n
         r = o.run(seg, want_bits=True)
-        b.run(torch.from_numpy(seg).cuda())
+        b.run(seg if host_input else torch.from_numpy(seg).cuda())
         lb = b.last_bits()
         if not np.array_equal(b.maxval(), r["maxval"]):
             return f"maxval differs, call of {n} at {pos - n}"
