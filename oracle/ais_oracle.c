@@ -362,8 +362,11 @@ static uint32_t pll_channel(ais_oracle *o, int c, const float *filtered, int len
 	return nb;
 }
 
-int ais_oracle_run_range(ais_oracle *o, const int16_t *in, int len, int ch0, int ch1,
-			 ais_run_out *out)
+/* `planar` != 0: channel c's samples are contiguous at in + c*len (a de-interleaved copy of the
+ * reference's layout; only the benchmark's "CPU best case" leg uses it), else interleaved with
+ * stride n_ch as receiver_run() reads them (receiver.c:102,107). */
+static int run_range(ais_oracle *o, const int16_t *in, int len, int ch0, int ch1, ais_run_out *out,
+		     int planar)
 {
 	float *w, *filt;
 	int c, i;
@@ -375,7 +378,8 @@ int ais_oracle_run_range(ais_oracle *o, const int16_t *in, int len, int ch0, int
 	for (c = ch0; c < ch1; c++) {
 		int16_t mv;
 		uint32_t nb;
-		fir_channel(o, o->hist + (size_t) c * (size_t) o->n_taps, in + c, o->n_ch, len,
+		fir_channel(o, o->hist + (size_t) c * (size_t) o->n_taps,
+			    planar ? in + (size_t) c * (size_t) len : in + c, planar ? 1 : o->n_ch, len,
 			    filt, &mv, w);
 		if (out && out->filtered)
 			for (i = 0; i < len; i++)
@@ -393,6 +397,12 @@ int ais_oracle_run_range(ais_oracle *o, const int16_t *in, int len, int ch0, int
 	return 0;
 }
 
+int ais_oracle_run_range(ais_oracle *o, const int16_t *in, int len, int ch0, int ch1,
+			 ais_run_out *out)
+{
+	return run_range(o, in, len, ch0, ch1, out, 0);
+}
+
 int ais_oracle_run(ais_oracle *o, const int16_t *in, int len, ais_run_out *out)
 {
 	return ais_oracle_run_range(o, in, len, 0, o->n_ch, out);
@@ -401,17 +411,29 @@ int ais_oracle_run(ais_oracle *o, const int16_t *in, int len, ais_run_out *out)
 struct mt_job {
 	ais_oracle *o;
 	const int16_t *in;
-	int len, ch0, ch1;
+	int len, ch0, ch1, planar;
 };
 
 static void *mt_main(void *p)
 {
 	struct mt_job *j = p;
-	ais_oracle_run_range(j->o, j->in, j->len, j->ch0, j->ch1, NULL);
+	run_range(j->o, j->in, j->len, j->ch0, j->ch1, NULL, j->planar);
 	return NULL;
 }
 
+static int run_mt(ais_oracle *o, const int16_t *in, int len, int n_threads, int planar);
+
 int ais_oracle_run_mt(ais_oracle *o, const int16_t *in, int len, int n_threads)
+{
+	return run_mt(o, in, len, n_threads, 0);
+}
+
+int ais_oracle_run_planar_mt(ais_oracle *o, const int16_t *in_planar, int len, int n_threads)
+{
+	return run_mt(o, in_planar, len, n_threads, 1);
+}
+
+static int run_mt(ais_oracle *o, const int16_t *in, int len, int n_threads, int planar)
 {
 	pthread_t *th;
 	struct mt_job *jobs;
@@ -427,6 +449,7 @@ int ais_oracle_run_mt(ais_oracle *o, const int16_t *in, int len, int n_threads)
 		jobs[t].o = o;
 		jobs[t].in = in;
 		jobs[t].len = len;
+		jobs[t].planar = planar;
 		jobs[t].ch0 = (int) ((long) o->n_ch * t / n_threads);
 		jobs[t].ch1 = (int) ((long) o->n_ch * (t + 1) / n_threads);
 		pthread_create(&th[t], NULL, mt_main, &jobs[t]);

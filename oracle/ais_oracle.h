@@ -83,6 +83,8 @@ int ais_oracle_run_range(ais_oracle *o, const int16_t *in, int len, int ch0, int
 			 ais_run_out *out);
 /* channels statically partitioned over n_threads pthreads */
 int ais_oracle_run_mt(ais_oracle *o, const int16_t *in, int len, int n_threads);
+/* same work on a de-interleaved copy: channel c at in_planar + c*len (benchmark context only) */
+int ais_oracle_run_planar_mt(ais_oracle *o, const int16_t *in_planar, int len, int n_threads);
 
 /* stage entry points */
 void ais_oracle_filter_channel(ais_oracle *o, int ch, const int16_t *in, int step, int len,

@@ -75,6 +75,7 @@ def _oracle_lib():
         lib.ais_oracle_reset.argtypes = [C.c_void_p]
         lib.ais_oracle_run.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
         lib.ais_oracle_run_mt.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int]
+        lib.ais_oracle_run_planar_mt.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int]
         lib.ais_oracle_filter_channel.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int,
                                                   C.c_int, C.c_void_p, C.c_void_p]
         lib.ais_oracle_decode_bits.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int]
@@ -148,6 +149,12 @@ class Oracle:
         if want_bits:
             res["bits"] = [bits[c, : nbits[c]].copy() for c in range(self.n_ch)]
         return res
+
+    def run_planar(self, xp: np.ndarray, threads: int):
+        """xp: int16 [n_ch][len], each channel contiguous (benchmark context: the CPU's best case)."""
+        xp = np.ascontiguousarray(xp, dtype=np.int16)
+        assert xp.ndim == 2 and xp.shape[0] == self.n_ch
+        self.lib.ais_oracle_run_planar_mt(self.h, xp.ctypes.data_as(C.c_void_p), int(xp.shape[1]), threads)
 
     def decode_bits(self, ch: int, bits: np.ndarray):
         b = np.ascontiguousarray(bits, dtype=np.uint8)
