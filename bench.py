@@ -33,6 +33,25 @@ TIMING_STRIDE = 4              # per-kernel events on every 4th call of the time
                                # per SIMD x 1024 SIMDs, unfused v_mul_f32/v_add_f32
 
 
+def effective_cpus():
+    """Host CPUs this process may actually use: affinity mask, capped by the cgroup CPU quota
+    (the GPU box's container shows 256 logical CPUs and a quota of 16)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                n = min(n, max(1, q // per))
+        except Exception:
+            pass
+    return n
+
+
 def cpu_baseline(x_host, n_sample_ch, total, x_wide=None):
     """The reference's own code (oracle/_ref, kind 'reference') -- or the C
     restatement (kind 'port') when the prebuilt reference is absent -- timed on a
@@ -60,7 +79,7 @@ def cpu_baseline(x_host, n_sample_ch, total, x_wide=None):
     # context: the same work on every host core (the reference itself is single-threaded by
     # design; this is the C restatement with channels partitioned over pthreads)
     if x_wide is not None:
-        cores = os.cpu_count() or 1
+        cores = effective_cpus()
         o = oracle_lib.Oracle(x_wide.shape[1])
         o.run(x_wide[:1020], threads=cores)                       # thread start-up, page faults
         o = oracle_lib.Oracle(x_wide.shape[1])
