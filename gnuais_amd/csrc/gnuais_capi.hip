@@ -99,6 +99,11 @@ struct gnuais_batch {
     int max_cur = 0, max_last = 0;
     gnuais_frame *frames = nullptr;
     float *d_taps = nullptr;
+    // f1 on the device (gnuais_batch_drain_nmea): allocated on first use
+    uint8_t *d_seq[2] = {nullptr, nullptr};
+    char *d_text = nullptr;
+    void *nmea_scratch = nullptr;
+    size_t nmea_scratch_bytes = 0, d_text_bytes = 0;
     std::vector<gnuais_frame> drain_tmp;
     std::vector<uint32_t> drain_chunks;
     int16_t *stage_x = nullptr;
@@ -164,7 +169,7 @@ void gnuais_batch_destroy(gnuais_batch *b)
     }
     void *ptrs[] = {b->hist[0], b->hist[1], b->pll, b->lastbit, b->ctl, b->cand,
                     b->frame_count, b->chunks, b->counters, b->maxval[0], b->maxval[1], b->frames, b->d_taps,
-                    b->stage_x};
+                    b->stage_x, b->d_seq[0], b->d_seq[1], b->d_text, b->nmea_scratch};
     for (void *p : ptrs)
         if (p) (void) hipFree(p);
     for (auto &set : b->evr)
@@ -809,6 +814,64 @@ int gnuais_batch_drain_frames(gnuais_batch *b, gnuais_frame *h_out, int max, int
         return fail(GNUAIS_E_HIP, "drain_frames: the PLL stage's watchdog fired (device hung or badly oversubscribed); results are incomplete");
     if (overflow)
         return fail(GNUAIS_E_OVERFLOW, "drain_frames: frame ring overflowed, frames were dropped");
+    return GNUAIS_OK;
+}
+
+int gnuais_batch_drain_nmea(gnuais_batch *b, uint8_t *seqnr, char *out, size_t out_cap, size_t *out_len,
+                            int *n_sentences, int *n_frames)
+{
+    if (!b || !seqnr || !out_len || (out_cap > 0 && !out)) return fail(GNUAIS_E_ARG, "drain_nmea: argument");
+    *out_len = 0;
+    if (n_sentences) *n_sentences = 0;
+    if (n_frames) *n_frames = 0;
+    if (int rc = gnuais_batch_sync(b)) return rc;
+    uint32_t cnt[4] = {0, 0, 0, 0};
+    HIP_TRY(hipMemcpy(cnt, b->frame_count, sizeof cnt, hipMemcpyDeviceToHost));
+    const uint32_t have = std::min<uint32_t>(cnt[0], (uint32_t) b->frame_cap);
+    const bool overflow = cnt[1] || cnt[0] > (uint32_t) b->frame_cap || cnt[2] > (uint32_t) b->chunk_cap;
+    const bool watchdog = cnt[3] != 0;
+    if (have) {
+        const size_t N = (size_t) b->N;
+        if (!b->d_seq[0]) {
+            HIP_TRY(hipMalloc((void **) &b->d_seq[0], N));
+            HIP_TRY(hipMalloc((void **) &b->d_seq[1], N));
+        }
+        const size_t need_text = (size_t) have * 164, need_scratch = nmea_scratch_bytes((int) have);
+        if (b->d_text_bytes < need_text) {
+            if (b->d_text) (void) hipFree(b->d_text);
+            b->d_text = nullptr;
+            b->d_text_bytes = 0;
+            HIP_TRY(hipMalloc((void **) &b->d_text, need_text));
+            b->d_text_bytes = need_text;
+        }
+        if (b->nmea_scratch_bytes < need_scratch) {
+            if (b->nmea_scratch) (void) hipFree(b->nmea_scratch);
+            b->nmea_scratch = nullptr;
+            b->nmea_scratch_bytes = 0;
+            HIP_TRY(hipMalloc(&b->nmea_scratch, need_scratch));
+            b->nmea_scratch_bytes = need_scratch;
+        }
+        HIP_TRY(hipMemcpy(b->d_seq[0], seqnr, N, hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(b->d_seq[1], b->d_seq[0], N, hipMemcpyDeviceToDevice));
+        uint32_t info[3] = {0, 0, 0};
+        HIP_TRY(nmea_format(b->frames, (int) have, b->N, b->d_seq[0], b->d_seq[1], b->d_text, b->d_text_bytes,
+                            b->nmea_scratch, b->nmea_scratch_bytes, info, nullptr));
+        if (info[2]) return fail(GNUAIS_E_HIP, "drain_nmea: a frame record names a channel outside the batch");
+        if ((size_t) info[0] > out_cap) {
+            *out_len = info[0];
+            return fail(GNUAIS_E_ARG, "drain_nmea: output buffer too small");
+        }
+        if (info[0]) HIP_TRY(hipMemcpy(out, b->d_text, info[0], hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(seqnr, b->d_seq[1], N, hipMemcpyDeviceToHost));
+        *out_len = info[0];
+        if (n_sentences) *n_sentences = (int) info[1];
+        if (n_frames) *n_frames = (int) have;
+    }
+    HIP_TRY(hipMemset(b->frame_count, 0, sizeof cnt));
+    b->hdlc_calls = 0;
+    if (watchdog)
+        return fail(GNUAIS_E_HIP, "drain_nmea: the PLL stage's watchdog fired (device hung or badly oversubscribed); results are incomplete");
+    if (overflow) return fail(GNUAIS_E_OVERFLOW, "drain_nmea: frame ring overflowed, frames were dropped");
     return GNUAIS_OK;
 }
 

@@ -78,4 +78,13 @@ hipError_t launch_tile_channels(const int16_t *base, int n_base, int len, int16_
 hipError_t launch_crc16(const uint8_t *data, int stride, const int32_t *len, int n,
                         uint16_t *crc, hipStream_t stream);
 
+// ---- f1 on the device (nmea_device.hip) ---------------------------------------
+size_t nmea_scratch_bytes(int n_frames);
+// frames: device gnuais_frame[n]; seq_in/seq_out: device u8[n_channels] (seq_out preloaded with
+// seq_in); out: device text buffer.  h_info: [0] bytes written, [1] sentences, [2] != 0 if a
+// frame named a channel >= n_channels.  Synchronises `s`.
+hipError_t nmea_format(const struct gnuais_frame *frames, int n, int n_channels, const uint8_t *seq_in,
+                       uint8_t *seq_out, char *out, size_t out_cap, void *scratch, size_t scratch_bytes,
+                       uint32_t *h_info, hipStream_t s);
+
 } // namespace gnuais

@@ -144,6 +144,17 @@ class ReceiverBatch:
                                                   C.byref(got)))
         return out[: got.value].copy()
 
+    def drain_nmea(self, seqnr: np.ndarray):
+        """The queued frames as !AIVDM sentences, formatted on the device (row f1); consumes them.
+        seqnr: uint8[n_channels], updated in place.  Returns (text bytes, sentences, frames)."""
+        assert seqnr.dtype == np.uint8 and seqnr.flags.c_contiguous and len(seqnr) == self.n_channels
+        n = self.pending_frames()
+        out = np.empty(164 * max(n, 1), dtype=np.uint8)
+        ln, ns, nf = C.c_size_t(0), C.c_int(0), C.c_int(0)
+        check(self._lib.gnuais_batch_drain_nmea(self._h, seqnr.ctypes.data, out.ctypes.data, out.size,
+                                                C.byref(ln), C.byref(ns), C.byref(nf)))
+        return out[: ln.value].tobytes(), ns.value, nf.value
+
     def _struct_array(self, fn, dtype):
         out = np.zeros(self.n_channels, dtype=dtype)
         check(fn(self._h, out.ctypes.data))

@@ -178,6 +178,14 @@ int  gnuais_messages_from_frames(const gnuais_frame *frames, int n_frames, uint8
 				 const char *chanid, int n_channels, char *nmea, size_t nmea_cap,
 				 size_t *nmea_len, int *n_sentences, char *text, size_t text_cap,
 				 size_t *text_len, int *n_lines);
+/* The same sentences formatted ON THE DEVICE, straight from the HBM frame ring (sort into the
+ * reference's order, prefix sums for the text offsets and the per-channel sequence digit, one
+ * thread per frame): consumes the queued frames like gnuais_batch_drain_frames() and copies only
+ * the text to the host.  Byte-identical to gnuais_nmea_from_frames() over the drained records.
+ * seqnr[n_channels] in/out as there.  GNUAIS_E_ARG if `out_cap` is too small (nothing consumed;
+ * 164 bytes per pending frame always suffice). */
+int  gnuais_batch_drain_nmea(gnuais_batch *b, uint8_t *seqnr, char *out, size_t out_cap,
+			     size_t *out_len, int *n_sentences, int *n_frames);
 /* Range statistics (range.c:32-45, called from the position decoders protodec.c:399,441,628):
  * best_range_km[channel] = max(itself, great-circle km from the station to every plausible
  * position in frames of type 1-3, 4 and 18), the reference's float arithmetic step for step.

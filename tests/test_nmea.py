@@ -185,3 +185,66 @@ def test_wav_file_to_sentences_end_to_end(tmp_path):
         nm, tx = messages_from_frames(fr, seq)
         assert nm == g["chain_48k_text"].tobytes()
         assert tx == g["chain_48k_stdout"].tobytes()
+
+
+@pytest.mark.gpu
+def test_device_formatter_matches_host_formatter_on_arbitrary_frames():
+    """gnuais_batch_drain_nmea(): sentences formatted on the device from the HBM frame ring.  Frames of
+    every length (1..53 bytes: one- and two-part sentences, every fill-bit count) and every type
+    field (accepted and ignored ones) are put into the ring through the device deframer; the text,
+    the sentence count and the carried sequence digits must equal the host formatter's over the
+    drained records -- which the tests above pin to the reference."""
+    from gnuais_amd import ReceiverBatch, synth
+    rng = np.random.default_rng(77)
+    n_ch = 7
+    streams = []
+    for c in range(n_ch):
+        parts = [np.zeros(8, dtype=np.uint8)]
+        for k in range(int(rng.integers(0, 60)) if c != 3 else 0):       # channel 3 stays empty
+            nbytes = int(rng.integers(1, 54)) if k % 3 else int(rng.choice([1, 21, 45, 46, 47, 53]))
+            body = bytearray(rng.integers(0, 256, nbytes, dtype=np.uint8).tobytes())
+            t = int(rng.integers(0, 64)) if k % 4 == 0 else int(rng.integers(1, 25))
+            body[0] = (t << 2) | (body[0] & 3)
+            parts.append(synth.hdlc_frame_bits(bytes(body), training_bits=24))
+            parts.append(np.zeros(int(rng.integers(1, 30)), dtype=np.uint8))
+        streams.append(np.concatenate(parts).astype(np.uint8))
+    seq0 = rng.integers(0, 10, n_ch).astype(np.uint8)
+    a, b = ReceiverBatch(n_ch, max_len=48000), ReceiverBatch(n_ch, max_len=48000)
+    for piece in (0, 1):                                  # two spans: the digits carry over
+        half = [st[: len(st) // 2] if piece == 0 else st[len(st) // 2:] for st in streams]
+        a.decode_bits(half)
+        b.decode_bits(half)
+        if piece == 0:
+            seq_a, seq_b = seq0.copy(), seq0.copy()
+        frames = a.drain_frames()
+        want = nmea(frames, n_ch, seq_a)[0]
+        got, n_sent, n_frames = b.drain_nmea(seq_b)
+        assert n_frames == len(frames) > 20
+        assert got == want
+        assert n_sent == want.count(b"\r\n")
+        assert np.array_equal(seq_a, seq_b)
+        assert b.pending_frames() == 0
+    assert b"!AIVDM,2,2," in want or b"!AIVDM,2,2," in got
+
+
+@pytest.mark.gpu
+def test_device_formatter_on_the_chain_over_several_calls():
+    """Full chain, three calls queued before one drain (frames of different calls interleave per
+    channel in the ring), more channels than a block: device text == host text == golden order."""
+    import torch
+    from gnuais_amd import ReceiverBatch, synth
+    n_ch, per = 300, 6 * 1280
+    x = np.stack([synth.make_stream(3 * per, seed=81, channel=c, occupancy=0.9)[0] for c in range(n_ch)], axis=1)
+    a, b = ReceiverBatch(n_ch, max_len=per), ReceiverBatch(n_ch, max_len=per)
+    xd = torch.from_numpy(x).cuda()
+    for i in range(3):
+        a.run(xd[i * per:(i + 1) * per])
+        b.run(xd[i * per:(i + 1) * per])
+    frames = a.drain_frames()
+    seq_a, seq_b = np.zeros(n_ch, dtype=np.uint8), np.zeros(n_ch, dtype=np.uint8)
+    want = nmea(frames, n_ch, seq_a)[0]
+    got, n_sent, n_frames = b.drain_nmea(seq_b)
+    assert n_frames == len(frames) > 3000 and n_sent == n_frames
+    assert got == want and np.array_equal(seq_a, seq_b)
+    got2, n2, f2 = b.drain_nmea(seq_b)                     # nothing left
+    assert got2 == b"" and n2 == 0 and f2 == 0
