@@ -41,6 +41,9 @@
 namespace {
 
 constexpr int CHARS_PER_SENTENCE = 61;      // protodec.c:793
+// bufferlen of the longest frame the deframer delivers: bufferpos 448 - 22 (protodec.c:1023,1096).
+// The record holds its 53 whole bytes; the bits past them are 0 here as in d->rbuffer (:150-162).
+constexpr int MAX_NBITS = 426;
 constexpr int MAX_TYPE = 24;                // cfg.h:48 MAX_AIS_PACKET_TYPE
 const char HEX[] = "0123456789ABCDEF";
 
@@ -255,7 +258,7 @@ static int format_range(const gnuais_frame *frames, int k0, int k1, uint8_t *seq
         const gnuais_frame &f = frames[k];
         if (f.channel >= (uint32_t) n_channels) return GNUAIS_E_ARG;
         const int nbits = f.nbits;
-        if (nbits > 8 * (int) sizeof f.payload) return GNUAIS_E_ARG;
+        if (nbits > MAX_NBITS) return GNUAIS_E_ARG;
         const Bits b(f, nbits);
         const unsigned type = (unsigned) b.get(0, 6);
         if (type < 1 || type > MAX_TYPE) continue;
@@ -396,7 +399,7 @@ extern "C" int gnuais_range_from_frames(const gnuais_frame *frames, int n_frames
     const float mylat = to_rad(my_lat_deg), mylng = to_rad(my_lon_deg);
     for (int k = 0; k < n_frames; ++k) {
         const gnuais_frame &f = frames[k];
-        if (f.channel >= (uint32_t) n_channels || f.nbits > 8 * sizeof f.payload) return GNUAIS_E_ARG;
+        if (f.channel >= (uint32_t) n_channels || f.nbits > MAX_NBITS) return GNUAIS_E_ARG;
         const Bits b(f, (int) f.nbits);
         long latitude, longitude;
         switch ((unsigned) b.get(0, 6)) {
@@ -540,7 +543,7 @@ extern "C" int gnuais_vessels_from_frames(const gnuais_frame *frames, int n_fram
     upd.reserve((size_t) n_frames);
     for (int k = 0; k < n_frames; ++k) {
         const gnuais_frame &f = frames[k];
-        if (f.nbits > 8 * sizeof f.payload) return GNUAIS_E_ARG;
+        if (f.nbits > MAX_NBITS) return GNUAIS_E_ARG;
         const Bits b(f, (int) f.nbits);
         const unsigned type = (unsigned) b.get(0, 6);
         if (type < 1 || type > MAX_TYPE || !touches_cache(b, type)) continue;

@@ -338,7 +338,7 @@ void ref_getdata(int idx, const uint8_t *payload, int nbits)
 	int i;
 	memset(d->rbuffer, 0, DEMOD_BUFFER_LEN);
 	for (i = 0; i < nbits && i < DEMOD_BUFFER_LEN - 8; i++)
-		d->rbuffer[i] = (payload[i >> 3] >> (7 - (i & 7))) & 1;
+		d->rbuffer[i] = (i >> 3) < 53 ? (payload[i >> 3] >> (7 - (i & 7))) & 1 : 0;   /* 53 payload bytes */
 	d->serial = dummy;
 	protodec_getdata(nbits, d);
 	d->serial = NULL;
@@ -472,7 +472,7 @@ double ref_getdata_many(const uint8_t *records, int n, int serial_fd, int with_t
 		const int nbits = *(const uint16_t *) (r + 62);
 		memset(d->rbuffer, 0, DEMOD_BUFFER_LEN);
 		for (i = 0; i < nbits && i < DEMOD_BUFFER_LEN - 8; i++)
-			d->rbuffer[i] = (r[8 + (i >> 3)] >> (7 - (i & 7))) & 1;
+			d->rbuffer[i] = (i >> 3) < 53 ? (r[8 + (i >> 3)] >> (7 - (i & 7))) & 1 : 0;
 		d->serial = serial_fd >= 0 ? &port : NULL;
 		protodec_getdata(nbits, d);
 		d->serial = NULL;

@@ -16,7 +16,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import torch                                                        # noqa: E402
-from gnuais_amd import ReceiverBatch, params, synth                 # noqa: E402
+from gnuais_amd import ReceiverBatch, nmea_from_frames, params, synth   # noqa: E402
 from oracle_lib import Oracle                                       # noqa: E402
 
 FSM_KEYS = ("state", "nstartsign", "antallpreamble", "antallenner", "bitstuff", "last", "bufferpos")
@@ -215,6 +215,7 @@ def deframer_case(seed):
         streams.append(np.concatenate(parts).astype(np.uint8) if parts else np.zeros(0, dtype=np.uint8))
     o = Oracle(n_ch)
     b = ReceiverBatch(n_ch, max_len=48000)
+    b2 = ReceiverBatch(n_ch, max_len=48000)                    # the same frames, formatted on the device
     if rng.integers(0, 2):
         b.set_option("hdlc_lpw", int(rng.choice([1, 2, 8, 32, 64])))
     pos = [0] * n_ch
@@ -227,8 +228,16 @@ def deframer_case(seed):
         for c in range(n_ch):
             o.decode_bits(c, piece[c])
         b.decode_bits(piece)
-    if b.drain_frames().tobytes() != o.frames().tobytes():
+        b2.decode_bits(piece)
+    got_frames = b.drain_frames()
+    if got_frames.tobytes() != o.frames().tobytes():
         return "frames differ"
+    seq_h = (np.arange(n_ch) % 10).astype(np.uint8)
+    seq_d = seq_h.copy()
+    text_h = nmea_from_frames(got_frames, seq_h)
+    text_d, _, nf = b2.drain_nmea(seq_d)
+    if text_h != text_d or nf != len(got_frames) or not np.array_equal(seq_h, seq_d):
+        return f"device NMEA differs from the host formatter ({len(text_d)} vs {len(text_h)} bytes)"
     cnt = b.counters()
     if not np.array_equal(np.stack([cnt["receivedframes"], cnt["lostframes"], cnt["lostframes2"]], axis=1),
                           o.counters()):

@@ -119,7 +119,7 @@ def nmea_frames(seed=51, n_channels=5, n_random=600):
     import numpy as np
     from oracle_lib import FRAME_DTYPE
     rng = np.random.default_rng(seed)
-    lens = [0, 6, 8, 16, 38, 40, 96, 160, 168, 200, 256, 312, 360, 366, 368, 372, 376, 408, 416, 424]
+    lens = [0, 6, 8, 16, 38, 40, 96, 160, 168, 200, 256, 312, 360, 366, 368, 372, 376, 408, 416, 424, 425, 426]
     types = [0, 1, 2, 3, 4, 5, 6, 9, 18, 19, 21, 24, 25, 31, 63]
     rows = []
     for k in range(n_random):
@@ -153,6 +153,19 @@ def nmea_frames(seed=51, n_channels=5, n_random=600):
         f = np.zeros(1, dtype=FRAME_DTYPE)[0]
         f["channel"] = k % n_channels
         f["end_bit"] = n_random + k
+        f["payload"] = np.packbits(bits)
+        f["flags"] = 1
+        f["nbits"] = nbits
+        rows.append(f)
+    for t in range(1, 25):                                 # and every accepted type at least once
+        nbits = (168, 424, 256)[t % 3]
+        bits = rng.integers(0, 2, 53 * 8).astype(np.uint8)
+        for i in range(6):
+            bits[i] = (t >> (5 - i)) & 1
+        bits[nbits:] = 0
+        f = np.zeros(1, dtype=FRAME_DTYPE)[0]
+        f["channel"] = t % n_channels
+        f["end_bit"] = n_random + 100 + t
         f["payload"] = np.packbits(bits)
         f["flags"] = 1
         f["nbits"] = nbits
