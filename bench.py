@@ -201,6 +201,20 @@ def main():
     b.set_timing(False)
     b.set_option("timing_stride", 1)
     msgs = float(rx1 - rx0)
+    # context, outside the timed region: delivering one step's frames to the host as NMEA text,
+    # formatted on the device (row f1)
+    post = None
+    if rank == 0:
+        b.discard_frames(stream)
+        step_frames_seq = np.zeros(n_ch, dtype=np.uint8)
+        for _ in range(2):                          # the first use allocates the text / scratch buffers
+            b.run(x, stream=stream, sync=True)
+            t_post = time.perf_counter()
+            text, n_sent, n_fr = b.drain_nmea(step_frames_seq)
+            t_post = time.perf_counter() - t_post
+        post = {"what": "gnuais_batch_drain_nmea of one step's frames (device formatter + D2H of the text)",
+                "frames": n_fr, "sentences": n_sent, "text_bytes": len(text), "ms": t_post * 1e3,
+                "frames_per_s": n_fr / t_post}
     if use_dist:
         from gnuais_amd.shard import reduce_bench
         dt, msgs, _ = reduce_bench(dist, device, dt, msgs, float(n_ch * total * args.steps))
@@ -233,6 +247,7 @@ def main():
             "valid_crc_msgs_per_s": msgs / dt,
             "x_realtime_channels": value / 0.048,
             "kernel_ms": kavg, "kernel_ms_isolated": kiso, "kernel_ms_calls": int(live["calls"]),
+            "post_stage": post,
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": pmc_traffic(dom),
                          "algorithmic_bytes_per_launch": alg[dom],
