@@ -104,8 +104,6 @@ struct gnuais_batch {
     char *d_text = nullptr;
     void *nmea_scratch = nullptr;
     size_t nmea_scratch_bytes = 0, d_text_bytes = 0;
-    std::vector<gnuais_frame> drain_tmp;
-    std::vector<uint32_t> drain_chunks;
     int16_t *stage_x = nullptr;
     size_t stage_bytes = 0;
     // options
@@ -765,6 +763,27 @@ int gnuais_batch_last_bits(gnuais_batch *b, uint8_t *h_bits, int stride, int32_t
     return GNUAIS_OK;
 }
 
+// device buffers of the post-stage (sorted records / text, rocPRIM scratch): allocated on first use
+static int ensure_post_buffers(gnuais_batch *b, uint32_t have)
+{
+    const size_t need_text = (size_t) have * 164, need_scratch = nmea_scratch_bytes((int) have);
+    if (b->d_text_bytes < need_text) {
+        if (b->d_text) (void) hipFree(b->d_text);
+        b->d_text = nullptr;
+        b->d_text_bytes = 0;
+        HIP_TRY(hipMalloc((void **) &b->d_text, need_text));
+        b->d_text_bytes = need_text;
+    }
+    if (b->nmea_scratch_bytes < need_scratch) {
+        if (b->nmea_scratch) (void) hipFree(b->nmea_scratch);
+        b->nmea_scratch = nullptr;
+        b->nmea_scratch_bytes = 0;
+        HIP_TRY(hipMalloc(&b->nmea_scratch, need_scratch));
+        b->nmea_scratch_bytes = need_scratch;
+    }
+    return GNUAIS_OK;
+}
+
 int gnuais_batch_drain_frames(gnuais_batch *b, gnuais_frame *h_out, int max, int *n_out)
 {
     if (!b || !n_out || (max > 0 && !h_out)) return fail(GNUAIS_E_ARG, "drain_frames: argument");
@@ -773,40 +792,18 @@ int gnuais_batch_drain_frames(gnuais_batch *b, gnuais_frame *h_out, int max, int
     uint32_t cnt[4] = {0, 0, 0, 0};
     HIP_TRY(hipMemcpy(cnt, b->frame_count, sizeof cnt, hipMemcpyDeviceToHost));
     const uint32_t have = std::min<uint32_t>(cnt[0], (uint32_t) b->frame_cap);
-    const uint32_t nchunks = std::min<uint32_t>(cnt[2], (uint32_t) b->chunk_cap);
     if ((uint32_t) max < have) return fail(GNUAIS_E_ARG, "drain_frames: output buffer too small");
     bool overflow = cnt[1] || cnt[0] > (uint32_t) b->frame_cap || cnt[2] > (uint32_t) b->chunk_cap;
     const bool watchdog = cnt[3] != 0;          // a PLL-stage wave timed out waiting for its partner
     if (have) {
-        // K3 leaves the frames in chunks that are internally in the reference's print
-        // order (channel, then time); chunks are keyed by (channel block, call, pass)
-        b->drain_tmp.resize(have);
-        b->drain_chunks.resize((size_t) nchunks * 4);
-        HIP_TRY(hipMemcpy(b->drain_tmp.data(), b->frames, sizeof(gnuais_frame) * have,
-                          hipMemcpyDeviceToHost));
-        HIP_TRY(hipMemcpy(b->drain_chunks.data(), b->chunks, sizeof(uint32_t) * 4 * nchunks,
-                          hipMemcpyDeviceToHost));
-        std::vector<uint32_t> order(nchunks);
-        for (uint32_t i = 0; i < nchunks; ++i) order[i] = i;
-        const uint32_t *ck = b->drain_chunks.data();
-        std::sort(order.begin(), order.end(), [ck](uint32_t x, uint32_t y) {
-            if (ck[4 * x] != ck[4 * y]) return ck[4 * x] < ck[4 * y];
-            return ck[4 * x + 1] < ck[4 * y + 1];
-        });
-        uint32_t w = 0;
-        for (uint32_t oi = 0; oi < nchunks; ++oi) {
-            const uint32_t *ch = ck + 4 * (size_t) order[oi];
-            uint32_t base = ch[2], n = ch[3];
-            if (base >= have) { overflow = true; continue; }
-            if (base + n > have) { n = have - base; overflow = true; }
-            memcpy(h_out + w, b->drain_tmp.data() + base, sizeof(gnuais_frame) * n);
-            w += n;
-        }
-        *n_out = (int) w;
-        if (b->hdlc_calls > 1)      // several calls in the span: interleave them per channel
-            std::stable_sort(h_out, h_out + w, [](const gnuais_frame &x, const gnuais_frame &y) {
-                return x.channel != y.channel ? x.channel < y.channel : x.end_bit < y.end_bit;
-            });
+        // K3 appends the frames in chunks, in whatever order its blocks finish; the reference's
+        // print order (channel, then time) is restored on the device -- radix sort of
+        // (channel, end_bit), gather -- and the records cross PCIe once, straight into h_out
+        if (int rc = ensure_post_buffers(b, have)) return rc;
+        gnuais_frame *sorted = reinterpret_cast<gnuais_frame *>(b->d_text);
+        HIP_TRY(frames_sort(b->frames, (int) have, sorted, b->nmea_scratch, b->nmea_scratch_bytes, nullptr));
+        HIP_TRY(hipMemcpy(h_out, sorted, sizeof(gnuais_frame) * have, hipMemcpyDeviceToHost));
+        *n_out = (int) have;
     }
     HIP_TRY(hipMemset(b->frame_count, 0, sizeof cnt));
     b->hdlc_calls = 0;
@@ -836,21 +833,7 @@ int gnuais_batch_drain_nmea(gnuais_batch *b, uint8_t *seqnr, char *out, size_t o
             HIP_TRY(hipMalloc((void **) &b->d_seq[0], N));
             HIP_TRY(hipMalloc((void **) &b->d_seq[1], N));
         }
-        const size_t need_text = (size_t) have * 164, need_scratch = nmea_scratch_bytes((int) have);
-        if (b->d_text_bytes < need_text) {
-            if (b->d_text) (void) hipFree(b->d_text);
-            b->d_text = nullptr;
-            b->d_text_bytes = 0;
-            HIP_TRY(hipMalloc((void **) &b->d_text, need_text));
-            b->d_text_bytes = need_text;
-        }
-        if (b->nmea_scratch_bytes < need_scratch) {
-            if (b->nmea_scratch) (void) hipFree(b->nmea_scratch);
-            b->nmea_scratch = nullptr;
-            b->nmea_scratch_bytes = 0;
-            HIP_TRY(hipMalloc(&b->nmea_scratch, need_scratch));
-            b->nmea_scratch_bytes = need_scratch;
-        }
+        if (int rc = ensure_post_buffers(b, have)) return rc;
         HIP_TRY(hipMemcpy(b->d_seq[0], seqnr, N, hipMemcpyHostToDevice));
         HIP_TRY(hipMemcpy(b->d_seq[1], b->d_seq[0], N, hipMemcpyDeviceToDevice));
         uint32_t info[3] = {0, 0, 0};

@@ -83,6 +83,9 @@ size_t nmea_scratch_bytes(int n_frames);
 // frames: device gnuais_frame[n]; seq_in/seq_out: device u8[n_channels] (seq_out preloaded with
 // seq_in); out: device text buffer.  h_info: [0] bytes written, [1] sentences, [2] != 0 if a
 // frame named a channel >= n_channels.  Synchronises `s`.
+// frames[n] (device) -> out[n] (device) in print order: channel, then end_bit
+hipError_t frames_sort(const struct gnuais_frame *frames, int n, struct gnuais_frame *out, void *scratch,
+                       size_t scratch_bytes, hipStream_t s);
 hipError_t nmea_format(const struct gnuais_frame *frames, int n, int n_channels, const uint8_t *seq_in,
                        uint8_t *seq_out, char *out, size_t out_cap, void *scratch, size_t scratch_bytes,
                        uint32_t *h_info, hipStream_t s);

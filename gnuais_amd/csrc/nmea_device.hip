@@ -155,6 +155,17 @@ __global__ __launch_bounds__(256) void nmea_write_kernel(
     atomicAdd(&totals[0], (uint32_t) g.parts);
 }
 
+// records gathered into sorted order: one thread moves one 16-byte quarter of a record
+__global__ __launch_bounds__(256) void frames_gather_kernel(const gnuais_frame *__restrict__ frames,
+                                                            const uint32_t *__restrict__ order, int n,
+                                                            gnuais_frame *__restrict__ out)
+{
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    const int j = t >> 2, q = t & 3;
+    if (j >= n) return;
+    reinterpret_cast<uint4 *>(out + j)[q] = reinterpret_cast<const uint4 *>(frames + order[j])[q];
+}
+
 struct MaxOp {
     __device__ __host__ uint32_t operator()(uint32_t a, uint32_t b) const { return a > b ? a : b; }
 };
@@ -175,6 +186,27 @@ size_t nmea_scratch_bytes(int n)
     tmp = tmp > scan_tmp2 ? tmp : scan_tmp2;
     // keys x2, idx x2, bytes, off, acc, accpre, head, headpos, totals, rocPRIM temp (256-byte slots)
     return 2 * 8 * m + 8 * 4 * m + 256 * 12 + tmp + 64;
+}
+
+// The ring's records in the reference's print order (channel, then time = end_bit), on the device:
+// what gnuais_batch_drain_frames() copies out.
+hipError_t frames_sort(const gnuais_frame *frames, int n, gnuais_frame *out, void *scratch, size_t scratch_bytes,
+                       hipStream_t s)
+{
+    if (n <= 0) return hipSuccess;
+    if (scratch_bytes < nmea_scratch_bytes(n)) return hipErrorInvalidValue;
+    const size_t m = (size_t) n;
+    char *p = static_cast<char *>(scratch);
+    auto take = [&](size_t bytes) { char *q = p; p += (bytes + 255) / 256 * 256; return (void *) q; };
+    uint64_t *keys = (uint64_t *) take(8 * m), *keys2 = (uint64_t *) take(8 * m);
+    uint32_t *idx = (uint32_t *) take(4 * m), *idx2 = (uint32_t *) take(4 * m);
+    void *tmp = p;
+    size_t t = scratch_bytes - (size_t) (p - static_cast<char *>(scratch));
+    hipLaunchKernelGGL(nmea_keys_kernel, dim3((n + 255) / 256), dim3(256), 0, s, frames, n, keys, idx);
+    hipError_t e = rocprim::radix_sort_pairs(tmp, t, keys, keys2, idx, idx2, m, 0, 56, s);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(frames_gather_kernel, dim3((4 * n + 255) / 256), dim3(256), 0, s, frames, idx2, n, out);
+    return hipGetLastError();
 }
 
 hipError_t nmea_format(const gnuais_frame *frames, int n, int n_channels, const uint8_t *seq_in,
