@@ -91,8 +91,7 @@ struct gnuais_batch {
     bool pipeline = true;
     uint32_t *ctl = nullptr, *cand = nullptr;
     uint32_t *cand_first[NBUF] = {}, *cand_count[NBUF] = {};   // K2b -> K3
-    uint32_t *frame_count = nullptr, *chunks = nullptr;
-    int chunk_cap = 0;
+    uint32_t *frame_count = nullptr;
     int cand_K = 64;
     int32_t *counters = nullptr;
     int *maxval[2] = {nullptr, nullptr};   // ping-pong with the history buffers
@@ -166,7 +165,7 @@ void gnuais_batch_destroy(gnuais_batch *b)
             if (p) (void) hipFree(p);
     }
     void *ptrs[] = {b->hist[0], b->hist[1], b->pll, b->lastbit, b->ctl, b->cand,
-                    b->frame_count, b->chunks, b->counters, b->maxval[0], b->maxval[1], b->frames, b->d_taps,
+                    b->frame_count, b->counters, b->maxval[0], b->maxval[1], b->frames, b->d_taps,
                     b->stage_x, b->d_seq[0], b->d_seq[1], b->d_text, b->nmea_scratch};
     for (void *p : ptrs)
         if (p) (void) hipFree(p);
@@ -296,8 +295,6 @@ int gnuais_batch_create(gnuais_batch **out, int device, int n_channels, const fl
     b->cand_K = std::max(64, b->bits_words * 32 / 30 + 2);
     alloc((void **) &b->cand, sizeof(uint32_t) * N * (size_t) b->cand_K * CAND_WORDS);
     alloc((void **) &b->frame_count, sizeof(uint32_t) * 4);
-    b->chunk_cap = std::max(65536, 16 * ((b->N + 31) / 32));
-    alloc((void **) &b->chunks, sizeof(uint32_t) * 4 * (size_t) b->chunk_cap);
     alloc((void **) &b->counters, sizeof(int32_t) * N * 3);
     alloc((void **) &b->maxval[0], sizeof(int) * N);
     alloc((void **) &b->maxval[1], sizeof(int) * N);
@@ -449,8 +446,6 @@ static void fill_hdlc(const gnuais_batch *b, HdlcLaunch &h, int k)
     h.segbits = b->segbits[k]; h.segcnt = b->segcnt[k]; h.ctl = b->ctl; h.cand = b->cand;
     h.cand_first = b->cand_first[k]; h.cand_count = b->cand_count[k];
     h.counters = b->counters; h.frames = b->frames; h.frame_count = b->frame_count;
-    h.chunks = b->chunks; h.chunk_cap = (uint32_t) b->chunk_cap;
-    h.call_seq = (uint32_t) (b->hdlc_calls & 0xfffffu);
     h.frame_cap = (uint32_t) b->frame_cap; h.N = b->N; h.n_seg = b->n_seg;
     h.seg_words = b->seg_words; h.K = b->cand_K;
     h.lanes_per_wave = b->hdlc_lpw;
@@ -793,7 +788,7 @@ int gnuais_batch_drain_frames(gnuais_batch *b, gnuais_frame *h_out, int max, int
     HIP_TRY(hipMemcpy(cnt, b->frame_count, sizeof cnt, hipMemcpyDeviceToHost));
     const uint32_t have = std::min<uint32_t>(cnt[0], (uint32_t) b->frame_cap);
     if ((uint32_t) max < have) return fail(GNUAIS_E_ARG, "drain_frames: output buffer too small");
-    bool overflow = cnt[1] || cnt[0] > (uint32_t) b->frame_cap || cnt[2] > (uint32_t) b->chunk_cap;
+    const bool overflow = cnt[1] || cnt[0] > (uint32_t) b->frame_cap;
     const bool watchdog = cnt[3] != 0;          // a PLL-stage wave timed out waiting for its partner
     if (have) {
         // K3 appends the frames in chunks, in whatever order its blocks finish; the reference's
@@ -825,7 +820,7 @@ int gnuais_batch_drain_nmea(gnuais_batch *b, uint8_t *seqnr, char *out, size_t o
     uint32_t cnt[4] = {0, 0, 0, 0};
     HIP_TRY(hipMemcpy(cnt, b->frame_count, sizeof cnt, hipMemcpyDeviceToHost));
     const uint32_t have = std::min<uint32_t>(cnt[0], (uint32_t) b->frame_cap);
-    const bool overflow = cnt[1] || cnt[0] > (uint32_t) b->frame_cap || cnt[2] > (uint32_t) b->chunk_cap;
+    const bool overflow = cnt[1] || cnt[0] > (uint32_t) b->frame_cap;
     const bool watchdog = cnt[3] != 0;
     if (have) {
         const size_t N = (size_t) b->N;

@@ -363,15 +363,13 @@ __global__ __launch_bounds__(64) void hdlc_deframe_kernel(
 // LDS and the candidates, enumerated channel-major then in time, are taken 256 at
 // a time (one per thread).  CRC-16/X-25 by bytes through a 256-entry table built
 // in LDS from the bitwise definition (protodec.c:106-118).  The good frames of a
-// pass are compacted in order (ballot ranks), the block reserves one contiguous
-// piece of the frame ring for them and logs a chunk {key, base, count}: frames are
-// in the reference's print order inside every chunk, and chunks sort by key, so the
-// host reorders a few hundred chunks instead of sorting every frame.
+// pass are compacted in order (ballot ranks) and the block reserves one contiguous
+// piece of the frame ring for them.  Pieces land in whatever order the blocks finish;
+// the drain restores the reference's print order with a device sort on (channel, end_bit).
 __global__ __launch_bounds__(256) void hdlc_crc_kernel(
     const uint32_t *__restrict__ cand, const uint32_t *__restrict__ cand_first,
     const uint32_t *__restrict__ cand_count, int32_t *__restrict__ counters,
-    uint32_t *__restrict__ frames, uint32_t *__restrict__ flags, uint32_t *__restrict__ chunks,
-    uint32_t frame_cap, uint32_t chunk_cap, uint32_t call_seq, int N, int K)
+    uint32_t *__restrict__ frames, uint32_t *__restrict__ flags, uint32_t frame_cap, int N, int K)
 {
     __shared__ uint32_t tab[256];
     __shared__ uint32_t pre[K3_CH + 1];
@@ -400,7 +398,7 @@ __global__ __launch_bounds__(256) void hdlc_crc_kernel(
     const uint32_t total = pre[K3_CH];
     const size_t n_ = (size_t) N;
 
-    for (uint32_t i0 = 0, pass = 0; i0 < total; i0 += 256, ++pass) {
+    for (uint32_t i0 = 0; i0 < total; i0 += 256) {
         const uint32_t i = i0 + (uint32_t) tid;
         bool good = false;
         uint32_t out[16];
@@ -500,16 +498,6 @@ __global__ __launch_bounds__(256) void hdlc_crc_kernel(
         if (tid == 0 && npass) {
             const uint32_t base = atomicAdd(&flags[0], npass);
             pass_base = base;
-            const uint32_t ci = atomicAdd(&flags[2], 1u);
-            if (ci < chunk_cap) {
-                uint32_t *ch = chunks + (size_t) ci * 4;
-                ch[0] = (uint32_t) blockIdx.x;          // key, major: channel block
-                ch[1] = (call_seq << 12) | pass;        // key, minor: call, then pass
-                ch[2] = base;
-                ch[3] = npass;
-            } else {
-                flags[1] = 1;
-            }
         }
         __syncthreads();
         if (good) {
@@ -543,8 +531,7 @@ hipError_t launch_hdlc_crc(const HdlcLaunch &a, hipStream_t stream)
 {
     hipLaunchKernelGGL(hdlc_crc_kernel, dim3((unsigned) ((a.N + K3_CH - 1) / K3_CH)), dim3(256), 0,
                        stream, a.cand, a.cand_first, a.cand_count, a.counters,
-                       (uint32_t *) a.frames, a.frame_count, a.chunks, a.frame_cap, a.chunk_cap,
-                       a.call_seq, a.N, a.K);
+                       (uint32_t *) a.frames, a.frame_count, a.frame_cap, a.N, a.K);
     return hipGetLastError();
 }
 

@@ -62,9 +62,8 @@ struct HdlcLaunch {
     uint32_t *cand_count;  // [N] slots closed in this call
     int32_t *counters;     // [3][N] receivedframes, lostframes, lostframes2
     void *frames;          // gnuais_frame[frame_cap]
-    uint32_t *frame_count; // [4]: frames appended, overflow flag, chunks logged, -
-    uint32_t *chunks;      // [chunk_cap][4]: channel block, call<<12|pass, ring base, count
-    uint32_t frame_cap, chunk_cap, call_seq;
+    uint32_t *frame_count; // [4]: frames appended, overflow flag, -, PLL watchdog
+    uint32_t frame_cap;
     int N, n_seg, seg_words, K;
     int lanes_per_wave;    // channels per wave in K2b (blockDim)
 };
