@@ -779,34 +779,65 @@ static int ensure_post_buffers(gnuais_batch *b, uint32_t have)
     return GNUAIS_OK;
 }
 
-int gnuais_batch_drain_frames(gnuais_batch *b, gnuais_frame *h_out, int max, int *n_out)
+// drain: records and / or sentences of everything queued, consumed once
+static int drain_impl(gnuais_batch *b, gnuais_frame *h_frames, int max_frames, int *n_frames,
+                      uint8_t *seqnr, char *out, size_t out_cap, size_t *out_len, int *n_sentences)
 {
-    if (!b || !n_out || (max > 0 && !h_out)) return fail(GNUAIS_E_ARG, "drain_frames: argument");
-    *n_out = 0;
     if (int rc = gnuais_batch_sync(b)) return rc;
     uint32_t cnt[4] = {0, 0, 0, 0};
     HIP_TRY(hipMemcpy(cnt, b->frame_count, sizeof cnt, hipMemcpyDeviceToHost));
     const uint32_t have = std::min<uint32_t>(cnt[0], (uint32_t) b->frame_cap);
-    if ((uint32_t) max < have) return fail(GNUAIS_E_ARG, "drain_frames: output buffer too small");
     const bool overflow = cnt[1] || cnt[0] > (uint32_t) b->frame_cap;
     const bool watchdog = cnt[3] != 0;          // a PLL-stage wave timed out waiting for its partner
+    if (h_frames && (uint32_t) max_frames < have) return fail(GNUAIS_E_ARG, "drain: frame buffer too small");
     if (have) {
-        // K3 appends the frames in chunks, in whatever order its blocks finish; the reference's
-        // print order (channel, then time) is restored on the device -- radix sort of
-        // (channel, end_bit), gather -- and the records cross PCIe once, straight into h_out
+        const size_t N = (size_t) b->N;
         if (int rc = ensure_post_buffers(b, have)) return rc;
-        gnuais_frame *sorted = reinterpret_cast<gnuais_frame *>(b->d_text);
-        HIP_TRY(frames_sort(b->frames, (int) have, sorted, b->nmea_scratch, b->nmea_scratch_bytes, nullptr));
-        HIP_TRY(hipMemcpy(h_out, sorted, sizeof(gnuais_frame) * have, hipMemcpyDeviceToHost));
-        *n_out = (int) have;
+        if (seqnr) {
+            // sentences first (the formatter sorts for itself and leaves the ring untouched)
+            if (!b->d_seq[0]) {
+                HIP_TRY(hipMalloc((void **) &b->d_seq[0], N));
+                HIP_TRY(hipMalloc((void **) &b->d_seq[1], N));
+            }
+            HIP_TRY(hipMemcpy(b->d_seq[0], seqnr, N, hipMemcpyHostToDevice));
+            HIP_TRY(hipMemcpy(b->d_seq[1], b->d_seq[0], N, hipMemcpyDeviceToDevice));
+            uint32_t info[3] = {0, 0, 0};
+            HIP_TRY(nmea_format(b->frames, (int) have, b->N, b->d_seq[0], b->d_seq[1], b->d_text, b->d_text_bytes,
+                                b->nmea_scratch, b->nmea_scratch_bytes, info, nullptr));
+            if (info[2]) return fail(GNUAIS_E_HIP, "drain: a frame record names a channel outside the batch");
+            if ((size_t) info[0] > out_cap) {
+                *out_len = info[0];
+                return fail(GNUAIS_E_ARG, "drain: text buffer too small");
+            }
+            if (info[0]) HIP_TRY(hipMemcpy(out, b->d_text, info[0], hipMemcpyDeviceToHost));
+            HIP_TRY(hipMemcpy(seqnr, b->d_seq[1], N, hipMemcpyDeviceToHost));
+            *out_len = info[0];
+            if (n_sentences) *n_sentences = (int) info[1];
+        }
+        if (h_frames) {
+            // K3 appends the frames in pieces, in whatever order its blocks finish; the reference's
+            // print order (channel, then time) is restored on the device -- radix sort of
+            // (channel, end_bit), gather -- and the records cross PCIe once, straight into h_frames
+            gnuais_frame *sorted = reinterpret_cast<gnuais_frame *>(b->d_text);
+            HIP_TRY(frames_sort(b->frames, (int) have, sorted, b->nmea_scratch, b->nmea_scratch_bytes, nullptr));
+            HIP_TRY(hipMemcpy(h_frames, sorted, sizeof(gnuais_frame) * have, hipMemcpyDeviceToHost));
+        }
+        if (n_frames) *n_frames = (int) have;
     }
     HIP_TRY(hipMemset(b->frame_count, 0, sizeof cnt));
     b->hdlc_calls = 0;
     if (watchdog)
-        return fail(GNUAIS_E_HIP, "drain_frames: the PLL stage's watchdog fired (device hung or badly oversubscribed); results are incomplete");
-    if (overflow)
-        return fail(GNUAIS_E_OVERFLOW, "drain_frames: frame ring overflowed, frames were dropped");
+        return fail(GNUAIS_E_HIP, "drain: the PLL stage's watchdog fired (device hung or badly oversubscribed); results are incomplete");
+    if (overflow) return fail(GNUAIS_E_OVERFLOW, "drain: frame ring overflowed, frames were dropped");
     return GNUAIS_OK;
+}
+
+int gnuais_batch_drain_frames(gnuais_batch *b, gnuais_frame *h_out, int max, int *n_out)
+{
+    if (!b || !n_out || (max > 0 && !h_out)) return fail(GNUAIS_E_ARG, "drain_frames: argument");
+    *n_out = 0;
+    static gnuais_frame none;
+    return drain_impl(b, h_out ? h_out : &none, max, n_out, nullptr, nullptr, 0, nullptr, nullptr);
 }
 
 int gnuais_batch_drain_nmea(gnuais_batch *b, uint8_t *seqnr, char *out, size_t out_cap, size_t *out_len,
@@ -816,41 +847,18 @@ int gnuais_batch_drain_nmea(gnuais_batch *b, uint8_t *seqnr, char *out, size_t o
     *out_len = 0;
     if (n_sentences) *n_sentences = 0;
     if (n_frames) *n_frames = 0;
-    if (int rc = gnuais_batch_sync(b)) return rc;
-    uint32_t cnt[4] = {0, 0, 0, 0};
-    HIP_TRY(hipMemcpy(cnt, b->frame_count, sizeof cnt, hipMemcpyDeviceToHost));
-    const uint32_t have = std::min<uint32_t>(cnt[0], (uint32_t) b->frame_cap);
-    const bool overflow = cnt[1] || cnt[0] > (uint32_t) b->frame_cap;
-    const bool watchdog = cnt[3] != 0;
-    if (have) {
-        const size_t N = (size_t) b->N;
-        if (!b->d_seq[0]) {
-            HIP_TRY(hipMalloc((void **) &b->d_seq[0], N));
-            HIP_TRY(hipMalloc((void **) &b->d_seq[1], N));
-        }
-        if (int rc = ensure_post_buffers(b, have)) return rc;
-        HIP_TRY(hipMemcpy(b->d_seq[0], seqnr, N, hipMemcpyHostToDevice));
-        HIP_TRY(hipMemcpy(b->d_seq[1], b->d_seq[0], N, hipMemcpyDeviceToDevice));
-        uint32_t info[3] = {0, 0, 0};
-        HIP_TRY(nmea_format(b->frames, (int) have, b->N, b->d_seq[0], b->d_seq[1], b->d_text, b->d_text_bytes,
-                            b->nmea_scratch, b->nmea_scratch_bytes, info, nullptr));
-        if (info[2]) return fail(GNUAIS_E_HIP, "drain_nmea: a frame record names a channel outside the batch");
-        if ((size_t) info[0] > out_cap) {
-            *out_len = info[0];
-            return fail(GNUAIS_E_ARG, "drain_nmea: output buffer too small");
-        }
-        if (info[0]) HIP_TRY(hipMemcpy(out, b->d_text, info[0], hipMemcpyDeviceToHost));
-        HIP_TRY(hipMemcpy(seqnr, b->d_seq[1], N, hipMemcpyDeviceToHost));
-        *out_len = info[0];
-        if (n_sentences) *n_sentences = (int) info[1];
-        if (n_frames) *n_frames = (int) have;
-    }
-    HIP_TRY(hipMemset(b->frame_count, 0, sizeof cnt));
-    b->hdlc_calls = 0;
-    if (watchdog)
-        return fail(GNUAIS_E_HIP, "drain_nmea: the PLL stage's watchdog fired (device hung or badly oversubscribed); results are incomplete");
-    if (overflow) return fail(GNUAIS_E_OVERFLOW, "drain_nmea: frame ring overflowed, frames were dropped");
-    return GNUAIS_OK;
+    return drain_impl(b, nullptr, 0, n_frames, seqnr, out, out_cap, out_len, n_sentences);
+}
+
+int gnuais_batch_drain_frames_nmea(gnuais_batch *b, gnuais_frame *h_frames, int max, int *n_frames,
+                                   uint8_t *seqnr, char *out, size_t out_cap, size_t *out_len, int *n_sentences)
+{
+    if (!b || !h_frames || !n_frames || !seqnr || !out_len || (out_cap > 0 && !out))
+        return fail(GNUAIS_E_ARG, "drain_frames_nmea: argument");
+    *n_frames = 0;
+    *out_len = 0;
+    if (n_sentences) *n_sentences = 0;
+    return drain_impl(b, h_frames, max, n_frames, seqnr, out, out_cap, out_len, n_sentences);
 }
 
 int gnuais_batch_pending_frames(gnuais_batch *b, int *n_out)

@@ -155,6 +155,18 @@ class ReceiverBatch:
                                                 C.byref(ln), C.byref(ns), C.byref(nf)))
         return out[: ln.value].tobytes(), ns.value, nf.value
 
+    def drain_frames_nmea(self, seqnr: np.ndarray):
+        """Records and device-formatted sentences of the same drained span: (frames, text, sentences)."""
+        assert seqnr.dtype == np.uint8 and seqnr.flags.c_contiguous and len(seqnr) == self.n_channels
+        n = self.pending_frames()
+        fr = np.zeros(max(n, 1), dtype=FRAME_DTYPE)
+        out = np.empty(164 * max(n, 1), dtype=np.uint8)
+        ln, ns, nf = C.c_size_t(0), C.c_int(0), C.c_int(0)
+        check(self._lib.gnuais_batch_drain_frames_nmea(self._h, fr.ctypes.data, int(fr.size), C.byref(nf),
+                                                       seqnr.ctypes.data, out.ctypes.data, out.size,
+                                                       C.byref(ln), C.byref(ns)))
+        return fr[: nf.value].copy(), out[: ln.value].tobytes(), ns.value
+
     def _struct_array(self, fn, dtype):
         out = np.zeros(self.n_channels, dtype=dtype)
         check(fn(self._h, out.ctypes.data))

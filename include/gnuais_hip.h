@@ -186,6 +186,11 @@ int  gnuais_messages_from_frames(const gnuais_frame *frames, int n_frames, uint8
  * 164 bytes per pending frame always suffice). */
 int  gnuais_batch_drain_nmea(gnuais_batch *b, uint8_t *seqnr, char *out, size_t out_cap,
 			     size_t *out_len, int *n_sentences, int *n_frames);
+/* both at once: the records (for the host-side consumers: stdout text, vessel table, range) and the
+ * device-formatted sentences (for serial / IPC) of the same drained span */
+int  gnuais_batch_drain_frames_nmea(gnuais_batch *b, gnuais_frame *h_frames, int max, int *n_frames,
+				    uint8_t *seqnr, char *out, size_t out_cap, size_t *out_len,
+				    int *n_sentences);
 /* Range statistics (range.c:32-45, called from the position decoders protodec.c:399,441,628):
  * best_range_km[channel] = max(itself, great-circle km from the station to every plausible
  * position in frames of type 1-3, 4 and 18), the reference's float arithmetic step for step.

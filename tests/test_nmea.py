@@ -248,3 +248,12 @@ def test_device_formatter_on_the_chain_over_several_calls():
     assert got == want and np.array_equal(seq_a, seq_b)
     got2, n2, f2 = b.drain_nmea(seq_b)                     # nothing left
     assert got2 == b"" and n2 == 0 and f2 == 0
+    # records and sentences of one span in one drain
+    for i in range(2):
+        a.run(xd[i * per:(i + 1) * per])
+        b.run(xd[i * per:(i + 1) * per])
+    frames = a.drain_frames()
+    want = nmea(frames, n_ch, seq_a)[0]
+    fr_b, text_b, n_sent = b.drain_frames_nmea(seq_b)
+    assert fr_b.tobytes() == frames.tobytes() and text_b == want and n_sent == len(frames)
+    assert np.array_equal(seq_a, seq_b) and b.pending_frames() == 0
