@@ -36,7 +36,9 @@ extern "C" {
 typedef struct gnuais_frame {
 	uint32_t channel;      /* interleaved channel index (receiver ch_ofs)      */
 	uint32_t end_bit;      /* bits fed to the deframer since reset before the
-	                          bit that closed the frame (orders frames in time) */
+	                          bit that closed the frame (orders frames in time;
+	                          wraps after 2^32 bits = 5 days of 9600 bit/s, so a
+	                          drained span must be shorter than that) */
 	uint8_t  payload[53];  /* nbits/8 bytes used, rest zero                     */
 	uint8_t  flags;        /* bit0: CRC ok (always set for delivered frames)    */
 	uint16_t nbits;        /* bufferpos - 22, src/protodec.c:1096               */
