@@ -342,6 +342,9 @@ __global__ __launch_bounds__(64) void fir_slice_kernel(
 #ifndef FIR_SIGN_FENCE
 #define FIR_SIGN_FENCE 4
 #endif
+#ifndef FIR_BUFFER_LOADS
+#define FIR_BUFFER_LOADS 1
+#endif
 // zero-instruction fence (see touch16): bounds how many samples the scheduler interleaves,
 // i.e. how many products are alive at once; without it the kernel needs 98 VGPRs (4 waves per
 // SIMD) instead of <= 88 (5 waves)
@@ -448,6 +451,16 @@ __global__ __launch_bounds__(64) void fir_sign_kernel(
     };
     bool zprev_known = false, zprev = false;    // was the previous word's block of 32 samples all 0?
 
+    // Buffer descriptor for the interior loads of the main loop: every interior row this segment
+    // reads lies in [row0, row0 + T + NC + 32), far less than the 4 GB a descriptor spans.
+    const int row0 = m0 > 0 ? m0 : 0;
+    const uint32_t rowbytes = (uint32_t) N * 2u;
+    const unsigned long long span = (unsigned long long) (L - row0) * rowbytes;
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<int16_t *>(x) + (size_t) row0 * (size_t) N, 0,
+        (int) (span > 0xffffffffull ? 0xffffffffull : span), 0x00020000);
+    const int coff = c * 2;
+
   if constexpr (NC % 32 != 16) {
         const int nblk = (t1 - t0 + 95) / 96;
         for (int b = 0; b < nblk; ++b) {
@@ -459,9 +472,19 @@ __global__ __launch_bounds__(64) void fir_sign_kernel(
                 const int mb = m0 + NC - 1 + obase;             // sample of phase 0
                 const bool interior = (mb >= 0) && (mb + 31 < L);
                 if (interior) {
+                    // buffer loads: descriptor (wave-uniform base = this segment's first row) in SGPRs, the
+                    // row in the scalar offset, the lane's constant byte offset in the vector offset -- no
+                    // per-load 64-bit VALU address add (a sixth of this kernel's issue cycles otherwise)
+#if FIR_BUFFER_LOADS
+    #pragma unroll
+                    for (int p = 0; p < 32; ++p)
+                        xi[p] = (int) (int16_t) __builtin_amdgcn_raw_buffer_load_b16(
+                            rsrc, coff, (int) ((uint32_t) (mb - row0 + p) * rowbytes), 0);
+#else
                     const int16_t *row = x + (size_t) mb * (size_t) N + c;
     #pragma unroll
                     for (int p = 0; p < 32; ++p) xi[p] = (int) row[(size_t) p * (size_t) N];
+#endif
                 } else {
     #pragma unroll
                     for (int p = 0; p < 32; ++p) {
@@ -638,6 +661,8 @@ __global__ __launch_bounds__(64) void fir_sign_kernel(
                 const int mb = m0 + NC - 1 + gbase;             // sample of the group's first phase
                 const bool interior = (mb >= 0) && (mb + GROUP - 1 < L);
                 if (interior) {
+                    // (buffer loads as in the 12-tap path cost this instantiation more in SGPR spills -- 48
+                    // taps live in SGPRs -- than the address adds they save: 6.8 vs 6.6 ms)
                     const int16_t *row = x + (size_t) mb * (size_t) N + c;
     #pragma unroll
                     for (int p = 0; p < GROUP; ++p) xi[p] = (int) row[(size_t) p * (size_t) N];
