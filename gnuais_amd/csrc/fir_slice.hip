@@ -342,9 +342,16 @@ __global__ __launch_bounds__(64) void fir_slice_kernel(
 #ifndef FIR_SIGN_FENCE
 #define FIR_SIGN_FENCE 4
 #endif
+// main-loop loads of the 12-tap instantiation: 0 plain global loads, 1 buffer loads (no VALU address
+// adds), 2 typed buffer loads (16-bit SSCALED descriptor: the memory pipeline also does the int16 ->
+// float conversion, exactly -- scripts/ubench/fmt_load.hip checks all 65536 values)
 #ifndef FIR_BUFFER_LOADS
-#define FIR_BUFFER_LOADS 1
+#define FIR_BUFFER_LOADS 2
 #endif
+typedef int fir_v4i __attribute__((ext_vector_type(4)));
+// clang has no builtin for llvm.amdgcn.raw.buffer.load.format; the intrinsic is reached by name
+extern "C" __device__ float fir_load_format_f32(fir_v4i rsrc, int voffset, int soffset, int aux)
+    __asm("llvm.amdgcn.raw.buffer.load.format.f32");
 // zero-instruction fence (see touch16): bounds how many samples the scheduler interleaves,
 // i.e. how many products are alive at once; without it the kernel needs 98 VGPRs (4 waves per
 // SIMD) instead of <= 88 (5 waves)
@@ -389,6 +396,7 @@ __global__ __launch_bounds__(64) void fir_sign_kernel(
 #pragma unroll
     for (int q = 0; q < NC; ++q) acc[q] = 0.0f;
     int peak = 0;
+    int peakbits = 0;                           // 12-tap path: the peak as float bits (see there)
     const int m0 = t0 - dc;                     // local sample i <-> m = m0 + i, feeds output o = i - q
 
     // exact value of output n: filter.h:40-49 order, samples re-read from memory 32 at a time
@@ -460,6 +468,12 @@ __global__ __launch_bounds__(64) void fir_sign_kernel(
         const_cast<int16_t *>(x) + (size_t) row0 * (size_t) N, 0,
         (int) (span > 0xffffffffull ? 0xffffffffull : span), 0x00020000);
     const int coff = c * 2;
+    // the same range as a typed descriptor: DST_SEL_X = R, NUM_FORMAT = SSCALED, DATA_FORMAT = 16
+    const unsigned long long xbase = (unsigned long long) (x + (size_t) row0 * (size_t) N);
+    const fir_v4i rsrc_f = {(int) (xbase & 0xffffffffull), (int) ((xbase >> 32) & 0xffffull),
+                            (int) (span > 0xffffffffull ? 0xffffffffull : span), 0x13004};
+    (void) rsrc_f;
+    (void) rsrc;
 
   if constexpr (NC % 32 != 16) {
         const int nblk = (t1 - t0 + 95) / 96;
@@ -468,45 +482,52 @@ __global__ __launch_bounds__(64) void fir_sign_kernel(
             for (int w3 = 0; w3 < 3; ++w3) {
                 const int obase = b * 96 + w3 * 32;             // outputs obase .. obase+31
                 if (t0 + obase >= t1) break;
-                int xi[32];
+                float xf[32];                                   // the word's samples, as floats (exact)
                 const int mb = m0 + NC - 1 + obase;             // sample of phase 0
                 const bool interior = (mb >= 0) && (mb + 31 < L);
                 if (interior) {
                     // buffer loads: descriptor (wave-uniform base = this segment's first row) in SGPRs, the
                     // row in the scalar offset, the lane's constant byte offset in the vector offset -- no
-                    // per-load 64-bit VALU address add (a sixth of this kernel's issue cycles otherwise)
-#if FIR_BUFFER_LOADS
+                    // per-load 64-bit VALU address add (a sixth of this kernel's issue cycles otherwise);
+                    // typed, the load also delivers the sample as a float
+#if FIR_BUFFER_LOADS == 2
     #pragma unroll
                     for (int p = 0; p < 32; ++p)
-                        xi[p] = (int) (int16_t) __builtin_amdgcn_raw_buffer_load_b16(
+                        xf[p] = fir_load_format_f32(rsrc_f, coff, (int) ((uint32_t) (mb - row0 + p) * rowbytes), 0);
+#elif FIR_BUFFER_LOADS == 1
+    #pragma unroll
+                    for (int p = 0; p < 32; ++p)
+                        xf[p] = (float) (int) (int16_t) __builtin_amdgcn_raw_buffer_load_b16(
                             rsrc, coff, (int) ((uint32_t) (mb - row0 + p) * rowbytes), 0);
 #else
                     const int16_t *row = x + (size_t) mb * (size_t) N + c;
     #pragma unroll
-                    for (int p = 0; p < 32; ++p) xi[p] = (int) row[(size_t) p * (size_t) N];
+                    for (int p = 0; p < 32; ++p) xf[p] = (float) (int) row[(size_t) p * (size_t) N];
 #endif
                 } else {
     #pragma unroll
                     for (int p = 0; p < 32; ++p) {
                         int m = mb + p;
                         m = (m < L) ? m : L - 1;
-                        xi[p] = load_sample(x, hist, m, N, NTaps, c);
+                        xf[p] = (float) load_sample(x, hist, m, N, NTaps, c);
                     }
                 }
-                {   // filter.c:118-119 peak (same bookkeeping as K1, shift = dc - NC + 1)
+                {   // filter.c:118-119 peak (same bookkeeping as K1, shift = dc - NC + 1).  For values >= 0
+                    // the order of floats is the order of their bit patterns as signed integers, and
+                    // negative floats are negative integers: an integer max against 0 is the float max
                     int bp = 0;
                     if (interior) {
     #pragma unroll
-                        for (int p = 0; p < 32; ++p) bp = xi[p] > bp ? xi[p] : bp;
+                        for (int p = 0; p < 32; ++p) bp = __float_as_int(xf[p]) > bp ? __float_as_int(xf[p]) : bp;
                     } else {
     #pragma unroll
                         for (int p = 0; p < 32; ++p) {
                             const int m = mb + p;
-                            const int v = (m >= 0 && m < L) ? xi[p] : 0;
+                            const int v = (m >= 0 && m < L) ? __float_as_int(xf[p]) : 0;
                             bp = v > bp ? v : bp;
                         }
                     }
-                    peak = bp > peak ? bp : peak;
+                    peakbits = bp > peakbits ? bp : peakbits;
                 }
                 // Two flag bits per sample, each gathered with ONE v_alignbit_b32 (shift the word
                 // left, take the new bit from another register's bit 31) instead of compare +
@@ -518,7 +539,7 @@ __global__ __launch_bounds__(64) void fir_sign_kernel(
     #pragma unroll
                 for (int p = 0; p < 32; ++p) {
                     const int P = w3 * 32 + p;                  // phase 0..95, P % 12 static
-                    const float xs = (float) xi[p];
+                    const float xs = xf[p];
     #pragma unroll
                     for (int q = 0; q < NC / 2; ++q) {
                         const float pr = ctap(q) * xs;      // == central tap NC-1-q times xs, bit for bit
@@ -547,7 +568,7 @@ __global__ __launch_bounds__(64) void fir_sign_kernel(
                 if (__popc(amb) >= 8) {                         // a silent stretch?
                     uint32_t o = 0;
     #pragma unroll
-                    for (int p = 0; p < 32; ++p) o |= (uint32_t) xi[p];
+                    for (int p = 0; p < 32; ++p) o |= __float_as_uint(xf[p]);      // (float) 0 is +0.0: all bits clear
                     zc = o == 0;
                     zc_known = true;
                     const int before = J0 + NC - 1;
@@ -725,6 +746,10 @@ __global__ __launch_bounds__(64) void fir_sign_kernel(
         }
   }
 
+    {
+        const int pk = (int) __int_as_float(peakbits);
+        peak = pk > peak ? pk : peak;
+    }
     if (t1 == L) {                              // the last dc-NC+1 samples of the call
         const int shift = dc - NC + 1;
         for (int n = (L - shift > 0 ? L - shift : 0); n < L; ++n) {

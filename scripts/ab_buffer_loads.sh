@@ -5,6 +5,7 @@ cd $GRAFT_REPO_ROOT
 run() { for i in 1 2; do timeout 300 python bench.py --no-cpu 2>&1 | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('$1', round(d['ms_per_step'],4), round(d['kernel_ms']['fir_slice'],4), round(d['kernel_ms_isolated']['fir_slice'],4))"; done; }
 build() { rm -f gnuais_amd/csrc/build/fir_scalar.o; make -s -C gnuais_amd/csrc EXTRA="$1" 2>&1 | grep -i error; }
 for rep in 1 2; do
-  build "-DFIR_BUFFER_LOADS=0"; run plain
-  build "-DFIR_BUFFER_LOADS=1"; run buffer
+  build "-DFIR_BUFFER_LOADS=${A:-0}"; run "loads=${A:-0}"
+  build "-DFIR_BUFFER_LOADS=${B:-1}"; run "loads=${B:-1}"
 done
+build ""
