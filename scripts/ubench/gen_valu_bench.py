@@ -26,6 +26,21 @@ modes["mul32"] = [f"v_mul_f32 v{100+i}, %0, v{100+i}" for i in range(32)]
 modes["iadd32"] = [f"v_add_u32 v{100+i}, v{100+i}, %0" for i in range(32)]
 # G: 32 x v_fma_f32
 modes["fma32"] = [f"v_fma_f32 v{100+i}, v{100+i}, %0, %0" for i in range(32)]
+# G2: 32 x v_fmac_f32 (VOP2 encoding, accumulate in place), SGPR and VGPR multiplicand
+modes["fmac32"] = [f"v_fmac_f32 v{100+i}, %0, v{140+i%8}" for i in range(32)]
+modes["fmac32_sgpr"] = ["s_mov_b32 s20, 0x3f000000"] + [f"v_fmac_f32 v{100+i}, s20, v{140+i%8}" for i in range(32)]
+# K1s-like with FMA: 1 mul + 11 fmac per "sample" on 12 rotating accumulators
+kf = []
+for smp in range(4):
+    for q in range(6):
+        a0 = 100 + (smp + 11 - q) % 12
+        a1 = 100 + (smp + q) % 12
+        if q == 0:
+            kf.append(f"v_mul_f32 v{a0}, s20, v{140+smp}")
+        else:
+            kf.append(f"v_fmac_f32 v{a0}, s20, v{140+smp}")
+        kf.append(f"v_fmac_f32 v{a1}, s20, v{140+smp}")
+modes["k1s_fma_4samples"] = ["s_mov_b32 s20, 0x3f000000"] + kf
 # H: 32 x v_pk_fma
 modes["pk_fma32"] = [f"v_pk_fma_f32 v[{100+2*i}:{101+2*i}], v[{100+2*i}:{101+2*i}], %1, %1" for i in range(32)]
 
