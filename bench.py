@@ -27,8 +27,10 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.3 TB/s measured)
 N_SIMD = 1024                  # 256 CUs x 4
 # SIMD time one 64-channel wave of the sign-exact slicer needs per sample, from the measured
-# per-instruction issue costs (scripts/ubench/valu_rate): 18 x 1.04 ns + 7.5 x 1.9 ns
-K1S_NS_PER_WAVE_SAMPLE = 33.0
+# per-instruction issue costs (scripts/ubench/valu_rate): 19 two-operand ops (6 mul, 12 add, the
+# peak's max) x 1.04 ns + 4 three-operand-class ops (|y| - eps, two alignbits, spill / misc) x 1.9 ns;
+# 23.0 VALU instructions per wave-sample measured (profiles/r01_pmc_sq_counters.json)
+K1S_NS_PER_WAVE_SAMPLE = 27.4
 TIMING_STRIDE = 4              # per-kernel events on every 4th call of the timed region
                                # per SIMD x 1024 SIMDs, unfused v_mul_f32/v_add_f32
 
@@ -252,9 +254,8 @@ def main():
                          "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": pmc_traffic(dom),
                          "algorithmic_bytes_per_launch": alg[dom],
                          "achieved_isolated": alg[dom] / (kiso[dom] * 1e-3) / 1e9,
-                         # K1s is VALU-issue bound, not HBM bound: per sample and wave 18 plain
-                         # fp32 ops (1.04 ns each at saturation, scripts/ubench) + 7.5 VOP3/VOPC
-                         # class ops (1.9 ns each) = 33 ns of SIMD time
+                         # K1s is VALU-issue bound, not HBM bound: 27.4 ns of SIMD time per
+                         # sample and wave (see K1S_NS_PER_WAVE_SAMPLE)
                          "valu_floor_ms": K1S_NS_PER_WAVE_SAMPLE * 1e-6 * (n_ch / 64.0) * total / N_SIMD,
                          "valu_frac_isolated": (K1S_NS_PER_WAVE_SAMPLE * 1e-6 * (n_ch / 64.0) * total
                                                 / N_SIMD) / kiso["fir_slice"]},
