@@ -426,12 +426,15 @@ __global__ __launch_bounds__(64) void fir_sign_kernel(
     };
 
     // warm-up: samples i = 0 .. NC-2
+    float tail[NC - 1];                         // direct form: the NC-1 samples before the current word
     {
         int xw[NC - 1];
 #pragma unroll
         for (int i = 0; i < NC - 1; ++i) xw[i] = load_sample(x, hist, m0 + i, N, NTaps, c);
 #pragma unroll
-        for (int i = 0; i < NC - 1; ++i) {
+        for (int i = 0; i < NC - 1; ++i) tail[i] = (float) xw[i];
+#pragma unroll
+        for (int i = 0; i < NC - 1 && !K1S_DIRECT(NC); ++i) {
             const float xs = (float) xw[i];
 #pragma unroll
             for (int q = 0; q <= i; ++q) {
@@ -539,24 +542,44 @@ __global__ __launch_bounds__(64) void fir_sign_kernel(
     #pragma unroll
                 for (int p = 0; p < 32; ++p) {
                     const int P = w3 * 32 + p;                  // phase 0..95, P % 12 static
-                    const float xs = xf[p];
+                    float y;
+                    if constexpr (K1S_DIRECT(NC)) {
+                        // direct form on the word's own registers: the window of output p is
+                        // xf[p-NC+1 .. p] (older than the word: tail[]); symmetric taps share a product,
+                        // and the sum of two int16-valued floats is exact: NC/2 adds, NC/2 muls,
+                        // NC/2-1 adds -- one op less than the transposed form, no accumulator ring.
+                        // Edge taps first, so the big central terms see the fewest roundings.
+                        auto xb = [&](int k) -> float {     // the sample k steps before the newest
+                            return p - k >= 0 ? xf[p - k >= 0 ? p - k : 0] : tail[p - k >= 0 ? 0 : NC - 1 + p - k];
+                        };
+                        y = ctap(0) * (xb(0) + xb(NC - 1));
     #pragma unroll
-                    for (int q = 0; q < NC / 2; ++q) {
-                        const float pr = ctap(q) * xs;      // == central tap NC-1-q times xs, bit for bit
-                        const int s0 = (P + NC - 1 - q) % NC;
-                        const int s1 = (P + q) % NC;
-                        if (q == 0) acc[s0] = pr; else acc[s0] = acc[s0] + pr;
-                        acc[s1] = acc[s1] + pr;
+                        for (int q = 1; q < NC / 2; ++q) y = y + ctap(q) * (xb(q) + xb(NC - 1 - q));
+                        (void) P;
+                    } else {
+                        const float xs = xf[p];
+    #pragma unroll
+                        for (int q = 0; q < NC / 2; ++q) {
+                            const float pr = ctap(q) * xs;  // == central tap NC-1-q times xs, bit for bit
+                            const int s0 = (P + NC - 1 - q) % NC;
+                            const int s1 = (P + q) % NC;
+                            if (q == 0) acc[s0] = pr; else acc[s0] = acc[s0] + pr;
+                            acc[s1] = acc[s1] + pr;
+                        }
+                        y = acc[P % NC];                    // y_c of output obase + p
                     }
-                    const float y = acc[P % NC];                // y_c of output obase + p
                     neg = __builtin_amdgcn_alignbit(neg, __float_as_uint(y), 31);
                     amb = __builtin_amdgcn_alignbit(amb, __float_as_uint(__builtin_fabsf(y) - eps_up), 31);
     #if FIR_SIGN_FENCE > 0
-                    if (p % FIR_SIGN_FENCE == FIR_SIGN_FENCE - 1) {
+                    if (p % FIR_SIGN_FENCE == FIR_SIGN_FENCE - 1 && !K1S_DIRECT(NC)) {
     #pragma unroll
                         for (int g = 0; g < NC; g += 12) touch12(acc + g);
                     }
     #endif
+                }
+                if constexpr (K1S_DIRECT(NC)) {
+    #pragma unroll
+                    for (int k = 0; k < NC - 1; ++k) tail[k] = xf[32 - (NC - 1) + k];
                 }
                 uint32_t w = ~neg;
                 const int valid = t1 - (t0 + obase);

@@ -248,7 +248,17 @@ int gnuais_batch_create(gnuais_batch **out, int device, int n_channels, const fl
             for (int j = 0; j < NE; ++j)
                 if (j < J0 || j >= J0 + NC) sum_out += std::fabs((double) b->te[j]);
             // + NE subnormal products, each off by at most 2^-150 (absolute)
-            const double bound = X * (ordered(0, NE) + ordered(J0, NC) + sum_out) + 1e-30;
+            // NC = 12 is evaluated in direct form: s_q = x_a + x_b (exact: both are int16-valued), then
+            // y = fl(t_0 s_0), y = fl(y + fl(t_q s_q)) for q = 1..NC/2-1, edge taps first; |s_q| <= 2X
+            auto paired = [&]() {
+                double e = 0;
+                const int n = NC / 2;
+                for (int i = 1; i <= n; ++i)
+                    e += 2.0 * std::fabs((double) b->te[J0 + i - 1]) * (std::pow(1 + u, i == 1 ? n : n - i + 2) - 1);
+                return e;
+            };
+            const double central = K1S_DIRECT(NC) ? paired() : ordered(J0, NC);
+            const double bound = X * (ordered(0, NE) + central + sum_out) + 1e-30;
             if (std::isfinite(bound) && bound < 2.0) {
                 b->sign_eps = (float) (bound * 1.1);
                 b->sign_NC = NC;

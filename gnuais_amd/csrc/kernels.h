@@ -77,6 +77,13 @@ hipError_t launch_tile_channels(const int16_t *base, int n_base, int len, int16_
 hipError_t launch_crc16(const uint8_t *data, int stride, const int32_t *len, int n,
                         uint16_t *crc, hipStream_t stream);
 
+// K1s evaluates the NC = 12 central taps in direct form with symmetric pre-adds (fir_slice.hip); the
+// host's error bound for y_c follows the same order of operations (gnuais_capi.hip)
+#ifndef K1S_DIRECT_12
+#define K1S_DIRECT_12 1
+#endif
+#define K1S_DIRECT(nc) (K1S_DIRECT_12 && (nc) == 12)
+
 // ---- f1 on the device (nmea_device.hip) ---------------------------------------
 size_t nmea_scratch_bytes(int n_frames);
 // frames: device gnuais_frame[n]; seq_in/seq_out: device u8[n_channels] (seq_out preloaded with
