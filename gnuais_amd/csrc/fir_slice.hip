@@ -345,6 +345,9 @@ __global__ __launch_bounds__(64) void fir_slice_kernel(
 // main-loop loads of the 12-tap instantiation: 0 plain global loads, 1 buffer loads (no VALU address
 // adds), 2 typed buffer loads (16-bit SSCALED descriptor: the memory pipeline also does the int16 ->
 // float conversion, exactly -- scripts/ubench/fmt_load.hip checks all 65536 values)
+#ifndef FIR_DIRECT_UNROLL
+#define FIR_DIRECT_UNROLL 3
+#endif
 #ifndef FIR_BUFFER_LOADS
 #define FIR_BUFFER_LOADS 2
 #endif
@@ -479,11 +482,15 @@ __global__ __launch_bounds__(64) void fir_sign_kernel(
     (void) rsrc;
 
   if constexpr (NC % 32 != 16) {
-        const int nblk = (t1 - t0 + 95) / 96;
+        // words unrolled per loop turn: three for the transposed form (whole turns of its accumulator
+        // ring); the direct form has no ring and takes FIR_DIRECT_UNROLL (the tail registers are renamed
+        // inside the unrolled body, moved only at the back edge)
+        constexpr int UW = K1S_DIRECT(NC) ? FIR_DIRECT_UNROLL : 3;
+        const int nblk = (t1 - t0 + UW * 32 - 1) / (UW * 32);
         for (int b = 0; b < nblk; ++b) {
     #pragma unroll
-            for (int w3 = 0; w3 < 3; ++w3) {
-                const int obase = b * 96 + w3 * 32;             // outputs obase .. obase+31
+            for (int w3 = 0; w3 < UW; ++w3) {
+                const int obase = (b * UW + w3) * 32;           // outputs obase .. obase+31
                 if (t0 + obase >= t1) break;
                 float xf[32];                                   // the word's samples, as floats (exact)
                 const int mb = m0 + NC - 1 + obase;             // sample of phase 0
