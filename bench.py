@@ -29,7 +29,7 @@ N_SIMD = 1024                  # 256 CUs x 4
 # SIMD time one 64-channel wave of the sign-exact slicer needs per sample, from the measured
 # per-instruction issue costs (scripts/ubench/valu_rate): 19 two-operand ops (6 mul, 12 add, the
 # peak's max) x 1.04 ns + 4 three-operand-class ops (|y| - eps, two alignbits, spill / misc) x 1.9 ns;
-# 23.0 VALU instructions per wave-sample measured (profiles/r01_pmc_sq_counters.json)
+# 22.6 VALU instructions per wave-sample measured (profiles/r01_pmc_sq_counters.json)
 K1S_NS_PER_WAVE_SAMPLE = 27.4
 TIMING_STRIDE = 4              # per-kernel events on every 4th call of the timed region
                                # per SIMD x 1024 SIMDs, unfused v_mul_f32/v_add_f32
