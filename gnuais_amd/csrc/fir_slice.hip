@@ -345,6 +345,9 @@ __global__ __launch_bounds__(64) void fir_slice_kernel(
 // main-loop loads of the 12-tap instantiation: 0 plain global loads, 1 buffer loads (no VALU address
 // adds), 2 typed buffer loads (16-bit SSCALED descriptor: the memory pipeline also does the int16 ->
 // float conversion, exactly -- scripts/ubench/fmt_load.hip checks all 65536 values)
+#ifndef FIR_TYPED_LOADS_48
+#define FIR_TYPED_LOADS_48 1
+#endif
 #ifndef FIR_DIRECT_UNROLL
 #define FIR_DIRECT_UNROLL 3
 #endif
@@ -708,42 +711,51 @@ __global__ __launch_bounds__(64) void fir_sign_kernel(
                 const int gi = b * NG + g;                      // group index within the segment
                 const int gbase = gi * GROUP;                   // outputs gbase .. gbase+GROUP-1
                 if (gi >= ngroups) break;
-                int xi[GROUP];
+                float xf[GROUP];                                // the group's samples as floats (exact)
                 const int mb = m0 + NC - 1 + gbase;             // sample of the group's first phase
                 const bool interior = (mb >= 0) && (mb + GROUP - 1 < L);
                 if (interior) {
-                    // (buffer loads as in the 12-tap path cost this instantiation more in SGPR spills -- 48
-                    // taps live in SGPRs -- than the address adds they save: 6.8 vs 6.6 ms)
+#if FIR_TYPED_LOADS_48
+                    // typed buffer loads as in the 12-tap path, but with the row in the VECTOR offset (one
+                    // two-operand add per load): this instantiation has no SGPRs to spare for 16 row offsets
+                    // -- with them it lost 6.8 vs 6.6 ms -- and still sheds the 64-bit address add and the
+                    // int -> float convert
+                    const int voff0 = coff + (int) ((uint32_t) (mb - row0) * rowbytes);
+    #pragma unroll
+                    for (int p = 0; p < GROUP; ++p)
+                        xf[p] = fir_load_format_f32(rsrc_f, voff0 + (int) ((uint32_t) p * rowbytes), 0, 0);
+#else
                     const int16_t *row = x + (size_t) mb * (size_t) N + c;
     #pragma unroll
-                    for (int p = 0; p < GROUP; ++p) xi[p] = (int) row[(size_t) p * (size_t) N];
+                    for (int p = 0; p < GROUP; ++p) xf[p] = (float) (int) row[(size_t) p * (size_t) N];
+#endif
                 } else {
     #pragma unroll
                     for (int p = 0; p < GROUP; ++p) {
                         int m = mb + p;
                         m = (m < L) ? m : L - 1;
-                        xi[p] = load_sample(x, hist, m, N, NTaps, c);
+                        xf[p] = (float) load_sample(x, hist, m, N, NTaps, c);
                     }
                 }
-                {   // filter.c:118-119 peak (same bookkeeping as K1, shift = dc - NC + 1)
+                {   // filter.c:118-119 peak, on the float bit patterns (see the 12-tap path)
                     int bp = 0;
                     if (interior) {
     #pragma unroll
-                        for (int p = 0; p < GROUP; ++p) bp = xi[p] > bp ? xi[p] : bp;
+                        for (int p = 0; p < GROUP; ++p) bp = __float_as_int(xf[p]) > bp ? __float_as_int(xf[p]) : bp;
                     } else {
     #pragma unroll
                         for (int p = 0; p < GROUP; ++p) {
                             const int m = mb + p;
-                            const int v = (m >= 0 && m < L) ? xi[p] : 0;
+                            const int v = (m >= 0 && m < L) ? __float_as_int(xf[p]) : 0;
                             bp = v > bp ? v : bp;
                         }
                     }
-                    peak = bp > peak ? bp : peak;
+                    peakbits = bp > peakbits ? bp : peakbits;
                 }
     #pragma unroll
                 for (int p = 0; p < GROUP; ++p) {
                     const int P = g * GROUP + p;                // phase within the unrolled block, P % NC static
-                    const float xs = (float) xi[p];
+                    const float xs = xf[p];
     #pragma unroll
                     for (int q = 0; q < NC / 2; ++q) {
                         const float pr = ctap(q) * xs;      // == central tap NC-1-q times xs, bit for bit
@@ -767,7 +779,7 @@ __global__ __launch_bounds__(64) void fir_sign_kernel(
                 // to a silent word, whatever its samples are.
                 if (amb != 0) {
     #pragma unroll
-                    for (int p = 0; p < GROUP; ++p) zor |= (uint32_t) xi[p];
+                    for (int p = 0; p < GROUP; ++p) zor |= __float_as_uint(xf[p]);
                 } else {
                     zor |= 1u;
                 }
