@@ -2,8 +2,9 @@
 //
 // Owns the per-batch device state (FIR history, PLL phase, deframer state,
 // frame ring) and sequences the kernels of one receiver_run() pass:
-//   K1 fir_slice (+ history carry) -> K2a pll_core -> K2x nrzi_extract -> K2b hdlc_deframe -> K3 hdlc_crc
-// K1 on the caller's stream, every later stage on an internal stream of its own, chained by
+//   K1 fir_slice (+ history carry) -> K2t pll_edges -> K2a pll_phase -> K2x nrzi_bits -> K2b hdlc_deframe
+//   -> K3 hdlc_crc
+// K1 and K2t on the caller's stream, every later stage on an internal stream of its own, chained by
 // events over four sets of hand-off buffers, so that the stages of consecutive calls overlap
 // (DESIGN.md 4.6); `pipeline` = 0 runs them back to back on the caller's stream instead.
 // No CPU implementation of the chain exists here: without a usable HIP device every entry
@@ -70,9 +71,16 @@ struct gnuais_batch {
     // every hand-off buffer exists NBUF times (index = call % NBUF), so K1 can run up
     // to NBUF-1 calls ahead of the sequential stages
     static constexpr int NBUF = 4;
-    uint32_t *sgn[NBUF] = {};                   // K1 -> K2a/K2x
-    uint32_t *ovf[NBUF] = {};                   // K2a -> K2x
+    uint32_t *sgn[NBUF] = {};                   // K1 -> K2t/K2x
+    void *edges[NBUF] = {};                     // K2t -> K2a: transition lists
+    uint32_t *en4p[NBUF] = {};                  //   rows K2a streams per (segment, channel group)
+    uint32_t *xs[NBUF] = {};                    // K2a -> K2x: phase at every segment start
+    uint32_t *prev0[NBUF] = {};                 // K2t -> K2x: sign before the call's first sample
+    uint32_t *seglast[NBUF] = {};               // K2x -> level carry
     uint32_t *pll = nullptr, *lastbit = nullptr;
+    uint32_t *prev[2] = {nullptr, nullptr};     // sign of the last sample, ping-pong like hist
+    int prev_cur = 0;
+    int n_cu = 256;
     uint32_t *segbits[NBUF] = {};               // K2x -> K2b
     uint32_t *segcnt[NBUF] = {};
     int n_seg = 0, seg_words = 0;
@@ -120,7 +128,7 @@ struct gnuais_batch {
     // timing: a ring of per-call event sets so that kernel durations can be read back
     // for every call of a timed region, not just the last one
     static constexpr int TIMING_RING = 64;
-    hipEvent_t evr[TIMING_RING][10] = {};  // 0,1 K1 | 2,6 K2a | 8,3 K2x | 5,7 K2b | 9,4 K3
+    hipEvent_t evr[TIMING_RING][11] = {};  // 0,1 K1 | 1,10 K2t | 2,6 K2a | 8,3 K2x | 5,7 K2b | 9,4 K3
     unsigned long long timed_calls = 0;
     int last_k = 0;
     bool timed_last = false;
@@ -159,12 +167,12 @@ void gnuais_batch_destroy(gnuais_batch *b)
     if (!b) return;
     (void) hipSetDevice(b->device);
     for (int q = 0; q < gnuais_batch::NBUF; ++q) {
-        void *set[] = {b->sgn[q], b->ovf[q], b->segbits[q], b->segcnt[q], b->cand_first[q],
-                       b->cand_count[q]};
+        void *set[] = {b->sgn[q], b->edges[q], b->en4p[q], b->xs[q], b->prev0[q], b->seglast[q],
+                       b->segbits[q], b->segcnt[q], b->cand_first[q], b->cand_count[q]};
         for (void *p : set)
             if (p) (void) hipFree(p);
     }
-    void *ptrs[] = {b->hist[0], b->hist[1], b->pll, b->lastbit, b->ctl, b->cand,
+    void *ptrs[] = {b->hist[0], b->hist[1], b->pll, b->lastbit, b->prev[0], b->prev[1], b->ctl, b->cand,
                     b->frame_count, b->counters, b->maxval[0], b->maxval[1], b->frames, b->d_taps,
                     b->stage_x, b->d_seq[0], b->d_seq[1], b->d_text, b->nmea_scratch};
     for (void *p : ptrs)
@@ -193,9 +201,12 @@ int gnuais_batch_create(gnuais_batch **out, int device, int n_channels, const fl
     if (ndev <= 0) return fail(GNUAIS_E_HIP, "create: no HIP device");
     if (device < 0 || device >= ndev) return fail(GNUAIS_E_ARG, "create: device index");
     HIP_TRY(hipSetDevice(device));
+    HIP_TRY(pll_prepare_device());              // per device: the PLL stage's LDS reservation
 
     gnuais_batch *b = new gnuais_batch;
     b->device = device;
+    if (hipDeviceGetAttribute(&b->n_cu, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || b->n_cu <= 0)
+        b->n_cu = 256;
     b->N = n_channels;
     if (taps) {
         b->taps.assign(taps, taps + n_taps);
@@ -287,16 +298,23 @@ int gnuais_batch_create(gnuais_batch **out, int device, int n_channels, const fl
     }
     for (int k = 0; k < gnuais_batch::NBUF; ++k) {
         alloc((void **) &b->sgn[k], sizeof(uint32_t) * N * (b->sgn_words + PLL_PAD_ROWS));
-        alloc((void **) &b->segbits[k], sizeof(uint32_t) * N * (size_t) b->n_seg * b->seg_words);
+        alloc((void **) &b->segbits[k], sizeof(uint32_t) * N * (size_t) b->n_seg * PACK_STRIDE);
         alloc((void **) &b->segcnt[k], sizeof(uint32_t) * N * (size_t) b->n_seg);
     }
     for (int k = 0; k < gnuais_batch::NBUF; ++k) {
-        alloc((void **) &b->ovf[k], sizeof(uint32_t) * N * (b->sgn_words + PLL_PAD_ROWS));
+        // transition lists: worst case one entry per sample (2 bytes each), normally ~0.15
+        alloc((void **) &b->edges[k], sizeof(uint4) * N * (size_t) b->n_seg * EDGE_PAIRS);
+        alloc((void **) &b->en4p[k], sizeof(uint32_t) * (size_t) ((b->N + 63) / 64) * b->n_seg);
+        alloc((void **) &b->xs[k], sizeof(uint32_t) * N * (size_t) b->n_seg);
+        alloc((void **) &b->prev0[k], sizeof(uint32_t) * N);
+        alloc((void **) &b->seglast[k], sizeof(uint32_t) * N * (size_t) b->n_seg);
         alloc((void **) &b->cand_first[k], sizeof(uint32_t) * N);
         alloc((void **) &b->cand_count[k], sizeof(uint32_t) * N);
     }
     alloc((void **) &b->pll, sizeof(uint32_t) * N);
     alloc((void **) &b->lastbit, sizeof(uint32_t) * N);
+    alloc((void **) &b->prev[0], sizeof(uint32_t) * N);
+    alloc((void **) &b->prev[1], sizeof(uint32_t) * N);
     alloc((void **) &b->ctl, sizeof(uint32_t) * N * HDLC_CTL_WORDS);
     // candidate ring, per channel and call.  The deframer cannot open frames faster than one per
     // 30 bits (16 alternating bits to leave ST_SKURR, protodec.c:1030-1043, six ones each for the
@@ -383,6 +401,9 @@ int gnuais_batch_reset(gnuais_batch *b)
     b->hist_cur = 0;
     HIP_TRY(hipMemset(b->pll, 0, sizeof(uint32_t) * N));              // receiver.c:66-71
     HIP_TRY(hipMemset(b->lastbit, 0, sizeof(uint32_t) * N));
+    HIP_TRY(hipMemset(b->prev[0], 0, sizeof(uint32_t) * N));
+    HIP_TRY(hipMemset(b->prev[1], 0, sizeof(uint32_t) * N));
+    b->prev_cur = 0;
     for (int k = 0; k < gnuais_batch::NBUF; ++k)
         HIP_TRY(hipMemset(b->segcnt[k], 0, sizeof(uint32_t) * N * (size_t) b->n_seg));
     b->calls = 0;
@@ -490,9 +511,12 @@ static int run_fir(gnuais_batch *b, const int16_t *x, int len, float *dump, hipS
 
 static void fill_pll(const gnuais_batch *b, PllLaunch &p, int k, int len)
 {
-    p.sgn = b->sgn[k]; p.ovf = b->ovf[k]; p.pll = b->pll; p.watchdog = b->frame_count + 3; p.lastbit = b->lastbit;
-    p.segbits = b->segbits[k]; p.segcnt = b->segcnt[k];
+    p.sgn = b->sgn[k]; p.edges = b->edges[k]; p.en4p = b->en4p[k]; p.xs = b->xs[k]; p.pll = b->pll;
+    p.prev_in = b->prev[b->prev_cur]; p.prev_out = b->prev[b->prev_cur ^ 1]; p.prev0 = b->prev0[k];
+    p.watchdog = b->frame_count + 3; p.lastbit = b->lastbit;
+    p.segbits = b->segbits[k]; p.segcnt = b->segcnt[k]; p.seglast = b->seglast[k];
     p.N = b->N; p.L = len; p.n_seg = b->n_seg; p.seg_words = b->seg_words; p.pllinc = b->pllinc;
+    p.n_cu = b->n_cu;
 }
 
 
@@ -505,10 +529,10 @@ static int run_tail(gnuais_batch *b, int k, int len, bool tm, hipEvent_t *ev,
     hipStream_t sB = pl ? b->s_k[1] : s0, sC = pl ? b->s_k[2] : s0, sD = pl ? b->s_k[3] : s0;
     PllLaunch p;
     fill_pll(b, p, k, len);
-    // K2x: needs ovf[k]; fills segbits[k] (read by K2b of call - NBUF)
+    // K2x: needs xs[k]; fills segbits[k] (read by K2b of call - NBUF)
     if (pl && after) HIP_TRY(hipStreamWaitEvent(sB, after, 0));
     if (tm) HIP_TRY(hipEventRecord(ev[8], sB));
-    if (b->stage_mask & 4) HIP_TRY(launch_nrzi_extract(p, sB));
+    if (b->stage_mask & 4) HIP_TRY(launch_nrzi_bits(p, sB));
     if (tm) HIP_TRY(hipEventRecord(ev[3], sB));
     if (pl) HIP_TRY(hipEventRecord(b->e_done[2][k], sB));
 
@@ -553,15 +577,19 @@ int gnuais_batch_run(gnuais_batch *b, const int16_t *d_samples, int len, void *s
         if (b->stage_mask & 1)
             if (int rc = run_fir(b, d_samples, len, nullptr, s0, k)) return rc;
         if (tm) HIP_TRY(hipEventRecord(ev[1], s0));
-        if (pl) HIP_TRY(hipEventRecord(b->e_done[0][k], s0));
-        // K2a: needs this call's sign words; fills ovf[k] (read by K2x of call i-NBUF)
+        // K2t: this call's sign words -> transition lists edges[k]; parallel, so it stays with the FIR
         PllLaunch p;
         fill_pll(b, p, k, len);
+        if (b->stage_mask & 2) HIP_TRY(launch_pll_edges(p, s0));
+        b->prev_cur ^= 1;
+        if (tm) HIP_TRY(hipEventRecord(ev[10], s0));
+        if (pl) HIP_TRY(hipEventRecord(b->e_done[0][k], s0));
+        // K2a: walks edges[k]; fills xs[k] (read by K2x of call i-NBUF)
         if (pl) {
             HIP_TRY(hipStreamWaitEvent(sA, b->e_done[0][k], 0));
         }
         if (tm) HIP_TRY(hipEventRecord(ev[2], sA));
-        if (b->stage_mask & 2) HIP_TRY(launch_pll_core(p, sA));
+        if (b->stage_mask & 2) HIP_TRY(launch_pll_phase(p, sA));
         if (tm) HIP_TRY(hipEventRecord(ev[6], sA));
         if (pl) HIP_TRY(hipEventRecord(b->e_done[1][k], sA));
         if (int rc = run_tail(b, k, len, tm, ev, s0, pl ? b->e_done[1][k] : nullptr)) return rc;
@@ -713,7 +741,7 @@ int gnuais_batch_decode_bits(gnuais_batch *b, const uint8_t *h_bits, int stride,
         if (h_count[c] < 0 || h_count[c] > stride) return fail(GNUAIS_E_ARG, "decode_bits: count");
         maxc = std::max(maxc, h_count[c]);
     }
-    const size_t rowlen = (size_t) b->n_seg * b->seg_words;
+    const size_t rowlen = (size_t) b->n_seg * PACK_STRIDE;
     std::vector<uint32_t> words(rowlen * N), cnt((size_t) b->n_seg * N);
     for (int pos = 0; pos < maxc; pos += chunk) {
         std::fill(words.begin(), words.end(), 0u);
@@ -724,7 +752,7 @@ int gnuais_batch_decode_bits(gnuais_batch *b, const uint8_t *h_bits, int stride,
             for (int k = 0; k < n; ++k) {
                 const int seg = k / segcap, kk = k % segcap;
                 if (src[k] & 1)
-                    words[(size_t) c * rowlen + (size_t) seg * b->seg_words + (kk >> 5)] |= 1u << (kk & 31);
+                    words[(size_t) c * rowlen + (size_t) seg * PACK_STRIDE + (kk >> 5)] |= 1u << (kk & 31);
             }
             for (int seg = 0; seg * segcap < n; ++seg)
                 cnt[(size_t) c * b->n_seg + seg] = (uint32_t) std::min(segcap, n - seg * segcap);
@@ -747,7 +775,7 @@ int gnuais_batch_last_bits(gnuais_batch *b, uint8_t *h_bits, int stride, int32_t
     if (!b || !h_bits || !h_count || stride <= 0) return fail(GNUAIS_E_ARG, "last_bits: argument");
     if (int rc = gnuais_batch_sync(b)) return rc;
     const int N = b->N;
-    const size_t rowlen = (size_t) b->n_seg * b->seg_words;
+    const size_t rowlen = (size_t) b->n_seg * PACK_STRIDE;
     std::vector<uint32_t> words(rowlen * N), cnt((size_t) b->n_seg * N);
     HIP_TRY(hipMemcpy(words.data(), b->segbits[b->last_k], words.size() * 4, hipMemcpyDeviceToHost));
     HIP_TRY(hipMemcpy(cnt.data(), b->segcnt[b->last_k], cnt.size() * 4, hipMemcpyDeviceToHost));
@@ -759,7 +787,7 @@ int gnuais_batch_last_bits(gnuais_batch *b, uint8_t *h_bits, int stride, int32_t
             const int m = (int) std::min<uint32_t>(cnt[(size_t) c * b->n_seg + seg],
                                                    (uint32_t) b->seg_words * 32);
             if (n + m > stride) return fail(GNUAIS_E_ARG, "last_bits: stride too small");
-            const uint32_t *w = &words[(size_t) c * rowlen + (size_t) seg * b->seg_words];
+            const uint32_t *w = &words[(size_t) c * rowlen + (size_t) seg * PACK_STRIDE];
             for (int k = 0; k < m; ++k) dst[n + k] = (w[k >> 5] >> (k & 31)) & 1u;
             n += m;
         }
@@ -932,12 +960,13 @@ int gnuais_batch_pll_state(gnuais_batch *b, gnuais_pll_state *h_out)
 {
     if (!b || !h_out) return fail(GNUAIS_E_ARG, "pll_state: argument");
     if (int rc = gnuais_batch_sync(b)) return rc;
-    std::vector<uint32_t> v((size_t) b->N), lb((size_t) b->N);
+    std::vector<uint32_t> v((size_t) b->N), lb((size_t) b->N), pv((size_t) b->N);
     HIP_TRY(hipMemcpy(v.data(), b->pll, v.size() * 4, hipMemcpyDeviceToHost));
     HIP_TRY(hipMemcpy(lb.data(), b->lastbit, lb.size() * 4, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(pv.data(), b->prev[b->prev_cur], pv.size() * 4, hipMemcpyDeviceToHost));
     for (int c = 0; c < b->N; ++c) {
         h_out[c].pll = v[c] & 0xffffu;
-        h_out[c].prev = (v[c] >> 16) & 1;
+        h_out[c].prev = pv[c] & 1;
         h_out[c].lastbit = lb[c] & 1;
     }
     return GNUAIS_OK;
@@ -985,41 +1014,42 @@ int gnuais_batch_set_timing(gnuais_batch *b, int on)
     return GNUAIS_OK;
 }
 
-// ms[0] K1 fir_slice  [1] K2a pll_core  [2] K2x nrzi_extract (+ lastbit)
-// [3] K2b hdlc_deframe  [4] K3 hdlc_crc  [5] first event to last event of the call
+// ms[0] K1 fir_slice  [1] K2t pll_edges  [2] K2a pll_phase  [3] K2x nrzi_bits (+ level carry)
+// [4] K2b hdlc_deframe  [5] K3 hdlc_crc  [6] first event to last event of the call
 static int timing_of(gnuais_batch *b, unsigned long long call, float *ms)
 {
     hipEvent_t *ev = b->evr[call % gnuais_batch::TIMING_RING];
     HIP_TRY(hipEventElapsedTime(&ms[0], ev[0], ev[1]));
-    HIP_TRY(hipEventElapsedTime(&ms[1], ev[2], ev[6]));
-    HIP_TRY(hipEventElapsedTime(&ms[2], ev[8], ev[3]));
-    HIP_TRY(hipEventElapsedTime(&ms[3], ev[5], ev[7]));
-    HIP_TRY(hipEventElapsedTime(&ms[4], ev[9], ev[4]));
-    HIP_TRY(hipEventElapsedTime(&ms[5], ev[0], ev[4]));
+    HIP_TRY(hipEventElapsedTime(&ms[1], ev[1], ev[10]));
+    HIP_TRY(hipEventElapsedTime(&ms[2], ev[2], ev[6]));
+    HIP_TRY(hipEventElapsedTime(&ms[3], ev[8], ev[3]));
+    HIP_TRY(hipEventElapsedTime(&ms[4], ev[5], ev[7]));
+    HIP_TRY(hipEventElapsedTime(&ms[5], ev[9], ev[4]));
+    HIP_TRY(hipEventElapsedTime(&ms[6], ev[0], ev[4]));
     return GNUAIS_OK;
 }
 
-int gnuais_batch_last_timing(gnuais_batch *b, float *ms6)
+int gnuais_batch_last_timing(gnuais_batch *b, float *ms7)
 {
-    if (!b || !ms6) return fail(GNUAIS_E_ARG, "last_timing: argument");
+    if (!b || !ms7) return fail(GNUAIS_E_ARG, "last_timing: argument");
     if (!b->timed_calls) return fail(GNUAIS_E_STATE, "last_timing: no timed run");
     if (int rc = gnuais_batch_sync(b)) return rc;
-    return timing_of(b, b->timed_calls - 1, ms6);
+    return timing_of(b, b->timed_calls - 1, ms7);
 }
 
-int gnuais_batch_mean_timing(gnuais_batch *b, float *ms4, int *n_calls)
+int gnuais_batch_mean_timing(gnuais_batch *b, float *ms7, int *n_calls)
 {
-    if (!b || !ms4 || !n_calls) return fail(GNUAIS_E_ARG, "mean_timing: argument");
+    if (!b || !ms7 || !n_calls) return fail(GNUAIS_E_ARG, "mean_timing: argument");
     if (!b->timed_calls) return fail(GNUAIS_E_STATE, "mean_timing: no timed run");
     if (int rc = gnuais_batch_sync(b)) return rc;
     const unsigned long long n = std::min<unsigned long long>(b->timed_calls, gnuais_batch::TIMING_RING);
-    double acc[6] = {0, 0, 0, 0, 0, 0};
+    double acc[7] = {0, 0, 0, 0, 0, 0, 0};
     for (unsigned long long i = 0; i < n; ++i) {
-        float t[6];
+        float t[7];
         if (int rc = timing_of(b, b->timed_calls - 1 - i, t)) return rc;
-        for (int q = 0; q < 6; ++q) acc[q] += t[q];
+        for (int q = 0; q < 7; ++q) acc[q] += t[q];
     }
-    for (int q = 0; q < 6; ++q) ms4[q] = (float) (acc[q] / (double) n);
+    for (int q = 0; q < 7; ++q) ms7[q] = (float) (acc[q] / (double) n);
     *n_calls = (int) n;
     return GNUAIS_OK;
 }

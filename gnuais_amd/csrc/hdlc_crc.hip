@@ -50,7 +50,7 @@ enum { ST_SKURR = 1, ST_PREAMBLE = 2, ST_STARTSIGN = 3, ST_DATA = 4, ST_STOPSIGN
 // ctl[4]: raw bits in the open frame record
 constexpr uint32_t CAND_VALID = 0x10000u;
 constexpr int K3_CH = 32;               // channels per K3 block
-constexpr int PACK_MAX = 16;            // words per segment pack held in registers/LDS
+constexpr int PACK_MAX = PACK_STRIDE;   // words per segment pack held in registers/LDS
 
 __global__ void hdlc_reset_kernel(uint32_t *__restrict__ ctl, int N)
 {
@@ -116,11 +116,15 @@ __global__ __launch_bounds__(64) void hdlc_deframe_kernel(
     // while the current one is walked out of LDS.
     extern __shared__ uint32_t lds_pack[];                    // [PACK_MAX + 1][blockDim.x]
     const int tpb = (int) blockDim.x, tx = (int) threadIdx.x;
-    const uint32_t *__restrict__ rows = segbits + c * (size_t) n_seg * (size_t) seg_words;
+    const uint32_t *__restrict__ rows = segbits + c * (size_t) n_seg * (size_t) PACK_STRIDE;
     uint32_t pf[PACK_MAX];
     int pf_cnt = live ? (int) segcnt[c * (size_t) n_seg] : 0;
+    // a pack is PACK_STRIDE words, 64-byte aligned, zero beyond its bits: four 16-byte loads
 #pragma unroll
-    for (int q = 0; q < PACK_MAX; ++q) pf[q] = (q < seg_words) ? rows[q] : 0u;
+    for (int q = 0; q < PACK_MAX / 4; ++q) {
+        const uint4 v = reinterpret_cast<const uint4 *>(rows)[q];
+        pf[4 * q] = v.x; pf[4 * q + 1] = v.y; pf[4 * q + 2] = v.z; pf[4 * q + 3] = v.w;
+    }
 
     for (int seg = 0; seg < n_seg; ++seg) {
         int tile_end = pf_cnt;
@@ -129,10 +133,13 @@ __global__ __launch_bounds__(64) void hdlc_deframe_kernel(
         for (int q = 0; q < PACK_MAX; ++q) lds_pack[q * tpb + tx] = pf[q];
         lds_pack[PACK_MAX * tpb + tx] = 0;
         if (seg + 1 < n_seg) {
-            const uint32_t *__restrict__ nrow = rows + (size_t) (seg + 1) * (size_t) seg_words;
+            const uint32_t *__restrict__ nrow = rows + (size_t) (seg + 1) * (size_t) PACK_STRIDE;
             pf_cnt = live ? (int) segcnt[c * (size_t) n_seg + seg + 1] : 0;
 #pragma unroll
-            for (int q = 0; q < PACK_MAX; ++q) pf[q] = (q < seg_words) ? nrow[q] : 0u;
+            for (int q = 0; q < PACK_MAX / 4; ++q) {
+                const uint4 v = reinterpret_cast<const uint4 *>(nrow)[q];
+                pf[4 * q] = v.x; pf[4 * q + 1] = v.y; pf[4 * q + 2] = v.z; pf[4 * q + 3] = v.w;
+            }
         }
         int pos = 0;
         // A wave executes the union of what its lanes do, so the walk is batched by

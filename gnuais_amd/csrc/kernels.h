@@ -29,24 +29,35 @@ hipError_t launch_fir_generic(const FirLaunch &a, hipStream_t stream);
 hipError_t launch_fir_history(const int16_t *x, const int16_t *hist_in, int16_t *hist_out,
                               int N, int L, int NT, hipStream_t stream);
 
-// ---- K2a: PLL clock recovery, K2x: slice + NRZI (pll_nrzi.hip) --------------
-constexpr int PLL_PAD = 8;           // words per prefetch group (= unroll of the PLL loop body)
-constexpr int PLL_PAD_ROWS = 32;     // spare rows sgn/ovf carry so that batched reads need no bounds test
-constexpr int PLL_LDS_BYTES = 81 * 1024;   // > half of a CU's LDS: one PLL wave per CU
-constexpr int SEG_WORDS = 64;        // K2x segment: 64 sign words = 2048 samples
+// ---- K2t / K2a / K2x: PLL clock recovery, slice + NRZI (pll_nrzi.hip) ------------
+constexpr int PLL_PAD_ROWS = 32;     // spare rows sgn carries so that batched reads need no bounds test
+constexpr int PLL_LDS_BYTES = 81 * 1024;   // > half of a CU's LDS: one PLL workgroup per CU
+constexpr int SEG_WORDS = 64;        // segment: 64 sign words
+constexpr int SEG_LEN = SEG_WORDS * 32;    //   = 2048 samples
+constexpr int EDGE_PAIRS = 1 + SEG_LEN / 8;   // 16-byte rows per lane and segment: header + 8 entries each
+constexpr int PACK_STRIDE = 16;      // words reserved per (channel, segment) bit pack: 64 bytes
 struct PllLaunch {
     const uint32_t *sgn;   // [ceil(L/32) + PLL_PAD_ROWS][N]
-    uint32_t *ovf;         // same shape: slice marks (pll overflow), bit 31 = oldest sample
-    uint32_t *pll;         // [N] phase (bits 15:0), prev sign (bit 16)
+    void *edges;           // uint4 [n_seg][EDGE_PAIRS][N]: K2t -> K2a
+    uint32_t *en4p;        // [n_seg][ceil(N/64)] list pairs K2a streams per segment and channel group
+    uint32_t *xs;          // [n_seg][N] phase before each segment's first sample: K2a -> K2x
+    uint32_t *pll;         // [N] phase (receiver.h:40), carried
+    const uint32_t *prev_in;  // [N] sign of the last sample of the previous call (receiver.h:44)
+    uint32_t *prev_out;    // [N] ... of this call
+    uint32_t *prev0;       // [N] copy of prev_in that stays valid for this call's K2x
     uint32_t *watchdog;    // one word: set to 1 if a wave of the launch gave up waiting for its partner
-    uint32_t *lastbit;     // [N] level at the last slice (receiver.h:38)
-    uint32_t *segbits;     // [N][n_seg][seg_words] recovered bits per segment, LSB first
+    uint32_t *lastbit;     // [N] level at the last slice (receiver.h:38), carried
+    uint32_t *segbits;     // [N][n_seg][PACK_STRIDE] recovered bits per segment, LSB first
     uint32_t *segcnt;      // [N][n_seg] bits in each pack
+    uint32_t *seglast;     // [n_seg][N] level at the segment's last slice, 2 = none
     int N, L, n_seg, seg_words;
     uint32_t pllinc;
+    int n_cu;              // compute units of the batch's device
 };
-hipError_t launch_pll_core(const PllLaunch &a, hipStream_t stream);      // K2a
-hipError_t launch_nrzi_extract(const PllLaunch &a, hipStream_t stream);  // K2x + lastbit carry
+hipError_t pll_prepare_device();                                         // once per device, after hipSetDevice
+hipError_t launch_pll_edges(const PllLaunch &a, hipStream_t stream);     // K2t
+hipError_t launch_pll_phase(const PllLaunch &a, hipStream_t stream);     // K2a
+hipError_t launch_nrzi_bits(const PllLaunch &a, hipStream_t stream);     // K2x + level carry
 
 // ---- K2b: HDLC deframer, K3: CRC-16 + frame delivery (hdlc_crc.hip) ---------
 constexpr int HDLC_CTL_WORDS = 5;
@@ -54,7 +65,7 @@ constexpr int HDLC_BUF_WORDS = 15;   // 449 bits max (protodec.c:1024)
 constexpr int CAND_HDR = 2;          // [0] nbits | valid flag, [1] end_bit
 constexpr int CAND_WORDS = 20;       // header + 17 raw words (449 frame bits + stuffing) = 80 bytes
 struct HdlcLaunch {
-    const uint32_t *segbits;  // as above
+    const uint32_t *segbits;  // as above (PACK_STRIDE words per pack)
     const uint32_t *segcnt;
     uint32_t *ctl;         // [HDLC_CTL_WORDS][N] control state
     uint32_t *cand;        // [N][K][CAND_WORDS] per-channel ring of candidate frames
