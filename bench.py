@@ -232,8 +232,8 @@ def main():
         dom = "fir_slice"
         # algorithmic bytes of one launch: every int16 sample read once
         # by K1; K2a/K2b consume K1's 1-bit/sample and ~0.2-bit/sample streams
-        alg = {"fir_slice": n_ch * total * 2.0, "pll_edges": n_ch * total / 8.0, "pll_phase": n_ch * total / 8.0,
-               "nrzi_bits": n_ch * total / 8.0, "hdlc_deframe": n_ch * total * 0.2 / 8.0,
+        alg = {"fir_slice": n_ch * total * 2.0, "pll_edges": n_ch * total / 8.0, "pll_phase": n_ch * total * 0.15 * 2.0,
+               "hdlc_deframe": n_ch * total * 0.2 / 8.0,
                "hdlc_crc": msgs_per_step * 80.0}
         ach = alg[dom] / (kavg[dom] * 1e-3) / 1e9
         out = {

@@ -76,7 +76,7 @@ __device__ __forceinline__ int clz32(uint32_t v)        // 32 for v == 0
     return v ? __clz((int) v) : 32;
 }
 
-__global__ __launch_bounds__(64) void hdlc_deframe_kernel(
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(7, 8))) void hdlc_deframe_kernel(
     const uint32_t *__restrict__ segbits, const uint32_t *__restrict__ segcnt,
     uint32_t *__restrict__ ctl, uint32_t *__restrict__ cand, uint32_t *__restrict__ cand_first,
     uint32_t *__restrict__ cand_count, int32_t *__restrict__ counters,

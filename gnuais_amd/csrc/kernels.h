@@ -29,7 +29,7 @@ hipError_t launch_fir_generic(const FirLaunch &a, hipStream_t stream);
 hipError_t launch_fir_history(const int16_t *x, const int16_t *hist_in, int16_t *hist_out,
                               int N, int L, int NT, hipStream_t stream);
 
-// ---- K2t / K2a / K2x: PLL clock recovery, slice + NRZI (pll_nrzi.hip) ------------
+// ---- K2t / K2a: PLL clock recovery, slice + NRZI (pll_nrzi.hip) -------------------
 constexpr int PLL_PAD_ROWS = 32;     // spare rows sgn carries so that batched reads need no bounds test
 constexpr int PLL_LDS_BYTES = 81 * 1024;   // > half of a CU's LDS: one PLL workgroup per CU
 constexpr int SEG_WORDS = 64;        // segment: 64 sign words
@@ -40,24 +40,22 @@ struct PllLaunch {
     const uint32_t *sgn;   // [ceil(L/32) + PLL_PAD_ROWS][N]
     void *edges;           // uint4 [n_seg][EDGE_PAIRS][N]: K2t -> K2a
     uint32_t *en4p;        // [n_seg][ceil(N/64)] list pairs K2a streams per segment and channel group
-    uint32_t *xs;          // [n_seg][N] phase before each segment's first sample: K2a -> K2x
     uint32_t *pll;         // [N] phase (receiver.h:40), carried
     const uint32_t *prev_in;  // [N] sign of the last sample of the previous call (receiver.h:44)
     uint32_t *prev_out;    // [N] ... of this call
-    uint32_t *prev0;       // [N] copy of prev_in that stays valid for this call's K2x
+    uint32_t *prev0;       // [N] copy of prev_in that stays valid for this call's K2a
     uint32_t *watchdog;    // one word: set to 1 if a wave of the launch gave up waiting for its partner
     uint32_t *lastbit;     // [N] level at the last slice (receiver.h:38), carried
     uint32_t *segbits;     // [N][n_seg][PACK_STRIDE] recovered bits per segment, LSB first
     uint32_t *segcnt;      // [N][n_seg] bits in each pack
-    uint32_t *seglast;     // [n_seg][N] level at the segment's last slice, 2 = none
+    uint32_t *pend;        // [n_seg][N] parity of the transitions after the segment's last slice
     int N, L, n_seg, seg_words;
     uint32_t pllinc;
     int n_cu;              // compute units of the batch's device
 };
 hipError_t pll_prepare_device();                                         // once per device, after hipSetDevice
 hipError_t launch_pll_edges(const PllLaunch &a, hipStream_t stream);     // K2t
-hipError_t launch_pll_phase(const PllLaunch &a, hipStream_t stream);     // K2a
-hipError_t launch_nrzi_bits(const PllLaunch &a, hipStream_t stream);     // K2x + level carry
+hipError_t launch_pll_phase(const PllLaunch &a, hipStream_t stream);     // K2a + carry across segments
 
 // ---- K2b: HDLC deframer, K3: CRC-16 + frame delivery (hdlc_crc.hip) ---------
 constexpr int HDLC_CTL_WORDS = 5;
