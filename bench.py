@@ -2,14 +2,24 @@
 """bench.py -- throughput of the batch AIS receive chain on MI355X.
 
 Metric (BASELINE.json): Msamples/s demodulated (+ valid-CRC AIS msgs/s) over an
-N-channel 48 kHz batch.  Workload at every GPU count: BASELINE config C3 per GPU
--- 16384 synthetic GMSK channels x 48000 samples (1 s at 48 kHz), full chain
-FIR -> slicer/PLL/NRZI -> HDLC deframe + CRC-16, int16 input resident in HBM.
-(C3 rather than configs[1]: the metric counts valid-CRC messages, which only the
-full chain produces; configs[1] stops before the deframer.)  One step = one pass
-of the chain over the batch.  Channels shard embarrassingly over GPUs (weak
-scaling, no data-path collective); torch.distributed is used only for the
-barrier and the max-over-ranks time.
+N-channel batch.  One step = one pass of the chain over one batch of synthetic
+input resident in HBM.  Workloads (BASELINE.json configs):
+
+  C3 (default, the headline): 16384 synthetic GMSK channels x 48000 samples (1 s at
+      48 kHz) per GPU, full chain FIR -> slicer/PLL/NRZI -> HDLC deframe + CRC-16.
+      (C3 rather than configs[1]: the metric counts valid-CRC messages, which only
+      the full chain produces; configs[1] stops before the deframer.)
+  C2: 256 channels x 48000 samples, filter.c + receiver.c only (no protodec).
+  C5: 16384 channels x 192000 samples at 192 kHz (144 taps, pllinc 0x10000/20).
+
+`--config` picks the one the headline line is about; a default single-GPU run also
+measures the other two briefly and reports them under "other_configs".
+
+Channels shard embarrassingly over GPUs (weak scaling, no data-path collective):
+`--gpus N` starts one worker process per device -- N independent batches, nothing
+shared but a start/stop barrier -- unless the process was launched by
+torch.distributed.run, in which case the ranks it created are used and RCCL
+provides the barrier and the max-over-ranks time.
 
 Prints ONE JSON line on rank 0.
 """
@@ -25,14 +35,18 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.3 TB/s measured)
-N_SIMD = 1024                  # 256 CUs x 4
-# SIMD time one 64-channel wave of the sign-exact slicer needs per sample, from the measured
-# per-instruction issue costs (scripts/ubench/valu_rate): 19 two-operand ops (6 mul, 12 add, the
-# peak's max) x 1.04 ns + 4 three-operand-class ops (|y| - eps, two alignbits, spill / misc) x 1.9 ns;
-# 22.6 VALU instructions per wave-sample measured (profiles/r01_pmc_sq_counters.json)
-K1S_NS_PER_WAVE_SAMPLE = 27.4
 TIMING_STRIDE = 4              # per-kernel events on every 4th call of the timed region
-                               # per SIMD x 1024 SIMDs, unfused v_mul_f32/v_add_f32
+
+CONFIGS = {
+    # stage_mask: bit 0 FIR/slicer, bit 1 PLL + NRZI, bit 3 HDLC deframer, bit 4 CRC + delivery
+    "C2": dict(channels=256, len=48000, rate=48000, sps=5, wide=False, stage_mask=0x03,
+               what="C2: 256 ch x 48000 samples @48 kHz, filter.c + receiver.c only (no protodec)"),
+    "C3": dict(channels=16384, len=48000, rate=48000, sps=5, wide=False, stage_mask=0x1f,
+               what="C3: 16384 ch x 48000 samples @48 kHz per GPU, full chain incl. HDLC/CRC-16"),
+    "C5": dict(channels=16384, len=192000, rate=192000, sps=20, wide=True, stage_mask=0x1f,
+               what="C5: 16384 ch x 192000 samples @192 kHz (144 taps, pllinc 0x10000/20) per GPU, "
+                    "full chain incl. HDLC/CRC-16"),
+}
 
 
 def effective_cpus():
@@ -108,56 +122,59 @@ def cpu_baseline(x_host, n_sample_ch, total, x_wide=None):
     return res
 
 
-def pmc_traffic(kernel):
-    """HBM bytes per launch of `kernel` from the committed PMC passes
-    (profiles/r01_pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs of this
-    same command; FETCH_SIZE doubled per MI355X_MICROARCH.md's gfx950 correction)."""
-    path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
-    try:
-        with open(path) as f:
-            return float(json.load(f)["bytes_per_launch"][kernel])
-    except Exception:
-        return None
+class LocalSync:
+    """Start/stop barrier and result exchange of the one-process-per-GPU workers bench.py starts
+    itself: a multiprocessing barrier and a queue.  Nothing else is shared between the ranks."""
+
+    def __init__(self, rank, world, barrier, queue):
+        self.rank, self.world, self._barrier, self._queue = rank, world, barrier, queue
+
+    def barrier(self):
+        if self._barrier is not None:
+            self._barrier.wait()
+
+    def reduce(self, seconds, msgs, samples, per_rank):
+        """-> (max seconds, sum msgs, sum samples, list of per-rank dicts) on rank 0."""
+        if self.world == 1:
+            return seconds, msgs, samples, [per_rank]
+        if self.rank != 0:
+            self._queue.put((self.rank, seconds, msgs, samples, per_rank))
+            return None
+        got = [(0, seconds, msgs, samples, per_rank)] + [self._queue.get() for _ in range(self.world - 1)]
+        got.sort(key=lambda g: g[0])
+        return (max(g[1] for g in got), sum(g[2] for g in got), sum(g[3] for g in got), [g[4] for g in got])
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--channels", type=int, default=16384, help="channels per GPU")
-    ap.add_argument("--len", type=int, default=48000, help="samples per channel per step")
-    ap.add_argument("--base", type=int, default=256, help="distinct base streams")
-    ap.add_argument("--cpu-channels", type=int, default=8192,
-                    help="channels of the batch the single-core CPU baseline runs (about 13 s of CPU work)")
-    ap.add_argument("--no-cpu", action="store_true")
-    args = ap.parse_args()
+class DistSync:
+    """The same over torch.distributed (RCCL) when torch.distributed.run created the ranks."""
 
+    def __init__(self, dist, device, rank, world):
+        self.dist, self.device, self.rank, self.world = dist, device, rank, world
+
+    def barrier(self):
+        self.dist.barrier()
+
+    def reduce(self, seconds, msgs, samples, per_rank):
+        from gnuais_amd.shard import reduce_bench
+        t, m, s = reduce_bench(self.dist, self.device, seconds, msgs, samples)
+        ranks = [None] * self.world
+        self.dist.all_gather_object(ranks, per_rank)
+        return (t, m, s, ranks) if self.rank == 0 else None
+
+
+def measure(cfg, args, local, rank, sync, steps, warmup, isolated=True, post=False, keep_input=False):
+    """One workload on this rank's GPU.  Returns a dict of raw measurements."""
     import torch
-    import torch.distributed as dist
+    from gnuais_amd import ReceiverBatch, params, synth, tile_channels
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    # under torch.distributed.run (even with one rank) go through RCCL for the barrier
-    # and the reductions; a bare `python bench.py` needs no process group
-    use_dist = "RANK" in os.environ and "WORLD_SIZE" in os.environ
-    if use_dist:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29511")
-        dist.init_process_group("nccl", rank=rank, world_size=world)
-    torch.cuda.set_device(local)
     device = torch.device("cuda", local)
-
-    from gnuais_amd import ReceiverBatch, synth, tile_channels
-
-    n_ch, total = args.channels, args.len
+    n_ch, total = cfg["channels"], cfg["len"]
     # synthetic input (SURVEY 8d): base streams on the host once, tiled on the device
-    base, _ = synth.make_base_streams(args.base, total, seed=synth.SEED + rank)
+    base, _ = synth.make_base_streams(min(args.base, n_ch), total, seed=synth.SEED + rank, sps=cfg["sps"])
     x = tile_channels(torch.from_numpy(base).to(device), n_ch)
     torch.cuda.synchronize()
-
-    b = ReceiverBatch(n_ch, max_len=total, device=local)
+    kw = dict(taps=params.taps_192k(), pllinc=params.PLLINC_192K) if cfg["wide"] else {}
+    b = ReceiverBatch(n_ch, max_len=total, device=local, **kw)
     stream = torch.cuda.current_stream(device).cuda_stream
 
     def step():
@@ -165,109 +182,206 @@ def main():
         b.discard_frames(stream)
 
     # one-time calibration (untimed, before the warm-up): which internal stream serves which stage.
-    # The hardware queue a stream gets depends on what the process created before and decides up
-    # to 1.7x of the pipeline's speed; the library measures it on this input.
+    # The hardware queue a stream gets depends on what the process created before and decides a good
+    # part of the pipeline's speed; the library measures it on this input.
     b.autotune(x, stream)
-
-    for _ in range(args.warmup):
+    b.set_option("stage_mask", cfg["stage_mask"])
+    for _ in range(warmup):
         step()
     torch.cuda.synchronize()
 
-    # isolated kernel durations (one call at a time, nothing overlapping): context only
-    b.set_timing(True)
-    iso = {k: [] for k in b.KERNELS}
-    for _ in range(3):
-        step()
-        t = b.last_timing()
-        for k in iso:
-            iso[k].append(t[k])
-    torch.cuda.synchronize()
+    iso = None
+    if isolated:        # one call at a time, nothing overlapping: context only
+        b.set_timing(True)
+        acc = {k: [] for k in b.KERNELS}
+        for _ in range(3):
+            step()
+            t = b.last_timing()
+            for k in acc:
+                acc[k].append(t[k])
+        torch.cuda.synchronize()
+        iso = {k: float(np.mean(v)) for k, v in acc.items()}
     rx0 = b.total_received()
 
     # timed region: K steps, asynchronous; the library records HIP events around every
     # kernel on the stream it is launched on (event ring), read back after the region
     b.set_timing(True)
     b.set_option("timing_stride", TIMING_STRIDE)    # the event records themselves cost stream time
-    if use_dist:
-        dist.barrier()
+    sync.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(steps):
         step()
     torch.cuda.synchronize()
-    if use_dist:
-        dist.barrier()
+    dt_own = time.perf_counter() - t0
+    sync.barrier()
     dt = time.perf_counter() - t0
     rx1 = b.total_received()
     live = b.mean_timing()
     b.set_timing(False)
     b.set_option("timing_stride", 1)
-    msgs = float(rx1 - rx0)
-    # context, outside the timed region: delivering one step's frames to the host as NMEA text,
-    # formatted on the device (row f1)
-    post = None
-    if rank == 0:
+    out = {"n_ch": n_ch, "len": total, "dt": dt, "dt_own": dt_own, "steps": steps, "msgs": float(rx1 - rx0),
+           "kernel_ms": {k: float(live[k]) for k in b.KERNELS}, "kernel_ms_isolated": iso,
+           "kernel_ms_calls": int(live["calls"])}
+
+    if post and cfg["stage_mask"] == 0x1f:
+        # end to end: every step's frames leave the device as NMEA text (formatted on the device,
+        # row f1) before the next step is queued -- what a consumer of the messages gets
+        seq = np.zeros(n_ch, dtype=np.uint8)
         b.discard_frames(stream)
-        step_frames_seq = np.zeros(n_ch, dtype=np.uint8)
+        n_e2e = max(4, min(20, steps))
         for _ in range(2):                          # the first use allocates the text / scratch buffers
             b.run(x, stream=stream, sync=True)
-            t_post = time.perf_counter()
-            text, n_sent, n_fr = b.drain_nmea(step_frames_seq)
-            t_post = time.perf_counter() - t_post
-        post = {"what": "gnuais_batch_drain_nmea of one step's frames (device formatter + D2H of the text)",
-                "frames": n_fr, "sentences": n_sent, "text_bytes": len(text), "ms": t_post * 1e3,
-                "frames_per_s": n_fr / t_post}
-    if use_dist:
-        from gnuais_amd.shard import reduce_bench
-        dt, msgs, _ = reduce_bench(dist, device, dt, msgs, float(n_ch * total * args.steps))
-    msgs_per_step = msgs / args.steps
+            b.drain_nmea(seq)
+        torch.cuda.synchronize()
+        frames = text = sent = 0
+        t0 = time.perf_counter()
+        for _ in range(n_e2e):
+            b.run(x, stream=stream, sync=False)
+            tx, ns, nf = b.drain_nmea(seq)
+            frames += nf
+            sent += ns
+            text += len(tx)
+        t_e2e = time.perf_counter() - t0
+        out["end_to_end"] = {"what": "run + gnuais_batch_drain_nmea every step: chain, device sort + NMEA "
+                                     "formatter, D2H of the text (synchronous)",
+                             "steps": n_e2e, "ms_per_step": t_e2e / n_e2e * 1e3,
+                             "delivered_msgs_per_s": frames / t_e2e, "sentences": sent,
+                             "text_bytes_per_step": text / n_e2e,
+                             "Msamples_per_s": n_ch * total * n_e2e / t_e2e / 1e6}
+    if keep_input:
+        out["x_cpu"] = x[:, : args.cpu_channels].cpu().numpy()
+        out["x_wide"] = np.ascontiguousarray(x.cpu().numpy())
+    del b, x
+    torch.cuda.empty_cache()
+    return out
 
-    if rank == 0:
-        samples = float(world) * n_ch * total * args.steps
-        value = samples / dt / 1e6
-        kavg = {k: float(live[k]) for k in b.KERNELS}
-        kiso = {k: float(np.mean(v)) for k, v in iso.items()}
-        # the roofline object describes the FIR/slicer launch: 98 % of the chain's algorithmic bytes and
-        # the largest share of its issued instructions (the PLL launch can take as long, on 256 SIMDs)
-        dom = "fir_slice"
-        # algorithmic bytes of one launch: every int16 sample read once
-        # by K1; K2a/K2b consume K1's 1-bit/sample and ~0.2-bit/sample streams
-        alg = {"fir_slice": n_ch * total * 2.0, "pll_edges": n_ch * total / 8.0, "pll_phase": n_ch * total * 0.15 * 2.0,
-               "hdlc_deframe": n_ch * total * 0.2 / 8.0,
-               "hdlc_crc": msgs_per_step * 80.0}
-        ach = alg[dom] / (kavg[dom] * 1e-3) / 1e9
-        out = {
-            "metric": "Msamples/s demodulated (full chain, N-channel 48 kHz batch)",
-            "value": value, "unit": "Msamples/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32 FIR on int16 samples; u32 PLL/HDLC/CRC", "data": "synthetic",
-            "config": {"workload": "C3: 16384 ch x 48000 samples @48 kHz per GPU, full chain "
-                                   "incl. HDLC/CRC-16",
-                       "channels_per_gpu": n_ch, "samples_per_channel": total,
-                       "parallelism": f"channels sharded over {world} GPU(s), no collectives"},
-            "valid_crc_msgs_per_s": msgs / dt,
-            "x_realtime_channels": value / 0.048,
-            "kernel_ms": kavg, "kernel_ms_isolated": kiso, "kernel_ms_calls": int(live["calls"]),
-            "post_stage": post,
-            "roofline": {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": pmc_traffic(dom),
-                         "algorithmic_bytes_per_launch": alg[dom],
-                         "achieved_isolated": alg[dom] / (kiso[dom] * 1e-3) / 1e9,
-                         # K1s is VALU-issue bound, not HBM bound: 27.4 ns of SIMD time per
-                         # sample and wave (see K1S_NS_PER_WAVE_SAMPLE)
-                         "valu_floor_ms": K1S_NS_PER_WAVE_SAMPLE * 1e-6 * (n_ch / 64.0) * total / N_SIMD,
-                         "valu_frac_isolated": (K1S_NS_PER_WAVE_SAMPLE * 1e-6 * (n_ch / 64.0) * total
-                                                / N_SIMD) / kiso["fir_slice"]},
-        }
-        if world == 1 and not args.no_cpu:
-            wide = n_ch
-            out["cpu_baseline"] = cpu_baseline(x[:, : args.cpu_channels].cpu().numpy(),
-                                               args.cpu_channels, total,
-                                               np.ascontiguousarray(x[:, :wide].cpu().numpy()))
-        print(json.dumps(out), flush=True)
-    if use_dist:
+
+def roofline_of(m):
+    """The FIR/slicer launch: 98 % of the chain's algorithmic bytes (every int16 sample read once,
+    SURVEY 8d) and the largest share of its issued instructions."""
+    alg = m["n_ch"] * m["len"] * 2.0
+    ach = alg / (m["kernel_ms"]["fir_slice"] * 1e-3) / 1e9
+    r = {"bound": "hbm", "kernel": "fir_slice", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+         "frac": ach / HBM_PEAK_GBS,
+         # HBM bytes per launch come from separate rocprofv3 --pmc passes (profiles/r02_pmc_traffic.json,
+         # scripts/collect_profiles.sh); they cannot be measured inside this run
+         "traffic": None, "algorithmic_bytes_per_launch": alg}
+    if m["kernel_ms_isolated"]:
+        r["achieved_isolated"] = alg / (m["kernel_ms_isolated"]["fir_slice"] * 1e-3) / 1e9
+    return r
+
+
+def rank_main(rank, local, world, args, sync):
+    import torch
+    torch.cuda.set_device(local)
+    cfg = CONFIGS[args.config]
+    if args.channels:
+        cfg = dict(cfg, channels=args.channels)
+    if args.len:
+        cfg = dict(cfg, len=args.len)
+    want_cpu = rank == 0 and world == 1 and args.cpu and args.config == "C3"
+    m = measure(cfg, args, local, rank, sync, args.steps, args.warmup, post=(rank == 0), keep_input=want_cpu)
+    x_cpu, x_wide = m.pop("x_cpu", None), m.pop("x_wide", None)
+    per_rank = {"rank": rank, "device": local, "ms_per_step": m["dt_own"] / m["steps"] * 1e3}
+    red = sync.reduce(m["dt"], m["msgs"], float(m["n_ch"]) * m["len"] * m["steps"], per_rank)
+    if rank != 0:
+        return
+    dt, msgs, samples, ranks = red
+    value = samples / dt / 1e6
+    out = {
+        "metric": "Msamples/s demodulated (N-channel batch, " + ("full chain" if cfg["stage_mask"] == 0x1f
+                                                                 else "FIR + receiver") + ")",
+        "value": value, "unit": "Msamples/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32 FIR on int16 samples; u32 PLL/HDLC/CRC", "data": "synthetic",
+        "config": {"workload": cfg["what"], "channels_per_gpu": m["n_ch"], "samples_per_channel": m["len"],
+                   "parallelism": f"channels sharded over {world} GPU(s), one process per GPU, no collectives"},
+        "valid_crc_msgs_per_s": msgs / dt,
+        "x_realtime_channels": value / (cfg["rate"] / 1e6),
+        "kernel_ms": m["kernel_ms"], "kernel_ms_isolated": m["kernel_ms_isolated"],
+        "kernel_ms_calls": m["kernel_ms_calls"],
+        "per_gpu": ranks,
+        "end_to_end": m.get("end_to_end"),
+        "roofline": roofline_of(m),
+        "note": "the receive path slices the sign of the filter output and never stores the pre-slicer "
+                "floats; gnuais_batch_filter() produces them (bit-exact, tests/test_hip_parity.py)",
+    }
+    if world == 1 and args.others and args.config == "C3" and not args.channels and not args.len:
+        others = {}
+        for name in ("C2", "C5"):
+            o = measure(CONFIGS[name], args, local, rank, sync, *((60, 10) if name == "C2" else (20, 4)))
+            v = o["n_ch"] * o["len"] * o["steps"] / o["dt"] / 1e6
+            others[name] = {"workload": CONFIGS[name]["what"], "value": v, "unit": "Msamples/s",
+                            "ms_per_step": o["dt"] / o["steps"] * 1e3, "steps": o["steps"],
+                            "valid_crc_msgs_per_s": o["msgs"] / o["dt"],
+                            "x_realtime_channels": v / (CONFIGS[name]["rate"] / 1e6),
+                            "kernel_ms": o["kernel_ms"], "kernel_ms_isolated": o["kernel_ms_isolated"],
+                            "dominant_kernel": max(o["kernel_ms_isolated"], key=o["kernel_ms_isolated"].get),
+                            "roofline": roofline_of(o)}
+        out["other_configs"] = others
+    if x_cpu is not None:
+        out["cpu_baseline"] = cpu_baseline(x_cpu, args.cpu_channels, m["len"], x_wide)
+    print(json.dumps(out), flush=True)
+
+
+def _worker(rank, world, args, barrier, queue):
+    devs = [int(d) for d in args.devices.split(",")] if args.devices else list(range(world))
+    rank_main(rank, devs[rank % len(devs)], world, args, LocalSync(rank, world, barrier, queue))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--config", choices=sorted(CONFIGS), default="C3")
+    ap.add_argument("--channels", type=int, default=0, help="override: channels per GPU")
+    ap.add_argument("--len", type=int, default=0, help="override: samples per channel per step")
+    ap.add_argument("--base", type=int, default=256, help="distinct base streams")
+    ap.add_argument("--cpu-channels", type=int, default=8192,
+                    help="channels of the batch the single-core CPU baseline runs (about 13 s of CPU work)")
+    ap.add_argument("--devices", default="", help="comma list: device of each worker (default 0..N-1); "
+                    "repeating a device runs several workers on it")
+    ap.add_argument("--no-cpu", dest="cpu", action="store_false")
+    ap.add_argument("--no-others", dest="others", action="store_false",
+                    help="skip the brief C2 / C5 measurements of a default single-GPU run")
+    args = ap.parse_args()
+
+    if "RANK" in os.environ and "WORLD_SIZE" in os.environ:
+        # launched by torch.distributed.run: its ranks, RCCL for the barrier and the reductions
+        import torch
+        import torch.distributed as dist
+        world, rank = int(os.environ["WORLD_SIZE"]), int(os.environ["RANK"])
+        local = int(os.environ.get("LOCAL_RANK", "0"))
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", rank=rank, world_size=world)
+        rank_main(rank, local, world, args, DistSync(dist, torch.device("cuda", local), rank, world))
         dist.destroy_process_group()
+        return
+
+    world = max(1, args.gpus)
+    if world == 1:
+        rank_main(0, 0, 1, args, LocalSync(0, 1, None, None))
+        return
+    # one worker process per device (SURVEY 8e: receivers share nothing, src/ais.c:141-147):
+    # independent batches and launches, a barrier around the timed region, no process group
+    import multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    barrier, queue = ctx.Barrier(world), ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, args, barrier, queue)) for r in range(1, world)]
+    for p in procs:
+        p.start()
+    try:
+        _worker(0, world, args, barrier, queue)
+    finally:
+        for p in procs:
+            p.join(timeout=600)
+    if any(p.exitcode not in (0, None) for p in procs):
+        sys.exit(1)
 
 
 if __name__ == "__main__":

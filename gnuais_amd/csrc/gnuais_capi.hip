@@ -997,6 +997,34 @@ int gnuais_batch_history(gnuais_batch *b, int16_t *h_out)
     return GNUAIS_OK;
 }
 
+int gnuais_batch_last_signs(gnuais_batch *b, uint8_t *h_out, int stride)
+{
+    if (!b || !h_out || stride < b->last_len) return fail(GNUAIS_E_ARG, "last_signs: argument");
+    if (int rc = gnuais_batch_sync(b)) return rc;
+    const int N = b->N, W = (b->last_len + 31) / 32;
+    std::vector<uint32_t> w((size_t) W * N);
+    if (W) HIP_TRY(hipMemcpy(w.data(), b->sgn[b->last_k], w.size() * 4, hipMemcpyDeviceToHost));
+    for (int c = 0; c < N; ++c)
+        for (int n = 0; n < b->last_len; ++n)
+            h_out[(size_t) c * stride + n] = (w[(size_t) (n >> 5) * N + c] >> (31 - (n & 31))) & 1u;
+    return GNUAIS_OK;
+}
+
+int gnuais_batch_info(const gnuais_batch *b, const char *name, double *value)
+{
+    if (!b || !name || !value) return fail(GNUAIS_E_ARG, "info: argument");
+    if (!strcmp(name, "sign_exact")) *value = b->sign_ok && b->fir_variant == 3;
+    else if (!strcmp(name, "sign_eps")) *value = b->sign_eps;
+    else if (!strcmp(name, "sign_central_taps")) *value = b->sign_NC;
+    else if (!strcmp(name, "first_effective_tap")) *value = b->k0;
+    else if (!strcmp(name, "n_effective_taps")) *value = b->NE;
+    else if (!strcmp(name, "compute_units")) *value = b->n_cu;
+    else if (!strcmp(name, "device")) *value = b->device;
+    else if (!strcmp(name, "segments")) *value = b->n_seg;
+    else return fail(GNUAIS_E_ARG, "info: unknown name");
+    return GNUAIS_OK;
+}
+
 int gnuais_batch_n_channels(const gnuais_batch *b) { return b ? b->N : 0; }
 int gnuais_batch_n_taps(const gnuais_batch *b) { return b ? b->NT : 0; }
 

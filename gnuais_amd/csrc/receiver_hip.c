@@ -20,6 +20,9 @@
  * refreshes the public counters -- the reference's order (per buffer: receiver
  * A's frames, then receiver B's).
  *
+ * Like the reference's main loop (one thread, ais.c:214-263) this file is single-threaded: the
+ * table of groups is process-global and not locked.
+ *
  * Build inside the gnuais tree with -DGNUAIS_TREE (uses the tree's headers and
  * hlog); outside it, include/gnuais_receiver_abi.h carries the two public
  * structs.  There is no CPU fallback: if the HIP library cannot run, this
@@ -124,16 +127,33 @@ struct receiver *init_receiver(char name, int num_ch, int ch_ofs, struct serial_
 	return rx;
 }
 
-/* src/receiver.c:76-82 */
+/* src/receiver.c:76-82.  The device batch of a group goes away with its last member. */
 void free_receiver(struct receiver *rx)
 {
-	int i;
+	int i, k, left;
 	if (!rx)
 		return;
-	for (i = 0; i < n_groups; i++)
-		if (groups[i].num_ch == rx->num_ch && groups[i].members[rx->ch_ofs] == rx)
-			groups[i].members[rx->ch_ofs] = NULL;
-	hfree(rx);
+	for (i = 0; i < n_groups; i++) {
+		struct rx_group *g = &groups[i];
+		if (g->num_ch != rx->num_ch || !g->members || g->members[rx->ch_ofs] != rx)
+			continue;
+		g->members[rx->ch_ofs] = NULL;
+		for (left = 0, k = 0; k < g->num_ch; k++)
+			left += g->members[k] != NULL;
+		if (left == 0) {
+			gnuais_batch_destroy(g->batch);
+			free(g->members);
+			free(g->ran);
+			free(g->frames);
+			free(g->counters);
+			free(g->pll);
+			free(g->maxval);
+			*g = groups[--n_groups];        /* keep the table dense */
+			memset(&groups[n_groups], 0, sizeof(groups[n_groups]));
+		}
+		break;
+	}
+	hfree(rx);      /* like the reference, the decoder itself is not freed (receiver.c:76-82) */
 }
 
 static void start_round(struct rx_group *g, const short *buf, int len)

@@ -36,6 +36,8 @@ SYMBOLS = {
     "gnuais_batch_filter": (_I, [_P, _P, _I, _P, _P]),
     "gnuais_batch_decode_bits": (_I, [_P, _P, _I, _P]),
     "gnuais_batch_last_bits": (_I, [_P, _P, _I, _P]),
+    "gnuais_batch_last_signs": (_I, [_P, _P, _I]),
+    "gnuais_batch_info": (_I, [_P, C.c_char_p, C.POINTER(C.c_double)]),
     "gnuais_batch_drain_frames": (_I, [_P, _P, _I, C.POINTER(_I)]),
     "gnuais_batch_pending_frames": (_I, [_P, C.POINTER(_I)]),
     "gnuais_batch_discard_frames": (_I, [_P, _P]),

@@ -124,6 +124,17 @@ class ReceiverBatch:
         check(self._lib.gnuais_batch_last_bits(self._h, buf.ctypes.data, stride, cnt.ctypes.data))
         return [buf[c, : cnt[c]].copy() for c in range(self.n_channels)]
 
+    def last_signs(self, length: int) -> np.ndarray:
+        """The slicer's decisions of the last run call: uint8 [n_channels][length]."""
+        out = np.zeros((self.n_channels, length), dtype=np.uint8)
+        check(self._lib.gnuais_batch_last_signs(self._h, out.ctypes.data, length))
+        return out
+
+    def info(self, name: str) -> float:
+        v = C.c_double()
+        check(self._lib.gnuais_batch_info(self._h, name.encode(), C.byref(v)))
+        return v.value
+
     # -- results --------------------------------------------------------------
     def pending_frames(self) -> int:
         n = C.c_int()

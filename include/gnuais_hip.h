@@ -131,6 +131,14 @@ int  gnuais_batch_decode_bits(gnuais_batch *b, const uint8_t *h_bits, int stride
  * h_bits HOST uint8 [n_channels][stride]; h_count[n_channels] = bits per channel */
 int  gnuais_batch_last_bits(gnuais_batch *b, uint8_t *h_bits, int stride, int32_t *h_count);
 
+/* the slicer's decisions of the LAST run call (`out > 0`, src/receiver.c:111), one byte per sample:
+ * h_out HOST uint8 [n_channels][stride], stride >= len of that call */
+int  gnuais_batch_last_signs(gnuais_batch *b, uint8_t *h_out, int stride);
+/* facts about a batch, by name: "sign_exact" (1 if the receive path runs the sign-exact slicer),
+ * "sign_eps" (its certification threshold), "sign_central_taps", "first_effective_tap",
+ * "n_effective_taps", "compute_units", "device", "segments" */
+int  gnuais_batch_info(const gnuais_batch *b, const char *name, double *value);
+
 /* ---- results ------------------------------------------------------------------
  * drain queued frames to the host, in the reference's print order within the
  * drained span (channel 0..N-1, then time).  *n_out = frames written. */

@@ -1,5 +1,5 @@
 cd $GRAFT_REPO_ROOT
-export STEPS=40
+export STEPS=60
 iso() {
 python - <<'PY' 2>&1 | grep -v amdgpu.ids
 import sys,os
@@ -15,10 +15,5 @@ print("isolated",{k:round(v,3) for k,v in r.items()})
 PY
 }
 python -m pytest tests/test_hip_parity.py -m gpu -x -q 2>&1 | tail -2
-echo "=== batch 16 prefetch"; iso
-SWEEP="edges_stream=0;stage_mask=3" python scripts/pipe_experiment.py 2>&1 | grep -v amdgpu.ids
-for v in "-DEDGE_BATCH_N=32" "-DEDGE_BATCH_N=8" "-DK2T_NOSTORE" "-DK2T_NOAPPEND -DK2T_NOSTORE"; do
-touch gnuais_amd/csrc/pll_nrzi.hip; make -s -C gnuais_amd/csrc EXTRA="$v" 2>&1 | grep -v warning | tail -3
-echo "=== $v"; iso
-SWEEP="edges_stream=0;stage_mask=3" python scripts/pipe_experiment.py 2>&1 | grep -v amdgpu.ids
-done
+echo "=== coalesced rows"; iso
+SWEEP="edges_stream=0,1;stage_mask=3,31" python scripts/pipe_experiment.py 2>&1 | grep -v amdgpu.ids

@@ -1,0 +1,287 @@
+"""Parity at BASELINE.json's full sizes, on the slicer's certification threshold, and over more
+than one device: the HIP path (through the C ABI) against the CPU oracle, bit for bit."""
+import os
+import subprocess
+import threading
+
+import numpy as np
+import pytest
+
+from gnuais_amd import params, shard, synth
+from oracle_lib import FRAME_DTYPE, Oracle
+
+pytestmark = pytest.mark.gpu
+
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def batch(*a, **k):
+    from gnuais_amd import ReceiverBatch
+    return ReceiverBatch(*a, **k)
+
+
+def dev(x, device=0):
+    import torch
+    return torch.from_numpy(np.ascontiguousarray(x)).to(f"cuda:{device}")
+
+
+def host_threads():
+    n = len(os.sched_getaffinity(0))
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return max(1, min(n, 32))
+
+
+def counters_of(b):
+    c = b.counters()
+    return np.stack([c["receivedframes"], c["lostframes"], c["lostframes2"]], axis=1)
+
+
+def pll_of(b):
+    p = b.pll_state()
+    return [(int(a), int(b_), int(c_)) for a, b_, c_ in zip(p["pll"], p["prev"], p["lastbit"])]
+
+
+# ---------------------------------------------------------------- C3: every channel
+
+def test_c3_full_size_every_channel():
+    """BASELINE C3 -- 16384 channels x 48000 samples, full chain -- and a second, shorter call on
+    the carried state: frames, counters and the PLL carry of EVERY channel against the oracle
+    (all host cores), plus the size-independent properties."""
+    from gnuais_amd import tile_channels
+    n_ch, total, k = 16384, 48000, 256
+    base, placed = synth.make_base_streams(k, total)
+    xb = tile_channels(dev(base), n_ch)
+    xh = xb.cpu().numpy()
+    b = batch(n_ch, max_len=total)
+    o = Oracle(n_ch)
+    for lo, hi in ((0, total), (1000, 12345)):
+        b.run(xb[lo:hi])
+        o.clear_frames()
+        o.run(xh[lo:hi], threads=host_threads())
+        frames, want = b.drain_frames(), o.frames()
+        assert len(want) > (200000 if hi == total else 20000)
+        assert frames.tobytes() == want.tobytes()
+        assert np.array_equal(counters_of(b), o.counters())
+        assert pll_of(b) == [o.pll(c) for c in range(n_ch)]
+        if hi == total:
+            # round trip: what was delivered is what was transmitted; reference order, no duplicates
+            key = frames["channel"].astype(np.int64) << 32 | frames["end_bit"]
+            assert np.all(np.diff(key) > 0)
+            sent = [set(p for _, p in pl) for pl in placed]
+            for f in frames[:: max(1, len(frames) // 5000)]:
+                assert f["nbits"] == 168 and bytes(f["payload"][:21]) in sent[int(f["channel"]) % k]
+
+
+def test_c2_exact_shape_bits_and_state():
+    """BASELINE C2's shape -- 256 channels x 48000 samples, filter.c + receiver.c: the slicer's
+    decisions, the recovered bit stream and the carried PLL state of every channel."""
+    n_ch, total = 256, 48000
+    base, _ = synth.make_base_streams(n_ch, total, seed=71)
+    x = np.ascontiguousarray(base.T)
+    b = batch(n_ch, max_len=total)
+    b.run(dev(x))
+    o = Oracle(n_ch)
+    r = o.run(x, want_filtered=True, want_bits=True)
+    assert np.array_equal(b.last_signs(total), (r["filtered"] > 0).T.astype(np.uint8))
+    got = b.last_bits()
+    for c in range(n_ch):
+        assert np.array_equal(got[c], r["bits"][c]), c
+    assert pll_of(b) == [o.pll(c) for c in range(n_ch)]
+    assert np.array_equal(b.maxval(), r["maxval"])
+
+
+# ---------------------------------------------------------------- C5: full size
+
+def test_c5_full_size():
+    """BASELINE C5 -- 16384 channels x 192000 samples at 192 kHz (144 taps, pllinc 0x10000/20): 256
+    channels spread over the batch bit-exactly against the oracle, all of them through the
+    properties."""
+    import torch
+    from gnuais_amd import tile_channels
+    n_ch, total, k = 16384, 192000, 256
+    base, placed = synth.make_base_streams(k, total, sps=20, seed=72)
+    xb = tile_channels(dev(base), n_ch)
+    taps = params.taps_192k()
+    b = batch(n_ch, taps=taps, pllinc=params.PLLINC_192K, max_len=total)
+    assert b.info("sign_exact") == 1 and b.info("sign_central_taps") == 48
+    b.run(xb)
+    frames = b.drain_frames()
+    cnt = counters_of(b)
+    assert int(cnt[:, 0].sum()) == len(frames) == b.total_received() > 200000
+    key = frames["channel"].astype(np.int64) << 32 | frames["end_bit"]
+    assert np.all(np.diff(key) > 0)
+    sent = [set(p for _, p in pl) for pl in placed]
+    for f in frames[:: max(1, len(frames) // 5000)]:
+        assert f["nbits"] == 168 and bytes(f["payload"][:21]) in sent[int(f["channel"]) % k]
+    rng = np.random.default_rng(44)
+    pick = np.sort(np.concatenate([rng.choice(n_ch, 250, replace=False), [0, 63, 64, n_ch - 65, n_ch - 64, n_ch - 1]]))
+    pick = np.unique(pick)
+    xs = xb[:, torch.from_numpy(pick).cuda()].cpu().numpy()
+    o = Oracle(len(pick), taps=taps, pllinc=params.PLLINC_192K)
+    o.run(xs, threads=host_threads())
+    sel = frames[np.isin(frames["channel"], pick)]
+    remap = {int(c): i for i, c in enumerate(pick)}
+    sel["channel"] = [remap[int(c)] for c in sel["channel"]]
+    assert sel.tobytes() == o.frames().tobytes()
+    assert np.array_equal(cnt[pick], o.counters())
+    p = pll_of(b)
+    assert [p[int(c)] for c in pick] == [o.pll(i) for i in range(len(pick))]
+
+
+# ---------------------------------------------------------------- the slicer's threshold
+
+def test_sign_exact_slicer_on_its_threshold():
+    """K1s certifies the sign of the reference's ordered 32-term sum from the 12 central taps when
+    |y_c| > eps and re-evaluates exactly otherwise.  Inputs built so that |y_c| lands within a few
+    percent of eps on BOTH sides (and of both signs), each alone in silence: the decisions must be
+    those of the exact filter, sample for sample."""
+    taps = params.taps_48k().astype(np.float64)
+    b0 = batch(64, max_len=4096)
+    assert b0.info("sign_exact") == 1 and b0.info("sign_central_taps") == 12
+    eps = b0.info("sign_eps")
+    k0 = int(b0.info("first_effective_tap"))
+    j0 = k0 + (int(b0.info("n_effective_taps")) - 12) // 2           # first central tap in the 36-tap table
+    assert 0.05 < eps < 0.5
+    # y(n) = sum_k taps[k] x[n - 36 + k]: three small integers under taps j0+3, j0+2, j0+1
+    # (0.0696, 0.0059, 0.00022) reach any value near eps in steps of 2e-4
+    t3, t2, t1 = taps[j0 + 3], taps[j0 + 2], taps[j0 + 1]
+    pats = []
+    for a in (-3, -2, -1, 1, 2, 3):
+        for frac in np.linspace(0.9, 1.1, 41):
+            for sgn in (1.0, -1.0):
+                target = sgn * eps * frac
+                rest = target - a * t3
+                bq = int(np.round(rest / t2))
+                if abs(bq) > 30000:
+                    continue
+                cq = int(np.round((rest - bq * t2) / t1))
+                if abs(cq) > 30000:
+                    continue
+                yc = a * t3 + bq * t2 + cq * t1
+                pats.append((a, bq, cq, yc))
+    below = [p for p in pats if abs(p[3]) < eps]
+    above = [p for p in pats if abs(p[3]) > eps]
+    assert len(below) > 100 and len(above) > 100
+    assert min(abs(abs(p[3]) - eps) for p in pats) < 2e-4            # some sit right on it
+    n_ch, gap = 64, 80
+    per_ch = (len(pats) + n_ch - 1) // n_ch
+    total = gap * (per_ch + 1)
+    x = np.zeros((total, n_ch), dtype=np.int16)
+    for i, (a, bq, cq, _) in enumerate(pats):
+        c, slot = i % n_ch, i // n_ch
+        n = gap * (slot + 1)                                         # the sample whose window holds the pattern
+        x[n - 36 + j0 + 3, c] = a
+        x[n - 36 + j0 + 2, c] = bq
+        x[n - 36 + j0 + 1, c] = cq
+    o = Oracle(n_ch)
+    r = o.run(x, want_filtered=True, want_bits=True)
+    want = (r["filtered"] > 0).T.astype(np.uint8)
+    # the construction does what it says: the oracle's float at the designated sample is the pattern's
+    # y_c up to the outer taps' 5e-8
+    for i, (_, _, _, yc) in enumerate(pats[:: 17]):
+        i *= 17
+        assert abs(float(r["filtered"][gap * (i // n_ch + 1), i % n_ch]) - yc) < 1e-4
+    xd = dev(x)
+    for chunk in (total, 33, 1):                                     # and under awkward call boundaries
+        b = batch(n_ch, max_len=total)
+        signs = []
+        for lo in range(0, total, chunk):
+            hi = min(total, lo + chunk)
+            b.run(xd[lo:hi])
+            signs.append(b.last_signs(hi - lo))
+        assert np.array_equal(np.concatenate(signs, axis=1), want), chunk
+        assert pll_of(b) == [o.pll(c) for c in range(n_ch)]
+    # the exact kernel agrees (it is the definition): floats bit for bit
+    f = b0.filter(dev(x)).cpu().numpy()
+    assert np.array_equal(f.view(np.uint32), r["filtered"].view(np.uint32))
+
+
+# ---------------------------------------------------------------- more than one device
+
+def test_shards_over_devices_from_host_threads():
+    """SURVEY 8e / BASELINE C4's code path: contiguous channel blocks, one batch and one host thread
+    per device (two batches on one device when only one is visible), no exchange between them; the
+    merged frames are the oracle's for the whole channel set."""
+    import torch
+    n_dev = torch.cuda.device_count()
+    world = 2
+    devices = [0, 1] if n_dev >= 2 else [0, 0]
+    n_ch, total = 1000, 6 * 1280
+    x = np.stack([synth.make_stream(total, seed=73, channel=c, occupancy=0.7)[0] for c in range(n_ch)], axis=1)
+    o = Oracle(n_ch)
+    o.run(x, threads=host_threads())
+    out, errs = [None] * world, []
+
+    def work(rank):
+        try:
+            lo, hi = shard.shard_range(n_ch, world, rank)
+            d = devices[rank]
+            torch.cuda.set_device(d)
+            bt = batch(hi - lo, max_len=2560, device=d)
+            assert bt.info("device") == d
+            xs = dev(x[:, lo:hi], d)
+            st = torch.cuda.Stream(device=d)
+            for a in range(0, total, 2560):
+                bt.run(xs[a:a + 2560], stream=st.cuda_stream, sync=False)
+            f = bt.drain_frames()
+            f["channel"] += lo
+            out[rank] = (f, counters_of(bt), pll_of(bt))
+        except Exception as e:                                       # surfaced below
+            errs.append((rank, repr(e)))
+
+    th = [threading.Thread(target=work, args=(r,)) for r in range(world)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert not errs, errs
+    assert np.concatenate([p[0] for p in out]).tobytes() == o.frames().tobytes()
+    assert np.array_equal(np.concatenate([p[1] for p in out]), o.counters())
+    assert [s for p in out for s in p[2]] == [o.pll(c) for c in range(n_ch)]
+
+
+def test_bench_two_workers_prints_n_gpus_2():
+    """`bench.py --gpus 2` without torch.distributed.run: one worker process per device (both on
+    device 0 when only one is visible), n_gpus 2 and a whole-job value in the line."""
+    import json
+    import sys
+    import torch
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    devs = "0,1" if torch.cuda.device_count() >= 2 else "0,0"
+    out = subprocess.check_output([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--devices", devs,
+                                   "--steps", "6", "--warmup", "2", "--channels", "2048", "--len", "9600",
+                                   "--base", "64", "--no-cpu"], timeout=600)
+    line = json.loads(out.decode().strip().splitlines()[-1])
+    assert line["n_gpus"] == 2 and len(line["per_gpu"]) == 2
+    assert line["value"] > 0 and line["valid_crc_msgs_per_s"] > 0
+    assert abs(line["value"] - 2 * 2048 * 9600 * 6 / (line["ms_per_step"] * 6e-3) / 1e6) < 1e-6 * line["value"]
+
+
+# ---------------------------------------------------------------- the drop-in with the reference's message layer
+
+def test_dropin_with_the_reference_message_layer(tmp_path):
+    """oracle/_ref/dropin_ais.bin = the reference's UNMODIFIED protodec.c message layer + support
+    files, with gnuais_amd/csrc/receiver_hip.c in place of filter.c / receiver.c, behind an
+    ais.c-shaped driver (built by `make -C oracle dropin` where the reference tree is present).
+    Its stdout on the golden stereo recording is the reference's own, line for line per receiver."""
+    exe = os.path.join(os.path.dirname(G), "..", "oracle", "_ref", "dropin_ais.bin")
+    if not os.path.exists(exe):
+        pytest.skip("oracle/_ref/dropin_ais.bin was not built (no reference tree at build time)")
+    g = np.load(os.path.join(G, "chain_48k.npz"))
+    raw = tmp_path / "stereo.raw"
+    g["x"].astype("<i2").tofile(raw)
+    p = subprocess.run([exe, str(raw)], capture_output=True, timeout=300)
+    assert p.returncode == 0, p.stderr.decode()
+    got = p.stdout.decode().splitlines()
+    want = bytes(np.load(os.path.join(G, "nmea.npz"))["chain_48k_stdout"]).decode().splitlines()
+    assert len(got) == len(want) == 8
+    for ch in "AB":     # per buffer the reference prints receiver A's frames, then B's (ais.c:237-247)
+        assert [l for l in got if l.startswith(f"ch {ch} ")] == [l for l in want if l.startswith(f"ch {ch} ")]
+    cnt = g["counters"]
+    tail = p.stderr.decode().splitlines()[-2:]
+    assert tail == [f"{'AB'[i]}: received {cnt[i][0]} lost {cnt[i][1]} lost2 {cnt[i][2]}" for i in range(2)]

@@ -409,40 +409,7 @@ def test_crc16_device_known_answers():
 
 # ---------------------------------------------------------------- full size (BASELINE C3)
 
-def test_c3_full_size_properties():
-    """16384 channels x 48000 samples, full chain: a random sample of channels is
-    compared bit-exactly with the oracle; the rest through size-independent
-    properties (round trip: every delivered payload was transmitted; frames sorted;
-    counters add up)."""
-    import torch
-    from gnuais_amd import tile_channels
-    n_ch, total, k = 16384, 48000, 256
-    base, placed = synth.make_base_streams(k, total)
-    xb = tile_channels(dev(base), n_ch)
-    b = batch(n_ch, max_len=total)
-    b.run(xb)
-    frames = b.drain_frames()
-    cnt = b.counters()
-    assert int(cnt["receivedframes"].sum()) == len(frames) == b.total_received() > 200000
-    key = frames["channel"].astype(np.int64) << 32 | frames["end_bit"]
-    assert np.all(np.diff(key) > 0)                                  # reference order, no dups
-    sent = [set(p for _, p in pl) for pl in placed]
-    for f in frames[:: max(1, len(frames) // 5000)]:
-        assert f["nbits"] == 168 and bytes(f["payload"][:21]) in sent[int(f["channel"]) % k]
-    # bit-exact on a sample of channels
-    rng = np.random.default_rng(43)
-    pick = np.sort(rng.choice(n_ch, 96, replace=False))
-    xs = xb[:, torch.from_numpy(pick).cuda()].cpu().numpy()
-    assert np.array_equal(xs[:, 0], np.roll(base[pick[0] % k], -synth.rotation_of(int(pick[0]), total)))
-    o = Oracle(len(pick))
-    o.run(xs)
-    fo = o.frames()
-    sel = frames[np.isin(frames["channel"], pick)]
-    remap = {int(c): i for i, c in enumerate(pick)}
-    sel["channel"] = [remap[int(c)] for c in sel["channel"]]
-    assert sel.tobytes() == fo.tobytes()
-    assert np.array_equal(np.stack([cnt["receivedframes"], cnt["lostframes"],
-                                    cnt["lostframes2"]], axis=1)[pick], o.counters())
+# (BASELINE's full sizes, every channel: tests/test_hip_fullsize.py)
 
 
 # ---------------------------------------------------------------- randomised soak (short form)
