@@ -21,7 +21,8 @@
 // and s + +-0 = s for every s reachable from +0): NE = 32 of the 36 reference
 // taps, d = 34.
 //
-// Output: 1 bit per sample, the sign words sgn[w][c] (bit 31 = oldest of the 32
+// Output: 1 bit per sample, the sign words (bit 31 = oldest of the 32; layout: sgn_index(), kernels.h:
+// word w of channel c next to words w^1, w^2, w^3 of the same channel;
 // samples of word w), optionally the fp32 filter output (parity dump), and the
 // per-channel peak positive sample (filter_run_buf's return value).
 #include <hip/hip_runtime.h>
@@ -285,7 +286,7 @@ __global__ __launch_bounds__(64) void fir_slice_kernel(
         // bits stay left-aligned (bit 31 = oldest)
         const int valid = t1 - (t0 + obase);
         if (valid < 32) w &= ~0u << (32 - valid);
-        if (live) sgn[(size_t) ((t0 + obase) >> 5) * (size_t) N + cg] = w;
+        if (live) sgn[sgn_index((t0 + obase) >> 5, N, cg)] = w;
     }
 
     // the last segment also owns the final `shift` samples of the call
@@ -620,7 +621,7 @@ __global__ __launch_bounds__(64) void fir_sign_kernel(
                     amb &= ~bit;
                     if (exact_positive(t0 + obase + pos)) w |= bit; else w &= ~bit;
                 }
-                if (live) sgn[(size_t) ((t0 + obase) >> 5) * (size_t) N + cg] = w;
+                if (live) sgn[sgn_index((t0 + obase) >> 5, N, cg)] = w;
             }
         }
   } else {
@@ -698,7 +699,7 @@ __global__ __launch_bounds__(64) void fir_sign_kernel(
                 amb &= ~bit;
                 if (exact_positive(t0 + obase + pos)) w |= bit; else w &= ~bit;
             }
-            if (live) sgn[(size_t) ((t0 + obase) >> 5) * (size_t) N + cg] = w;
+            if (live) sgn[sgn_index((t0 + obase) >> 5, N, cg)] = w;
             zor = 0;
         };
 
@@ -869,7 +870,7 @@ __global__ __launch_bounds__(64) void fir_slice_generic_kernel(
             }
             w = (w << 1) | ((n < t1 && y > 0.0f) ? 1u : 0u);
         }
-        if (live) sgn[(size_t) (nb >> 5) * (size_t) N + cg] = w;
+        if (live) sgn[sgn_index(nb >> 5, N, cg)] = w;
     }
     if (live && peak > 0) atomicMax(&maxval[cg], peak);
 }

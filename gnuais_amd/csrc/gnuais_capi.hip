@@ -2,8 +2,8 @@
 //
 // Owns the per-batch device state (FIR history, PLL phase, deframer state,
 // frame ring) and sequences the kernels of one receiver_run() pass:
-//   K1 fir_slice (+ history carry) -> K2t pll_edges -> K2a pll_phase -> K2b hdlc_deframe -> K3 hdlc_crc
-// K1 and K2t on the caller's stream, every later stage on an internal stream of its own, chained by
+//   K1 fir_slice (+ history carry) -> K2a pll -> K2b hdlc_deframe -> K3 hdlc_crc
+// K1 on the caller's stream, every later stage on an internal stream of its own, chained by
 // events over four sets of hand-off buffers, so that the stages of consecutive calls overlap
 // (DESIGN.md 4.6); `pipeline` = 0 runs them back to back on the caller's stream instead.
 // No CPU implementation of the chain exists here: without a usable HIP device every entry
@@ -70,14 +70,8 @@ struct gnuais_batch {
     // every hand-off buffer exists NBUF times (index = call % NBUF), so K1 can run up
     // to NBUF-1 calls ahead of the sequential stages
     static constexpr int NBUF = 4;
-    uint32_t *sgn[NBUF] = {};                   // K1 -> K2t
-    void *edges[NBUF] = {};                     // K2t -> K2a: transition lists
-    uint32_t *en4p[NBUF] = {};                  //   rows K2a streams per (segment, channel group)
-    uint32_t *prev0[NBUF] = {};                 // K2t -> K2a: sign before the call's first sample
-    uint32_t *pend[NBUF] = {};                  // K2a -> its carry kernel
-    uint32_t *pll = nullptr, *lastbit = nullptr;
-    uint32_t *prev[2] = {nullptr, nullptr};     // sign of the last sample, ping-pong like hist
-    int prev_cur = 0;
+    uint32_t *sgn[NBUF] = {};                   // K1 -> K2a
+    uint32_t *pll = nullptr, *lastbit = nullptr, *prev = nullptr;   // receiver.h:38-44, carried by K2a
     int n_cu = 256;
     uint32_t *segbits[NBUF] = {};               // K2a -> K2b
     uint32_t *segcnt[NBUF] = {};
@@ -86,14 +80,13 @@ struct gnuais_batch {
     // kernel, so that the short-on-parallelism stages of call i overlap the FIR of
     // call i+1 (and each other).  NBUF = 4 measured best: 3 starves the FIR (1.0 ms per C3 call),
     // 5..8 let it run further ahead and the stages get in each other's way more (0.84).
-    hipStream_t s_k[4] = {nullptr, nullptr, nullptr, nullptr};   // K2a, K2t, K2b, K3 (entries of pool[])
-    bool edges_stream = true;       // K2t on its own stream (false: behind the FIR on the caller's)
+    hipStream_t s_k[4] = {nullptr, nullptr, nullptr, nullptr};   // K2a, (spare), K2b, K3 (entries of pool[])
     hipStream_t s_k_default[4] = {nullptr, nullptr, nullptr, nullptr};
     static constexpr int POOL = 12;
     hipStream_t pool[POOL] = {};                // candidates for gnuais_batch_autotune(): [0..3] the default
                                                 // assignment, [0..7] high priority, [8..11] default priority
     hipEvent_t e_done[5][NBUF] = {};            // e_done[s][k]: stage s of the call using set k is done
-                                                // (0 K1, 1 K2a, 2 K2t, 3 K2b, 4 K3)
+                                                // (0 K1, 1 K2a, 3 K2b, 4 K3)
     unsigned long long calls = 0, hdlc_calls = 0;   // run calls / K3 launches since the last drain
     bool pipeline = true;
     uint32_t *ctl = nullptr, *cand = nullptr;
@@ -127,7 +120,7 @@ struct gnuais_batch {
     // timing: a ring of per-call event sets so that kernel durations can be read back
     // for every call of a timed region, not just the last one
     static constexpr int TIMING_RING = 64;
-    hipEvent_t evr[TIMING_RING][10] = {};  // 0,1 K1 | 8,3 K2t | 2,6 K2a | 5,7 K2b | 9,4 K3
+    hipEvent_t evr[TIMING_RING][10] = {};  // 0,1 K1 | 2,6 K2a | 5,7 K2b | 9,4 K3
     unsigned long long timed_calls = 0;
     int last_k = 0;
     bool timed_last = false;
@@ -166,12 +159,11 @@ void gnuais_batch_destroy(gnuais_batch *b)
     if (!b) return;
     (void) hipSetDevice(b->device);
     for (int q = 0; q < gnuais_batch::NBUF; ++q) {
-        void *set[] = {b->sgn[q], b->edges[q], b->en4p[q], b->prev0[q], b->pend[q],
-                       b->segbits[q], b->segcnt[q], b->cand_first[q], b->cand_count[q]};
+        void *set[] = {b->sgn[q], b->segbits[q], b->segcnt[q], b->cand_first[q], b->cand_count[q]};
         for (void *p : set)
             if (p) (void) hipFree(p);
     }
-    void *ptrs[] = {b->hist[0], b->hist[1], b->pll, b->lastbit, b->prev[0], b->prev[1], b->ctl, b->cand,
+    void *ptrs[] = {b->hist[0], b->hist[1], b->pll, b->lastbit, b->prev, b->ctl, b->cand,
                     b->frame_count, b->counters, b->maxval[0], b->maxval[1], b->frames, b->d_taps,
                     b->stage_x, b->d_seq[0], b->d_seq[1], b->d_text, b->nmea_scratch};
     for (void *p : ptrs)
@@ -296,23 +288,17 @@ int gnuais_batch_create(gnuais_batch **out, int device, int n_channels, const fl
         return fail(GNUAIS_E_ARG, "create: pllinc too large (more than one slice per ~4.6 samples)");
     }
     for (int k = 0; k < gnuais_batch::NBUF; ++k) {
-        alloc((void **) &b->sgn[k], sizeof(uint32_t) * N * (b->sgn_words + PLL_PAD_ROWS));
+        alloc((void **) &b->sgn[k], sizeof(uint32_t) * sgn_words_alloc(b->sgn_words, b->N));
         alloc((void **) &b->segbits[k], sizeof(uint32_t) * N * (size_t) b->n_seg * PACK_STRIDE);
         alloc((void **) &b->segcnt[k], sizeof(uint32_t) * N * (size_t) b->n_seg);
     }
     for (int k = 0; k < gnuais_batch::NBUF; ++k) {
-        // transition lists: worst case one entry per sample (2 bytes each), normally ~0.15
-        alloc((void **) &b->edges[k], sizeof(uint4) * N * (size_t) b->n_seg * EDGE_PAIRS);
-        alloc((void **) &b->en4p[k], sizeof(uint32_t) * (size_t) ((b->N + 63) / 64) * b->n_seg);
-        alloc((void **) &b->prev0[k], sizeof(uint32_t) * N);
-        alloc((void **) &b->pend[k], sizeof(uint32_t) * N * (size_t) b->n_seg);
         alloc((void **) &b->cand_first[k], sizeof(uint32_t) * N);
         alloc((void **) &b->cand_count[k], sizeof(uint32_t) * N);
     }
     alloc((void **) &b->pll, sizeof(uint32_t) * N);
     alloc((void **) &b->lastbit, sizeof(uint32_t) * N);
-    alloc((void **) &b->prev[0], sizeof(uint32_t) * N);
-    alloc((void **) &b->prev[1], sizeof(uint32_t) * N);
+    alloc((void **) &b->prev, sizeof(uint32_t) * N);
     alloc((void **) &b->ctl, sizeof(uint32_t) * N * HDLC_CTL_WORDS);
     // candidate ring, per channel and call.  The deframer cannot open frames faster than one per
     // 30 bits (16 alternating bits to leave ST_SKURR, protodec.c:1030-1043, six ones each for the
@@ -399,9 +385,7 @@ int gnuais_batch_reset(gnuais_batch *b)
     b->hist_cur = 0;
     HIP_TRY(hipMemset(b->pll, 0, sizeof(uint32_t) * N));              // receiver.c:66-71
     HIP_TRY(hipMemset(b->lastbit, 0, sizeof(uint32_t) * N));
-    HIP_TRY(hipMemset(b->prev[0], 0, sizeof(uint32_t) * N));
-    HIP_TRY(hipMemset(b->prev[1], 0, sizeof(uint32_t) * N));
-    b->prev_cur = 0;
+    HIP_TRY(hipMemset(b->prev, 0, sizeof(uint32_t) * N));
     for (int k = 0; k < gnuais_batch::NBUF; ++k)
         HIP_TRY(hipMemset(b->segcnt[k], 0, sizeof(uint32_t) * N * (size_t) b->n_seg));
     b->calls = 0;
@@ -435,8 +419,7 @@ int gnuais_batch_set_option(gnuais_batch *b, const char *name, int value)
         b->timing_stride = value;
     } else if (!strcmp(name, "pipeline")) {
         b->pipeline = value != 0;
-    } else if (!strcmp(name, "edges_stream")) {
-        b->edges_stream = value != 0;
+
     } else if (!strcmp(name, "hdlc_lpw")) {
         if (value < 1 || value > 64) return fail(GNUAIS_E_ARG, "hdlc_lpw must be 1..64");
         b->hdlc_lpw = value;
@@ -511,10 +494,9 @@ static int run_fir(gnuais_batch *b, const int16_t *x, int len, float *dump, hipS
 
 static void fill_pll(const gnuais_batch *b, PllLaunch &p, int k, int len)
 {
-    p.sgn = b->sgn[k]; p.edges = b->edges[k]; p.en4p = b->en4p[k]; p.pll = b->pll;
-    p.prev_in = b->prev[b->prev_cur]; p.prev_out = b->prev[b->prev_cur ^ 1]; p.prev0 = b->prev0[k];
+    p.sgn = b->sgn[k]; p.pll = b->pll; p.prev = b->prev;
     p.watchdog = b->frame_count + 3; p.lastbit = b->lastbit;
-    p.segbits = b->segbits[k]; p.segcnt = b->segcnt[k]; p.pend = b->pend[k];
+    p.segbits = b->segbits[k]; p.segcnt = b->segcnt[k];
     p.N = b->N; p.L = len; p.n_seg = b->n_seg; p.seg_words = b->seg_words; p.pllinc = b->pllinc;
     p.n_cu = b->n_cu;
 }
@@ -559,7 +541,6 @@ int gnuais_batch_run(gnuais_batch *b, const int16_t *d_samples, int len, void *s
 
     {
         hipStream_t sA = pl ? b->s_k[0] : s0;
-        hipStream_t sT = (pl && b->edges_stream) ? b->s_k[1] : s0;
         // Hand-off set k was last used by call i-NBUF.  Its last user is that call's K3; wait for
         // it on the HOST (normally long done): five stream-wait packets per call, each ~20 us of
         // queue time on the stream it sits in, for a condition that is practically always true.
@@ -570,20 +551,13 @@ int gnuais_batch_run(gnuais_batch *b, const int16_t *d_samples, int len, void *s
             if (int rc = run_fir(b, d_samples, len, nullptr, s0, k)) return rc;
         if (tm) HIP_TRY(hipEventRecord(ev[1], s0));
         if (pl) HIP_TRY(hipEventRecord(b->e_done[0][k], s0));
-        // K2t: this call's sign words -> transition lists edges[k].  Parallel over (channel, segment);
-        // in order across calls (the sign of a call's last sample is carried).
+        // K2a: this call's sign words -> bit packs segbits[k] (read by K2b of call i-NBUF); in order
+        // across calls (it carries the receivers' pll / prev / lastbit)
         PllLaunch p;
         fill_pll(b, p, k, len);
-        if (sT != s0) HIP_TRY(hipStreamWaitEvent(sT, b->e_done[0][k], 0));
-        if (tm) HIP_TRY(hipEventRecord(ev[8], sT));
-        if (b->stage_mask & 2) HIP_TRY(launch_pll_edges(p, sT));
-        b->prev_cur ^= 1;
-        if (tm) HIP_TRY(hipEventRecord(ev[3], sT));
-        if (pl) HIP_TRY(hipEventRecord(b->e_done[2][k], sT));
-        // K2a: walks edges[k]; fills segbits[k] (read by K2b of call i-NBUF)
-        if (pl) HIP_TRY(hipStreamWaitEvent(sA, b->e_done[2][k], 0));
+        if (pl) HIP_TRY(hipStreamWaitEvent(sA, b->e_done[0][k], 0));
         if (tm) HIP_TRY(hipEventRecord(ev[2], sA));
-        if (b->stage_mask & 2) HIP_TRY(launch_pll_phase(p, sA));
+        if (b->stage_mask & 2) HIP_TRY(launch_pll(p, sA));
         if (tm) HIP_TRY(hipEventRecord(ev[6], sA));
         if (pl) HIP_TRY(hipEventRecord(b->e_done[1][k], sA));
         if (int rc = run_tail(b, k, len, tm, ev, s0, pl ? b->e_done[1][k] : nullptr)) return rc;
@@ -957,7 +931,7 @@ int gnuais_batch_pll_state(gnuais_batch *b, gnuais_pll_state *h_out)
     std::vector<uint32_t> v((size_t) b->N), lb((size_t) b->N), pv((size_t) b->N);
     HIP_TRY(hipMemcpy(v.data(), b->pll, v.size() * 4, hipMemcpyDeviceToHost));
     HIP_TRY(hipMemcpy(lb.data(), b->lastbit, lb.size() * 4, hipMemcpyDeviceToHost));
-    HIP_TRY(hipMemcpy(pv.data(), b->prev[b->prev_cur], pv.size() * 4, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(pv.data(), b->prev, pv.size() * 4, hipMemcpyDeviceToHost));
     for (int c = 0; c < b->N; ++c) {
         h_out[c].pll = v[c] & 0xffffu;
         h_out[c].prev = pv[c] & 1;
@@ -1002,11 +976,11 @@ int gnuais_batch_last_signs(gnuais_batch *b, uint8_t *h_out, int stride)
     if (!b || !h_out || stride < b->last_len) return fail(GNUAIS_E_ARG, "last_signs: argument");
     if (int rc = gnuais_batch_sync(b)) return rc;
     const int N = b->N, W = (b->last_len + 31) / 32;
-    std::vector<uint32_t> w((size_t) W * N);
+    std::vector<uint32_t> w(sgn_words_alloc(W, N));
     if (W) HIP_TRY(hipMemcpy(w.data(), b->sgn[b->last_k], w.size() * 4, hipMemcpyDeviceToHost));
     for (int c = 0; c < N; ++c)
         for (int n = 0; n < b->last_len; ++n)
-            h_out[(size_t) c * stride + n] = (w[(size_t) (n >> 5) * N + c] >> (31 - (n & 31))) & 1u;
+            h_out[(size_t) c * stride + n] = (w[sgn_index(n >> 5, N, c)] >> (31 - (n & 31))) & 1u;
     return GNUAIS_OK;
 }
 
@@ -1036,41 +1010,40 @@ int gnuais_batch_set_timing(gnuais_batch *b, int on)
     return GNUAIS_OK;
 }
 
-// ms[0] K1 fir_slice  [1] K2t pll_edges  [2] K2a pll_phase (+ carry)
-// [3] K2b hdlc_deframe  [4] K3 hdlc_crc  [5] first event to last event of the call
+// ms[0] K1 fir_slice  [1] K2a pll  [2] K2b hdlc_deframe  [3] K3 hdlc_crc
+// [4] first event to last event of the call
 static int timing_of(gnuais_batch *b, unsigned long long call, float *ms)
 {
     hipEvent_t *ev = b->evr[call % gnuais_batch::TIMING_RING];
     HIP_TRY(hipEventElapsedTime(&ms[0], ev[0], ev[1]));
-    HIP_TRY(hipEventElapsedTime(&ms[1], ev[8], ev[3]));
-    HIP_TRY(hipEventElapsedTime(&ms[2], ev[2], ev[6]));
-    HIP_TRY(hipEventElapsedTime(&ms[3], ev[5], ev[7]));
-    HIP_TRY(hipEventElapsedTime(&ms[4], ev[9], ev[4]));
-    HIP_TRY(hipEventElapsedTime(&ms[5], ev[0], ev[4]));
+    HIP_TRY(hipEventElapsedTime(&ms[1], ev[2], ev[6]));
+    HIP_TRY(hipEventElapsedTime(&ms[2], ev[5], ev[7]));
+    HIP_TRY(hipEventElapsedTime(&ms[3], ev[9], ev[4]));
+    HIP_TRY(hipEventElapsedTime(&ms[4], ev[0], ev[4]));
     return GNUAIS_OK;
 }
 
-int gnuais_batch_last_timing(gnuais_batch *b, float *ms6)
+int gnuais_batch_last_timing(gnuais_batch *b, float *ms5)
 {
-    if (!b || !ms6) return fail(GNUAIS_E_ARG, "last_timing: argument");
+    if (!b || !ms5) return fail(GNUAIS_E_ARG, "last_timing: argument");
     if (!b->timed_calls) return fail(GNUAIS_E_STATE, "last_timing: no timed run");
     if (int rc = gnuais_batch_sync(b)) return rc;
-    return timing_of(b, b->timed_calls - 1, ms6);
+    return timing_of(b, b->timed_calls - 1, ms5);
 }
 
-int gnuais_batch_mean_timing(gnuais_batch *b, float *ms6, int *n_calls)
+int gnuais_batch_mean_timing(gnuais_batch *b, float *ms5, int *n_calls)
 {
-    if (!b || !ms6 || !n_calls) return fail(GNUAIS_E_ARG, "mean_timing: argument");
+    if (!b || !ms5 || !n_calls) return fail(GNUAIS_E_ARG, "mean_timing: argument");
     if (!b->timed_calls) return fail(GNUAIS_E_STATE, "mean_timing: no timed run");
     if (int rc = gnuais_batch_sync(b)) return rc;
     const unsigned long long n = std::min<unsigned long long>(b->timed_calls, gnuais_batch::TIMING_RING);
-    double acc[6] = {0, 0, 0, 0, 0, 0};
+    double acc[5] = {0, 0, 0, 0, 0};
     for (unsigned long long i = 0; i < n; ++i) {
-        float t[6];
+        float t[5];
         if (int rc = timing_of(b, b->timed_calls - 1 - i, t)) return rc;
-        for (int q = 0; q < 6; ++q) acc[q] += t[q];
+        for (int q = 0; q < 5; ++q) acc[q] += t[q];
     }
-    for (int q = 0; q < 6; ++q) ms6[q] = (float) (acc[q] / (double) n);
+    for (int q = 0; q < 5; ++q) ms5[q] = (float) (acc[q] / (double) n);
     *n_calls = (int) n;
     return GNUAIS_OK;
 }

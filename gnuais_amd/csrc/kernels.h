@@ -10,7 +10,7 @@ namespace gnuais {
 struct FirLaunch {
     const int16_t *x;      // [L][N] interleaved input
     const int16_t *hist;   // [NT][N] previous call's last NT samples, oldest first
-    uint32_t *sgn;         // [ceil(L/32)][N] sign words, bit 31 = oldest sample
+    uint32_t *sgn;         // sign words, bit 31 = oldest sample; layout: sgn_index() below
     float *dump;           // optional [L][N] filter output
     int *maxval;           // [N] peak positive sample (atomicMax into a zeroed buffer)
     int16_t *hist_out;     // [NT][N] the other history buffer: written by the specialised kernel
@@ -29,33 +29,36 @@ hipError_t launch_fir_generic(const FirLaunch &a, hipStream_t stream);
 hipError_t launch_fir_history(const int16_t *x, const int16_t *hist_in, int16_t *hist_out,
                               int N, int L, int NT, hipStream_t stream);
 
-// ---- K2t / K2a: PLL clock recovery, slice + NRZI (pll_nrzi.hip) -------------------
-constexpr int PLL_PAD_ROWS = 32;     // spare rows sgn carries so that batched reads need no bounds test
+// ---- K2a: PLL clock recovery, slice + NRZI (pll_nrzi.hip) --------------------------
 constexpr int PLL_LDS_BYTES = 81 * 1024;   // > half of a CU's LDS: one PLL workgroup per CU
-constexpr int SEG_WORDS = 64;        // segment: 64 sign words
+constexpr int SEG_WORDS = 64;        // segment (one bit pack per channel): 64 sign words
 constexpr int SEG_LEN = SEG_WORDS * 32;    //   = 2048 samples
-constexpr int EDGE_PAIRS = 1 + SEG_LEN / 8;   // 16-byte rows per lane and segment: header + 8 entries each
 constexpr int PACK_STRIDE = 16;      // words reserved per (channel, segment) bit pack: 64 bytes
+// Sign words: word w (samples 32w .. 32w+31, bit 31 = oldest) of channel c.  Four consecutive
+// words of a channel lie side by side, so that K2a fetches 128 samples of a channel with one
+// 16-byte load and a wave's fetch is 1 KB of contiguous memory.
+__host__ __device__ inline size_t sgn_index(int w, int N, int c)
+{
+    return ((size_t) (w >> 2) * (size_t) N + (size_t) c) * 4 + (size_t) (w & 3);
+}
+__host__ __device__ inline size_t sgn_words_alloc(int W, int N)   // words for W sign words per channel
+{
+    return (size_t) ((W + 3) / 4 + 1) * 4 * (size_t) N;
+}
 struct PllLaunch {
-    const uint32_t *sgn;   // [ceil(L/32) + PLL_PAD_ROWS][N]
-    void *edges;           // uint4 [n_seg][EDGE_PAIRS][N]: K2t -> K2a
-    uint32_t *en4p;        // [n_seg][ceil(N/64)] list pairs K2a streams per segment and channel group
+    const uint32_t *sgn;   // sgn_index() layout
     uint32_t *pll;         // [N] phase (receiver.h:40), carried
-    const uint32_t *prev_in;  // [N] sign of the last sample of the previous call (receiver.h:44)
-    uint32_t *prev_out;    // [N] ... of this call
-    uint32_t *prev0;       // [N] copy of prev_in that stays valid for this call's K2a
-    uint32_t *watchdog;    // one word: set to 1 if a wave of the launch gave up waiting for its partner
+    uint32_t *prev;        // [N] sign of the last sample (receiver.h:44), carried
     uint32_t *lastbit;     // [N] level at the last slice (receiver.h:38), carried
+    uint32_t *watchdog;    // one word: set to 1 if a wave of the launch gave up waiting for its partner
     uint32_t *segbits;     // [N][n_seg][PACK_STRIDE] recovered bits per segment, LSB first
     uint32_t *segcnt;      // [N][n_seg] bits in each pack
-    uint32_t *pend;        // [n_seg][N] parity of the transitions after the segment's last slice
     int N, L, n_seg, seg_words;
     uint32_t pllinc;
     int n_cu;              // compute units of the batch's device
 };
 hipError_t pll_prepare_device();                                         // once per device, after hipSetDevice
-hipError_t launch_pll_edges(const PllLaunch &a, hipStream_t stream);     // K2t
-hipError_t launch_pll_phase(const PllLaunch &a, hipStream_t stream);     // K2a + carry across segments
+hipError_t launch_pll(const PllLaunch &a, hipStream_t stream);           // K2a
 
 // ---- K2b: HDLC deframer, K3: CRC-16 + frame delivery (hdlc_crc.hip) ---------
 constexpr int HDLC_CTL_WORDS = 5;

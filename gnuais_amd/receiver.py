@@ -208,13 +208,13 @@ class ReceiverBatch:
         return out
 
     # -- timing ---------------------------------------------------------------
-    KERNELS = ("fir_slice", "pll_edges", "pll_phase", "hdlc_deframe", "hdlc_crc")
+    KERNELS = ("fir_slice", "pll", "hdlc_deframe", "hdlc_crc")
 
     def set_timing(self, on: bool):
         check(self._lib.gnuais_batch_set_timing(self._h, int(on)))
 
     def mean_timing(self):
-        ms = (C.c_float * 6)()
+        ms = (C.c_float * 5)()
         n = C.c_int()
         check(self._lib.gnuais_batch_mean_timing(self._h, ms, C.byref(n)))
         d = dict(zip(self.KERNELS + ("total",), ms))
@@ -222,7 +222,7 @@ class ReceiverBatch:
         return d
 
     def last_timing(self):
-        ms = (C.c_float * 6)()
+        ms = (C.c_float * 5)()
         check(self._lib.gnuais_batch_last_timing(self._h, ms))
         return dict(zip(self.KERNELS + ("total",), ms))
 

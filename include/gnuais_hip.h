@@ -221,20 +221,19 @@ int  gnuais_vessels_from_frames(const gnuais_frame *frames, int n_frames, gnuais
 int  gnuais_tile_channels(const int16_t *d_base, int n_base, int len, int16_t *d_out,
 			  int n_channels, void *stream);
 /* per-kernel timing of the last run (HIP events recorded on the stream each
- * kernel is launched on), ms[6]: [0] K1 fir_slice  [1] K2t pll_edges  [2] K2a pll_phase
- * [3] K2b hdlc_deframe  [4] K3 hdlc_crc  [5] whole call.
- * Needs gnuais_batch_set_timing(b, 1) before the run. */
+ * kernel is launched on), ms[5]: [0] K1 fir_slice  [1] K2a pll  [2] K2b hdlc_deframe
+ * [3] K3 hdlc_crc  [4] whole call.  Needs gnuais_batch_set_timing(b, 1) before the run. */
 int  gnuais_batch_set_timing(gnuais_batch *b, int on);
-int  gnuais_batch_last_timing(gnuais_batch *b, float *ms6);
+int  gnuais_batch_last_timing(gnuais_batch *b, float *ms5);
 /* mean over the (up to 64) most recent timed runs since set_timing(b, 1); with the
  * stage pipeline on, these are the durations WHILE the stages of neighbouring
  * calls overlap */
-int  gnuais_batch_mean_timing(gnuais_batch *b, float *ms6, int *n_calls);
+int  gnuais_batch_mean_timing(gnuais_batch *b, float *ms5, int *n_calls);
 /* tunables: "fir_T" (outputs per wave in K1, multiple of 32), "fir_variant"
  * (3 = sign-exact slicer, the default on the receive path; 0 = exact v_mul/v_add K1,
  * 1 = its v_pk build, 2 = its MFMA-product build), "pipeline", "hdlc_lpw" (channels
  * per wave in the deframer, 1..64), "timing_stride" (with set_timing on, time every n-th
- * call only: the ten event records of a timed call cost ~0.05 ms of stream time),
+ * call only: the eight event records of a timed call cost ~0.05 ms of stream time),
  * "stage_mask" (experiments: bit s = launch stage s; results are wrong unless 0x1f) */
 int  gnuais_batch_set_option(gnuais_batch *b, const char *name, int value);
 /* Optional, once, before real work: time the stage -> stream assignments on `d_samples` (about 0.5 s

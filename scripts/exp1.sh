@@ -1,6 +1,5 @@
 cd $GRAFT_REPO_ROOT
-export STEPS=60
-iso() {
+python -m pytest tests/test_hip_parity.py -m gpu -x -q 2>&1 | tail -3
 python - <<'PY' 2>&1 | grep -v amdgpu.ids
 import sys,os
 sys.path.insert(0,os.getcwd())
@@ -13,7 +12,4 @@ for i in range(4):
     b.run(x); r=b.last_timing(); b.drain_frames()
 print("isolated",{k:round(v,3) for k,v in r.items()})
 PY
-}
-python -m pytest tests/test_hip_parity.py -m gpu -x -q 2>&1 | tail -2
-echo "=== coalesced rows"; iso
-SWEEP="edges_stream=0,1;stage_mask=3,31" python scripts/pipe_experiment.py 2>&1 | grep -v amdgpu.ids
+STEPS=60 SWEEP="stage_mask=31,3,1" python scripts/pipe_experiment.py 2>&1 | grep -v amdgpu.ids

@@ -11,7 +11,7 @@ for r in rows:
     n = r["Kernel_Name"].split("(")[0].split("::")[-1]
     if "hdlc_reset" in n:
         batch += 1
-    if batch >= 0 and any(k in n for k in ("fir_sign", "pll_edges", "pll_phase", "nrzi_bits", "hdlc_deframe", "hdlc_crc_kernel")):
+    if batch >= 0 and any(k in n for k in ("fir_sign", "pll_kernel", "hdlc_deframe", "hdlc_crc_kernel")):
         seen[batch].setdefault(n[:20], set()).add(r["Queue_Id"])
 for b, d in seen.items():
     print("batch", b, {k: sorted(v) for k, v in d.items()})

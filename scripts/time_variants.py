@@ -18,7 +18,7 @@ for variant in (0, 2):
         for it in range(4):
             b.run(x); res.append(b.last_timing()); b.drain_frames()
         r = res[-1]
-        print(f"variant={variant} T={T}: fir {r['fir_slice']:.3f} ms  pll {r['pll_edges']:.3f}+{r['pll_phase']:.3f}+{r['nrzi_bits']:.3f} ms  hdlc {r['hdlc_deframe']:.3f}+{r['hdlc_crc']:.3f} ms  total {r['total']:.3f} ms  "
+        print(f"variant={variant} T={T}: fir {r['fir_slice']:.3f} ms  pll {r['pll']:.3f} ms  hdlc {r['hdlc_deframe']:.3f}+{r['hdlc_crc']:.3f} ms  total {r['total']:.3f} ms  "
               f"-> fir {n_ch*total/r['fir_slice']/1e9:.3f} Tsample/s, chain {n_ch*total/r['total']/1e9:.3f} Tsample/s", flush=True)
 for lpw in (1, 2, 4, 8, 16, 32, 64):
     b.set_option("hdlc_lpw", lpw)
