@@ -438,22 +438,43 @@ __global__ __launch_bounds__(256) void hdlc_crc_kernel(
                     for (int q = 0; q < CAND_WORDS - CAND_HDR; ++q) raw[q] = rec[CAND_HDR + q];
 #pragma unroll
                     for (int q = 0; q < CAND_WORDS - CAND_HDR; ++q) rawlds[tid][q] = raw[q];
-                    uint32_t curw = 0, rw = 0;
-                    int bp = 0, ones = 0;
-                    bool drop = false;
+                    // A word at a time.  Inside a candidate a run of 1s is at most five long (a sixth
+                    // closed the frame), so the bits to drop are exactly the 0s that follow five 1s:
+                    // bit i of `five` = raw[i-1] & ... & raw[i-5], across the word boundary through the
+                    // previous word.  The few such bits of a word are cut out one by one, the rest is
+                    // appended to the output through a 64-bit window.
+                    unsigned long long acc = 0;
+                    uint32_t prevw = 0;
+                    int fill = 0, ow = 0;
+                    const int nwords = (rawlen + 31) >> 5;
 #pragma unroll 1
-                    for (int r = 0; r < rawlen; ++r) {
-                        if ((r & 31) == 0) rw = rawlds[tid][r >> 5];
-                        const uint32_t x = rw & 1u;
-                        rw >>= 1;
-                        if (drop) { drop = false; continue; }
-                        curw |= x << (bp & 31);
-                        if ((bp & 31) == 31) { stage[tid][bp >> 5] = curw; curw = 0; }
-                        ++bp;
-                        ones = x ? ones + 1 : 0;
-                        if (ones == 5) { drop = true; ones = 0; }
+                    for (int q = 0; q < nwords; ++q) {
+                        uint32_t rw = rawlds[tid][q];
+                        const int nvq = rawlen - 32 * q < 32 ? rawlen - 32 * q : 32;
+                        const unsigned long long cc = ((unsigned long long) rw << 32) | prevw;
+                        const uint32_t five = (uint32_t) (cc >> 31) & (uint32_t) (cc >> 30) & (uint32_t) (cc >> 29) &
+                                              (uint32_t) (cc >> 28) & (uint32_t) (cc >> 27);
+                        uint32_t stf = five & ~rw & (nvq >= 32 ? ~0u : (1u << nvq) - 1u);
+                        prevw = rw;
+                        int nout = nvq;
+                        while (stf) {                               // highest first: lower positions stay valid
+                            const int pz = 31 - __clz((int) stf);
+                            stf &= ~(1u << pz);
+                            rw = (rw & ((1u << pz) - 1u)) | ((pz >= 31 ? 0u : rw >> (pz + 1)) << pz);
+                            --nout;
+                        }
+                        if (nout < 32) rw &= (1u << nout) - 1u;
+                        acc |= (unsigned long long) rw << fill;
+                        fill += nout;
+                        if (fill >= 32) {
+                            if (ow <= HDLC_BUF_WORDS) stage[tid][ow] = (uint32_t) acc;
+                            ++ow;
+                            acc >>= 32;
+                            fill -= 32;
+                        }
                     }
-                    if (bp < 32 * (HDLC_BUF_WORDS + 1)) stage[tid][bp >> 5] = curw;
+                    if (ow <= HDLC_BUF_WORDS) stage[tid][ow] = (uint32_t) acc;
+                    for (int q = ow + 1; q <= HDLC_BUF_WORDS; ++q) stage[tid][q] = 0;
                 }
                 uint32_t w[HDLC_BUF_WORDS];
 #pragma unroll
