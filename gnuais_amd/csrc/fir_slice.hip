@@ -563,19 +563,22 @@ __global__ __launch_bounds__(64) void fir_sign_kernel(
                         auto xb = [&](int k) -> float {     // the sample k steps before the newest
                             return p - k >= 0 ? xf[p - k >= 0 ? p - k : 0] : tail[p - k >= 0 ? 0 : NC - 1 + p - k];
                         };
+                        // y_c only has to stay within the certified distance of the exact central sum,
+                        // so its products are FUSED into the accumulation (one rounding per term instead
+                        // of two: inside the host's bound, which is taken for mul + add)
                         y = ctap(0) * (xb(0) + xb(NC - 1));
     #pragma unroll
-                        for (int q = 1; q < NC / 2; ++q) y = y + ctap(q) * (xb(q) + xb(NC - 1 - q));
+                        for (int q = 1; q < NC / 2; ++q) y = __builtin_fmaf(ctap(q), xb(q) + xb(NC - 1 - q), y);
                         (void) P;
                     } else {
                         const float xs = xf[p];
     #pragma unroll
                         for (int q = 0; q < NC / 2; ++q) {
-                            const float pr = ctap(q) * xs;  // == central tap NC-1-q times xs, bit for bit
+                            // central taps q and NC-1-q are the same float; fused: see the direct form
                             const int s0 = (P + NC - 1 - q) % NC;
                             const int s1 = (P + q) % NC;
-                            if (q == 0) acc[s0] = pr; else acc[s0] = acc[s0] + pr;
-                            acc[s1] = acc[s1] + pr;
+                            if (q == 0) acc[s0] = ctap(q) * xs; else acc[s0] = __builtin_fmaf(ctap(q), xs, acc[s0]);
+                            acc[s1] = __builtin_fmaf(ctap(q), xs, acc[s1]);
                         }
                         y = acc[P % NC];                    // y_c of output obase + p
                     }
@@ -759,11 +762,14 @@ __global__ __launch_bounds__(64) void fir_sign_kernel(
                     const float xs = xf[p];
     #pragma unroll
                     for (int q = 0; q < NC / 2; ++q) {
-                        const float pr = ctap(q) * xs;      // == central tap NC-1-q times xs, bit for bit
+                        // central taps q and NC-1-q are the same float.  y_c only has to stay within the
+                        // certified distance of the exact central sum, so the products are FUSED into the
+                        // accumulation: two v_fmac instead of a multiply and two adds, and one rounding per
+                        // term instead of two (inside the host's bound, which is taken for mul + add)
                         const int s0 = (P + NC - 1 - q) % NC;
                         const int s1 = (P + q) % NC;
-                        if (q == 0) acc[s0] = pr; else acc[s0] = acc[s0] + pr;
-                        acc[s1] = acc[s1] + pr;
+                        if (q == 0) acc[s0] = ctap(q) * xs; else acc[s0] = __builtin_fmaf(ctap(q), xs, acc[s0]);
+                        acc[s1] = __builtin_fmaf(ctap(q), xs, acc[s1]);
                     }
                     const float y = acc[P % NC];                // y_c of output gbase + p
                     neg = __builtin_amdgcn_alignbit(neg, __float_as_uint(y), 31);

@@ -24,7 +24,7 @@
 //     bits = ~( XOR over the transitions of  1 << floor(U(t_j) / 2^16) )
 //
 // That turns 48 000 dependent steps per channel and call into ~10 000 (one per transition; the max
-// over the 64 channels of a wave, re-synchronised every 128 samples).  One kernel, one workgroup
+// over the 64 channels of a wave, re-synchronised every 256 samples).  One kernel, one workgroup
 // per 64 channels, three waves that hand work to each other through LDS (pll_kernel below): a
 // scanner turns sign words into lists of transition positions, the recurrence walks them, a writer
 // takes the finished bit packs to HBM.
@@ -49,8 +49,8 @@ __device__ __forceinline__ uint32_t wave_max(uint32_t v)
     return v;
 }
 
-// Unit of hand-over: a "block" = 128 samples = the four sign words K1 stores side by side.
-//   scanner    (wave 1) loads a block's 16 bytes of sign bits per lane (PLL_AHEAD blocks in flight),
+// Unit of hand-over: a "block" = 256 samples = two of the four-word pieces K1 stores side by side.
+//   scanner    (wave 1) loads a block's 32 bytes of sign bits per lane (PLL_AHEAD blocks in flight),
 //              forms the transition bits D = S ^ (S >> 1) (receiver.c:113) and expands them BYTE BY
 //              BYTE through a 256-entry table in LDS -- the positions of a byte's set bits, eight to
 //              an 8-byte entry -- appending each entry with one unaligned ds_write_b64 to the lane's
@@ -67,12 +67,13 @@ __device__ __forceinline__ uint32_t wave_max(uint32_t v)
 // Monotonic LDS counters hand things over: blocks scanned / consumed, segments finished / written.
 // The launch asks for more than half a CU's 160 KB of LDS, so the dispatcher places at most ONE of
 // these workgroups per CU and two chains never share a SIMD.
-constexpr int BLK_LEN = 128;         // samples per block
+constexpr int BLK_QUADS = 2;         // 16-byte pieces (four sign words) per block
+constexpr int BLK_LEN = 128 * BLK_QUADS;   // samples per block: positions fit a byte
 constexpr int SEG_BLKS = SEG_LEN / BLK_LEN;
-constexpr int PLL_STRIP = 140;       // bytes per lane and slot: 128 positions + an 8-byte store's overhang +
-                                     // the recurrence's read-ahead; 35 dwords (odd): lanes hit different banks
-constexpr int PLL_SLOTS = 6;         // block slots between scanner and recurrence
-constexpr int PLL_AHEAD = 4;         // blocks of sign words the scanner has in flight
+constexpr int PLL_STRIP = BLK_LEN + 12;    // bytes per lane and slot: the positions + an 8-byte store's overhang +
+                                     // the recurrence's read-ahead; 67 dwords (odd): lanes hit different banks
+constexpr int PLL_SLOTS = 4;         // block slots between scanner and recurrence
+constexpr int PLL_AHEAD = 2;         // blocks of sign words the scanner has in flight
 constexpr int PLL_SLOT_BYTES = 64 * PLL_STRIP + 64 * 4 + 64;     // strips, counts, rows
 constexpr int PLL_PACKW = PACK_STRIDE + 1;   // words per lane and pack buffer: the pack + its bit count
 constexpr int PLL_WAVES = 3;
@@ -80,6 +81,7 @@ constexpr int PLL_LUT_BYTES = 2048;
 constexpr int PLL_FLAG_WORDS = 16 + 2 * 64;  // counters, then the sign before / after the call per lane
 constexpr int PLL_NEED_LDS = PLL_LUT_BYTES + PLL_SLOTS * PLL_SLOT_BYTES + 2 * PLL_PACKW * 64 * 4 + PLL_FLAG_WORDS * 4;
 static_assert(SEG_LEN % BLK_LEN == 0, "segments are whole blocks");
+static_assert(BLK_LEN <= 256 && (PLL_STRIP / 4) % 2 == 1 && PLL_STRIP % 4 == 0, "byte positions, odd dword stride");
 
 // The hand-over counters live in LDS and guard LDS data only.  The LDS unit executes a wave's DS
 // instructions in order, so "data, then counter" on the producer side and "counter, then data" on
@@ -202,22 +204,31 @@ __global__ __launch_bounds__(64 * PLL_WAVES) __attribute__((amdgpu_waves_per_eu(
     };
 
     if (role == 1) {                              // ---- the scanner ----
-        const uint4 *__restrict__ src = sgn4 + c;                  // block b of this lane: src[b * N]
+        const uint4 *__restrict__ src = sgn4 + c;                  // piece i of this lane: src[i * N]
         uint32_t prev = sign0[lane];
-        uint4 q[PLL_AHEAD];
+        uint4 q[PLL_AHEAD][BLK_QUADS];
 #pragma unroll
-        for (int j = 0; j < PLL_AHEAD; ++j) q[j] = src[(size_t) (j < n_blk ? j : 0) * (size_t) N];
+        for (int j = 0; j < PLL_AHEAD; ++j)
+#pragma unroll
+            for (int h = 0; h < BLK_QUADS; ++h)
+                q[j][h] = src[(size_t) ((j < n_blk ? j : 0) * BLK_QUADS + h) * (size_t) N];
         int seen = 0;
         bool dead = false;
         for (int b0 = 0; b0 < n_blk && !dead; b0 += PLL_AHEAD) {
 #pragma unroll
             for (int j = 0; j < PLL_AHEAD; ++j) {
                 const int b = b0 + j;
-                const uint4 sv = q[j];
+                uint32_t S[4 * BLK_QUADS];
+#pragma unroll
+                for (int h = 0; h < BLK_QUADS; ++h) {
+                    S[4 * h] = q[j][h].x; S[4 * h + 1] = q[j][h].y; S[4 * h + 2] = q[j][h].z; S[4 * h + 3] = q[j][h].w;
+                }
                 {   // loads are unconditional (past the end: block 0 again), so that the compiler
                     // counts them and waits for exactly the oldest
                     const int nb = b + PLL_AHEAD;
-                    q[j] = src[(size_t) (nb < n_blk ? nb : 0) * (size_t) N];
+#pragma unroll
+                    for (int h = 0; h < BLK_QUADS; ++h)
+                        q[j][h] = src[(size_t) ((nb < n_blk ? nb : 0) * BLK_QUADS + h) * (size_t) N];
                 }
                 if (b < n_blk && !dead) {
                     while (b - seen >= PLL_SLOTS && !dead) {       // slot b % PLL_SLOTS still in use?
@@ -232,9 +243,8 @@ __global__ __launch_bounds__(64 * PLL_WAVES) __attribute__((amdgpu_waves_per_eu(
                         uint32_t cur = (uint32_t) (slot - lds) + (uint32_t) (lane * PLL_STRIP);   // LDS address
                         const uint32_t cur0 = cur;
                         const int nv = L - b * BLK_LEN;            // valid samples of this block (>= 1)
-                        const uint32_t S[4] = {sv.x, sv.y, sv.z, sv.w};
 #pragma unroll
-                        for (int w = 0; w < 4; ++w) {
+                        for (int w = 0; w < 4 * BLK_QUADS; ++w) {
                             const int k = nv - 32 * w;             // valid samples of this word
                             uint32_t d = S[w] ^ ((S[w] >> 1) | (prev << 31));      // receiver.c:113
                             if (k <= 0) {

@@ -1,5 +1,5 @@
 cd $GRAFT_REPO_ROOT
-python -m pytest tests/test_hip_parity.py tests/test_nmea.py -m gpu -x -q 2>&1 | tail -3
+python -m pytest tests/test_hip_parity.py -m gpu -x -q 2>&1 | tail -2
 python - <<'PY' 2>&1 | grep -v amdgpu.ids
 import sys,os
 sys.path.insert(0,os.getcwd())
@@ -12,4 +12,4 @@ for i in range(4):
     b.run(x); r=b.last_timing(); b.drain_frames()
 print("isolated",{k:round(v,3) for k,v in r.items()})
 PY
-STEPS=100 SWEEP="stage_mask=31" python scripts/pipe_experiment.py 2>&1 | grep -v amdgpu.ids
+STEPS=100 SWEEP="stage_mask=31,3" python scripts/pipe_experiment.py 2>&1 | grep -v amdgpu.ids
