@@ -105,6 +105,12 @@ struct gnuais_batch {
     size_t nmea_scratch_bytes = 0, d_text_bytes = 0;
     int16_t *stage_x = nullptr;
     size_t stage_bytes = 0;
+    // gnuais_batch_run_host_async: two pinned host buffers + two device buffers, one internal stream
+    int16_t *pin[2] = {nullptr, nullptr}, *dev_in[2] = {nullptr, nullptr};
+    size_t pin_bytes = 0;
+    hipStream_t s_io = nullptr;
+    hipEvent_t e_in[2] = {nullptr, nullptr};    // the FIR of the call that used staging pair q is done
+    unsigned long long host_calls = 0;
     // options
     int fir_T = 512;
     int stage_mask = 0x1f;                      // experiments only: bit s = launch stage s
@@ -176,6 +182,12 @@ void gnuais_batch_destroy(gnuais_batch *b)
             if (e) (void) hipEventDestroy(e);
     for (auto &st : b->pool)
         if (st) (void) hipStreamDestroy(st);
+    for (int q = 0; q < 2; ++q) {
+        if (b->pin[q]) (void) hipHostFree(b->pin[q]);
+        if (b->dev_in[q]) (void) hipFree(b->dev_in[q]);
+        if (b->e_in[q]) (void) hipEventDestroy(b->e_in[q]);
+    }
+    if (b->s_io) (void) hipStreamDestroy(b->s_io);
     delete b;
 }
 
@@ -511,8 +523,12 @@ static int run_tail(gnuais_batch *b, int k, int len, bool tm, hipEvent_t *ev,
     hipStream_t sC = pl ? b->s_k[2] : s0, sD = pl ? b->s_k[3] : s0;
     HdlcLaunch h;
     fill_hdlc(b, h, k);
-    // K2b: needs segbits[k]; fills cand_first/count[k] (read by K3 of call - NBUF)
+    // K2b: needs segbits[k]; fills cand_first/count[k] (read by K3 of call - NBUF).  It also writes
+    // the per-channel candidate ring that K3 of the PREVIOUS call may still be reading: slots are
+    // reused after cand_K frame starts, which one call cannot exceed but two could
     if (pl && after) HIP_TRY(hipStreamWaitEvent(sC, after, 0));
+    if (pl && b->calls > 0)
+        HIP_TRY(hipStreamWaitEvent(sC, b->e_done[4][(k + gnuais_batch::NBUF - 1) % gnuais_batch::NBUF], 0));
     if (tm) HIP_TRY(hipEventRecord(ev[5], sC));
     if (b->stage_mask & 8) HIP_TRY(launch_hdlc_deframe(h, sC));
     if (tm) HIP_TRY(hipEventRecord(ev[7], sC));
@@ -546,6 +562,9 @@ int gnuais_batch_run(gnuais_batch *b, const int16_t *d_samples, int len, void *s
         // queue time on the stream it sits in, for a condition that is practically always true.
         // A caller that runs more than NBUF-1 calls ahead of the device blocks here.
         if (reuse) HIP_TRY(hipEventSynchronize(b->e_done[4][k]));
+        // K1 carries the FIR history and the peak buffers from call to call in stream order: a caller
+        // that changes streams between calls gets the old stream drained first
+        if (b->calls > 0 && s0 != b->last_stream) HIP_TRY(hipStreamSynchronize(b->last_stream));
         if (tm) HIP_TRY(hipEventRecord(ev[0], s0));
         if (b->stage_mask & 1)
             if (int rc = run_fir(b, d_samples, len, nullptr, s0, k)) return rc;
@@ -682,6 +701,45 @@ int gnuais_batch_run_host(gnuais_batch *b, const int16_t *h_samples, int len)
     HIP_TRY(hipMemcpy(b->stage_x, h_samples, bytes, hipMemcpyHostToDevice));
     if (int rc = gnuais_batch_run(b, b->stage_x, len, nullptr)) return rc;
     return gnuais_batch_sync(b);
+}
+
+int gnuais_batch_run_host_async(gnuais_batch *b, const int16_t *h_samples, int len)
+{
+    if (!b || !h_samples) return fail(GNUAIS_E_ARG, "run_host_async: NULL argument");
+    if (len <= 0 || len > b->max_len) return fail(GNUAIS_E_ARG, "run_host_async: len out of range");
+    if (int rc = set_device(b)) return rc;
+    const size_t bytes = sizeof(int16_t) * (size_t) len * (size_t) b->N;
+    if (!b->s_io) {
+        HIP_TRY(hipStreamCreateWithFlags(&b->s_io, hipStreamNonBlocking));
+        for (auto &e : b->e_in) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    }
+    if (b->pin_bytes < bytes) {                 // (re)size for the largest call seen
+        HIP_TRY(hipStreamSynchronize(b->s_io));
+        const size_t cap = sizeof(int16_t) * (size_t) b->max_len * (size_t) b->N;
+        const size_t want = std::min(cap, std::max(bytes, (size_t) 1 << 20));
+        for (int q = 0; q < 2; ++q) {
+            if (b->pin[q]) HIP_TRY(hipHostFree(b->pin[q]));
+            if (b->dev_in[q]) HIP_TRY(hipFree(b->dev_in[q]));
+            b->pin[q] = b->dev_in[q] = nullptr;
+        }
+        b->pin_bytes = 0;
+        for (int q = 0; q < 2; ++q) {
+            HIP_TRY(hipHostMalloc((void **) &b->pin[q], want, hipHostMallocDefault));
+            HIP_TRY(hipMalloc((void **) &b->dev_in[q], want));
+        }
+        b->pin_bytes = want;
+        b->host_calls = 0;
+    }
+    const int q = (int) (b->host_calls & 1);
+    // the pair was last used two calls ago: its transfer and the FIR that read it must be done
+    if (b->host_calls >= 2) HIP_TRY(hipEventSynchronize(b->e_in[q]));
+    memcpy(b->pin[q], h_samples, bytes);
+    HIP_TRY(hipMemcpyAsync(b->dev_in[q], b->pin[q], bytes, hipMemcpyHostToDevice, b->s_io));
+    if (int rc = gnuais_batch_run(b, b->dev_in[q], len, b->s_io)) return rc;
+    // K1 is the only reader of the input and runs on s_io itself
+    HIP_TRY(hipEventRecord(b->e_in[q], b->s_io));
+    b->host_calls++;
+    return GNUAIS_OK;
 }
 
 int gnuais_batch_filter(gnuais_batch *b, const int16_t *d_samples, int len, float *d_out,

@@ -45,7 +45,7 @@ enum { ST_SKURR = 1, ST_PREAMBLE = 2, ST_STARTSIGN = 3, ST_DATA = 4, ST_STOPSIGN
 // ctl[0]: state[2:0] nstartsign[6:3] antallpreamble[10:7] antallenner[13:11]
 //         bitstuff[14] last[15] bufferpos[24:16]
 // ctl[1]: partially filled word of the raw frame record
-// ctl[2]: bits fed since reset
+// ctl[2]: bits fed since reset, low word; ctl[5]: high word (a frame carries 5 of its bits, see below)
 // ctl[3]: ST_DATA entries since reset (candidate slots handed out)
 // ctl[4]: raw bits in the open frame record
 constexpr uint32_t CAND_VALID = 0x10000u;
@@ -61,6 +61,7 @@ __global__ void hdlc_reset_kernel(uint32_t *__restrict__ ctl, int N)
     ctl[(size_t) 2 * N + c] = 0;
     ctl[(size_t) 3 * N + c] = 0;
     ctl[(size_t) 4 * N + c] = 0;
+    ctl[(size_t) 5 * N + c] = 0;
 }
 
 __device__ __forceinline__ uint32_t lowmask(int k)      // k in [0, 32]
@@ -93,7 +94,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(7, 8))) void
     uint32_t last = (c0 >> 15) & 1;
     int bufferpos = (c0 >> 16) & 511;
     uint32_t cur = ctl[n_ + c];
-    const uint32_t seen0 = ctl[2 * n_ + c];
+    const uint32_t seen0 = ctl[2 * n_ + c], seenhi0 = ctl[5 * n_ + c];
     uint32_t nstart = ctl[3 * n_ + c];
     int rawpos = (int) ctl[4 * n_ + c];
     int lost2 = 0;
@@ -194,8 +195,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(7, 8))) void
                         if (x == 0 && nb > 0) {
                             if (rec_ok) {
                                 rec[CAND_HDR + (rawpos >> 5)] = cur;
-                                rec[1] = seenbase + (uint32_t) pos;
-                                rec[0] = (uint32_t) nb | CAND_VALID | ((uint32_t) rawpos << 17);
+                                // when the frame ended: bits fed so far, 37 of them (32 in the record's
+                                // end_bit, 5 in its flags byte): 9600 bit/s wrap that after 165 days
+                                const uint32_t eb = seenbase + (uint32_t) pos;
+                                const uint32_t ebhi = (seenhi0 + (eb < seen0 ? 1u : 0u)) & 31u;
+                                rec[1] = eb;
+                                rec[0] = (uint32_t) nb | CAND_VALID | ((uint32_t) rawpos << 17) | (ebhi << 27);
                             }
                         } else {
                             ++lost2;                            // protodec.c:1112
@@ -354,6 +359,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(7, 8))) void
                  ((uint32_t) bufferpos << 16);
         ctl[n_ + c] = cur;
         ctl[2 * n_ + c] = seenbase;
+        ctl[5 * n_ + c] = seenhi0 + (seenbase < seen0 ? 1u : 0u);
         ctl[3 * n_ + c] = nstart;
         ctl[4 * n_ + c] = (uint32_t) rawpos;
         const bool open1 = (state == ST_DATA || state == ST_STOPSIGN);
@@ -425,7 +431,7 @@ __global__ __launch_bounds__(256) void hdlc_crc_kernel(
             const uint32_t hdr = rec[0];
             if (hdr & CAND_VALID) {                     // else: abandoned before its closing flag
                 const int n = (int) (hdr & 0xffffu);
-                const int rawlen = (int) (hdr >> 17);
+                const int rawlen = (int) ((hdr >> 17) & 0x3ffu);
                 const int nbytes = n >> 3, buflen = nbytes + 2; // protodec.c:133-134
                 // protodec.c:1008-1023 on the raw bits: store every bit except the one
                 // that follows five 1s (it is a stuffed 0 inside a frame)
@@ -503,7 +509,8 @@ __global__ __launch_bounds__(256) void hdlc_crc_kernel(
                             const int keep = nbytes - q * 4;
                             if (keep < 4) v &= (1u << (8 * keep)) - 1u;
                         }
-                        if (q == 13) v = (v & 0xffu) | (1u << 8) | ((uint32_t) n << 16);
+                        // flags: bit 0 CRC ok, bits 5:1 = bits 36:32 of end_bit
+                        if (q == 13) v = (v & 0xffu) | ((1u | ((hdr >> 27) << 1)) << 8) | ((uint32_t) n << 16);
                         out[2 + q] = v;
                     }
                 } else {

@@ -61,9 +61,9 @@ hipError_t pll_prepare_device();                                         // once
 hipError_t launch_pll(const PllLaunch &a, hipStream_t stream);           // K2a
 
 // ---- K2b: HDLC deframer, K3: CRC-16 + frame delivery (hdlc_crc.hip) ---------
-constexpr int HDLC_CTL_WORDS = 5;
+constexpr int HDLC_CTL_WORDS = 6;
 constexpr int HDLC_BUF_WORDS = 15;   // 449 bits max (protodec.c:1024)
-constexpr int CAND_HDR = 2;          // [0] nbits | valid flag, [1] end_bit
+constexpr int CAND_HDR = 2;          // [0] nbits | valid flag | raw length << 17 | end_bit[36:32] << 27, [1] end_bit[31:0]
 constexpr int CAND_WORDS = 20;       // header + 17 raw words (449 frame bits + stuffing) = 80 bytes
 struct HdlcLaunch {
     const uint32_t *segbits;  // as above (PACK_STRIDE words per pack)

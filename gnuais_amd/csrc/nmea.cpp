@@ -49,16 +49,16 @@ const char HEX[] = "0123456789ABCDEF";
 
 // the frame's payload as the reference's d->rbuffer: bit k, 0 beyond the frame
 struct Bits {
-    // the frame's bits below `nbits`, zero beyond (as d->rbuffer is, protodec.c:150), padded so that
-    // any field can be fetched with one 8-byte load
+    // the frame's nbits / 8 whole bytes, zero beyond: protodec_calculate_crc() clears d->rbuffer and
+    // fills in whole bytes only (protodec.c:133,150-162), so the nbits % 8 bits of a ragged frame are 0
+    // whatever the record holds there; padded so that any field can be fetched with one 8-byte load
     uint8_t w[72];
     int nbits;
     Bits(const gnuais_frame &f, int n) : nbits(n)
     {
         memset(w, 0, sizeof w);
-        const int whole = std::min(n, 8 * (int) sizeof f.payload) >> 3, rest = n & 7;
+        const int whole = std::min(n, 8 * (int) sizeof f.payload) >> 3;
         memcpy(w, f.payload, (size_t) whole);
-        if (rest && whole < (int) sizeof f.payload) w[whole] = (uint8_t) (f.payload[whole] & (0xff00 >> rest));
     }
     // `count` (<= 32) bits from `pos`, MSB first (protodec_henten, protodec.c:205-214)
     unsigned long get(int pos, int count) const

@@ -5,7 +5,7 @@
 // The host formatter (nmea.cpp) does 1.6e7 frames/s on sixteen threads; the chain delivers 3.6e8.
 // This is per-frame byte work with one piece of per-channel state, the rolling sequence digit
 // (d->seqnr, :922-926: +1 per accepted frame, 9 -> 0), so it maps onto sort + scan + gather:
-//   1. key = channel << 32 | end_bit for every frame of the ring (the ring holds K3's chunks in
+//   1. key = channel << 37 | time stamp (end_bit + 5 bits of the flags byte) for every frame of the ring (the ring holds K3's chunks in
 //      whatever order the blocks finished); radix sort (rocPRIM) gives the reference's order;
 //   2. per frame, in that order: accepted (AIS type 1..24, :899-900), bytes it will print
 //      (nchars + 21 per sentence: 14 of header, 5 of ",f*hh", CR LF), head-of-channel flag;
@@ -31,6 +31,7 @@ namespace gnuais {
 namespace {
 
 constexpr int CHARS_PER_SENTENCE = 61;      // protodec.c:793
+constexpr int KEY_CH_SHIFT = 37;            // sort key = channel << 37 | 37-bit time stamp
 constexpr unsigned MAX_TYPE = 24;           // cfg.h:48 MAX_AIS_PACKET_TYPE
 
 struct FrameView {
@@ -39,13 +40,14 @@ struct FrameView {
     __device__ uint32_t end_bit() const { return w[1]; }
     __device__ int nbits() const { return (int) (w[15] >> 16); }
     __device__ unsigned byte(int k) const { return (w[2 + (k >> 2)] >> (8 * (k & 3))) & 0xffu; }   // payload[k]
-    // the i-th six-bit group of d->rbuffer, MSB first; bits at and beyond nbits are 0 (protodec.c:150)
+    // the i-th six-bit group of d->rbuffer, MSB first; only the nbits / 8 whole bytes are ever filled in
+    // (protodec.c:133,150-162), everything beyond is 0
     __device__ unsigned six(int i) const
     {
         const int bit = 6 * i, k = bit >> 3, sh = bit & 7;
         const unsigned two = (byte(k) << 8) | (k + 1 < 53 ? byte(k + 1) : 0u);
         unsigned v = (two >> (10 - sh)) & 63u;
-        const int valid = nbits() - bit;
+        const int valid = (nbits() & ~7) - bit;
         if (valid < 6) v = valid <= 0 ? 0u : (v & ~((1u << (6 - valid)) - 1u));
         return v;
     }
@@ -68,8 +70,10 @@ __global__ __launch_bounds__(256) void nmea_keys_kernel(const gnuais_frame *__re
 {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
+    // print order: channel, then the 37-bit time stamp (end_bit + 5 bits of the flags byte)
     const uint2 h = *reinterpret_cast<const uint2 *>(frames + i);
-    keys[i] = ((uint64_t) h.x << 32) | h.y;
+    const uint32_t hi = (reinterpret_cast<const uint32_t *>(frames + i)[15] >> 9) & 31u;
+    keys[i] = ((uint64_t) h.x << KEY_CH_SHIFT) | ((uint64_t) hi << 32) | h.y;
     idx[i] = (uint32_t) i;
 }
 
@@ -100,7 +104,7 @@ __global__ __launch_bounds__(256) void nmea_meta_kernel(const gnuais_frame *__re
     const Geo g = geometry(nbits);
     bytes[j] = ok ? (uint32_t) (g.nchars + 21 * g.parts) : 0u;
     acc[j] = ok ? 1u : 0u;
-    head[j] = (j > 0 && (keys_sorted[j] >> 32) != (keys_sorted[j - 1] >> 32)) ? (uint32_t) j : 0u;
+    head[j] = (j > 0 && (keys_sorted[j] >> KEY_CH_SHIFT) != (keys_sorted[j - 1] >> KEY_CH_SHIFT)) ? (uint32_t) j : 0u;
 }
 
 __device__ __forceinline__ char armor(unsigned v) { return (char) (v < 40 ? v + 48 : v + 56); }   // protodec.c:826-830
@@ -115,14 +119,14 @@ __global__ __launch_bounds__(256) void nmea_write_kernel(
 {
     const int j = blockIdx.x * 256 + threadIdx.x;
     if (j >= n) return;
-    const uint32_t ch = (uint32_t) (keys_sorted[j] >> 32);
+    const uint32_t ch = (uint32_t) (keys_sorted[j] >> KEY_CH_SHIFT);
     if (ch >= (uint32_t) n_channels) {
         atomicOr(&totals[1], 1u);
         return;
     }
     const bool ok = bytes[j] != 0;
     const uint32_t before = accpre[j] - accpre[headpos[j]];          // accepted frames of this channel before j
-    const bool last = (j + 1 == n) || (uint32_t) (keys_sorted[j + 1] >> 32) != ch;
+    const bool last = (j + 1 == n) || (uint32_t) (keys_sorted[j + 1] >> KEY_CH_SHIFT) != ch;
     if (last) seq_out[ch] = (uint8_t) ((seq_in[ch] + before + (ok ? 1u : 0u)) % 10u);
     if (!ok) return;
     if ((unsigned long long) off[j] + bytes[j] > out_cap) return;    // the host reports the overflow
@@ -203,7 +207,7 @@ hipError_t frames_sort(const gnuais_frame *frames, int n, gnuais_frame *out, voi
     void *tmp = p;
     size_t t = scratch_bytes - (size_t) (p - static_cast<char *>(scratch));
     hipLaunchKernelGGL(nmea_keys_kernel, dim3((n + 255) / 256), dim3(256), 0, s, frames, n, keys, idx);
-    hipError_t e = rocprim::radix_sort_pairs(tmp, t, keys, keys2, idx, idx2, m, 0, 56, s);
+    hipError_t e = rocprim::radix_sort_pairs(tmp, t, keys, keys2, idx, idx2, m, 0, 61, s);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(frames_gather_kernel, dim3((4 * n + 255) / 256), dim3(256), 0, s, frames, idx2, n, out);
     return hipGetLastError();
@@ -231,9 +235,9 @@ hipError_t nmea_format(const gnuais_frame *frames, int n, int n_channels, const 
     hipError_t e;
     if ((e = hipMemsetAsync(totals, 0, 16, s)) != hipSuccess) return e;
     hipLaunchKernelGGL(nmea_keys_kernel, dim3(grid), dim3(256), 0, s, frames, n, keys, idx);
-    // channel < 2^24 in any realistic batch; the key's top byte is never set
+    // channel < 2^24 in any realistic batch; the key's top three bits are never set
     size_t t = tmp_bytes;
-    if ((e = rocprim::radix_sort_pairs(tmp, t, keys, keys2, idx, idx2, m, 0, 56, s)) != hipSuccess) return e;
+    if ((e = rocprim::radix_sort_pairs(tmp, t, keys, keys2, idx, idx2, m, 0, 61, s)) != hipSuccess) return e;
     hipLaunchKernelGGL(nmea_meta_kernel, dim3(grid), dim3(256), 0, s, frames, keys2, idx2, n, bytes, acc, head);
     t = tmp_bytes;
     if ((e = rocprim::exclusive_scan(tmp, t, bytes, off, 0u, m, rocprim::plus<uint32_t>(), s)) != hipSuccess) return e;

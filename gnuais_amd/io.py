@@ -8,6 +8,7 @@ read_wav()  a proper RIFF/WAVE reader: 16-bit PCM (plain or WAVE_FORMAT_EXTENSIB
             channels, unknown chunks skipped, odd chunk sizes padded, truncated data tolerated.
 planar()    [channels][frames] (one file or array per channel) -> interleaved.
 chunks()    the reference's read loop: 1020 frames per receiver_run() call.
+SampleFile  the same two readers on the C boundary (gnuais_wav_*, gnuais_amd/csrc/wavio.c), streaming.
 """
 from __future__ import annotations
 
@@ -75,3 +76,40 @@ def planar(channels: Sequence[np.ndarray]) -> np.ndarray:
 def chunks(x: np.ndarray, frames: int = REFERENCE_CHUNK) -> Iterator[np.ndarray]:
     for i in range(0, x.shape[0], frames):
         yield x[i:i + frames]
+
+
+class SampleFile:
+    """Streaming reader over the C ABI (include/gnuais_hip.h gnuais_wav_*): `raw_channels` > 0 reads the
+    file as the reference does (src/ais.c:216), 0 parses RIFF/WAVE."""
+
+    def __init__(self, path: str, raw_channels: int = 0):
+        import ctypes as C
+        from . import lib as _lib
+        self._lib = _lib.load()
+        self._h = C.c_void_p()
+        rc = self._lib.gnuais_wav_open(C.byref(self._h), path.encode(), raw_channels)
+        if rc != _lib.OK:
+            raise ValueError(f"{path}: not a readable {'raw' if raw_channels else '16-bit PCM RIFF/WAVE'} file")
+        self.channels = self._lib.gnuais_wav_channels(self._h)
+        self.rate = self._lib.gnuais_wav_rate(self._h)
+
+    def read(self, frames: int) -> np.ndarray:
+        out = np.empty((frames, self.channels), dtype=np.int16)
+        got = self._lib.gnuais_wav_read(self._h, out.ctypes.data, frames)
+        if got < 0:
+            raise ValueError("gnuais_wav_read failed")
+        return out[:got]
+
+    def __iter__(self) -> Iterator[np.ndarray]:
+        while True:
+            x = self.read(REFERENCE_CHUNK)
+            if not len(x):
+                return
+            yield x
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.gnuais_wav_close(self._h)
+            self._h = None
+
+    __del__ = close

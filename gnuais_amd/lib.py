@@ -32,6 +32,12 @@ SYMBOLS = {
     "gnuais_batch_reset": (_I, [_P]),
     "gnuais_batch_run": (_I, [_P, _P, _I, _P]),
     "gnuais_batch_run_host": (_I, [_P, _P, _I]),
+    "gnuais_batch_run_host_async": (_I, [_P, _P, _I]),
+    "gnuais_wav_open": (_I, [C.POINTER(_P), C.c_char_p, _I]),
+    "gnuais_wav_channels": (_I, [_P]),
+    "gnuais_wav_rate": (_I, [_P]),
+    "gnuais_wav_read": (C.c_long, [_P, _P, C.c_long]),
+    "gnuais_wav_close": (None, [_P]),
     "gnuais_batch_sync": (_I, [_P]),
     "gnuais_batch_filter": (_I, [_P, _P, _I, _P, _P]),
     "gnuais_batch_decode_bits": (_I, [_P, _P, _I, _P]),

@@ -77,6 +77,13 @@ class ReceiverBatch:
             assert x.ndim == 2 and x.shape[1] == self.n_channels
             check(self._lib.gnuais_batch_run_host(self._h, x.ctypes.data, int(x.shape[0])))
 
+    def run_host_async(self, samples: np.ndarray):
+        """Host input without waiting for the device: pinned double-buffered staging inside the
+        library (gnuais_batch_run_host_async); results after sync()."""
+        x = np.ascontiguousarray(samples, dtype=np.int16)
+        assert x.ndim == 2 and x.shape[1] == self.n_channels
+        check(self._lib.gnuais_batch_run_host_async(self._h, x.ctypes.data, int(x.shape[0])))
+
     def autotune(self, samples, stream: Optional[int] = None) -> float:
         """Measure the stage -> stream assignments on `samples` (CUDA/HIP int16 tensor) and keep the
         fastest; resets the batch.  Returns the best ms per call seen."""

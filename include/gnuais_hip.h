@@ -36,11 +36,12 @@ extern "C" {
 typedef struct gnuais_frame {
 	uint32_t channel;      /* interleaved channel index (receiver ch_ofs)      */
 	uint32_t end_bit;      /* bits fed to the deframer since reset before the
-	                          bit that closed the frame (orders frames in time;
-	                          wraps after 2^32 bits = 5 days of 9600 bit/s, so a
-	                          drained span must be shorter than that) */
+	                          bit that closed the frame, low 32 bits (orders
+	                          frames in time together with flags[5:1]) */
 	uint8_t  payload[53];  /* nbits/8 bytes used, rest zero                     */
-	uint8_t  flags;        /* bit0: CRC ok (always set for delivered frames)    */
+	uint8_t  flags;        /* bit0: CRC ok (always set for delivered frames);
+	                          bits 5:1 = bits 36:32 of end_bit: the 37-bit stamp
+	                          wraps after 165 days of 9600 bit/s                */
 	uint16_t nbits;        /* bufferpos - 22, src/protodec.c:1096               */
 } gnuais_frame;
 
@@ -112,11 +113,30 @@ int  gnuais_batch_reset(gnuais_batch *b);
  * d_samples: DEVICE pointer, interleaved int16 [len][n_channels] (the layout
  *   receiver_run reads with step = num_ch, src/receiver.c:102,107).
  * stream: hipStream_t (NULL = default stream).  Asynchronous; results are
- *   read after gnuais_batch_sync().  len may exceed the reference's 4096. */
+ *   read after gnuais_batch_sync().  len may exceed the reference's 4096.
+ *   The calls of one batch are ordered (each continues the receivers' state): use one stream for a
+ *   batch; when the stream changes between two calls the previous one is synchronised first.
+ *   One batch must not be driven from two host threads at once; different batches may. */
 int  gnuais_batch_run(gnuais_batch *b, const int16_t *d_samples, int len, void *stream);
 /* same from a HOST buffer (what src/ais.c:216-247 holds): copies H2D, runs, syncs */
 int  gnuais_batch_run_host(gnuais_batch *b, const int16_t *h_samples, int len);
+/* the same without waiting for the device: the samples are copied into one of two pinned staging
+ * buffers (the call returns when that copy is done and `h_samples` may be reused), the transfer and
+ * the chain run asynchronously on an internal stream; the next call's copy overlaps them.  Results
+ * after gnuais_batch_sync().  For callers that read a file or a socket in large pieces. */
+int  gnuais_batch_run_host_async(gnuais_batch *b, const int16_t *h_samples, int len);
 int  gnuais_batch_sync(gnuais_batch *b);
+
+/* ---- input side, row f2: sample files -> interleaved int16 frames (src/ais.c:173-182,214-217) ---
+ * raw_channels > 0: the file is a bare stream of little-endian int16 frames of that many channels,
+ *   header and all, exactly as the reference reads a sound file; 0: parse RIFF/WAVE (16-bit PCM,
+ *   plain or extensible, any channel count).  gnuais_wav_read(): whole frames read, 0 at the end. */
+typedef struct gnuais_wav gnuais_wav;
+int  gnuais_wav_open(gnuais_wav **out, const char *path, int raw_channels);
+int  gnuais_wav_channels(const gnuais_wav *w);
+int  gnuais_wav_rate(const gnuais_wav *w);
+long gnuais_wav_read(gnuais_wav *w, int16_t *frames, long max_frames);
+void gnuais_wav_close(gnuais_wav *w);
 
 /* ---- stage entry points (parity taps; not needed by a drop-in user) ---------
  * filter_run_buf(), src/filter.c:106-143: d_out = DEVICE float [len][n_channels];

@@ -285,3 +285,33 @@ def test_dropin_with_the_reference_message_layer(tmp_path):
     cnt = g["counters"]
     tail = p.stderr.decode().splitlines()[-2:]
     assert tail == [f"{'AB'[i]}: received {cnt[i][0]} lost {cnt[i][1]} lost2 {cnt[i][2]}" for i in range(2)]
+
+
+# ---------------------------------------------------------------- host input: C reader + staged transfers
+
+def test_file_to_frames_through_the_async_host_path(tmp_path):
+    """Row f2 on the C boundary: a RIFF file read by gnuais_wav_read() in the reference's 1020-frame
+    chunks (and in big pieces), fed through gnuais_batch_run_host_async() -- pinned double-buffered
+    staging, nothing waited for between calls -- decodes to the oracle's frames and state."""
+    from gnuais_amd import io
+    n_ch, total = 6, 40 * 1280
+    x = np.stack([synth.make_stream(total, seed=74, channel=c, occupancy=0.8)[0] for c in range(n_ch)], axis=1)
+    p = tmp_path / "six.wav"
+    io.write_wav(str(p), 48000, x)
+    o = Oracle(n_ch)
+    o.run(x)
+    want = o.frames()
+    assert len(want) > 100
+    for chunk in (io.REFERENCE_CHUNK, 4096, 20000):
+        f = io.SampleFile(str(p))
+        assert f.channels == n_ch
+        b = batch(n_ch, max_len=chunk)
+        while True:
+            part = f.read(chunk)
+            if not len(part):
+                break
+            b.run_host_async(part)
+            part[:] = 0                                   # the caller's buffer is free again at once
+        assert b.drain_frames().tobytes() == want.tobytes(), chunk
+        assert np.array_equal(counters_of(b), o.counters())
+        assert pll_of(b) == [o.pll(c) for c in range(n_ch)]
