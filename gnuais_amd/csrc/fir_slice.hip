@@ -376,7 +376,7 @@ __global__ __launch_bounds__(64) void fir_sign_kernel(
     uint32_t *__restrict__ sgn, int *__restrict__ maxval,
     int16_t *__restrict__ hist_out, int *__restrict__ maxval_next,
     const float *__restrict__ te_mem, int N, int L, int T, int d, int NTaps, int NE_rt, float eps_up,
-    FirTaps<NT> taps)
+    int map, FirTaps<NT> taps)
 {
     const int NE = NES > 0 ? NES : NE_rt;
     const int J0 = (NE - NC) / 2;               // first central tap (10 of 32 for the reference table)
@@ -391,10 +391,20 @@ __global__ __launch_bounds__(64) void fir_sign_kernel(
 #endif
     static_assert(96 % NC == 0 && NC % 2 == 0, "96 unrolled phases must hold whole turns of the accumulator ring");
     const int lane = threadIdx.x;
-    const int cg = blockIdx.x * 64 + lane;
+    // Workgroup -> (channel group, time segment).  The dispatcher deals consecutive workgroup ids
+    // round-robin over the 8 XCDs.  map 0: id = segment * groups + group, so an XCD works on every
+    // 8th channel group (its 128-byte pieces of a sample row are 1 KB apart); map 1: every XCD takes
+    // a contiguous eighth of the channel groups (4 KB of each row for 16384 channels).
+    int bx = (int) blockIdx.x, by = (int) blockIdx.y;
+    if (map == 1) {
+        const int G = (int) gridDim.x, id = by * G + bx, per = G >> 3;
+        bx = (id & 7) * per + (id >> 3) % per;
+        by = (id >> 3) / per;
+    }
+    const int cg = bx * 64 + lane;
     const int c = cg < N ? cg : N - 1;
     const bool live = cg < N;
-    const int t0 = blockIdx.y * T;              // T is a multiple of 96
+    const int t0 = by * T;                      // T is a multiple of 96
     const int t1 = (t0 + T < L) ? t0 + T : L;
     if (t0 >= L) return;
     const int dc = d - J0;                      // y_c[n] = sum_q tc[q] * x[n - dc + q]
@@ -823,21 +833,22 @@ hipError_t launch_fir_sign(const FirLaunch &a, hipStream_t stream)
         return hipErrorInvalidValue;
     dim3 grid((a.N + 63) / 64, (a.L + a.T - 1) / a.T), block(64);
     const float eps_up = __builtin_nextafterf(a.eps, INFINITY);
+    const int map = (a.map == 1 && grid.x % 8 == 0) ? 1 : 0;
     if (a.NC == 12 && a.NE == 32) {
         FirTaps<32> t;
         for (int j = 0; j < 32; ++j) t.te[j] = a.te[j];
         hipLaunchKernelGGL((fir_sign_kernel<32, 12, 32>), grid, block, 0, stream, a.x, a.hist, a.sgn, a.maxval,
-                           a.hist_out, a.maxval_next, a.te_mem, a.N, a.L, a.T, a.d, a.NT, a.NE, eps_up, t);
+                           a.hist_out, a.maxval_next, a.te_mem, a.N, a.L, a.T, a.d, a.NT, a.NE, eps_up, map, t);
     } else if (a.NC == 12) {
         FirTaps<12> t;
         for (int j = 0; j < 12; ++j) t.te[j] = a.ctaps[j];
         hipLaunchKernelGGL((fir_sign_kernel<0, 12, 12>), grid, block, 0, stream, a.x, a.hist, a.sgn, a.maxval,
-                           a.hist_out, a.maxval_next, a.te_mem, a.N, a.L, a.T, a.d, a.NT, a.NE, eps_up, t);
+                           a.hist_out, a.maxval_next, a.te_mem, a.N, a.L, a.T, a.d, a.NT, a.NE, eps_up, map, t);
     } else {
         FirTaps<48> t;
         for (int j = 0; j < 48; ++j) t.te[j] = a.ctaps[j];
         hipLaunchKernelGGL((fir_sign_kernel<0, 48, 48>), grid, block, 0, stream, a.x, a.hist, a.sgn, a.maxval,
-                           a.hist_out, a.maxval_next, a.te_mem, a.N, a.L, a.T, a.d, a.NT, a.NE, eps_up, t);
+                           a.hist_out, a.maxval_next, a.te_mem, a.N, a.L, a.T, a.d, a.NT, a.NE, eps_up, map, t);
     }
     return hipGetLastError();
 }

@@ -113,6 +113,7 @@ struct gnuais_batch {
     unsigned long long host_calls = 0;
     // options
     int fir_T = 512;
+    int fir_map = 1;                            // K1s workgroup mapping (fir_slice.hip): XCD-contiguous channel groups
     int stage_mask = 0x1f;                      // experiments only: bit s = launch stage s
     int fir_variant = 3;            // 3 sign-exact slicer (default when the table allows);
                                     // 0 exact scalar VALU, 1 exact packed, 2 exact MFMA products
@@ -376,6 +377,7 @@ int gnuais_batch_create(gnuais_batch **out, int device, int n_channels, const fl
         return fail(GNUAIS_E_HIP, "create: device allocation", e);
     }
     if (const char *v = getenv("GNUAIS_FIR_VARIANT")) b->fir_variant = atoi(v);
+    if (const char *v = getenv("GNUAIS_EXPERIMENT_EPS_SCALE")) b->sign_eps *= (float) atof(v);   // timing experiments: WRONG results
     if (const char *v = getenv("GNUAIS_FIR_T")) b->fir_T = std::max(64, atoi(v) / 32 * 32);
     *out = b;
     int rc = gnuais_batch_reset(b);
@@ -423,6 +425,8 @@ int gnuais_batch_set_option(gnuais_batch *b, const char *name, int value)
     if (!strcmp(name, "fir_T")) {
         if (value < 64 || value % 32) return fail(GNUAIS_E_ARG, "fir_T must be a multiple of 32, >= 64");
         b->fir_T = value;
+    } else if (!strcmp(name, "fir_map")) {
+        b->fir_map = value;
     } else if (!strcmp(name, "fir_variant")) {
         if (value < 0 || value > 3) return fail(GNUAIS_E_ARG, "fir_variant must be 0..3");
         b->fir_variant = value;
@@ -465,6 +469,7 @@ static void fill_fir(const gnuais_batch *b, FirLaunch &f, const int16_t *x, int 
     if (b->sign_ok)
         for (int j = 0; j < b->sign_NC; ++j) f.ctaps[j] = b->te[(b->NE - b->sign_NC) / 2 + j];
     f.te_mem = b->d_taps + b->k0;
+    f.map = b->fir_map;
 }
 
 static void fill_hdlc(const gnuais_batch *b, HdlcLaunch &h, int k)

@@ -23,6 +23,7 @@ struct FirLaunch {
     int NC;                //   central taps used (12 or 48)
     float ctaps[48];       //   te[(NE-NC)/2 .. +NC)
     const float *te_mem;   //   the NE effective taps in device memory (exact re-evaluation)
+    int map;               // K1s workgroup -> (channel group, segment) mapping, see fir_sign_kernel
 };
 hipError_t launch_fir_sign(const FirLaunch &a, hipStream_t stream);
 hipError_t launch_fir_generic(const FirLaunch &a, hipStream_t stream);
