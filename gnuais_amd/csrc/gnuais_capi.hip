@@ -103,6 +103,28 @@ struct gnuais_batch {
     char *d_text = nullptr;
     void *nmea_scratch = nullptr;
     size_t nmea_scratch_bytes = 0, d_text_bytes = 0;
+    // gnuais_batch_stream_nmea: the frame ring exists NRING times (ring 0 is `frames` / `frame_count`
+    // above until the first streaming call); a ring is filled by K3, counted and formatted two calls
+    // later, its text copied one call after that and handed out one call after that -- every host-side
+    // wait is for work the device was given at least one whole call earlier
+    static constexpr int NRING = 5;
+    gnuais_frame *ring[NRING] = {};
+    uint32_t *ring_count[NRING] = {};
+    int ring_cur = 0;
+    bool streaming = false;
+    hipStream_t s_post = nullptr, s_copy = nullptr, s_cnt = nullptr;
+    hipEvent_t e_fill[NRING] = {}, e_fmt[NRING] = {}, e_txt[NRING] = {};
+    char *sd_text[NRING] = {};                  // device text per slot
+    size_t sd_text_bytes[NRING] = {};
+    char *sh_text[NRING] = {};                  // pinned host text per slot
+    size_t sh_text_bytes[NRING] = {};
+    uint32_t *sh_info = nullptr;                // pinned: [NRING][8]: format's 4 words, the ring's 4 counters
+    int s_frames[NRING] = {}, s_stage[NRING] = {};     // stage: 0 idle, 1 filled, 2 formatting, 3 copying
+    size_t s_len[NRING] = {};
+    int s_sent[NRING] = {};
+    uint8_t *sd_seq[2] = {nullptr, nullptr};    // per-channel sequence digit, carried on the device
+    int sd_seq_cur = 0;
+    unsigned long long stream_calls = 0;
     int16_t *stage_x = nullptr;
     size_t stage_bytes = 0;
     // gnuais_batch_run_host_async: two pinned host buffers + two device buffers, one internal stream
@@ -182,6 +204,19 @@ void gnuais_batch_destroy(gnuais_batch *b)
         for (auto &e : pair)
             if (e) (void) hipEventDestroy(e);
     for (auto &st : b->pool)
+        if (st) (void) hipStreamDestroy(st);
+    for (int q = 0; q < gnuais_batch::NRING; ++q) {
+        if (q > 0 && b->ring[q]) (void) hipFree(b->ring[q]);          // ring 0 is frames / frame_count
+        if (q > 0 && b->ring_count[q]) (void) hipFree(b->ring_count[q]);
+        if (b->sd_text[q]) (void) hipFree(b->sd_text[q]);
+        if (b->sh_text[q]) (void) hipHostFree(b->sh_text[q]);
+        for (hipEvent_t e : {b->e_fill[q], b->e_fmt[q], b->e_txt[q]})
+            if (e) (void) hipEventDestroy(e);
+    }
+    if (b->sh_info) (void) hipHostFree(b->sh_info);
+    for (auto p : b->sd_seq)
+        if (p) (void) hipFree(p);
+    for (hipStream_t st : {b->s_post, b->s_copy, b->s_cnt})
         if (st) (void) hipStreamDestroy(st);
     for (int q = 0; q < 2; ++q) {
         if (b->pin[q]) (void) hipHostFree(b->pin[q]);
@@ -409,6 +444,13 @@ int gnuais_batch_reset(gnuais_batch *b)
     HIP_TRY(hipMemset(b->maxval[1], 0, sizeof(int) * N));
     b->max_cur = 0;
     HIP_TRY(hipMemset(b->frame_count, 0, sizeof(uint32_t) * 4));
+    for (int q = 1; q < gnuais_batch::NRING; ++q)
+        if (b->ring_count[q]) HIP_TRY(hipMemset(b->ring_count[q], 0, sizeof(uint32_t) * 4));
+    for (auto p : b->sd_seq)
+        if (p) HIP_TRY(hipMemset(p, 0, N));
+    for (int q = 0; q < gnuais_batch::NRING; ++q) b->s_stage[q] = 0;
+    b->ring_cur = 0;
+    b->stream_calls = 0;
     HIP_TRY(launch_hdlc_reset(b->ctl, b->N, nullptr));                // protodec.c:87-100
     HIP_TRY(hipDeviceSynchronize());
     b->last_len = 0;
@@ -476,7 +518,9 @@ static void fill_hdlc(const gnuais_batch *b, HdlcLaunch &h, int k)
 {
     h.segbits = b->segbits[k]; h.segcnt = b->segcnt[k]; h.ctl = b->ctl; h.cand = b->cand;
     h.cand_first = b->cand_first[k]; h.cand_count = b->cand_count[k];
-    h.counters = b->counters; h.frames = b->frames; h.frame_count = b->frame_count;
+    h.counters = b->counters;
+    h.frames = b->streaming ? b->ring[b->ring_cur] : b->frames;
+    h.frame_count = b->streaming ? b->ring_count[b->ring_cur] : b->frame_count;
     h.frame_cap = (uint32_t) b->frame_cap; h.N = b->N; h.n_seg = b->n_seg;
     h.seg_words = b->seg_words; h.K = b->cand_K;
     h.lanes_per_wave = b->hdlc_lpw;
@@ -512,7 +556,7 @@ static int run_fir(gnuais_batch *b, const int16_t *x, int len, float *dump, hipS
 static void fill_pll(const gnuais_batch *b, PllLaunch &p, int k, int len)
 {
     p.sgn = b->sgn[k]; p.pll = b->pll; p.prev = b->prev;
-    p.watchdog = b->frame_count + 3; p.lastbit = b->lastbit;
+    p.watchdog = (b->streaming ? b->ring_count[b->ring_cur] : b->frame_count) + 3; p.lastbit = b->lastbit;
     p.segbits = b->segbits[k]; p.segcnt = b->segcnt[k];
     p.N = b->N; p.L = len; p.n_seg = b->n_seg; p.seg_words = b->seg_words; p.pllinc = b->pllinc;
     p.n_cu = b->n_cu;
@@ -928,6 +972,139 @@ int gnuais_batch_drain_frames_nmea(gnuais_batch *b, gnuais_frame *h_frames, int 
     *out_len = 0;
     if (n_sentences) *n_sentences = 0;
     return drain_impl(b, h_frames, max, n_frames, seqnr, out, out_cap, out_len, n_sentences);
+}
+
+// Streaming delivery (row f1 end to end).  Call after every gnuais_batch_run(): the frames of the
+// runs since the previous call are taken off (K3 moves on to the next ring at once) and go through
+// three later calls -- two calls on: count read + device formatter queued; then: text copy into pinned
+// memory queued; then: text handed out -- so that no call waits for work queued in the same call.
+int gnuais_batch_stream_nmea(gnuais_batch *b, const char **text, size_t *len, int *n_sentences, int *n_frames)
+{
+    if (!b || !text || !len) return fail(GNUAIS_E_ARG, "stream_nmea: argument");
+    if (int rc = set_device(b)) return rc;
+    *text = nullptr;
+    *len = 0;
+    if (n_sentences) *n_sentences = 0;
+    if (n_frames) *n_frames = -1;               // nothing handed out yet
+    constexpr int NR = gnuais_batch::NRING;
+    const size_t N = (size_t) b->N;
+    if (!b->streaming) {                        // first use: the other rings, streams, events
+        if (int rc = gnuais_batch_sync(b)) return rc;
+        b->ring[0] = b->frames;
+        b->ring_count[0] = b->frame_count;
+        for (int q = 1; q < NR; ++q) {
+            HIP_TRY(hipMalloc((void **) &b->ring[q], sizeof(gnuais_frame) * (size_t) b->frame_cap));
+            HIP_TRY(hipMalloc((void **) &b->ring_count[q], sizeof(uint32_t) * 4));
+            HIP_TRY(hipMemset(b->ring_count[q], 0, sizeof(uint32_t) * 4));
+        }
+        for (int q = 0; q < NR; ++q) {
+            HIP_TRY(hipEventCreateWithFlags(&b->e_fill[q], hipEventDisableTiming));
+            HIP_TRY(hipEventCreateWithFlags(&b->e_fmt[q], hipEventDisableTiming));
+            HIP_TRY(hipEventCreateWithFlags(&b->e_txt[q], hipEventDisableTiming));
+        }
+        HIP_TRY(hipStreamCreateWithFlags(&b->s_post, hipStreamNonBlocking));
+        HIP_TRY(hipStreamCreateWithFlags(&b->s_copy, hipStreamNonBlocking));
+        HIP_TRY(hipStreamCreateWithFlags(&b->s_cnt, hipStreamNonBlocking));
+        HIP_TRY(hipHostMalloc((void **) &b->sh_info, sizeof(uint32_t) * 8 * NR, hipHostMallocDefault));
+        memset(b->sh_info, 0, sizeof(uint32_t) * 8 * NR);
+        for (auto &p : b->sd_seq) {
+            HIP_TRY(hipMalloc((void **) &p, N));
+            HIP_TRY(hipMemset(p, 0, N));
+        }
+        HIP_TRY(hipDeviceSynchronize());
+        b->streaming = true;
+    }
+    hipStream_t sD = b->pipeline ? b->s_k[3] : b->last_stream;
+    const int c = b->ring_cur;
+    // (1) ring c: everything K3 has been asked to append so far
+    HIP_TRY(hipEventRecord(b->e_fill[c], sD));
+    b->s_stage[c] = 1;
+    // (2) K3 moves on to the next ring; that ring's formatter (queued two calls ago) must be done
+    const int nx = (c + 1) % NR;
+    if (b->stream_calls >= (unsigned) (NR - 1)) HIP_TRY(hipStreamWaitEvent(sD, b->e_fmt[nx], 0));   // long done
+    b->ring_cur = nx;
+    // (5) first, because it frees a slot: hand out the text whose copy was queued a call ago
+    const int u = (c + NR - 4) % NR;
+    if (b->s_stage[u] == 3) {
+        HIP_TRY(hipEventSynchronize(b->e_txt[u]));
+        *text = b->sh_text[u];
+        *len = b->s_len[u];
+        if (n_sentences) *n_sentences = b->s_sent[u];
+        if (n_frames) *n_frames = b->s_frames[u];
+        b->s_stage[u] = 0;
+    }
+    // (4) the slot formatted a call ago: its size is known now; queue the copy of the text
+    const int t = (c + NR - 3) % NR;
+    if (b->s_stage[t] == 2) {
+        uint32_t *info = b->sh_info + 8 * t;
+        if (b->s_frames[t] > 0) {
+            HIP_TRY(hipEventSynchronize(b->e_fmt[t]));
+            if (info[3]) return fail(GNUAIS_E_HIP, "stream_nmea: a frame record names a channel outside the batch");
+            b->s_len[t] = (size_t) info[0] + info[1];
+            b->s_sent[t] = (int) info[2];
+            if (b->sh_text_bytes[t] < b->s_len[t]) {
+                if (b->sh_text[t]) HIP_TRY(hipHostFree(b->sh_text[t]));
+                b->sh_text[t] = nullptr;
+                b->sh_text_bytes[t] = 0;
+                const size_t want = b->s_len[t] + b->s_len[t] / 4 + 4096;
+                HIP_TRY(hipHostMalloc((void **) &b->sh_text[t], want, hipHostMallocDefault));
+                b->sh_text_bytes[t] = want;
+            }
+            if (b->s_len[t])
+                HIP_TRY(hipMemcpyAsync(b->sh_text[t], b->sd_text[t], b->s_len[t], hipMemcpyDeviceToHost, b->s_copy));
+        } else {
+            b->s_len[t] = 0;
+            b->s_sent[t] = 0;
+        }
+        HIP_TRY(hipEventRecord(b->e_txt[t], b->s_copy));
+        b->s_stage[t] = 3;
+    }
+    // (3) the ring filled two calls ago: read its counters (that K3 is done unless the host is more than
+    // a call ahead of the device), queue sort + formatter
+    const int a = (c + NR - 2) % NR;
+    if (b->s_stage[a] == 1) {
+        uint32_t *cnt = b->sh_info + 8 * a + 4;
+        HIP_TRY(hipStreamWaitEvent(b->s_cnt, b->e_fill[a], 0));
+        HIP_TRY(hipMemcpyAsync(cnt, b->ring_count[a], 16, hipMemcpyDeviceToHost, b->s_cnt));
+        HIP_TRY(hipStreamSynchronize(b->s_cnt));
+        const uint32_t have = std::min<uint32_t>(cnt[0], (uint32_t) b->frame_cap);
+        const bool overflow = cnt[1] || cnt[0] > (uint32_t) b->frame_cap, watchdog = cnt[3] != 0;
+        b->s_frames[a] = (int) have;
+        HIP_TRY(hipStreamWaitEvent(b->s_post, b->e_fill[a], 0));
+        if (have) {
+            const size_t need_text = (size_t) have * 164, need_scratch = nmea_scratch_bytes((int) have);
+            if (b->sd_text_bytes[a] < need_text) {
+                HIP_TRY(hipStreamSynchronize(b->s_copy));
+                if (b->sd_text[a]) HIP_TRY(hipFree(b->sd_text[a]));
+                b->sd_text[a] = nullptr;
+                b->sd_text_bytes[a] = 0;
+                HIP_TRY(hipMalloc((void **) &b->sd_text[a], need_text + need_text / 4));
+                b->sd_text_bytes[a] = need_text + need_text / 4;
+            }
+            if (b->nmea_scratch_bytes < need_scratch) {
+                HIP_TRY(hipStreamSynchronize(b->s_post));
+                if (b->nmea_scratch) HIP_TRY(hipFree(b->nmea_scratch));
+                b->nmea_scratch = nullptr;
+                b->nmea_scratch_bytes = 0;
+                HIP_TRY(hipMalloc(&b->nmea_scratch, need_scratch + need_scratch / 4));
+                b->nmea_scratch_bytes = need_scratch + need_scratch / 4;
+            }
+            uint8_t *sin = b->sd_seq[b->sd_seq_cur], *sout = b->sd_seq[b->sd_seq_cur ^ 1];
+            HIP_TRY(hipMemcpyAsync(sout, sin, N, hipMemcpyDeviceToDevice, b->s_post));
+            HIP_TRY(nmea_format_enqueue(b->ring[a], (int) have, b->N, sin, sout, b->sd_text[a], b->sd_text_bytes[a],
+                                        b->nmea_scratch, b->nmea_scratch_bytes, b->sh_info + 8 * a, b->s_post));
+            b->sd_seq_cur ^= 1;
+        }
+        HIP_TRY(hipMemsetAsync(b->ring_count[a], 0, 16, b->s_post));
+        HIP_TRY(hipEventRecord(b->e_fmt[a], b->s_post));
+        b->s_stage[a] = 2;
+        if (watchdog)
+            return fail(GNUAIS_E_HIP, "stream_nmea: the PLL stage's watchdog fired (device hung or badly oversubscribed)");
+        if (overflow) return fail(GNUAIS_E_OVERFLOW, "stream_nmea: frame ring overflowed, frames were dropped");
+    }
+    b->hdlc_calls = 0;
+    b->stream_calls++;
+    return GNUAIS_OK;
 }
 
 int gnuais_batch_pending_frames(gnuais_batch *b, int *n_out)

@@ -105,6 +105,11 @@ size_t nmea_scratch_bytes(int n_frames);
 // frames[n] (device) -> out[n] (device) in print order: channel, then end_bit
 hipError_t frames_sort(const struct gnuais_frame *frames, int n, struct gnuais_frame *out, void *scratch,
                        size_t scratch_bytes, hipStream_t s);
+// the device part only, queued without waiting; h_info4 (host, pinned): [0] + [1] bytes written,
+// [2] sentences, [3] != 0 if a frame named a channel >= n_channels -- valid once `s` has got there
+hipError_t nmea_format_enqueue(const struct gnuais_frame *frames, int n, int n_channels, const uint8_t *seq_in,
+                               uint8_t *seq_out, char *out, size_t out_cap, void *scratch, size_t scratch_bytes,
+                               uint32_t *h_info4, hipStream_t s);
 hipError_t nmea_format(const struct gnuais_frame *frames, int n, int n_channels, const uint8_t *seq_in,
                        uint8_t *seq_out, char *out, size_t out_cap, void *scratch, size_t scratch_bytes,
                        uint32_t *h_info, hipStream_t s);

@@ -213,12 +213,12 @@ hipError_t frames_sort(const gnuais_frame *frames, int n, gnuais_frame *out, voi
     return hipGetLastError();
 }
 
-hipError_t nmea_format(const gnuais_frame *frames, int n, int n_channels, const uint8_t *seq_in,
-                       uint8_t *seq_out, char *out, size_t out_cap, void *scratch, size_t scratch_bytes,
-                       uint32_t *h_info /* [0] bytes, [1] sentences, [2] bad channel */, hipStream_t s)
+// everything of nmea_format() that runs on the device, queued on `s` without waiting for it (n > 0)
+hipError_t nmea_format_enqueue(const gnuais_frame *frames, int n, int n_channels, const uint8_t *seq_in,
+                               uint8_t *seq_out, char *out, size_t out_cap, void *scratch, size_t scratch_bytes,
+                               uint32_t *h_info4, hipStream_t s)
 {
-    h_info[0] = h_info[1] = h_info[2] = 0;
-    if (n <= 0) return hipSuccess;
+    if (n <= 0) return hipErrorInvalidValue;
     if (scratch_bytes < nmea_scratch_bytes(n)) return hipErrorInvalidValue;
     const size_t m = (size_t) n;
     char *p = static_cast<char *>(scratch);
@@ -248,14 +248,26 @@ hipError_t nmea_format(const gnuais_frame *frames, int n, int n_channels, const 
     hipLaunchKernelGGL(nmea_write_kernel, dim3(grid), dim3(256), 0, s, frames, keys2, idx2, off, accpre, headpos,
                        bytes, n, n_channels, seq_in, seq_out, out, (unsigned long long) out_cap, totals);
     if ((e = hipGetLastError()) != hipSuccess) return e;
-    uint32_t last_off = 0, last_bytes = 0, tot[4] = {0, 0, 0, 0};
-    if ((e = hipMemcpyAsync(&last_off, off + (m - 1), 4, hipMemcpyDeviceToHost, s)) != hipSuccess) return e;
-    if ((e = hipMemcpyAsync(&last_bytes, bytes + (m - 1), 4, hipMemcpyDeviceToHost, s)) != hipSuccess) return e;
-    if ((e = hipMemcpyAsync(tot, totals, 16, hipMemcpyDeviceToHost, s)) != hipSuccess) return e;
+    // h_info4 (pinned host memory when the caller does not wait here): [0] offset of the last frame's
+    // text, [1] its length, [2] sentences, [3] frames that named a channel outside the batch
+    if ((e = hipMemcpyAsync(&h_info4[0], off + (m - 1), 4, hipMemcpyDeviceToHost, s)) != hipSuccess) return e;
+    if ((e = hipMemcpyAsync(&h_info4[1], bytes + (m - 1), 4, hipMemcpyDeviceToHost, s)) != hipSuccess) return e;
+    return hipMemcpyAsync(&h_info4[2], totals, 8, hipMemcpyDeviceToHost, s);
+}
+
+hipError_t nmea_format(const gnuais_frame *frames, int n, int n_channels, const uint8_t *seq_in,
+                       uint8_t *seq_out, char *out, size_t out_cap, void *scratch, size_t scratch_bytes,
+                       uint32_t *h_info /* [0] bytes, [1] sentences, [2] bad channel */, hipStream_t s)
+{
+    h_info[0] = h_info[1] = h_info[2] = 0;
+    if (n <= 0) return hipSuccess;
+    uint32_t raw[4] = {0, 0, 0, 0};
+    hipError_t e = nmea_format_enqueue(frames, n, n_channels, seq_in, seq_out, out, out_cap, scratch, scratch_bytes, raw, s);
+    if (e != hipSuccess) return e;
     if ((e = hipStreamSynchronize(s)) != hipSuccess) return e;
-    h_info[0] = last_off + last_bytes;
-    h_info[1] = tot[0];
-    h_info[2] = tot[1];
+    h_info[0] = raw[0] + raw[1];
+    h_info[1] = raw[2];
+    h_info[2] = raw[3];
     return hipSuccess;
 }
 

@@ -173,6 +173,18 @@ class ReceiverBatch:
                                                 C.byref(ln), C.byref(ns), C.byref(nf)))
         return out[: ln.value].tobytes(), ns.value, nf.value
 
+    def stream_nmea(self, copy: bool = True):
+        """gnuais_batch_stream_nmea(): call after every run(); returns (text, sentences, frames) of the
+        call four calls ago -- frames == -1 while the pipeline fills.  copy=False returns a uint8 view
+        of the library's pinned buffer (valid until the next call) instead of bytes."""
+        ptr, ln, ns, nf = C.c_void_p(), C.c_size_t(0), C.c_int(0), C.c_int(0)
+        check(self._lib.gnuais_batch_stream_nmea(self._h, C.cast(C.byref(ptr), C.POINTER(C.c_char_p)), C.byref(ln),
+                                                 C.byref(ns), C.byref(nf)))
+        if not ln.value:
+            return (b"" if copy else np.zeros(0, dtype=np.uint8)), ns.value, nf.value
+        view = np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_uint8)), shape=(ln.value,))
+        return (view.tobytes() if copy else view), ns.value, nf.value
+
     def drain_frames_nmea(self, seqnr: np.ndarray):
         """Records and device-formatted sentences of the same drained span: (frames, text, sentences)."""
         assert seqnr.dtype == np.uint8 and seqnr.flags.c_contiguous and len(seqnr) == self.n_channels

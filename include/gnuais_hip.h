@@ -216,6 +216,15 @@ int  gnuais_messages_from_frames(const gnuais_frame *frames, int n_frames, uint8
  * 164 bytes per pending frame always suffice). */
 int  gnuais_batch_drain_nmea(gnuais_batch *b, uint8_t *seqnr, char *out, size_t out_cap,
 			     size_t *out_len, int *n_sentences, int *n_frames);
+/* Streaming delivery of the same sentences.  Call once after every gnuais_batch_run(): the frames of
+ * the runs since the previous call are taken off at once (the chain moves on to another frame ring) and
+ * are formatted, copied into pinned host memory and handed out over the following four calls, so that
+ * no call waits for device work it has queued itself.  *text / *len: the sentences of the call four
+ * calls ago (valid until the next call; *n_frames = -1 while the pipeline fills); the per-channel
+ * sequence digit is carried on the device.  Calls without runs in between flush what is in flight.
+ * Not to be mixed with the gnuais_batch_drain_*() calls on one batch. */
+int  gnuais_batch_stream_nmea(gnuais_batch *b, const char **text, size_t *len, int *n_sentences,
+			      int *n_frames);
 /* both at once: the records (for the host-side consumers: stdout text, vessel table, range) and the
  * device-formatted sentences (for serial / IPC) of the same drained span */
 int  gnuais_batch_drain_frames_nmea(gnuais_batch *b, gnuais_frame *h_frames, int max, int *n_frames,

@@ -1,3 +1,7 @@
-cd $GRAFT_REPO_ROOT
-STEPS=100 SWEEP="fir_T=288,384,480,576,768,960;stage_mask=1" python scripts/pipe_experiment.py 2>&1 | grep -v amdgpu.ids
-STEPS=100 SWEEP="fir_T=384,576,768;stage_mask=31" python scripts/pipe_experiment.py 2>&1 | grep -v amdgpu.ids
+cd /tmp && export TMPDIR=/tmp
+R=$GRAFT_REPO_ROOT
+O=$R/gpurun_out/tl
+rm -rf $O; mkdir -p $O
+rocprofv3 --kernel-trace --memory-copy-trace --output-format csv -d $O -o tl -- python $R/scripts/exp3.py 2>&1 | grep "ms/step"
+f=$(find $O -name "*kernel_trace.csv" | head -1)
+python $R/scripts/timeline.py $f 70 | cut -c1-110

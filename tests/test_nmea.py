@@ -257,3 +257,33 @@ def test_device_formatter_on_the_chain_over_several_calls():
     fr_b, text_b, n_sent = b.drain_frames_nmea(seq_b)
     assert fr_b.tobytes() == frames.tobytes() and text_b == want and n_sent == len(frames)
     assert np.array_equal(seq_a, seq_b) and b.pending_frames() == 0
+
+
+@pytest.mark.gpu
+def test_streamed_sentences_equal_drained_sentences():
+    """gnuais_batch_stream_nmea(): one call per run, the text arriving four calls later from pinned
+    memory -- byte for byte what gnuais_batch_drain_nmea() returns for the same runs, the sequence
+    digits carried across runs, empty runs and the final flush included."""
+    import torch
+    from gnuais_amd import ReceiverBatch, synth
+    n_ch, call, n_calls = 300, 2 * 1280, 9
+    x = np.stack([synth.make_stream(call * n_calls, seed=81, channel=c, occupancy=0.8)[0] for c in range(n_ch)], axis=1)
+    x[3 * call:4 * call] = 0                                    # a run without a single frame
+    xd = torch.from_numpy(x).cuda()
+    a, b = ReceiverBatch(n_ch, max_len=call), ReceiverBatch(n_ch, max_len=call)
+    seq = np.zeros(n_ch, dtype=np.uint8)
+    want, got = [], []
+    for i in range(n_calls):
+        a.run(xd[i * call:(i + 1) * call])
+        want.append(a.drain_nmea(seq))
+        b.run(xd[i * call:(i + 1) * call], sync=False)
+        got.append(b.stream_nmea())
+    for _ in range(4):                                          # flush
+        got.append(b.stream_nmea())
+    assert all(g[2] == -1 for g in got[:4]) and all(g[2] >= 0 for g in got[4:])
+    out = got[4:]
+    assert len(out) == n_calls
+    assert sum(w[2] for w in want) > 1000 and want[3][2] < want[2][2]
+    for i, (w, g) in enumerate(zip(want, out)):
+        assert g[2] == w[2] and g[1] == w[1], i
+        assert g[0] == w[0], i
