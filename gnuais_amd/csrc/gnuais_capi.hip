@@ -143,7 +143,8 @@ struct gnuais_batch {
     float sign_eps = 0.0f;
     int sign_NC = 12;               // central taps K1s evaluates
     int k0 = 0;                     // first effective tap
-    int hdlc_lpw = 64;              // channels per wave in K2b
+    int hdlc_lpw = 64;              // channels per wave in K2b (window variant)
+    int hdlc_variant = 1;           // 1: the event-driven deframer (hdlc_events.hip), 0: window by window (hdlc_crc.hip)
     bool timing = false;
     int timing_stride = 1;          // time every n-th call only: ten event records a call are not free
     // timing: a ring of per-call event sets so that kernel durations can be read back
@@ -406,6 +407,7 @@ int gnuais_batch_create(gnuais_batch **out, int device, int n_channels, const fl
             if (e == hipSuccess) e = hipStreamCreateWithPriority(&b->pool[made], hipStreamNonBlocking, made < 8 ? hi : 0);
     }
     if (const char *v = getenv("GNUAIS_PIPELINE")) b->pipeline = atoi(v) != 0;
+    if (const char *v = getenv("GNUAIS_HDLC_VARIANT")) b->hdlc_variant = atoi(v) != 0;
     if (const char *v = getenv("GNUAIS_HDLC_LPW")) b->hdlc_lpw = std::min(64, std::max(1, atoi(v)));
     if (e != hipSuccess) {
         gnuais_batch_destroy(b);
@@ -478,6 +480,8 @@ int gnuais_batch_set_option(gnuais_batch *b, const char *name, int value)
     } else if (!strcmp(name, "pipeline")) {
         b->pipeline = value != 0;
 
+    } else if (!strcmp(name, "hdlc_variant")) {
+        b->hdlc_variant = value != 0;
     } else if (!strcmp(name, "hdlc_lpw")) {
         if (value < 1 || value > 64) return fail(GNUAIS_E_ARG, "hdlc_lpw must be 1..64");
         b->hdlc_lpw = value;
@@ -579,7 +583,7 @@ static int run_tail(gnuais_batch *b, int k, int len, bool tm, hipEvent_t *ev,
     if (pl && b->calls > 0)
         HIP_TRY(hipStreamWaitEvent(sC, b->e_done[4][(k + gnuais_batch::NBUF - 1) % gnuais_batch::NBUF], 0));
     if (tm) HIP_TRY(hipEventRecord(ev[5], sC));
-    if (b->stage_mask & 8) HIP_TRY(launch_hdlc_deframe(h, sC));
+    if (b->stage_mask & 8) HIP_TRY(b->hdlc_variant ? launch_hdlc_events(h, sC) : launch_hdlc_deframe(h, sC));
     if (tm) HIP_TRY(hipEventRecord(ev[7], sC));
     if (pl) HIP_TRY(hipEventRecord(b->e_done[3][k], sC));
     // K3
@@ -836,7 +840,7 @@ int gnuais_batch_decode_bits(gnuais_batch *b, const uint8_t *h_bits, int stride,
         HIP_TRY(hipMemcpy(b->segcnt[0], cnt.data(), cnt.size() * 4, hipMemcpyHostToDevice));
         HdlcLaunch h;
         fill_hdlc(b, h, 0);
-        HIP_TRY(launch_hdlc_deframe(h, nullptr));
+        HIP_TRY(b->hdlc_variant ? launch_hdlc_events(h, nullptr) : launch_hdlc_deframe(h, nullptr));
         HIP_TRY(launch_hdlc_crc(h, nullptr));
         b->hdlc_calls++;
         HIP_TRY(hipDeviceSynchronize());

@@ -80,7 +80,8 @@ struct HdlcLaunch {
     int N, n_seg, seg_words, K;
     int lanes_per_wave;    // channels per wave in K2b (blockDim)
 };
-hipError_t launch_hdlc_deframe(const HdlcLaunch &a, hipStream_t stream); // K2b
+hipError_t launch_hdlc_deframe(const HdlcLaunch &a, hipStream_t stream); // K2b, window by window (hdlc_crc.hip)
+hipError_t launch_hdlc_events(const HdlcLaunch &a, hipStream_t stream);  // K2b, event by event (hdlc_events.hip)
 hipError_t launch_hdlc_crc(const HdlcLaunch &a, hipStream_t stream);     // K3
 hipError_t launch_hdlc_reset(uint32_t *ctl, int N, hipStream_t stream);
 
