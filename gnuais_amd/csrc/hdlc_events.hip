@@ -287,6 +287,9 @@ __global__ __launch_bounds__(64) void hdlc_events_kernel(
         bool slow = false;              // this lane goes bit by bit until its state changes
 
         while (__any(pos < tile_end)) {
+#ifdef EV_DEBUG_COUNT
+            if (tx == 0) atomicAdd(&flags[2], 1u << 16);
+#endif
             if (pos < tile_end) {
                 // ---- hunting: protodec.c:1030-1043 -------------------------------------------------
                 if (state == ST_SKURR && !slow) {
@@ -393,7 +396,30 @@ __global__ __launch_bounds__(64) void hdlc_events_kernel(
                     const int e = e6 < tile_end ? e6 : tile_end;    // raw bits pos .. e-1 go into the record
                     const int stored = (e - pos) - stuffed(pos, e);
                     if (bufferpos + stored >= 449) {
-                        slow = true;                            // protodec.c:1024-1026 somewhere in there
+                        // protodec.c:1024-1026: the frame is given up at the bit that brings bufferpos to
+                        // 449 -- the `need`-th stored (not stuffed) bit from here.  Rare (a false start in
+                        // noise that finds no closing flag), but bit by bit it would hold the whole wave up
+                        // for hundreds of turns: find the word, then the bit.
+                        int need = 449 - bufferpos, p = pos, t = pos;
+                        for (;;) {
+                            const int q = p >> 5;
+                            const int we = (32 * (q + 1) < e) ? 32 * (q + 1) : e;
+                            uint32_t m = ~SFa[q * tpb] & (~0u << (p & 31)) & lowmask(we - 32 * q);   // stored bits p .. we-1
+                            const int n = __popc(m);
+                            if (n >= need) {
+                                for (int k = 1; k < need; ++k) m &= m - 1;
+                                t = 32 * q + ctz32(m);
+                                break;
+                            }
+                            need -= n;
+                            p = we;
+                        }
+                        if (rec_ok) rec[0] = 0;
+                        const uint32_t xt = bit_at(t);
+                        HDLC_RESET();
+                        last = xt;
+                        rs = t; hunt0 = false;
+                        pos = t + 1;
                     } else {
                         for (int p = pos; p < e;) {
                             const int sh = p & 31;
@@ -436,6 +462,9 @@ __global__ __launch_bounds__(64) void hdlc_events_kernel(
                 if (pos < tile_end && (slow || state < ST_SKURR || state > ST_STOPSIGN)) {
                     const int st0 = state;
                     const uint32_t x = bit_at(pos);
+#ifdef EV_DEBUG_COUNT
+                    atomicAdd(&flags[2], 1u);
+#endif
                     slow_bit(x, pos);
                     if (state == ST_SKURR && st0 != ST_SKURR) { rs = pos; hunt0 = false; }
                     if (state != st0) slow = false;
