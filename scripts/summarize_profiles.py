@@ -1,7 +1,7 @@
-"""Turn what scripts/collect_profiles.sh left under gpurun_out/r01 into the tracked summaries
-under profiles/ (per round: r01_*).
+"""Turn what scripts/collect_profiles.sh left under gpurun_out/<tag> into the tracked summaries
+under profiles/ (per round: r02_*).
 
-  python scripts/summarize_profiles.py [gpurun_out/r01] [r01]
+  python scripts/summarize_profiles.py [gpurun_out/r02] [r02]
 
 PMC units / corrections as MI355X_MICROARCH.md's HBM section prescribes: FETCH_SIZE and
 WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE reports half the bytes of a coalesced stream, so
@@ -10,14 +10,14 @@ it is doubled (cross-check: 2 x FETCH of the FIR = the 1.573 GB of samples + the
 import csv, json, os, shutil, sys
 from collections import defaultdict
 
-src = sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/r01"
-tag = sys.argv[2] if len(sys.argv) > 2 else "r01"
+src = sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/r02"
+tag = sys.argv[2] if len(sys.argv) > 2 else "r02"
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 out = os.path.join(root, "profiles")
 os.makedirs(out, exist_ok=True)
 
 SHORT = [("fir_sign_kernel", "fir_slice"), ("fir_slice_kernel", "fir_slice"), ("pll_kernel", "pll"),
-         ("nrzi_bits_kernel", "nrzi_bits"), ("hdlc_deframe_kernel", "hdlc_deframe"),
+         ("hdlc_events_kernel", "hdlc_deframe"), ("hdlc_deframe_kernel", "hdlc_deframe"),
          ("hdlc_crc_kernel", "hdlc_crc")]
 
 
@@ -41,19 +41,57 @@ def per_launch(path, n_ch=16384):
     return {k: {c: sum(v) / len(v) for c, v in d.items()} for k, d in acc.items()}
 
 
+def find(rel):
+    """rocprofv3 puts its files under <dir>/<host>/...: take the first match"""
+    base = os.path.join(src, os.path.dirname(rel))
+    for dp, _, fs in os.walk(base):
+        for f in fs:
+            if f.endswith(os.path.basename(rel)):
+                return os.path.join(dp, f)
+    return os.path.join(src, rel)
+
+
 for name, dst in (("stats/bench_kernel_stats.csv", f"{tag}_bench_kernel_stats_pipelined.csv"),
                   ("stats_nopipe/bench_kernel_stats.csv", f"{tag}_bench_kernel_stats_sequential.csv"),
                   ("bench.json", f"{tag}_bench.json"),
                   ("bench_under_rocprof.json", f"{tag}_bench_under_rocprof.json"),
-                  ("bench_nopipe.json", f"{tag}_bench_sequential.json")):
+                  ("bench_nopipe.json", f"{tag}_bench_sequential.json"),
+                  ("c5_stats/bench_kernel_stats.csv", f"{tag}_c5_kernel_stats.csv"),
+                  ("c5_bench_under_rocprof.json", f"{tag}_c5_bench_under_rocprof.json"),
+                  ("c2_stats/bench_kernel_stats.csv", f"{tag}_c2_kernel_stats.csv"),
+                  ("c2_bench_under_rocprof.json", f"{tag}_c2_bench_under_rocprof.json")):
     p = os.path.join(src, name)
+    if not os.path.exists(p) and name.endswith(".csv"):
+        p = find(name)
     if os.path.exists(p):
         shutil.copy(p, os.path.join(out, dst))
 
-fetch = per_launch(os.path.join(src, "pmc_fetch/pmc_counter_collection.csv"))
-write = per_launch(os.path.join(src, "pmc_write/pmc_counter_collection.csv"))
+def traffic_of(prefix, cmd):
+    fetch = per_launch(find(prefix + "pmc_fetch/pmc_counter_collection.csv"))
+    write = per_launch(find(prefix + "pmc_write/pmc_counter_collection.csv"))
+    t = {"command": cmd,
+         "units": "FETCH_SIZE/WRITE_SIZE are reported in KiB; FETCH_SIZE is doubled (gfx950 reports half the "
+                  "bytes of a coalesced stream, MI355X_MICROARCH.md HBM section)",
+         "raw_kib_per_launch": {}, "bytes_per_launch": {}}
+    for k in fetch:
+        f = fetch[k].get("FETCH_SIZE", 0.0)
+        w = write.get(k, {}).get("WRITE_SIZE", 0.0)
+        t["raw_kib_per_launch"][k] = {"FETCH_SIZE": f, "WRITE_SIZE": w}
+        t["bytes_per_launch"][k] = (2.0 * f + w) * 1024.0
+    t["chain_bytes_per_call"] = sum(t["bytes_per_launch"].values())
+    return t
+
+
+c5 = traffic_of("c5_", "rocprofv3 --kernel-trace --pmc FETCH_SIZE|WRITE_SIZE (separate passes) -- python bench.py "
+                "--config C5 --no-cpu --steps 4 --warmup 1")
+c5["algorithmic_bytes_per_call"] = 16384 * 192000 * 2.0
+with open(os.path.join(out, f"{tag}_c5_pmc_traffic.json"), "w") as f:
+    json.dump(c5, f, indent=1)
+
+fetch = per_launch(find("pmc_fetch/pmc_counter_collection.csv"))
+write = per_launch(find("pmc_write/pmc_counter_collection.csv"))
 traffic = {"command": "rocprofv3 --kernel-trace --pmc FETCH_SIZE|WRITE_SIZE (separate passes) -- "
-                      "python bench.py --no-cpu --steps 6 --warmup 1",
+                      "python bench.py --no-cpu --no-others --steps 6 --warmup 1",
            "units": "FETCH_SIZE/WRITE_SIZE are reported in KiB; FETCH_SIZE is doubled (gfx950 reports half the "
                     "bytes of a coalesced stream, MI355X_MICROARCH.md HBM section)",
            "raw_kib_per_launch": {}, "bytes_per_launch": {}}
@@ -62,10 +100,12 @@ for k in fetch:
     w = write.get(k, {}).get("WRITE_SIZE", 0.0)
     traffic["raw_kib_per_launch"][k] = {"FETCH_SIZE": f, "WRITE_SIZE": w}
     traffic["bytes_per_launch"][k] = (2.0 * f + w) * 1024.0
+traffic["chain_bytes_per_call"] = sum(traffic["bytes_per_launch"].values())
+traffic["algorithmic_bytes_per_call"] = 16384 * 48000 * 2.0
 with open(os.path.join(out, f"{tag}_pmc_traffic.json"), "w") as f:
     json.dump(traffic, f, indent=1)
 
-sq_path = os.path.join(src, "pmc_sq/pmc_counter_collection.csv")
+sq_path = find("pmc_sq/pmc_counter_collection.csv")
 if os.path.exists(sq_path):
     sq = per_launch(sq_path)
     for k, d in sq.items():
