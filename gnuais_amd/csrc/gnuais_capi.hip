@@ -414,7 +414,6 @@ int gnuais_batch_create(gnuais_batch **out, int device, int n_channels, const fl
         return fail(GNUAIS_E_HIP, "create: device allocation", e);
     }
     if (const char *v = getenv("GNUAIS_FIR_VARIANT")) b->fir_variant = atoi(v);
-    if (const char *v = getenv("GNUAIS_EXPERIMENT_EPS_SCALE")) b->sign_eps *= (float) atof(v);   // timing experiments: WRONG results
     if (const char *v = getenv("GNUAIS_FIR_T")) b->fir_T = std::max(64, atoi(v) / 32 * 32);
     *out = b;
     int rc = gnuais_batch_reset(b);

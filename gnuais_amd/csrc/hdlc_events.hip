@@ -287,9 +287,6 @@ __global__ __launch_bounds__(64) void hdlc_events_kernel(
         bool slow = false;              // this lane goes bit by bit until its state changes
 
         while (__any(pos < tile_end)) {
-#ifdef EV_DEBUG_COUNT
-            if (tx == 0) atomicAdd(&flags[2], 1u << 16);
-#endif
             if (pos < tile_end) {
                 // ---- hunting: protodec.c:1030-1043 -------------------------------------------------
                 if (state == ST_SKURR && !slow) {
@@ -462,9 +459,6 @@ __global__ __launch_bounds__(64) void hdlc_events_kernel(
                 if (pos < tile_end && (slow || state < ST_SKURR || state > ST_STOPSIGN)) {
                     const int st0 = state;
                     const uint32_t x = bit_at(pos);
-#ifdef EV_DEBUG_COUNT
-                    atomicAdd(&flags[2], 1u);
-#endif
                     slow_bit(x, pos);
                     if (state == ST_SKURR && st0 != ST_SKURR) { rs = pos; hunt0 = false; }
                     if (state != st0) slow = false;

@@ -260,10 +260,13 @@ int  gnuais_batch_last_timing(gnuais_batch *b, float *ms5);
 int  gnuais_batch_mean_timing(gnuais_batch *b, float *ms5, int *n_calls);
 /* tunables: "fir_T" (outputs per wave in K1, multiple of 32), "fir_variant"
  * (3 = sign-exact slicer, the default on the receive path; 0 = exact v_mul/v_add K1,
- * 1 = its v_pk build, 2 = its MFMA-product build), "pipeline", "hdlc_lpw" (channels
- * per wave in the deframer, 1..64), "timing_stride" (with set_timing on, time every n-th
- * call only: the eight event records of a timed call cost ~0.05 ms of stream time),
- * "stage_mask" (experiments: bit s = launch stage s; results are wrong unless 0x1f) */
+ * 1 = its v_pk build, 2 = its MFMA-product build), "fir_map" (1 = workgroups of one XCD
+ * walk neighbouring channel groups, the default; 0 = plain blockIdx order), "pipeline",
+ * "hdlc_variant" (1 = the event-driven deframer, the default; 0 = the bit-serial one),
+ * "hdlc_lpw" (channels per wave in the bit-serial deframer, 1..64), "timing_stride" (with
+ * set_timing on, time every n-th call only: the event records of a timed call cost ~0.05 ms
+ * of stream time), "stage_mask" (experiments: bit 0 = FIR/slicer, bit 1 = PLL/NRZI, bit 3 =
+ * deframer, bit 4 = unstuff/CRC; results are wrong unless 0x1f) */
 int  gnuais_batch_set_option(gnuais_batch *b, const char *name, int value);
 /* Optional, once, before real work: time the stage -> stream assignments on `d_samples` (about 0.5 s
  * of pipelined calls) and keep the fastest; RESETS the batch.  Which hardware queue a stream gets
