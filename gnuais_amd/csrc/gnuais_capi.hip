@@ -536,7 +536,8 @@ static int run_fir(gnuais_batch *b, const int16_t *x, int len, float *dump, hipS
     FirLaunch f;
     fill_fir(b, f, x, len, dump, k);
     if (b->fir_variant == 3 && b->sign_ok && !dump) {
-        f.T = (f.T + 95) / 96 * 96;
+        const int q = launch_fir_sign_quantum(f.NC);        // whole loop turns of the kernel's unrolled body
+        f.T = (f.T + q - 1) / q * q;
         HIP_TRY(launch_fir_sign(f, s));
     } else if (b->NE != 32) {
         HIP_TRY(hipMemsetAsync(b->maxval[b->max_cur ^ 1], 0, sizeof(int) * (size_t) b->N, s));

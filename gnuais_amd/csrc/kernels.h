@@ -25,6 +25,7 @@ struct FirLaunch {
     const float *te_mem;   //   the NE effective taps in device memory (exact re-evaluation)
     int map;               // K1s workgroup -> (channel group, segment) mapping, see fir_sign_kernel
 };
+int launch_fir_sign_quantum(int NC);           // T must be a multiple of this
 hipError_t launch_fir_sign(const FirLaunch &a, hipStream_t stream);
 hipError_t launch_fir_generic(const FirLaunch &a, hipStream_t stream);
 hipError_t launch_fir_history(const int16_t *x, const int16_t *hist_in, int16_t *hist_out,
