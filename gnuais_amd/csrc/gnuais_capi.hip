@@ -143,7 +143,7 @@ struct gnuais_batch {
     float sign_eps = 0.0f;
     int sign_NC = 12;               // central taps K1s evaluates
     int k0 = 0;                     // first effective tap
-    int hdlc_lpw = 64;              // channels per wave in K2b (window variant)
+    int hdlc_lpw = 0;               // channels per wave in K2b; 0 = the variant's own default (16 event-driven, 64 bit-serial)
     int hdlc_variant = 1;           // 1: the event-driven deframer (hdlc_events.hip), 0: window by window (hdlc_crc.hip)
     bool timing = false;
     int timing_stride = 1;          // time every n-th call only: ten event records a call are not free
@@ -526,7 +526,7 @@ static void fill_hdlc(const gnuais_batch *b, HdlcLaunch &h, int k)
     h.frame_count = b->streaming ? b->ring_count[b->ring_cur] : b->frame_count;
     h.frame_cap = (uint32_t) b->frame_cap; h.N = b->N; h.n_seg = b->n_seg;
     h.seg_words = b->seg_words; h.K = b->cand_K;
-    h.lanes_per_wave = b->hdlc_lpw;
+    h.lanes_per_wave = b->hdlc_lpw ? b->hdlc_lpw : (b->hdlc_variant ? 16 : 64);
 }
 
 // K1 + carry.  The specialised kernel updates the history and clears the next peak

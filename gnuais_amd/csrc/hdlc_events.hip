@@ -43,12 +43,13 @@ constexpr int NONE = 1 << 20;                   // "no such position"
 __device__ __forceinline__ uint32_t lowmask(int k) { return k >= 32 ? ~0u : k <= 0 ? 0u : ((1u << k) - 1u); }
 __device__ __forceinline__ int ctz32(uint32_t v) { return v ? __ffs((int) v) - 1 : 32; }
 __device__ __forceinline__ int clz32(uint32_t v) { return v ? __clz((int) v) : 32; }
-__device__ __forceinline__ int wave_max_i(int v)
+// max over the workgroup's lanes (one wave, possibly fewer than 64 lanes)
+__device__ __forceinline__ int wave_max_i(int v, int lanes, int lane)
 {
 #pragma unroll
     for (int o = 32; o; o >>= 1) {
         const int u = __shfl_xor(v, o);
-        v = u > v ? u : v;
+        v = ((lane ^ o) < lanes && u > v) ? u : v;
     }
     return v;
 }
@@ -220,7 +221,7 @@ __global__ __launch_bounds__(64) void hdlc_events_kernel(
                 pf[4 * q] = v.x; pf[4 * q + 1] = v.y; pf[4 * q + 2] = v.z; pf[4 * q + 3] = v.w;
             }
         }
-        const int nwq = __builtin_amdgcn_readfirstlane((int) wave_max_i((tile_end + 31) >> 5));
+        const int nwq = __builtin_amdgcn_readfirstlane((int) wave_max_i((tile_end + 31) >> 5, tpb, tx));
 #pragma unroll 1
         for (int q = 0; q < EW; ++q) {
             if (q >= nwq) {                 // beyond every lane's bits: empty
@@ -495,7 +496,7 @@ __global__ __launch_bounds__(64) void hdlc_events_kernel(
 hipError_t launch_hdlc_events(const HdlcLaunch &a, hipStream_t stream)
 {
     if (a.seg_words > PACK_STRIDE) return hipErrorInvalidValue;
-    const int lpw = 64;
+    const int lpw = a.lanes_per_wave >= 1 && a.lanes_per_wave <= 64 ? a.lanes_per_wave : 64;
     hipLaunchKernelGGL(hdlc_events_kernel, dim3((a.N + lpw - 1) / lpw), dim3(lpw), EV_ROWS * lpw * sizeof(uint32_t), stream,
                        a.segbits, a.segcnt, a.ctl, a.cand, a.cand_first, a.cand_count, a.counters,
                        a.frame_count, a.N, a.n_seg, a.seg_words, a.K);
