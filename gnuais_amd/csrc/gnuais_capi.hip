@@ -110,6 +110,9 @@ struct gnuais_batch {
     static constexpr int NRING = 5;
     gnuais_frame *ring[NRING] = {};
     uint32_t *ring_count[NRING] = {};
+    uint2 *ring_chunks[NRING] = {};             // K3's chunk table per ring (kernels.h: HdlcLaunch::chunks)
+    int ring_runs[NRING] = {};                  // K3 launches into the ring since it became current
+    int n_chunks = 0;
     int ring_cur = 0;
     bool streaming = false;
     hipStream_t s_post = nullptr, s_copy = nullptr, s_cnt = nullptr;
@@ -119,6 +122,7 @@ struct gnuais_batch {
     char *sh_text[NRING] = {};                  // pinned host text per slot
     size_t sh_text_bytes[NRING] = {};
     uint32_t *sh_info = nullptr;                // pinned: [NRING][8]: format's 4 words, the ring's 4 counters
+    int s_runs[NRING] = {};                     // K3 launches the slot's ring received
     int s_frames[NRING] = {}, s_stage[NRING] = {};     // stage: 0 idle, 1 filled, 2 formatting, 3 copying
     size_t s_len[NRING] = {};
     int s_sent[NRING] = {};
@@ -209,6 +213,7 @@ void gnuais_batch_destroy(gnuais_batch *b)
     for (int q = 0; q < gnuais_batch::NRING; ++q) {
         if (q > 0 && b->ring[q]) (void) hipFree(b->ring[q]);          // ring 0 is frames / frame_count
         if (q > 0 && b->ring_count[q]) (void) hipFree(b->ring_count[q]);
+        if (b->ring_chunks[q]) (void) hipFree(b->ring_chunks[q]);
         if (b->sd_text[q]) (void) hipFree(b->sd_text[q]);
         if (b->sh_text[q]) (void) hipHostFree(b->sh_text[q]);
         for (hipEvent_t e : {b->e_fill[q], b->e_fmt[q], b->e_txt[q]})
@@ -527,6 +532,8 @@ static void fill_hdlc(const gnuais_batch *b, HdlcLaunch &h, int k)
     h.frame_cap = (uint32_t) b->frame_cap; h.N = b->N; h.n_seg = b->n_seg;
     h.seg_words = b->seg_words; h.K = b->cand_K;
     h.lanes_per_wave = b->hdlc_lpw ? b->hdlc_lpw : (b->hdlc_variant ? 16 : 64);
+    // the chunk table describes ONE launch; a second one into the same ring would overwrite it
+    h.chunks = (b->streaming && b->ring_runs[b->ring_cur] == 0) ? b->ring_chunks[b->ring_cur] : nullptr;
 }
 
 // K1 + carry.  The specialised kernel updates the history and clears the next peak
@@ -590,6 +597,7 @@ static int run_tail(gnuais_batch *b, int k, int len, bool tm, hipEvent_t *ev,
     if (pl) HIP_TRY(hipStreamWaitEvent(sD, b->e_done[3][k], 0));
     if (tm) HIP_TRY(hipEventRecord(ev[9], sD));
     if (b->stage_mask & 16) HIP_TRY(launch_hdlc_crc(h, sD));
+    if (b->streaming) b->ring_runs[b->ring_cur]++;
     b->hdlc_calls++;
     if (tm) HIP_TRY(hipEventRecord(ev[4], sD));
     if (pl) HIP_TRY(hipEventRecord(b->e_done[4][k], sD));
@@ -842,6 +850,7 @@ int gnuais_batch_decode_bits(gnuais_batch *b, const uint8_t *h_bits, int stride,
         fill_hdlc(b, h, 0);
         HIP_TRY(b->hdlc_variant ? launch_hdlc_events(h, nullptr) : launch_hdlc_deframe(h, nullptr));
         HIP_TRY(launch_hdlc_crc(h, nullptr));
+        if (b->streaming) b->ring_runs[b->ring_cur]++;
         b->hdlc_calls++;
         HIP_TRY(hipDeviceSynchronize());
     }
@@ -1001,6 +1010,11 @@ int gnuais_batch_stream_nmea(gnuais_batch *b, const char **text, size_t *len, in
             HIP_TRY(hipMalloc((void **) &b->ring_count[q], sizeof(uint32_t) * 4));
             HIP_TRY(hipMemset(b->ring_count[q], 0, sizeof(uint32_t) * 4));
         }
+        b->n_chunks = k3_blocks(b->N) * k3_passes(b->cand_K);
+        for (int q = 0; q < NR; ++q) {
+            HIP_TRY(hipMalloc((void **) &b->ring_chunks[q], sizeof(uint2) * (size_t) b->n_chunks));
+            b->ring_runs[q] = 2;                // whatever ring 0 holds by now came without a table
+        }
         for (int q = 0; q < NR; ++q) {
             HIP_TRY(hipEventCreateWithFlags(&b->e_fill[q], hipEventDisableTiming));
             HIP_TRY(hipEventCreateWithFlags(&b->e_fmt[q], hipEventDisableTiming));
@@ -1023,10 +1037,12 @@ int gnuais_batch_stream_nmea(gnuais_batch *b, const char **text, size_t *len, in
     // (1) ring c: everything K3 has been asked to append so far
     HIP_TRY(hipEventRecord(b->e_fill[c], sD));
     b->s_stage[c] = 1;
+    b->s_runs[c] = b->ring_runs[c];
     // (2) K3 moves on to the next ring; that ring's formatter (queued two calls ago) must be done
     const int nx = (c + 1) % NR;
     if (b->stream_calls >= (unsigned) (NR - 1)) HIP_TRY(hipStreamWaitEvent(sD, b->e_fmt[nx], 0));   // long done
     b->ring_cur = nx;
+    b->ring_runs[nx] = 0;
     // (5) first, because it frees a slot: hand out the text whose copy was queued a call ago
     const int u = (c + NR - 4) % NR;
     if (b->s_stage[u] == 3) {
@@ -1076,7 +1092,8 @@ int gnuais_batch_stream_nmea(gnuais_batch *b, const char **text, size_t *len, in
         b->s_frames[a] = (int) have;
         HIP_TRY(hipStreamWaitEvent(b->s_post, b->e_fill[a], 0));
         if (have) {
-            const size_t need_text = (size_t) have * 164, need_scratch = nmea_scratch_bytes((int) have);
+            const bool by_chunks = b->s_runs[a] == 1;       // one launch filled it: its chunk table is the order
+            const size_t need_text = (size_t) have * 164, need_scratch = nmea_scratch_bytes((int) have, b->n_chunks);
             if (b->sd_text_bytes[a] < need_text) {
                 HIP_TRY(hipStreamSynchronize(b->s_copy));
                 if (b->sd_text[a]) HIP_TRY(hipFree(b->sd_text[a]));
@@ -1096,7 +1113,8 @@ int gnuais_batch_stream_nmea(gnuais_batch *b, const char **text, size_t *len, in
             uint8_t *sin = b->sd_seq[b->sd_seq_cur], *sout = b->sd_seq[b->sd_seq_cur ^ 1];
             HIP_TRY(hipMemcpyAsync(sout, sin, N, hipMemcpyDeviceToDevice, b->s_post));
             HIP_TRY(nmea_format_enqueue(b->ring[a], (int) have, b->N, sin, sout, b->sd_text[a], b->sd_text_bytes[a],
-                                        b->nmea_scratch, b->nmea_scratch_bytes, b->sh_info + 8 * a, b->s_post));
+                                        b->nmea_scratch, b->nmea_scratch_bytes, b->sh_info + 8 * a,
+                                        by_chunks ? b->ring_chunks[a] : nullptr, b->n_chunks, b->s_post));
             b->sd_seq_cur ^= 1;
         }
         HIP_TRY(hipMemsetAsync(b->ring_count[a], 0, 16, b->s_post));

@@ -49,7 +49,6 @@ enum { ST_SKURR = 1, ST_PREAMBLE = 2, ST_STARTSIGN = 3, ST_DATA = 4, ST_STOPSIGN
 // ctl[3]: ST_DATA entries since reset (candidate slots handed out)
 // ctl[4]: raw bits in the open frame record
 constexpr uint32_t CAND_VALID = 0x10000u;
-constexpr int K3_CH = 32;               // channels per K3 block
 constexpr int PACK_MAX = PACK_STRIDE;   // words per segment pack held in registers/LDS
 
 __global__ void hdlc_reset_kernel(uint32_t *__restrict__ ctl, int N)
@@ -382,7 +381,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(7, 8))) void
 __global__ __launch_bounds__(256) void hdlc_crc_kernel(
     const uint32_t *__restrict__ cand, const uint32_t *__restrict__ cand_first,
     const uint32_t *__restrict__ cand_count, int32_t *__restrict__ counters,
-    uint32_t *__restrict__ frames, uint32_t *__restrict__ flags, uint32_t frame_cap, int N, int K)
+    uint32_t *__restrict__ frames, uint32_t *__restrict__ flags, uint32_t frame_cap, int N, int K,
+    uint2 *__restrict__ chunks, int n_pass)
 {
     __shared__ uint32_t tab[256];
     __shared__ uint32_t pre[K3_CH + 1];
@@ -411,7 +411,8 @@ __global__ __launch_bounds__(256) void hdlc_crc_kernel(
     const uint32_t total = pre[K3_CH];
     const size_t n_ = (size_t) N;
 
-    for (uint32_t i0 = 0; i0 < total; i0 += 256) {
+    int pass = 0;
+    for (uint32_t i0 = 0; i0 < total; i0 += 256, ++pass) {
         const uint32_t i = i0 + (uint32_t) tid;
         bool good = false;
         uint32_t out[16];
@@ -530,9 +531,14 @@ __global__ __launch_bounds__(256) void hdlc_crc_kernel(
             if (q < wave) woff += wave_cnt[q];
             npass += wave_cnt[q];
         }
-        if (tid == 0 && npass) {
-            const uint32_t base = atomicAdd(&flags[0], npass);
+        if (tid == 0) {
+            const uint32_t base = npass ? atomicAdd(&flags[0], npass) : 0u;
             pass_base = base;
+            // candidates are walked channel by channel, each channel's in time order, and the compaction
+            // keeps that order: (block, pass, position in the pass) is the reference's print order
+            if (chunks && pass < n_pass)
+                chunks[(size_t) blockIdx.x * n_pass + pass] =
+                    make_uint2(base, base >= frame_cap ? 0u : (npass < frame_cap - base ? npass : frame_cap - base));
         }
         __syncthreads();
         if (good) {
@@ -549,6 +555,8 @@ __global__ __launch_bounds__(256) void hdlc_crc_kernel(
         }
         __syncthreads();
     }
+    if (chunks)
+        for (int q = pass + tid; q < n_pass; q += 256) chunks[(size_t) blockIdx.x * n_pass + q] = make_uint2(0u, 0u);
 }
 
 hipError_t launch_hdlc_deframe(const HdlcLaunch &a, hipStream_t stream)
@@ -566,7 +574,7 @@ hipError_t launch_hdlc_crc(const HdlcLaunch &a, hipStream_t stream)
 {
     hipLaunchKernelGGL(hdlc_crc_kernel, dim3((unsigned) ((a.N + K3_CH - 1) / K3_CH)), dim3(256), 0,
                        stream, a.cand, a.cand_first, a.cand_count, a.counters,
-                       (uint32_t *) a.frames, a.frame_count, a.frame_cap, a.N, a.K);
+                       (uint32_t *) a.frames, a.frame_count, a.frame_cap, a.N, a.K, a.chunks, k3_passes(a.K));
     return hipGetLastError();
 }
 

@@ -80,7 +80,13 @@ struct HdlcLaunch {
     uint32_t frame_cap;
     int N, n_seg, seg_words, K;
     int lanes_per_wave;    // channels per wave in K2b (blockDim)
+    uint2 *chunks = nullptr;   // optional [blocks of K3][k3_passes(K)]: where each pass of each K3 block put its
+                           // frames in the ring (start, count).  (block, pass, position) is the reference's
+                           // print order -- channel, then time -- so a ring that holds ONE call needs no sort
 };
+constexpr int K3_CH = 32;               // channels per K3 block
+inline int k3_blocks(int N) { return (N + K3_CH - 1) / K3_CH; }
+inline int k3_passes(int K) { return (K3_CH * K + 255) / 256; }
 hipError_t launch_hdlc_deframe(const HdlcLaunch &a, hipStream_t stream); // K2b, window by window (hdlc_crc.hip)
 hipError_t launch_hdlc_events(const HdlcLaunch &a, hipStream_t stream);  // K2b, event by event (hdlc_events.hip)
 hipError_t launch_hdlc_crc(const HdlcLaunch &a, hipStream_t stream);     // K3
@@ -100,7 +106,7 @@ hipError_t launch_crc16(const uint8_t *data, int stride, const int32_t *len, int
 #define K1S_DIRECT(nc) (K1S_DIRECT_12 && (nc) == 12)
 
 // ---- f1 on the device (nmea_device.hip) ---------------------------------------
-size_t nmea_scratch_bytes(int n_frames);
+size_t nmea_scratch_bytes(int n_frames, int n_chunks = 0);
 // frames: device gnuais_frame[n]; seq_in/seq_out: device u8[n_channels] (seq_out preloaded with
 // seq_in); out: device text buffer.  h_info: [0] bytes written, [1] sentences, [2] != 0 if a
 // frame named a channel >= n_channels.  Synchronises `s`.
@@ -109,9 +115,11 @@ hipError_t frames_sort(const struct gnuais_frame *frames, int n, struct gnuais_f
                        size_t scratch_bytes, hipStream_t s);
 // the device part only, queued without waiting; h_info4 (host, pinned): [0] + [1] bytes written,
 // [2] sentences, [3] != 0 if a frame named a channel >= n_channels -- valid once `s` has got there
+// chunks / n_chunks: K3's chunk table of this ring (HdlcLaunch::chunks) when the ring holds exactly one
+// call's frames -- the order then comes from a scan over the table instead of a radix sort; else null / 0
 hipError_t nmea_format_enqueue(const struct gnuais_frame *frames, int n, int n_channels, const uint8_t *seq_in,
                                uint8_t *seq_out, char *out, size_t out_cap, void *scratch, size_t scratch_bytes,
-                               uint32_t *h_info4, hipStream_t s);
+                               uint32_t *h_info4, const uint2 *chunks, int n_chunks, hipStream_t s);
 hipError_t nmea_format(const struct gnuais_frame *frames, int n, int n_channels, const uint8_t *seq_in,
                        uint8_t *seq_out, char *out, size_t out_cap, void *scratch, size_t scratch_bytes,
                        uint32_t *h_info, hipStream_t s);

@@ -9,11 +9,15 @@
 //      whatever order the blocks finished); radix sort (rocPRIM) gives the reference's order;
 //   2. per frame, in that order: accepted (AIS type 1..24, :899-900), bytes it will print
 //      (nchars + 21 per sentence: 14 of header, 5 of ",f*hh", CR LF), head-of-channel flag;
-//   3. exclusive scans of bytes and of accepted, max-scan of the head positions: every frame knows
-//      where its text starts and how many accepted frames of its channel came before it, hence
-//      its sequence digit (seq0[channel] + that) mod 10;
-//   4. one thread per frame writes its one or two sentences; the last frame of a channel leaves the
-//      channel's new digit.
+//   3. ONE scan over (bytes, accepted, head position) with (+, +, max): every frame knows where its
+//      text starts and how many accepted frames of its channel came before it, hence its sequence
+//      digit (seq0[channel] + that) mod 10;
+//   4. a workgroup builds the text of 256 consecutive frames in LDS (one thread per frame) and stores
+//      it 16 bytes per lane; the last frame of a channel leaves the channel's new digit.
+// When the ring holds exactly one call (gnuais_batch_stream_nmea) step 1 is not a sort at all: K3
+// walks its candidates channel by channel in time order, so (K3 block, pass, position) already IS
+// the print order, and a scan over K3's chunk table (a few thousand entries) turns a print position
+// into a ring index.
 // HBM-bound byte shuffling: 64 B read + ~50 B written per frame.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -88,75 +92,178 @@ __device__ __forceinline__ Geo geometry(int nbits)
     return g;
 }
 
+// Per frame, in print order: bytes of text, accepted or not, head-of-channel position -- one struct so
+// that ONE scan yields the text offset, the accepted frames before it and the head of its channel.
+struct Tri { uint32_t bytes, acc, head; };
+struct TriOp {
+    __device__ __host__ Tri operator()(const Tri &a, const Tri &b) const
+    {
+        return Tri{a.bytes + b.bytes, a.acc + b.acc, a.head > b.head ? a.head : b.head};
+    }
+};
+
+// Exclusive scan of the chunk table's counts (one workgroup; the table has a few thousand entries):
+// chunk_off[k] = frames in print order before chunk k, chunk_off[E] = all of them.
+__global__ __launch_bounds__(1024) void chunk_scan_kernel(const uint2 *__restrict__ chunks, int E,
+                                                          uint32_t *__restrict__ chunk_off, uint32_t *__restrict__ totals)
+{
+    __shared__ uint32_t wsum[16];
+    __shared__ uint32_t carry_s;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid < 4) totals[tid] = 0;
+    if (tid == 0) carry_s = 0;
+    __syncthreads();
+    for (int base = 0; base < E; base += 1024) {
+        const int k = base + tid;
+        const uint32_t v = k < E ? chunks[k].y : 0u;
+        uint32_t inc = v;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t u = __shfl_up(inc, o);
+            if (lane >= o) inc += u;
+        }
+        if (lane == 63) wsum[wave] = inc;
+        __syncthreads();
+        uint32_t before = carry_s;
+        for (int q = 0; q < wave; ++q) before += wsum[q];
+        if (k < E) chunk_off[k] = before + inc - v;
+        __syncthreads();
+        if (tid == 1023) carry_s = before + inc;
+        __syncthreads();
+    }
+    if (tid == 0) chunk_off[E] = carry_s;
+}
+
+// ring index of the frame at print position j, from the scanned chunk table
+__device__ __forceinline__ uint32_t chunk_lookup(const uint2 *__restrict__ chunks, const uint32_t *__restrict__ chunk_off,
+                                                 int E, uint32_t j)
+{
+    int lo = 0, hi = E - 1;                     // largest k with chunk_off[k] <= j: the chunk that holds j
+    while (lo < hi) {                           // (empty chunks share their successor's offset and lose)
+        const int mid = (lo + hi + 1) >> 1;
+        if (chunk_off[mid] <= j) lo = mid; else hi = mid - 1;
+    }
+    return chunks[lo].x + (j - chunk_off[lo]);
+}
+
+// order: in (sorted ring indices) when chunks == nullptr, else out (computed from the chunk table)
 __global__ __launch_bounds__(256) void nmea_meta_kernel(const gnuais_frame *__restrict__ frames,
-                                                        const uint64_t *__restrict__ keys_sorted,
-                                                        const uint32_t *__restrict__ order, int n,
-                                                        uint32_t *__restrict__ bytes, uint32_t *__restrict__ acc,
-                                                        uint32_t *__restrict__ head)
+                                                        uint32_t *__restrict__ order, int n,
+                                                        const uint2 *__restrict__ chunks,
+                                                        const uint32_t *__restrict__ chunk_off, int E,
+                                                        Tri *__restrict__ tri, uint32_t *__restrict__ chan)
 {
     const int j = blockIdx.x * 256 + threadIdx.x;
     if (j >= n) return;
-    const gnuais_frame *f = frames + order[j];
-    const unsigned first = reinterpret_cast<const uint32_t *>(f)[2] & 0xffu;       // payload[0]
-    const int nbits = (int) (reinterpret_cast<const uint32_t *>(f)[15] >> 16);
+    uint32_t r, rprev = 0;
+    if (chunks) {
+        r = chunk_lookup(chunks, chunk_off, E, (uint32_t) j);
+        if (j > 0) rprev = chunk_lookup(chunks, chunk_off, E, (uint32_t) j - 1u);
+        order[j] = r;
+    } else {
+        r = order[j];
+        if (j > 0) rprev = order[j - 1];
+    }
+    const uint32_t *f = reinterpret_cast<const uint32_t *>(frames + r);
+    const uint32_t ch = f[0];
+    const unsigned first = f[2] & 0xffu;                                            // payload[0]
+    const int nbits = (int) (f[15] >> 16);
     const unsigned type = nbits >= 6 ? first >> 2 : (nbits > 0 ? (first >> 2) & ~((1u << (6 - nbits)) - 1u) : 0u);
     const bool ok = type >= 1 && type <= MAX_TYPE;
     const Geo g = geometry(nbits);
-    bytes[j] = ok ? (uint32_t) (g.nchars + 21 * g.parts) : 0u;
-    acc[j] = ok ? 1u : 0u;
-    head[j] = (j > 0 && (keys_sorted[j] >> KEY_CH_SHIFT) != (keys_sorted[j - 1] >> KEY_CH_SHIFT)) ? (uint32_t) j : 0u;
+    Tri t;
+    t.bytes = ok ? (uint32_t) (g.nchars + 21 * g.parts) : 0u;
+    t.acc = ok ? 1u : 0u;
+    t.head = (j > 0 && reinterpret_cast<const uint32_t *>(frames + rprev)[0] != ch) ? (uint32_t) j : 0u;
+    tri[j] = t;
+    chan[j] = ch;
 }
 
 __device__ __forceinline__ char armor(unsigned v) { return (char) (v < 40 ? v + 48 : v + 56); }   // protodec.c:826-830
 __device__ __forceinline__ char hexdigit(unsigned v) { return (char) (v < 10 ? '0' + v : 'A' + v - 10); }
 
+constexpr int MAX_FRAME_TEXT = 164;         // two sentences of 82 bytes: 449 bits are at most 75 characters
+
+// 256 consecutive frames of the print order per workgroup: their text is one contiguous piece of the
+// output, built in LDS (a thread writes its own sentences byte by byte) and then stored 16 bytes per lane.
 __global__ __launch_bounds__(256) void nmea_write_kernel(
-    const gnuais_frame *__restrict__ frames, const uint64_t *__restrict__ keys_sorted,
-    const uint32_t *__restrict__ order, const uint32_t *__restrict__ off, const uint32_t *__restrict__ accpre,
-    const uint32_t *__restrict__ headpos, const uint32_t *__restrict__ bytes, int n, int n_channels,
+    const gnuais_frame *__restrict__ frames, const uint32_t *__restrict__ order, const uint32_t *__restrict__ chan,
+    const Tri *__restrict__ tri, const Tri *__restrict__ scan, int n, int n_channels,
     const uint8_t *__restrict__ seq_in, uint8_t *__restrict__ seq_out, char *__restrict__ out,
-    unsigned long long out_cap, uint32_t *__restrict__ totals /* [0] sentences, [1] bad channel */)
+    unsigned long long out_cap, uint32_t *__restrict__ totals /* [0] offset of the last frame's text, [1] its
+    length, [2] sentences, [3] bad channel */)
 {
-    const int j = blockIdx.x * 256 + threadIdx.x;
-    if (j >= n) return;
-    const uint32_t ch = (uint32_t) (keys_sorted[j] >> KEY_CH_SHIFT);
-    if (ch >= (uint32_t) n_channels) {
-        atomicOr(&totals[1], 1u);
-        return;
-    }
-    const bool ok = bytes[j] != 0;
-    const uint32_t before = accpre[j] - accpre[headpos[j]];          // accepted frames of this channel before j
-    const bool last = (j + 1 == n) || (uint32_t) (keys_sorted[j + 1] >> KEY_CH_SHIFT) != ch;
-    if (last) seq_out[ch] = (uint8_t) ((seq_in[ch] + before + (ok ? 1u : 0u)) % 10u);
-    if (!ok) return;
-    if ((unsigned long long) off[j] + bytes[j] > out_cap) return;    // the host reports the overflow
-    const FrameView f = load_frame(frames, order[j]);
-    const Geo g = geometry(f.nbits());
-    const char seq = (char) ('0' + (seq_in[ch] + before) % 10u);
-    char *o = out + off[j];
-    int done = 0;
-    for (int part = 1; part <= g.parts; ++part) {
-        char s[84];
-        int k = 0;
-        s[k++] = '!'; s[k++] = 'A'; s[k++] = 'I'; s[k++] = 'V'; s[k++] = 'D'; s[k++] = 'M'; s[k++] = ',';
-        s[k++] = (char) ('0' + g.parts); s[k++] = ',';
-        s[k++] = (char) ('0' + part); s[k++] = ',';
-        if (g.parts > 1) {                                          // protodec.c:847-849: no channel letter
-            s[k++] = seq; s[k++] = ','; s[k++] = ',';
-        } else {                                                    // :857-859: always 'A'
-            s[k++] = ','; s[k++] = 'A'; s[k++] = ',';
+    __shared__ __attribute__((aligned(16))) char buf[256 * MAX_FRAME_TEXT + 32];
+    __shared__ uint32_t s_base, s_end, s_sent;
+    const int tid = threadIdx.x;
+    const int j = blockIdx.x * 256 + tid;
+    const bool in = j < n;
+    Tri me = {0, 0, 0}, inc = {0, 0, 0};
+    uint32_t ch = 0;
+    if (in) { me = tri[j]; inc = scan[j]; ch = chan[j]; }
+    const uint32_t off = inc.bytes - me.bytes;
+    if (tid == 0) { s_base = off; s_sent = 0; }
+    if (in && (tid == 255 || j == n - 1)) s_end = inc.bytes;
+    __syncthreads();
+    const uint32_t base = s_base, shift = base & 15u;
+    int parts_written = 0;
+    if (in) {
+        if (ch >= (uint32_t) n_channels) {
+            atomicOr(&totals[3], 1u);
+        } else {
+            const bool ok = me.bytes != 0;
+            const uint32_t h = inc.head;                                  // position of this channel's first frame
+            const uint32_t before = (inc.acc - me.acc) - (scan[h].acc - tri[h].acc);   // accepted frames of the channel before j
+            const bool last = (j + 1 == n) || chan[j + 1] != ch;
+            if (last) seq_out[ch] = (uint8_t) ((seq_in[ch] + before + (ok ? 1u : 0u)) % 10u);
+            if (ok) {
+                const FrameView f = load_frame(frames, order[j]);
+                const Geo g = geometry(f.nbits());
+                const char seq = (char) ('0' + (seq_in[ch] + before) % 10u);
+                char *o = buf + shift + (off - base);
+                int done = 0;
+                for (int part = 1; part <= g.parts; ++part) {
+                    int k = 0;
+                    unsigned x = 0;
+                    auto put = [&](char c) { o[k++] = c; x ^= (unsigned char) c; };
+                    o[k++] = '!';
+                    put('A'); put('I'); put('V'); put('D'); put('M'); put(',');
+                    put((char) ('0' + g.parts)); put(',');
+                    put((char) ('0' + part)); put(',');
+                    if (g.parts > 1) {                                  // protodec.c:847-849: no channel letter
+                        put(seq); put(','); put(',');
+                    } else {                                            // :857-859: always 'A'
+                        put(','); put('A'); put(',');
+                    }
+                    for (int i = 0; i < CHARS_PER_SENTENCE && done < g.nchars; ++i, ++done) put(armor(f.six(done)));
+                    put(',');
+                    put((char) ((g.parts > 1 && part == g.parts) ? '0' + g.fill : '0'));
+                    o[k++] = '*'; o[k++] = hexdigit(x >> 4); o[k++] = hexdigit(x & 15u);      // :864-869
+                    o[k++] = '\r'; o[k++] = '\n';
+                    o += k;
+                }
+                parts_written = g.parts;
+            }
         }
-        for (int i = 0; i < CHARS_PER_SENTENCE && done < g.nchars; ++i, ++done) s[k++] = armor(f.six(done));
-        s[k++] = ',';
-        s[k++] = (char) ((g.parts > 1 && part == g.parts) ? '0' + g.fill : '0');
-        unsigned x = 0;
-        for (int i = 1; i < k; ++i) x ^= (unsigned char) s[i];      // :864-869
-        s[k++] = '*'; s[k++] = hexdigit(x >> 4); s[k++] = hexdigit(x & 15u);
-        s[k++] = '\r'; s[k++] = '\n';
-        for (int i = 0; i < k; ++i) o[i] = s[i];
-        o += k;
+        if (j == n - 1) { totals[0] = off; totals[1] = me.bytes; }
     }
-    atomicAdd(&totals[0], (uint32_t) g.parts);
+    if (parts_written) atomicAdd(&s_sent, (uint32_t) parts_written);
+    __syncthreads();
+    if (tid == 0 && s_sent) atomicAdd(&totals[2], s_sent);
+    // the piece [base, end) of the output = buf[shift, shift + end - base): whole 16-byte units where they
+    // lie inside it, single bytes at its two ragged ends (the neighbours' pieces share those units)
+    const uint32_t total = s_end - base;
+    const unsigned long long g0 = (unsigned long long) base - shift;
+    const uint32_t units = (shift + total + 15u) >> 4;
+    for (uint32_t u = tid; u < units; u += 256) {
+        const uint32_t lo = u * 16u, hi = lo + 16u;
+        if (lo >= shift && hi <= shift + total && g0 + hi <= out_cap) {
+            *reinterpret_cast<uint4 *>(out + g0 + lo) = *reinterpret_cast<const uint4 *>(buf + lo);
+        } else {
+            for (uint32_t q = lo; q < hi; ++q)
+                if (q >= shift && q < shift + total && g0 + q < out_cap) out[g0 + q] = buf[q];
+        }
+    }
 }
 
 // records gathered into sorted order: one thread moves one 16-byte quarter of a record
@@ -176,20 +283,16 @@ struct MaxOp {
 
 } // namespace
 
-size_t nmea_scratch_bytes(int n)
+size_t nmea_scratch_bytes(int n, int n_chunks)
 {
     const size_t m = (size_t) (n > 0 ? n : 1);
-    size_t sort_tmp = 0, scan_tmp = 0, scan_tmp2 = 0;
+    size_t sort_tmp = 0, scan_tmp = 0;
     (void) rocprim::radix_sort_pairs(nullptr, sort_tmp, (uint64_t *) nullptr, (uint64_t *) nullptr,
                                      (uint32_t *) nullptr, (uint32_t *) nullptr, m, 0, 64, (hipStream_t) 0);
-    (void) rocprim::exclusive_scan(nullptr, scan_tmp, (uint32_t *) nullptr, (uint32_t *) nullptr, 0u, m,
-                                   rocprim::plus<uint32_t>(), (hipStream_t) 0);
-    (void) rocprim::inclusive_scan(nullptr, scan_tmp2, (uint32_t *) nullptr, (uint32_t *) nullptr, m, MaxOp(),
-                                   (hipStream_t) 0);
-    size_t tmp = sort_tmp > scan_tmp ? sort_tmp : scan_tmp;
-    tmp = tmp > scan_tmp2 ? tmp : scan_tmp2;
-    // keys x2, idx x2, bytes, off, acc, accpre, head, headpos, totals, rocPRIM temp (256-byte slots)
-    return 2 * 8 * m + 8 * 4 * m + 256 * 12 + tmp + 64;
+    (void) rocprim::inclusive_scan(nullptr, scan_tmp, (Tri *) nullptr, (Tri *) nullptr, m, TriOp(), (hipStream_t) 0);
+    const size_t tmp = sort_tmp > scan_tmp ? sort_tmp : scan_tmp;
+    // keys x2, idx x2, chan, tri x2, chunk offsets, totals, rocPRIM temp (256-byte slots)
+    return 2 * 8 * m + 3 * 4 * m + 2 * sizeof(Tri) * m + 4 * ((size_t) n_chunks + 1) + 256 * 12 + tmp + 64;
 }
 
 // The ring's records in the reference's print order (channel, then time = end_bit), on the device:
@@ -216,43 +319,44 @@ hipError_t frames_sort(const gnuais_frame *frames, int n, gnuais_frame *out, voi
 // everything of nmea_format() that runs on the device, queued on `s` without waiting for it (n > 0)
 hipError_t nmea_format_enqueue(const gnuais_frame *frames, int n, int n_channels, const uint8_t *seq_in,
                                uint8_t *seq_out, char *out, size_t out_cap, void *scratch, size_t scratch_bytes,
-                               uint32_t *h_info4, hipStream_t s)
+                               uint32_t *h_info4, const uint2 *chunks, int n_chunks, hipStream_t s)
 {
     if (n <= 0) return hipErrorInvalidValue;
-    if (scratch_bytes < nmea_scratch_bytes(n)) return hipErrorInvalidValue;
+    if (!chunks) n_chunks = 0;
+    if (scratch_bytes < nmea_scratch_bytes(n, n_chunks)) return hipErrorInvalidValue;
     const size_t m = (size_t) n;
     char *p = static_cast<char *>(scratch);
     auto take = [&](size_t bytes) { char *q = p; p += (bytes + 255) / 256 * 256; return (void *) q; };
     uint64_t *keys = (uint64_t *) take(8 * m), *keys2 = (uint64_t *) take(8 * m);
     uint32_t *idx = (uint32_t *) take(4 * m), *idx2 = (uint32_t *) take(4 * m);
-    uint32_t *bytes = (uint32_t *) take(4 * m), *off = (uint32_t *) take(4 * m);
-    uint32_t *acc = (uint32_t *) take(4 * m), *accpre = (uint32_t *) take(4 * m);
-    uint32_t *head = (uint32_t *) take(4 * m), *headpos = (uint32_t *) take(4 * m);
+    uint32_t *chan = (uint32_t *) take(4 * m);
+    Tri *tri = (Tri *) take(sizeof(Tri) * m), *scan = (Tri *) take(sizeof(Tri) * m);
+    uint32_t *chunk_off = (uint32_t *) take(4 * ((size_t) n_chunks + 1));
     uint32_t *totals = (uint32_t *) take(16);
     void *tmp = p;
     size_t tmp_bytes = scratch_bytes - (size_t) (p - static_cast<char *>(scratch));
     const int grid = (n + 255) / 256;
     hipError_t e;
-    if ((e = hipMemsetAsync(totals, 0, 16, s)) != hipSuccess) return e;
-    hipLaunchKernelGGL(nmea_keys_kernel, dim3(grid), dim3(256), 0, s, frames, n, keys, idx);
-    // channel < 2^24 in any realistic batch; the key's top three bits are never set
     size_t t = tmp_bytes;
-    if ((e = rocprim::radix_sort_pairs(tmp, t, keys, keys2, idx, idx2, m, 0, 61, s)) != hipSuccess) return e;
-    hipLaunchKernelGGL(nmea_meta_kernel, dim3(grid), dim3(256), 0, s, frames, keys2, idx2, n, bytes, acc, head);
+    if (chunks) {
+        // the ring holds one call: K3's chunk table gives the print order (also clears totals)
+        hipLaunchKernelGGL(chunk_scan_kernel, dim3(1), dim3(1024), 0, s, chunks, n_chunks, chunk_off, totals);
+    } else {
+        if ((e = hipMemsetAsync(totals, 0, 16, s)) != hipSuccess) return e;
+        hipLaunchKernelGGL(nmea_keys_kernel, dim3(grid), dim3(256), 0, s, frames, n, keys, idx);
+        // channel < 2^24 in any realistic batch; the key's top three bits are never set
+        if ((e = rocprim::radix_sort_pairs(tmp, t, keys, keys2, idx, idx2, m, 0, 61, s)) != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(nmea_meta_kernel, dim3(grid), dim3(256), 0, s, frames, idx2, n, chunks, chunk_off, n_chunks,
+                       tri, chan);
     t = tmp_bytes;
-    if ((e = rocprim::exclusive_scan(tmp, t, bytes, off, 0u, m, rocprim::plus<uint32_t>(), s)) != hipSuccess) return e;
-    t = tmp_bytes;
-    if ((e = rocprim::exclusive_scan(tmp, t, acc, accpre, 0u, m, rocprim::plus<uint32_t>(), s)) != hipSuccess) return e;
-    t = tmp_bytes;
-    if ((e = rocprim::inclusive_scan(tmp, t, head, headpos, m, MaxOp(), s)) != hipSuccess) return e;
-    hipLaunchKernelGGL(nmea_write_kernel, dim3(grid), dim3(256), 0, s, frames, keys2, idx2, off, accpre, headpos,
-                       bytes, n, n_channels, seq_in, seq_out, out, (unsigned long long) out_cap, totals);
+    if ((e = rocprim::inclusive_scan(tmp, t, tri, scan, m, TriOp(), s)) != hipSuccess) return e;
+    hipLaunchKernelGGL(nmea_write_kernel, dim3(grid), dim3(256), 0, s, frames, idx2, chan, tri, scan, n, n_channels,
+                       seq_in, seq_out, out, (unsigned long long) out_cap, totals);
     if ((e = hipGetLastError()) != hipSuccess) return e;
     // h_info4 (pinned host memory when the caller does not wait here): [0] offset of the last frame's
     // text, [1] its length, [2] sentences, [3] frames that named a channel outside the batch
-    if ((e = hipMemcpyAsync(&h_info4[0], off + (m - 1), 4, hipMemcpyDeviceToHost, s)) != hipSuccess) return e;
-    if ((e = hipMemcpyAsync(&h_info4[1], bytes + (m - 1), 4, hipMemcpyDeviceToHost, s)) != hipSuccess) return e;
-    return hipMemcpyAsync(&h_info4[2], totals, 8, hipMemcpyDeviceToHost, s);
+    return hipMemcpyAsync(h_info4, totals, 16, hipMemcpyDeviceToHost, s);
 }
 
 hipError_t nmea_format(const gnuais_frame *frames, int n, int n_channels, const uint8_t *seq_in,
@@ -262,7 +366,8 @@ hipError_t nmea_format(const gnuais_frame *frames, int n, int n_channels, const 
     h_info[0] = h_info[1] = h_info[2] = 0;
     if (n <= 0) return hipSuccess;
     uint32_t raw[4] = {0, 0, 0, 0};
-    hipError_t e = nmea_format_enqueue(frames, n, n_channels, seq_in, seq_out, out, out_cap, scratch, scratch_bytes, raw, s);
+    hipError_t e = nmea_format_enqueue(frames, n, n_channels, seq_in, seq_out, out, out_cap, scratch, scratch_bytes, raw,
+                                       nullptr, 0, s);
     if (e != hipSuccess) return e;
     if ((e = hipStreamSynchronize(s)) != hipSuccess) return e;
     h_info[0] = raw[0] + raw[1];

@@ -287,3 +287,35 @@ def test_streamed_sentences_equal_drained_sentences():
     for i, (w, g) in enumerate(zip(want, out)):
         assert g[2] == w[2] and g[1] == w[1], i
         assert g[0] == w[0], i
+
+
+@pytest.mark.gpu
+def test_streamed_sentences_with_several_runs_per_call():
+    """A ring that received more than one run has no single chunk table: the formatter falls back to
+    the radix sort; rings with exactly one run take their order from K3's chunk table.  Both mixed in
+    one sequence, against drain_nmea() over the same spans."""
+    import torch
+    from gnuais_amd import ReceiverBatch, synth
+    n_ch, call = 200, 2 * 1280
+    plan = [1, 2, 1, 1, 3, 1, 2, 1, 1]                          # runs per stream call
+    total = sum(plan)
+    x = np.stack([synth.make_stream(call * total, seed=83, channel=c, occupancy=0.9)[0] for c in range(n_ch)], axis=1)
+    xd = torch.from_numpy(x).cuda()
+    a, b = ReceiverBatch(n_ch, max_len=call), ReceiverBatch(n_ch, max_len=call)
+    seq = np.zeros(n_ch, dtype=np.uint8)
+    want, got = [], []
+    i = 0
+    for runs in plan:
+        for _ in range(runs):
+            a.run(xd[i * call:(i + 1) * call])
+            b.run(xd[i * call:(i + 1) * call], sync=False)
+            i += 1
+        want.append(a.drain_nmea(seq))
+        got.append(b.stream_nmea())
+    for _ in range(4):
+        got.append(b.stream_nmea())
+    out = got[4:]
+    assert len(out) == len(plan) and sum(w[2] for w in want) > 1000
+    for k, (w, g) in enumerate(zip(want, out)):
+        assert g[2] == w[2] and g[1] == w[1], k
+        assert g[0] == w[0], k
