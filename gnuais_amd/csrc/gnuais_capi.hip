@@ -104,10 +104,12 @@ struct gnuais_batch {
     void *nmea_scratch = nullptr;
     size_t nmea_scratch_bytes = 0, d_text_bytes = 0;
     // gnuais_batch_stream_nmea: the frame ring exists NRING times (ring 0 is `frames` / `frame_count`
-    // above until the first streaming call); a ring is filled by K3, counted and formatted two calls
-    // later, its text copied one call after that and handed out one call after that -- every host-side
-    // wait is for work the device was given at least one whole call earlier
-    static constexpr int NRING = 5;
+    // above until the first streaming call).  A ring is filled by K3; its formatter and the copy of its
+    // text into pinned memory are queued behind that K3 at once, with every size taken on the device; the
+    // text is handed out NRING - 1 calls later, which is the only thing the host ever waits for.  A call
+    // is about 2.7 ms from its FIR to its text on the host (four chain stages, formatter, PCIe copy), so
+    // about six of them have to be in flight for one to finish every 0.55 ms.
+    static constexpr int NRING = 8;
     gnuais_frame *ring[NRING] = {};
     uint32_t *ring_count[NRING] = {};
     uint2 *ring_chunks[NRING] = {};             // K3's chunk table per ring (kernels.h: HdlcLaunch::chunks)
@@ -115,17 +117,17 @@ struct gnuais_batch {
     int n_chunks = 0;
     int ring_cur = 0;
     bool streaming = false;
-    hipStream_t s_post = nullptr, s_copy = nullptr, s_cnt = nullptr;
+    hipStream_t s_post = nullptr, s_copy = nullptr;
     hipEvent_t e_fill[NRING] = {}, e_fmt[NRING] = {}, e_txt[NRING] = {};
     char *sd_text[NRING] = {};                  // device text per slot
     size_t sd_text_bytes[NRING] = {};
     char *sh_text[NRING] = {};                  // pinned host text per slot
     size_t sh_text_bytes[NRING] = {};
     uint32_t *sh_info = nullptr;                // pinned: [NRING][8]: format's 4 words, the ring's 4 counters
-    int s_runs[NRING] = {};                     // K3 launches the slot's ring received
-    int s_frames[NRING] = {}, s_stage[NRING] = {};     // stage: 0 idle, 1 filled, 2 formatting, 3 copying
-    size_t s_len[NRING] = {};
-    int s_sent[NRING] = {};
+    int s_stage[NRING] = {};                    // 1: the slot's formatter is queued, its text not handed out yet
+    size_t sh_text_want = 0;                    // pinned text buffers grow to this (learnt from the traffic)
+    uint32_t *sd_info = nullptr;                // device: [NRING][8], what sh_info receives with the text
+    int copy_wgs = 16;                          // workgroups of the device -> pinned copy
     uint8_t *sd_seq[2] = {nullptr, nullptr};    // per-channel sequence digit, carried on the device
     int sd_seq_cur = 0;
     unsigned long long stream_calls = 0;
@@ -220,9 +222,10 @@ void gnuais_batch_destroy(gnuais_batch *b)
             if (e) (void) hipEventDestroy(e);
     }
     if (b->sh_info) (void) hipHostFree(b->sh_info);
+    if (b->sd_info) (void) hipFree(b->sd_info);
     for (auto p : b->sd_seq)
         if (p) (void) hipFree(p);
-    for (hipStream_t st : {b->s_post, b->s_copy, b->s_cnt})
+    for (hipStream_t st : {b->s_copy})
         if (st) (void) hipStreamDestroy(st);
     for (int q = 0; q < 2; ++q) {
         if (b->pin[q]) (void) hipHostFree(b->pin[q]);
@@ -454,7 +457,7 @@ int gnuais_batch_reset(gnuais_batch *b)
         if (b->ring_count[q]) HIP_TRY(hipMemset(b->ring_count[q], 0, sizeof(uint32_t) * 4));
     for (auto p : b->sd_seq)
         if (p) HIP_TRY(hipMemset(p, 0, N));
-    for (int q = 0; q < gnuais_batch::NRING; ++q) b->s_stage[q] = 0;
+    for (int q = 0; q < gnuais_batch::NRING; ++q) { b->s_stage[q] = 0; b->ring_runs[q] = 0; }
     b->ring_cur = 0;
     b->stream_calls = 0;
     HIP_TRY(launch_hdlc_reset(b->ctl, b->N, nullptr));                // protodec.c:87-100
@@ -1001,6 +1004,7 @@ int gnuais_batch_stream_nmea(gnuais_batch *b, const char **text, size_t *len, in
     if (n_frames) *n_frames = -1;               // nothing handed out yet
     constexpr int NR = gnuais_batch::NRING;
     const size_t N = (size_t) b->N;
+    const size_t text_cap = (size_t) b->frame_cap * 164;        // a full ring of two-sentence frames
     if (!b->streaming) {                        // first use: the other rings, streams, events
         if (int rc = gnuais_batch_sync(b)) return rc;
         b->ring[0] = b->frames;
@@ -1014,15 +1018,36 @@ int gnuais_batch_stream_nmea(gnuais_batch *b, const char **text, size_t *len, in
         for (int q = 0; q < NR; ++q) {
             HIP_TRY(hipMalloc((void **) &b->ring_chunks[q], sizeof(uint2) * (size_t) b->n_chunks));
             b->ring_runs[q] = 2;                // whatever ring 0 holds by now came without a table
-        }
-        for (int q = 0; q < NR; ++q) {
+            HIP_TRY(hipMalloc((void **) &b->sd_text[q], text_cap));
+            b->sd_text_bytes[q] = text_cap;
             HIP_TRY(hipEventCreateWithFlags(&b->e_fill[q], hipEventDisableTiming));
             HIP_TRY(hipEventCreateWithFlags(&b->e_fmt[q], hipEventDisableTiming));
             HIP_TRY(hipEventCreateWithFlags(&b->e_txt[q], hipEventDisableTiming));
+            // pinned text: a fifth of the worst case to begin with (single-sentence frames of average
+            // length fill it to about a third); a slot whose text does not fit grows, see (3)
+            b->sh_text_want = ((size_t) b->frame_cap * 32 + 65536) & ~(size_t) 15;
+            HIP_TRY(hipHostMalloc((void **) &b->sh_text[q], b->sh_text_want, hipHostMallocDefault));
+            b->sh_text_bytes[q] = b->sh_text_want;
         }
-        HIP_TRY(hipStreamCreateWithFlags(&b->s_post, hipStreamNonBlocking));
-        HIP_TRY(hipStreamCreateWithFlags(&b->s_copy, hipStreamNonBlocking));
-        HIP_TRY(hipStreamCreateWithFlags(&b->s_cnt, hipStreamNonBlocking));
+        HIP_TRY(hipMalloc((void **) &b->sd_info, sizeof(uint32_t) * 8 * NR));
+        HIP_TRY(hipMemset(b->sd_info, 0, sizeof(uint32_t) * 8 * NR));
+        if (const char *v = getenv("GNUAIS_COPY_WGS")) b->copy_wgs = std::max(1, atoi(v));
+        const size_t need_scratch = nmea_scratch_bytes(b->frame_cap, b->n_chunks);
+        if (b->nmea_scratch_bytes < need_scratch) {
+            if (b->nmea_scratch) HIP_TRY(hipFree(b->nmea_scratch));
+            b->nmea_scratch = nullptr;
+            b->nmea_scratch_bytes = 0;
+            HIP_TRY(hipMalloc(&b->nmea_scratch, need_scratch));
+            b->nmea_scratch_bytes = need_scratch;
+        }
+        {   // The formatter's kernels go onto K3's stream: they are small, K3's stream is idle most of a call,
+            // and every further stream is one more tenant for the few hardware queues (a formatter stream
+            // that shares its queue with a stage serialises with it: 0.8 or 1.5 ms per call, by luck).
+            // Only the copy, which lasts as long as PCIe needs, has a stream of its own.
+            int lo = 0, hi = 0;
+            HIP_TRY(hipDeviceGetStreamPriorityRange(&lo, &hi));
+            HIP_TRY(hipStreamCreateWithPriority(&b->s_copy, hipStreamNonBlocking, hi));
+        }
         HIP_TRY(hipHostMalloc((void **) &b->sh_info, sizeof(uint32_t) * 8 * NR, hipHostMallocDefault));
         memset(b->sh_info, 0, sizeof(uint32_t) * 8 * NR);
         for (auto &p : b->sd_seq) {
@@ -1036,97 +1061,83 @@ int gnuais_batch_stream_nmea(gnuais_batch *b, const char **text, size_t *len, in
     const int c = b->ring_cur;
     // (1) ring c: everything K3 has been asked to append so far
     HIP_TRY(hipEventRecord(b->e_fill[c], sD));
-    b->s_stage[c] = 1;
-    b->s_runs[c] = b->ring_runs[c];
-    // (2) K3 moves on to the next ring; that ring's formatter (queued two calls ago) must be done
+    const int runs = b->ring_runs[c];
+    // (2) K3 moves on to the next ring; that ring's formatter (queued NRING - 1 calls ago) must be done
     const int nx = (c + 1) % NR;
-    if (b->stream_calls >= (unsigned) (NR - 1)) HIP_TRY(hipStreamWaitEvent(sD, b->e_fmt[nx], 0));   // long done
+    if (b->s_stage[nx]) HIP_TRY(hipStreamWaitEvent(sD, b->e_fmt[nx], 0));
     b->ring_cur = nx;
     b->ring_runs[nx] = 0;
-    // (5) first, because it frees a slot: hand out the text whose copy was queued a call ago
-    const int u = (c + NR - 4) % NR;
-    if (b->s_stage[u] == 3) {
-        HIP_TRY(hipEventSynchronize(b->e_txt[u]));
-        *text = b->sh_text[u];
-        *len = b->s_len[u];
-        if (n_sentences) *n_sentences = b->s_sent[u];
-        if (n_frames) *n_frames = b->s_frames[u];
-        b->s_stage[u] = 0;
-    }
-    // (4) the slot formatted a call ago: its size is known now; queue the copy of the text
-    const int t = (c + NR - 3) % NR;
-    if (b->s_stage[t] == 2) {
-        uint32_t *info = b->sh_info + 8 * t;
-        if (b->s_frames[t] > 0) {
-            HIP_TRY(hipEventSynchronize(b->e_fmt[t]));
-            if (info[3]) return fail(GNUAIS_E_HIP, "stream_nmea: a frame record names a channel outside the batch");
-            b->s_len[t] = (size_t) info[0] + info[1];
-            b->s_sent[t] = (int) info[2];
-            if (b->sh_text_bytes[t] < b->s_len[t]) {
-                if (b->sh_text[t]) HIP_TRY(hipHostFree(b->sh_text[t]));
-                b->sh_text[t] = nullptr;
-                b->sh_text_bytes[t] = 0;
-                const size_t want = b->s_len[t] + b->s_len[t] / 4 + 4096;
-                HIP_TRY(hipHostMalloc((void **) &b->sh_text[t], want, hipHostMallocDefault));
-                b->sh_text_bytes[t] = want;
-            }
-            if (b->s_len[t])
-                HIP_TRY(hipMemcpyAsync(b->sh_text[t], b->sd_text[t], b->s_len[t], hipMemcpyDeviceToHost, b->s_copy));
-        } else {
-            b->s_len[t] = 0;
-            b->s_sent[t] = 0;
+    // (3) hand out the text of slot nx, queued NRING - 1 calls ago: the only wait of this call.  (Before (4): a slow-path copy below must not queue behind it.)
+    int rc_late = GNUAIS_OK;
+    if (b->s_stage[nx]) {
+        HIP_TRY(hipEventSynchronize(b->e_txt[nx]));
+        const uint32_t *info = b->sh_info + 8 * nx;
+        const uint32_t have = std::min<uint32_t>(info[4], (uint32_t) b->frame_cap);
+        const size_t n_text = (size_t) info[0] + info[1];
+        if (n_text > b->sh_text_bytes[nx]) {
+            // the pinned buffer was too small for this slot (the first calls, or traffic grew): make it larger
+            // and fetch the text from the device copy, which stays intact until the slot is formatted again
+            const size_t want = std::max(b->sh_text_want, (n_text + n_text / 2 + 65536) & ~(size_t) 15);
+            b->sh_text_want = want;
+            if (b->sh_text[nx]) HIP_TRY(hipHostFree(b->sh_text[nx]));
+            b->sh_text[nx] = nullptr;
+            b->sh_text_bytes[nx] = 0;
+            HIP_TRY(hipHostMalloc((void **) &b->sh_text[nx], want, hipHostMallocDefault));
+            b->sh_text_bytes[nx] = want;
+            HIP_TRY(hipMemcpyAsync(b->sh_text[nx], b->sd_text[nx], n_text, hipMemcpyDeviceToHost, b->s_copy));
+            HIP_TRY(hipStreamSynchronize(b->s_copy));
         }
-        HIP_TRY(hipEventRecord(b->e_txt[t], b->s_copy));
-        b->s_stage[t] = 3;
+        *text = b->sh_text[nx];
+        *len = n_text;
+        if (n_sentences) *n_sentences = (int) info[2];
+        if (n_frames) *n_frames = (int) have;
+        b->s_stage[nx] = 0;
+        if (info[3]) rc_late = fail(GNUAIS_E_HIP, "stream_nmea: a frame record names a channel outside the batch");
+        else if (info[7])
+            rc_late = fail(GNUAIS_E_HIP, "stream_nmea: the PLL stage's watchdog fired (device hung or badly oversubscribed)");
+        else if (info[5] || info[4] > (uint32_t) b->frame_cap)
+            rc_late = fail(GNUAIS_E_OVERFLOW, "stream_nmea: frame ring overflowed, frames were dropped");
     }
-    // (3) the ring filled two calls ago: read its counters (that K3 is done unless the host is more than
-    // a call ahead of the device), queue sort + formatter
-    const int a = (c + NR - 2) % NR;
-    if (b->s_stage[a] == 1) {
-        uint32_t *cnt = b->sh_info + 8 * a + 4;
-        HIP_TRY(hipStreamWaitEvent(b->s_cnt, b->e_fill[a], 0));
-        HIP_TRY(hipMemcpyAsync(cnt, b->ring_count[a], 16, hipMemcpyDeviceToHost, b->s_cnt));
-        HIP_TRY(hipStreamSynchronize(b->s_cnt));
-        const uint32_t have = std::min<uint32_t>(cnt[0], (uint32_t) b->frame_cap);
-        const bool overflow = cnt[1] || cnt[0] > (uint32_t) b->frame_cap, watchdog = cnt[3] != 0;
-        b->s_frames[a] = (int) have;
-        HIP_TRY(hipStreamWaitEvent(b->s_post, b->e_fill[a], 0));
-        if (have) {
-            const bool by_chunks = b->s_runs[a] == 1;       // one launch filled it: its chunk table is the order
-            const size_t need_text = (size_t) have * 164, need_scratch = nmea_scratch_bytes((int) have, b->n_chunks);
-            if (b->sd_text_bytes[a] < need_text) {
-                HIP_TRY(hipStreamSynchronize(b->s_copy));
-                if (b->sd_text[a]) HIP_TRY(hipFree(b->sd_text[a]));
-                b->sd_text[a] = nullptr;
-                b->sd_text_bytes[a] = 0;
-                HIP_TRY(hipMalloc((void **) &b->sd_text[a], need_text + need_text / 4));
-                b->sd_text_bytes[a] = need_text + need_text / 4;
-            }
-            if (b->nmea_scratch_bytes < need_scratch) {
-                HIP_TRY(hipStreamSynchronize(b->s_post));
-                if (b->nmea_scratch) HIP_TRY(hipFree(b->nmea_scratch));
-                b->nmea_scratch = nullptr;
-                b->nmea_scratch_bytes = 0;
-                HIP_TRY(hipMalloc(&b->nmea_scratch, need_scratch + need_scratch / 4));
-                b->nmea_scratch_bytes = need_scratch + need_scratch / 4;
-            }
+    // (4) ring c: order, sequence digits, text, copy into pinned memory -- queued now, behind its K3, with
+    // every size taken on the device
+    b->s_post = sD;                             // behind the K3 launches that filled the ring, in stream order
+    uint32_t *totals = nullptr;
+    if (b->sh_text_bytes[c] < b->sh_text_want) {                // catch up with a buffer that had to grow (slot c is idle)
+        if (b->sh_text[c]) HIP_TRY(hipHostFree(b->sh_text[c]));
+        b->sh_text[c] = nullptr;
+        b->sh_text_bytes[c] = 0;
+        HIP_TRY(hipHostMalloc((void **) &b->sh_text[c], b->sh_text_want, hipHostMallocDefault));
+        b->sh_text_bytes[c] = b->sh_text_want;
+    }
+    if (runs >= 1) {
+        int n_host = -1;                        // one run: K3's chunk table is the order, the count stays on the device
+        if (runs > 1) {                         // several runs share the ring: count on the host, radix sort
+            uint32_t cnt[4];
+            HIP_TRY(hipStreamSynchronize(b->s_post));
+            HIP_TRY(hipMemcpy(cnt, b->ring_count[c], 16, hipMemcpyDeviceToHost));
+            n_host = (int) std::min<uint32_t>(cnt[0], (uint32_t) b->frame_cap);
+        }
+        if (n_host != 0) {
             uint8_t *sin = b->sd_seq[b->sd_seq_cur], *sout = b->sd_seq[b->sd_seq_cur ^ 1];
             HIP_TRY(hipMemcpyAsync(sout, sin, N, hipMemcpyDeviceToDevice, b->s_post));
-            HIP_TRY(nmea_format_enqueue(b->ring[a], (int) have, b->N, sin, sout, b->sd_text[a], b->sd_text_bytes[a],
-                                        b->nmea_scratch, b->nmea_scratch_bytes, b->sh_info + 8 * a,
-                                        by_chunks ? b->ring_chunks[a] : nullptr, b->n_chunks, b->s_post));
+            HIP_TRY(nmea_format_enqueue(b->ring[c], n_host, b->frame_cap, b->N, sin, sout, b->sd_text[c],
+                                        b->sd_text_bytes[c], b->nmea_scratch, b->nmea_scratch_bytes, nullptr,
+                                        b->ring_chunks[c], b->n_chunks, &totals, b->s_post));
             b->sd_seq_cur ^= 1;
         }
-        HIP_TRY(hipMemsetAsync(b->ring_count[a], 0, 16, b->s_post));
-        HIP_TRY(hipEventRecord(b->e_fmt[a], b->s_post));
-        b->s_stage[a] = 2;
-        if (watchdog)
-            return fail(GNUAIS_E_HIP, "stream_nmea: the PLL stage's watchdog fired (device hung or badly oversubscribed)");
-        if (overflow) return fail(GNUAIS_E_OVERFLOW, "stream_nmea: frame ring overflowed, frames were dropped");
     }
+    HIP_TRY(nmea_slot_info_enqueue(totals, b->ring_count[c], b->sd_info + 8 * c, b->s_post));
+    HIP_TRY(hipMemsetAsync(b->ring_count[c], 0, 16, b->s_post));
+    HIP_TRY(hipEventRecord(b->e_fmt[c], b->s_post));          // the ring is free for K3 again
+    // (5) the copy has a stream of its own: it runs at PCIe speed beside the next slot's formatter
+    HIP_TRY(hipStreamWaitEvent(b->s_copy, b->e_fmt[c], 0));
+    HIP_TRY(nmea_text_copy_enqueue(b->sd_text[c], b->sd_info + 8 * c, b->sh_text[c], b->sh_text_bytes[c],
+                                   b->sh_info + 8 * c, b->copy_wgs, b->s_copy));
+    HIP_TRY(hipEventRecord(b->e_txt[c], b->s_copy));
+    b->s_stage[c] = 1;
     b->hdlc_calls = 0;
     b->stream_calls++;
-    return GNUAIS_OK;
+    return rc_late;
 }
 
 int gnuais_batch_pending_frames(gnuais_batch *b, int *n_out)
@@ -1257,6 +1268,7 @@ int gnuais_batch_info(const gnuais_batch *b, const char *name, double *value)
     else if (!strcmp(name, "compute_units")) *value = b->n_cu;
     else if (!strcmp(name, "device")) *value = b->device;
     else if (!strcmp(name, "segments")) *value = b->n_seg;
+    else if (!strcmp(name, "stream_depth")) *value = gnuais_batch::NRING - 1;
     else return fail(GNUAIS_E_ARG, "info: unknown name");
     return GNUAIS_OK;
 }

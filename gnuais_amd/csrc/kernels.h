@@ -115,11 +115,18 @@ hipError_t frames_sort(const struct gnuais_frame *frames, int n, struct gnuais_f
                        size_t scratch_bytes, hipStream_t s);
 // the device part only, queued without waiting; h_info4 (host, pinned): [0] + [1] bytes written,
 // [2] sentences, [3] != 0 if a frame named a channel >= n_channels -- valid once `s` has got there
-// chunks / n_chunks: K3's chunk table of this ring (HdlcLaunch::chunks) when the ring holds exactly one
-// call's frames -- the order then comes from a scan over the table instead of a radix sort; else null / 0
-hipError_t nmea_format_enqueue(const struct gnuais_frame *frames, int n, int n_channels, const uint8_t *seq_in,
-                               uint8_t *seq_out, char *out, size_t out_cap, void *scratch, size_t scratch_bytes,
-                               uint32_t *h_info4, const uint2 *chunks, int n_chunks, hipStream_t s);
+// n > 0: count known to the host, order by radix sort.  n < 0: the ring holds exactly one call; order and
+// count (<= n_max) come from K3's chunk table (HdlcLaunch::chunks), nothing is read back.  *totals_dev:
+// the device words h_info4 is copied from (h_info4 may be null).
+hipError_t nmea_format_enqueue(const struct gnuais_frame *frames, int n, int n_max, int n_channels,
+                               const uint8_t *seq_in, uint8_t *seq_out, char *out, size_t out_cap, void *scratch,
+                               size_t scratch_bytes, uint32_t *h_info4, const uint2 *chunks, int n_chunks,
+                               uint32_t **totals_dev, hipStream_t s);
+// info8 (device): the formatter's four words (totals; null: nothing was formatted) + the ring's four counters
+hipError_t nmea_slot_info_enqueue(const uint32_t *totals, const uint32_t *ring_count, uint32_t *info8_dev, hipStream_t s);
+// device text -> pinned host text, length taken from info8 on the device; the info words follow it to the host
+hipError_t nmea_text_copy_enqueue(const char *src, const uint32_t *info8_dev, char *dst_pinned, size_t dst_cap,
+                                  uint32_t *info8_pinned, int workgroups, hipStream_t s);
 hipError_t nmea_format(const struct gnuais_frame *frames, int n, int n_channels, const uint8_t *seq_in,
                        uint8_t *seq_out, char *out, size_t out_cap, void *scratch, size_t scratch_bytes,
                        uint32_t *h_info, hipStream_t s);

@@ -104,16 +104,16 @@ struct TriOp {
 
 // Exclusive scan of the chunk table's counts (one workgroup; the table has a few thousand entries):
 // chunk_off[k] = frames in print order before chunk k, chunk_off[E] = all of them.
-__global__ __launch_bounds__(1024) void chunk_scan_kernel(const uint2 *__restrict__ chunks, int E,
+__global__ __launch_bounds__(256) void chunk_scan_kernel(const uint2 *__restrict__ chunks, int E,
                                                           uint32_t *__restrict__ chunk_off, uint32_t *__restrict__ totals)
 {
-    __shared__ uint32_t wsum[16];
+    __shared__ uint32_t wsum[4];
     __shared__ uint32_t carry_s;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (tid < 4) totals[tid] = 0;
     if (tid == 0) carry_s = 0;
     __syncthreads();
-    for (int base = 0; base < E; base += 1024) {
+    for (int base = 0; base < E; base += 256) {
         const int k = base + tid;
         const uint32_t v = k < E ? chunks[k].y : 0u;
         uint32_t inc = v;
@@ -128,7 +128,7 @@ __global__ __launch_bounds__(1024) void chunk_scan_kernel(const uint2 *__restric
         for (int q = 0; q < wave; ++q) before += wsum[q];
         if (k < E) chunk_off[k] = before + inc - v;
         __syncthreads();
-        if (tid == 1023) carry_s = before + inc;
+        if (tid == 255) carry_s = before + inc;
         __syncthreads();
     }
     if (tid == 0) chunk_off[E] = carry_s;
@@ -151,10 +151,14 @@ __global__ __launch_bounds__(256) void nmea_meta_kernel(const gnuais_frame *__re
                                                         uint32_t *__restrict__ order, int n,
                                                         const uint2 *__restrict__ chunks,
                                                         const uint32_t *__restrict__ chunk_off, int E,
-                                                        Tri *__restrict__ tri, uint32_t *__restrict__ chan)
+                                                        Tri *__restrict__ tri, uint32_t *__restrict__ chan, int n_max)
 {
     const int j = blockIdx.x * 256 + threadIdx.x;
-    if (j >= n) return;
+    if (chunks) n = (int) chunk_off[E];         // the ring's count lives on the device; the grid covers n_max
+    if (j >= n) {
+        if (j < n_max) { tri[j] = Tri{0u, 0u, 0u}; chan[j] = ~0u; }
+        return;
+    }
     uint32_t r, rprev = 0;
     if (chunks) {
         r = chunk_lookup(chunks, chunk_off, E, (uint32_t) j);
@@ -191,11 +195,13 @@ __global__ __launch_bounds__(256) void nmea_write_kernel(
     const Tri *__restrict__ tri, const Tri *__restrict__ scan, int n, int n_channels,
     const uint8_t *__restrict__ seq_in, uint8_t *__restrict__ seq_out, char *__restrict__ out,
     unsigned long long out_cap, uint32_t *__restrict__ totals /* [0] offset of the last frame's text, [1] its
-    length, [2] sentences, [3] bad channel */)
+    length, [2] sentences, [3] bad channel */, const uint32_t *__restrict__ n_dev)
 {
     __shared__ __attribute__((aligned(16))) char buf[256 * MAX_FRAME_TEXT + 32];
     __shared__ uint32_t s_base, s_end, s_sent;
     const int tid = threadIdx.x;
+    if (n_dev) n = (int) *n_dev;
+    if ((int) blockIdx.x * 256 >= n) return;
     const int j = blockIdx.x * 256 + tid;
     const bool in = j < n;
     Tri me = {0, 0, 0}, inc = {0, 0, 0};
@@ -316,15 +322,60 @@ hipError_t frames_sort(const gnuais_frame *frames, int n, gnuais_frame *out, voi
     return hipGetLastError();
 }
 
-// everything of nmea_format() that runs on the device, queued on `s` without waiting for it (n > 0)
-hipError_t nmea_format_enqueue(const gnuais_frame *frames, int n, int n_channels, const uint8_t *seq_in,
-                               uint8_t *seq_out, char *out, size_t out_cap, void *scratch, size_t scratch_bytes,
-                               uint32_t *h_info4, const uint2 *chunks, int n_chunks, hipStream_t s)
+// The slot's eight info words, kept on the device: the formatter's four (offset and length of the last
+// frame's text, sentences, bad-channel flag; zero when nothing was formatted) and the ring's four counters.
+__global__ void slot_info_kernel(const uint32_t *__restrict__ totals, const uint32_t *__restrict__ ring_count,
+                                 uint32_t *__restrict__ info8)
 {
-    if (n <= 0) return hipErrorInvalidValue;
-    if (!chunks) n_chunks = 0;
-    if (scratch_bytes < nmea_scratch_bytes(n, n_chunks)) return hipErrorInvalidValue;
-    const size_t m = (size_t) n;
+    if (threadIdx.x < 4) {
+        info8[threadIdx.x] = totals ? totals[threadIdx.x] : 0u;
+        info8[4 + threadIdx.x] = ring_count[threadIdx.x];
+    }
+}
+
+// device text -> pinned host memory with the length taken on the device, plus the info words: nothing on
+// the host has to know a size before it hands the text out.  Few workgroups on purpose: the copy moves at
+// PCIe speed whatever its width, and every CU it occupies is a CU whose other waves queue behind its stores.
+__global__ __launch_bounds__(256) void text_copy_kernel(const char *__restrict__ src, const uint32_t *__restrict__ info_dev,
+                                                        char *__restrict__ dst, unsigned long long dst_cap,
+                                                        uint32_t *__restrict__ info)
+{
+    const unsigned long long len = (unsigned long long) info_dev[0] + info_dev[1];
+    const unsigned long long take = len < dst_cap ? len : dst_cap;          // both buffers are 16-byte multiples
+    const unsigned long long units = (take + 15ull) >> 4;
+    for (unsigned long long u = (unsigned long long) blockIdx.x * 256ull + threadIdx.x; u < units;
+         u += (unsigned long long) gridDim.x * 256ull)
+        reinterpret_cast<uint4 *>(dst)[u] = reinterpret_cast<const uint4 *>(src)[u];
+    if (blockIdx.x == 0 && threadIdx.x < 8) info[threadIdx.x] = info_dev[threadIdx.x];
+}
+
+hipError_t nmea_slot_info_enqueue(const uint32_t *totals, const uint32_t *ring_count, uint32_t *info8_dev, hipStream_t s)
+{
+    hipLaunchKernelGGL(slot_info_kernel, dim3(1), dim3(64), 0, s, totals, ring_count, info8_dev);
+    return hipGetLastError();
+}
+
+hipError_t nmea_text_copy_enqueue(const char *src, const uint32_t *info8_dev, char *dst_pinned, size_t dst_cap,
+                                  uint32_t *info8_pinned, int workgroups, hipStream_t s)
+{
+    hipLaunchKernelGGL(text_copy_kernel, dim3(workgroups > 0 ? workgroups : 16), dim3(256), 0, s, src, info8_dev,
+                       dst_pinned, (unsigned long long) (dst_cap & ~(size_t) 15), info8_pinned);
+    return hipGetLastError();
+}
+
+// everything of nmea_format() that runs on the device, queued on `s` without waiting for it.
+// n > 0: the host knows the count; the order comes from a radix sort.  n < 0: the ring holds exactly one
+// call, the order AND the count (at most n_max) come from K3's chunk table -- no host value needed.
+hipError_t nmea_format_enqueue(const gnuais_frame *frames, int n, int n_max, int n_channels, const uint8_t *seq_in,
+                               uint8_t *seq_out, char *out, size_t out_cap, void *scratch, size_t scratch_bytes,
+                               uint32_t *h_info4, const uint2 *chunks, int n_chunks, uint32_t **totals_dev,
+                               hipStream_t s)
+{
+    const bool by_chunks = n < 0;
+    if (n == 0 || (by_chunks && (!chunks || n_max <= 0))) return hipErrorInvalidValue;
+    if (!by_chunks) { chunks = nullptr; n_chunks = 0; n_max = n; }
+    if (scratch_bytes < nmea_scratch_bytes(n_max, n_chunks)) return hipErrorInvalidValue;
+    const size_t m = (size_t) n_max;
     char *p = static_cast<char *>(scratch);
     auto take = [&](size_t bytes) { char *q = p; p += (bytes + 255) / 256 * 256; return (void *) q; };
     uint64_t *keys = (uint64_t *) take(8 * m), *keys2 = (uint64_t *) take(8 * m);
@@ -335,12 +386,11 @@ hipError_t nmea_format_enqueue(const gnuais_frame *frames, int n, int n_channels
     uint32_t *totals = (uint32_t *) take(16);
     void *tmp = p;
     size_t tmp_bytes = scratch_bytes - (size_t) (p - static_cast<char *>(scratch));
-    const int grid = (n + 255) / 256;
+    const int grid = (n_max + 255) / 256;
     hipError_t e;
     size_t t = tmp_bytes;
-    if (chunks) {
-        // the ring holds one call: K3's chunk table gives the print order (also clears totals)
-        hipLaunchKernelGGL(chunk_scan_kernel, dim3(1), dim3(1024), 0, s, chunks, n_chunks, chunk_off, totals);
+    if (by_chunks) {
+        hipLaunchKernelGGL(chunk_scan_kernel, dim3(1), dim3(256), 0, s, chunks, n_chunks, chunk_off, totals);
     } else {
         if ((e = hipMemsetAsync(totals, 0, 16, s)) != hipSuccess) return e;
         hipLaunchKernelGGL(nmea_keys_kernel, dim3(grid), dim3(256), 0, s, frames, n, keys, idx);
@@ -348,15 +398,17 @@ hipError_t nmea_format_enqueue(const gnuais_frame *frames, int n, int n_channels
         if ((e = rocprim::radix_sort_pairs(tmp, t, keys, keys2, idx, idx2, m, 0, 61, s)) != hipSuccess) return e;
     }
     hipLaunchKernelGGL(nmea_meta_kernel, dim3(grid), dim3(256), 0, s, frames, idx2, n, chunks, chunk_off, n_chunks,
-                       tri, chan);
+                       tri, chan, n_max);
     t = tmp_bytes;
     if ((e = rocprim::inclusive_scan(tmp, t, tri, scan, m, TriOp(), s)) != hipSuccess) return e;
     hipLaunchKernelGGL(nmea_write_kernel, dim3(grid), dim3(256), 0, s, frames, idx2, chan, tri, scan, n, n_channels,
-                       seq_in, seq_out, out, (unsigned long long) out_cap, totals);
+                       seq_in, seq_out, out, (unsigned long long) out_cap, totals,
+                       by_chunks ? chunk_off + n_chunks : (const uint32_t *) nullptr);
     if ((e = hipGetLastError()) != hipSuccess) return e;
+    if (totals_dev) *totals_dev = totals;
     // h_info4 (pinned host memory when the caller does not wait here): [0] offset of the last frame's
     // text, [1] its length, [2] sentences, [3] frames that named a channel outside the batch
-    return hipMemcpyAsync(h_info4, totals, 16, hipMemcpyDeviceToHost, s);
+    return h_info4 ? hipMemcpyAsync(h_info4, totals, 16, hipMemcpyDeviceToHost, s) : hipSuccess;
 }
 
 hipError_t nmea_format(const gnuais_frame *frames, int n, int n_channels, const uint8_t *seq_in,
@@ -366,8 +418,8 @@ hipError_t nmea_format(const gnuais_frame *frames, int n, int n_channels, const 
     h_info[0] = h_info[1] = h_info[2] = 0;
     if (n <= 0) return hipSuccess;
     uint32_t raw[4] = {0, 0, 0, 0};
-    hipError_t e = nmea_format_enqueue(frames, n, n_channels, seq_in, seq_out, out, out_cap, scratch, scratch_bytes, raw,
-                                       nullptr, 0, s);
+    hipError_t e = nmea_format_enqueue(frames, n, n, n_channels, seq_in, seq_out, out, out_cap, scratch, scratch_bytes, raw,
+                                       nullptr, 0, nullptr, s);
     if (e != hipSuccess) return e;
     if ((e = hipStreamSynchronize(s)) != hipSuccess) return e;
     h_info[0] = raw[0] + raw[1];

@@ -173,10 +173,14 @@ class ReceiverBatch:
                                                 C.byref(ln), C.byref(ns), C.byref(nf)))
         return out[: ln.value].tobytes(), ns.value, nf.value
 
+    @property
+    def stream_depth(self) -> int:
+        return int(self.info("stream_depth"))
+
     def stream_nmea(self, copy: bool = True):
         """gnuais_batch_stream_nmea(): call after every run(); returns (text, sentences, frames) of the
-        call four calls ago -- frames == -1 while the pipeline fills.  copy=False returns a uint8 view
-        of the library's pinned buffer (valid until the next call) instead of bytes."""
+        call self.stream_depth calls ago -- frames == -1 while the pipeline fills.  copy=False returns a
+        uint8 view of the library's pinned buffer (valid until the next call) instead of bytes."""
         ptr, ln, ns, nf = C.c_void_p(), C.c_size_t(0), C.c_int(0), C.c_int(0)
         check(self._lib.gnuais_batch_stream_nmea(self._h, C.cast(C.byref(ptr), C.POINTER(C.c_char_p)), C.byref(ln),
                                                  C.byref(ns), C.byref(nf)))

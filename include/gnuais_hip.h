@@ -156,7 +156,8 @@ int  gnuais_batch_last_bits(gnuais_batch *b, uint8_t *h_bits, int stride, int32_
 int  gnuais_batch_last_signs(gnuais_batch *b, uint8_t *h_out, int stride);
 /* facts about a batch, by name: "sign_exact" (1 if the receive path runs the sign-exact slicer),
  * "sign_eps" (its certification threshold), "sign_central_taps", "first_effective_tap",
- * "n_effective_taps", "compute_units", "device", "segments" */
+ * "n_effective_taps", "compute_units", "device", "segments", "stream_depth" (calls between a
+ * gnuais_batch_stream_nmea() call and the one that hands its text out) */
 int  gnuais_batch_info(const gnuais_batch *b, const char *name, double *value);
 
 /* ---- results ------------------------------------------------------------------
@@ -217,12 +218,15 @@ int  gnuais_messages_from_frames(const gnuais_frame *frames, int n_frames, uint8
 int  gnuais_batch_drain_nmea(gnuais_batch *b, uint8_t *seqnr, char *out, size_t out_cap,
 			     size_t *out_len, int *n_sentences, int *n_frames);
 /* Streaming delivery of the same sentences.  Call once after every gnuais_batch_run(): the frames of
- * the runs since the previous call are taken off at once (the chain moves on to another frame ring) and
- * are formatted, copied into pinned host memory and handed out over the following four calls, so that
- * no call waits for device work it has queued itself.  *text / *len: the sentences of the call four
- * calls ago (valid until the next call; *n_frames = -1 while the pipeline fills); the per-channel
- * sequence digit is carried on the device.  Calls without runs in between flush what is in flight.
- * Not to be mixed with the gnuais_batch_drain_*() calls on one batch. */
+ * the runs since the previous call are taken off at once (the chain moves on to another frame ring);
+ * their formatter and the copy of the text into pinned host memory are queued behind the chain with every
+ * size taken on the device, so the call itself waits for nothing it has queued.  *text / *len: the
+ * sentences of the call D calls ago, D = gnuais_batch_info(b, "stream_depth", &D) (7: a call takes about
+ * five call periods from its first kernel to its text on the host); valid until the next call;
+ * *n_frames = -1 while the pipeline fills.  The per-channel sequence digit is carried on the device.
+ * Calls without runs in between flush what is in flight.  Errors of a call (ring overflow, watchdog)
+ * are reported when its text is handed out.  Not to be mixed with the gnuais_batch_drain_*() calls on
+ * one batch. */
 int  gnuais_batch_stream_nmea(gnuais_batch *b, const char **text, size_t *len, int *n_sentences,
 			      int *n_frames);
 /* both at once: the records (for the host-side consumers: stdout text, vessel table, range) and the

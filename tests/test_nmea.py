@@ -261,8 +261,8 @@ def test_device_formatter_on_the_chain_over_several_calls():
 
 @pytest.mark.gpu
 def test_streamed_sentences_equal_drained_sentences():
-    """gnuais_batch_stream_nmea(): one call per run, the text arriving four calls later from pinned
-    memory -- byte for byte what gnuais_batch_drain_nmea() returns for the same runs, the sequence
+    """gnuais_batch_stream_nmea(): one call per run, the text arriving from pinned
+    memory `stream_depth` calls later -- byte for byte what gnuais_batch_drain_nmea() returns for the same runs, the sequence
     digits carried across runs, empty runs and the final flush included."""
     import torch
     from gnuais_amd import ReceiverBatch, synth
@@ -278,10 +278,11 @@ def test_streamed_sentences_equal_drained_sentences():
         want.append(a.drain_nmea(seq))
         b.run(xd[i * call:(i + 1) * call], sync=False)
         got.append(b.stream_nmea())
-    for _ in range(4):                                          # flush
+    depth = b.stream_depth
+    for _ in range(depth):                                      # flush
         got.append(b.stream_nmea())
-    assert all(g[2] == -1 for g in got[:4]) and all(g[2] >= 0 for g in got[4:])
-    out = got[4:]
+    assert all(g[2] == -1 for g in got[:depth]) and all(g[2] >= 0 for g in got[depth:])
+    out = got[depth:]
     assert len(out) == n_calls
     assert sum(w[2] for w in want) > 1000 and want[3][2] < want[2][2]
     for i, (w, g) in enumerate(zip(want, out)):
@@ -312,9 +313,9 @@ def test_streamed_sentences_with_several_runs_per_call():
             i += 1
         want.append(a.drain_nmea(seq))
         got.append(b.stream_nmea())
-    for _ in range(4):
+    for _ in range(b.stream_depth):
         got.append(b.stream_nmea())
-    out = got[4:]
+    out = got[b.stream_depth:]
     assert len(out) == len(plan) and sum(w[2] for w in want) > 1000
     for k, (w, g) in enumerate(zip(want, out)):
         assert g[2] == w[2] and g[1] == w[1], k
