@@ -121,7 +121,7 @@ hipError_t frames_sort(const struct gnuais_frame *frames, int n, struct gnuais_f
 hipError_t nmea_format_enqueue(const struct gnuais_frame *frames, int n, int n_max, int n_channels,
                                const uint8_t *seq_in, uint8_t *seq_out, char *out, size_t out_cap, void *scratch,
                                size_t scratch_bytes, uint32_t *h_info4, const uint2 *chunks, int n_chunks,
-                               uint32_t **totals_dev, hipStream_t s);
+                               int chunk_passes, uint32_t **totals_dev, hipStream_t s);
 // info8 (device): the formatter's four words (totals; null: nothing was formatted) + the ring's four counters
 hipError_t nmea_slot_info_enqueue(const uint32_t *totals, const uint32_t *ring_count, uint32_t *info8_dev, hipStream_t s);
 // device text -> pinned host text, length taken from info8 on the device; the info words follow it to the host

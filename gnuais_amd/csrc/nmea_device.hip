@@ -102,10 +102,11 @@ struct TriOp {
     }
 };
 
-// Exclusive scan of the chunk table's counts (one workgroup; the table has a few thousand entries):
-// chunk_off[k] = frames in print order before chunk k, chunk_off[E] = all of them.
-__global__ __launch_bounds__(256) void chunk_scan_kernel(const uint2 *__restrict__ chunks, int E,
-                                                          uint32_t *__restrict__ chunk_off, uint32_t *__restrict__ totals)
+// Exclusive scan of the chunk table's counts, one workgroup: chunk_off[k] = frames in print order before
+// chunk k, chunk_off[E] = all of them.  The table is [K3 blocks][P passes] with only the first few passes of
+// a block in use: a thread sums one block's row, the row totals are scanned, the thread writes its row.
+__global__ __launch_bounds__(256) void chunk_scan_kernel(const uint2 *__restrict__ chunks, int n_blocks, int P,
+                                                         uint32_t *__restrict__ chunk_off, uint32_t *__restrict__ totals)
 {
     __shared__ uint32_t wsum[4];
     __shared__ uint32_t carry_s;
@@ -113,9 +114,12 @@ __global__ __launch_bounds__(256) void chunk_scan_kernel(const uint2 *__restrict
     if (tid < 4) totals[tid] = 0;
     if (tid == 0) carry_s = 0;
     __syncthreads();
-    for (int base = 0; base < E; base += 256) {
-        const int k = base + tid;
-        const uint32_t v = k < E ? chunks[k].y : 0u;
+    for (int base = 0; base < n_blocks; base += 256) {
+        const int b = base + tid;
+        const uint2 *row = chunks + (size_t) b * P;
+        uint32_t v = 0;
+        if (b < n_blocks)
+            for (int q = 0; q < P; ++q) v += row[q].y;
         uint32_t inc = v;
 #pragma unroll
         for (int o = 1; o < 64; o <<= 1) {
@@ -126,12 +130,18 @@ __global__ __launch_bounds__(256) void chunk_scan_kernel(const uint2 *__restrict
         __syncthreads();
         uint32_t before = carry_s;
         for (int q = 0; q < wave; ++q) before += wsum[q];
-        if (k < E) chunk_off[k] = before + inc - v;
+        if (b < n_blocks) {
+            uint32_t run = before + inc - v;
+            for (int q = 0; q < P; ++q) {
+                chunk_off[(size_t) b * P + q] = run;
+                run += row[q].y;
+            }
+        }
         __syncthreads();
         if (tid == 255) carry_s = before + inc;
         __syncthreads();
     }
-    if (tid == 0) chunk_off[E] = carry_s;
+    if (tid == 0) chunk_off[(size_t) n_blocks * P] = carry_s;
 }
 
 // ring index of the frame at print position j, from the scanned chunk table
@@ -336,15 +346,15 @@ __global__ void slot_info_kernel(const uint32_t *__restrict__ totals, const uint
 // device text -> pinned host memory with the length taken on the device, plus the info words: nothing on
 // the host has to know a size before it hands the text out.  Few workgroups on purpose: the copy moves at
 // PCIe speed whatever its width, and every CU it occupies is a CU whose other waves queue behind its stores.
-__global__ __launch_bounds__(256) void text_copy_kernel(const char *__restrict__ src, const uint32_t *__restrict__ info_dev,
-                                                        char *__restrict__ dst, unsigned long long dst_cap,
-                                                        uint32_t *__restrict__ info)
+__global__ __launch_bounds__(64) void text_copy_kernel(const char *__restrict__ src, const uint32_t *__restrict__ info_dev,
+                                                       char *__restrict__ dst, unsigned long long dst_cap,
+                                                       uint32_t *__restrict__ info)
 {
     const unsigned long long len = (unsigned long long) info_dev[0] + info_dev[1];
     const unsigned long long take = len < dst_cap ? len : dst_cap;          // both buffers are 16-byte multiples
     const unsigned long long units = (take + 15ull) >> 4;
-    for (unsigned long long u = (unsigned long long) blockIdx.x * 256ull + threadIdx.x; u < units;
-         u += (unsigned long long) gridDim.x * 256ull)
+    for (unsigned long long u = (unsigned long long) blockIdx.x * 64ull + threadIdx.x; u < units;
+         u += (unsigned long long) gridDim.x * 64ull)
         reinterpret_cast<uint4 *>(dst)[u] = reinterpret_cast<const uint4 *>(src)[u];
     if (blockIdx.x == 0 && threadIdx.x < 8) info[threadIdx.x] = info_dev[threadIdx.x];
 }
@@ -358,7 +368,7 @@ hipError_t nmea_slot_info_enqueue(const uint32_t *totals, const uint32_t *ring_c
 hipError_t nmea_text_copy_enqueue(const char *src, const uint32_t *info8_dev, char *dst_pinned, size_t dst_cap,
                                   uint32_t *info8_pinned, int workgroups, hipStream_t s)
 {
-    hipLaunchKernelGGL(text_copy_kernel, dim3(workgroups > 0 ? workgroups : 16), dim3(256), 0, s, src, info8_dev,
+    hipLaunchKernelGGL(text_copy_kernel, dim3(workgroups > 0 ? workgroups : 64), dim3(64), 0, s, src, info8_dev,
                        dst_pinned, (unsigned long long) (dst_cap & ~(size_t) 15), info8_pinned);
     return hipGetLastError();
 }
@@ -368,10 +378,11 @@ hipError_t nmea_text_copy_enqueue(const char *src, const uint32_t *info8_dev, ch
 // call, the order AND the count (at most n_max) come from K3's chunk table -- no host value needed.
 hipError_t nmea_format_enqueue(const gnuais_frame *frames, int n, int n_max, int n_channels, const uint8_t *seq_in,
                                uint8_t *seq_out, char *out, size_t out_cap, void *scratch, size_t scratch_bytes,
-                               uint32_t *h_info4, const uint2 *chunks, int n_chunks, uint32_t **totals_dev,
-                               hipStream_t s)
+                               uint32_t *h_info4, const uint2 *chunks, int n_chunks, int chunk_passes,
+                               uint32_t **totals_dev, hipStream_t s)
 {
     const bool by_chunks = n < 0;
+    if (by_chunks && (chunk_passes <= 0 || n_chunks % chunk_passes)) return hipErrorInvalidValue;
     if (n == 0 || (by_chunks && (!chunks || n_max <= 0))) return hipErrorInvalidValue;
     if (!by_chunks) { chunks = nullptr; n_chunks = 0; n_max = n; }
     if (scratch_bytes < nmea_scratch_bytes(n_max, n_chunks)) return hipErrorInvalidValue;
@@ -390,7 +401,8 @@ hipError_t nmea_format_enqueue(const gnuais_frame *frames, int n, int n_max, int
     hipError_t e;
     size_t t = tmp_bytes;
     if (by_chunks) {
-        hipLaunchKernelGGL(chunk_scan_kernel, dim3(1), dim3(256), 0, s, chunks, n_chunks, chunk_off, totals);
+        hipLaunchKernelGGL(chunk_scan_kernel, dim3(1), dim3(256), 0, s, chunks, n_chunks / chunk_passes, chunk_passes, chunk_off,
+                           totals);
     } else {
         if ((e = hipMemsetAsync(totals, 0, 16, s)) != hipSuccess) return e;
         hipLaunchKernelGGL(nmea_keys_kernel, dim3(grid), dim3(256), 0, s, frames, n, keys, idx);
@@ -419,7 +431,7 @@ hipError_t nmea_format(const gnuais_frame *frames, int n, int n_channels, const 
     if (n <= 0) return hipSuccess;
     uint32_t raw[4] = {0, 0, 0, 0};
     hipError_t e = nmea_format_enqueue(frames, n, n, n_channels, seq_in, seq_out, out, out_cap, scratch, scratch_bytes, raw,
-                                       nullptr, 0, nullptr, s);
+                                       nullptr, 0, 0, nullptr, s);
     if (e != hipSuccess) return e;
     if ((e = hipStreamSynchronize(s)) != hipSuccess) return e;
     h_info[0] = raw[0] + raw[1];
