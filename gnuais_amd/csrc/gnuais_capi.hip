@@ -149,6 +149,7 @@ struct gnuais_batch {
     float sign_eps = 0.0f;
     int sign_NC = 12;               // central taps K1s evaluates
     int k0 = 0;                     // first effective tap
+    int pll_variant = 0;            // 0: by channel count; 3 / 6 (kernels.h: PllLaunch::variant)
     int hdlc_lpw = 0;               // channels per wave in K2b; 0 = the variant's own default (16 event-driven, 64 bit-serial)
     int hdlc_variant = 1;           // 1: the event-driven deframer (hdlc_events.hip), 0: window by window (hdlc_crc.hip)
     bool timing = false;
@@ -487,6 +488,9 @@ int gnuais_batch_set_option(gnuais_batch *b, const char *name, int value)
     } else if (!strcmp(name, "pipeline")) {
         b->pipeline = value != 0;
 
+    } else if (!strcmp(name, "pll_variant")) {
+        if (value != 0 && value != 3 && value != 6) return fail(GNUAIS_E_ARG, "pll_variant must be 0, 3 or 6");
+        b->pll_variant = value;
     } else if (!strcmp(name, "hdlc_variant")) {
         b->hdlc_variant = value != 0;
     } else if (!strcmp(name, "hdlc_lpw")) {
@@ -572,7 +576,7 @@ static void fill_pll(const gnuais_batch *b, PllLaunch &p, int k, int len)
     p.sgn = b->sgn[k]; p.pll = b->pll; p.prev = b->prev;
     p.watchdog = (b->streaming ? b->ring_count[b->ring_cur] : b->frame_count) + 3; p.lastbit = b->lastbit;
     p.segbits = b->segbits[k]; p.segcnt = b->segcnt[k];
-    p.N = b->N; p.L = len; p.n_seg = b->n_seg; p.seg_words = b->seg_words; p.pllinc = b->pllinc;
+    p.N = b->N; p.L = len; p.n_seg = b->n_seg; p.seg_words = b->seg_words; p.pllinc = b->pllinc; p.variant = b->pll_variant;
     p.n_cu = b->n_cu;
 }
 

@@ -58,6 +58,7 @@ struct PllLaunch {
     int N, L, n_seg, seg_words;
     uint32_t pllinc;
     int n_cu;              // compute units of the batch's device
+    int variant = 0;       // 0: by channel count; 3 / 6: the three- / six-wave form
 };
 hipError_t pll_prepare_device();                                         // once per device, after hipSetDevice
 hipError_t launch_pll(const PllLaunch &a, hipStream_t stream);           // K2a

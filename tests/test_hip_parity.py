@@ -144,11 +144,12 @@ def test_full_chain_golden(name):
     assert np.array_equal(b.maxval(), g["maxval"])
 
 
-def run_both(x, chunks, n_ch, taps=None, pllinc=0, fir_T=None):
+def run_both(x, chunks, n_ch, taps=None, pllinc=0, fir_T=None, pll_variant=0):
     o = Oracle(n_ch, taps=taps, pllinc=pllinc)
     b = batch(n_ch, taps=taps, pllinc=pllinc, max_len=max(chunks))
     if fir_T:
         b.set_option("fir_T", fir_T)
+    b.set_option("pll_variant", pll_variant)      # 0: by channel count (six waves for these sizes)
     pos = 0
     gbits = [[] for _ in range(n_ch)]
     obits = [[] for _ in range(n_ch)]
@@ -175,18 +176,20 @@ def run_both(x, chunks, n_ch, taps=None, pllinc=0, fir_T=None):
     return o, b
 
 
-def test_chain_vs_oracle_ragged_chunks():
+@pytest.mark.parametrize("pll_variant", [3, 6])
+def test_chain_vs_oracle_ragged_chunks(pll_variant):
     n_ch, total = 70, 30 * 1280
     x = np.stack([synth.make_stream(total, seed=31, channel=c,
                                     sigma=(500.0, 1000.0, 3000.0, 6000.0, 20000.0)[c % 5])[0]
                   for c in range(n_ch)], axis=1)
     chunks = [1020] * 10 + [1, 31, 33, 4096, 4095, 7, 10000]
     chunks.append(total - sum(chunks))
-    o, b = run_both(x, chunks, n_ch, fir_T=512)
+    o, b = run_both(x, chunks, n_ch, fir_T=512, pll_variant=pll_variant)
     assert o.counters()[:, 0].sum() > 300
 
 
-def test_chain_vs_oracle_noise_only_and_extremes():
+@pytest.mark.parametrize("pll_variant", [3, 6])
+def test_chain_vs_oracle_noise_only_and_extremes(pll_variant):
     rng = np.random.default_rng(33)
     total = 40000
     cols = [rng.normal(0, s, total) for s in (30, 300, 3000, 12000)]
@@ -195,7 +198,8 @@ def test_chain_vs_oracle_noise_only_and_extremes():
     cols.append(np.full(total, 32767.0))
     cols.append(np.where(np.arange(total) // 5 % 2, 9000.0, -9000.0))   # endless 0101... training
     x = np.clip(np.rint(np.stack(cols, axis=1)), -32768, 32767).astype(np.int16)
-    run_both(x, [total], x.shape[1])
+    run_both(x, [total], x.shape[1], pll_variant=pll_variant)
+    run_both(x, [2049, 255, 257, total - 2561], x.shape[1], pll_variant=pll_variant)   # block / segment edges
 
 
 def test_chain_vs_oracle_digital_silence_patterns():
