@@ -16,7 +16,7 @@ root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 out = os.path.join(root, "profiles")
 os.makedirs(out, exist_ok=True)
 
-SHORT = [("fir_sign_kernel", "fir_slice"), ("fir_slice_kernel", "fir_slice"), ("pll_kernel", "pll"),
+SHORT = [("fir_sign_kernel", "fir_slice"), ("fir_slice_kernel", "fir_slice"), ("pll_kernel", "pll"), ("pll3_kernel", "pll"),
          ("hdlc_events_kernel", "hdlc_deframe"), ("hdlc_deframe_kernel", "hdlc_deframe"),
          ("hdlc_crc_kernel", "hdlc_crc")]
 
