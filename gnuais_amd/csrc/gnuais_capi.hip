@@ -102,6 +102,8 @@ struct gnuais_batch {
     uint8_t *d_seq[2] = {nullptr, nullptr};
     char *d_text = nullptr;
     void *nmea_scratch = nullptr;
+    char *d_msg = nullptr;          // gnuais_batch_drain_messages: lines, lengths, offsets, packed text
+    size_t d_msg_bytes = 0;
     size_t nmea_scratch_bytes = 0, d_text_bytes = 0;
     // gnuais_batch_stream_nmea: the frame ring exists NRING times (ring 0 is `frames` / `frame_count`
     // above until the first streaming call).  A ring is filled by K3; its formatter and the copy of its
@@ -202,7 +204,7 @@ void gnuais_batch_destroy(gnuais_batch *b)
     }
     void *ptrs[] = {b->hist[0], b->hist[1], b->pll, b->lastbit, b->prev, b->ctl, b->cand,
                     b->frame_count, b->counters, b->maxval[0], b->maxval[1], b->frames, b->d_taps,
-                    b->stage_x, b->d_seq[0], b->d_seq[1], b->d_text, b->nmea_scratch};
+                    b->stage_x, b->d_seq[0], b->d_seq[1], b->d_text, b->nmea_scratch, b->d_msg};
     for (void *p : ptrs)
         if (p) (void) hipFree(p);
     for (auto &set : b->evr)
@@ -962,6 +964,76 @@ static int drain_impl(gnuais_batch *b, gnuais_frame *h_frames, int max_frames, i
     if (watchdog)
         return fail(GNUAIS_E_HIP, "drain: the PLL stage's watchdog fired (device hung or badly oversubscribed); results are incomplete");
     if (overflow) return fail(GNUAIS_E_OVERFLOW, "drain: frame ring overflowed, frames were dropped");
+    return GNUAIS_OK;
+}
+
+// Row f1 complete on the device: sentences AND stdout lines of everything queued, consumed once
+int gnuais_batch_drain_messages(gnuais_batch *b, uint8_t *seqnr, const char *chanid, char *nmea, size_t nmea_cap,
+                                size_t *nmea_len, int *n_sentences, char *text, size_t text_cap, size_t *text_len,
+                                int *n_lines, int *n_frames)
+{
+    if (!b || !seqnr || !nmea_len || !text_len || (nmea_cap && !nmea) || (text_cap && !text))
+        return fail(GNUAIS_E_ARG, "drain_messages: argument");
+    if (b->streaming) return fail(GNUAIS_E_ARG, "drain_messages: the batch is streaming (gnuais_batch_stream_nmea)");
+    *nmea_len = *text_len = 0;
+    if (n_sentences) *n_sentences = 0;
+    if (n_lines) *n_lines = 0;
+    if (n_frames) *n_frames = 0;
+    if (int rc = gnuais_batch_sync(b)) return rc;
+    uint32_t cnt[4] = {0, 0, 0, 0};
+    HIP_TRY(hipMemcpy(cnt, b->frame_count, sizeof cnt, hipMemcpyDeviceToHost));
+    const uint32_t have = std::min<uint32_t>(cnt[0], (uint32_t) b->frame_cap);
+    const bool overflow = cnt[1] || cnt[0] > (uint32_t) b->frame_cap, watchdog = cnt[3] != 0;
+    if (have) {
+        const size_t N = (size_t) b->N, line = messages_line_bytes();
+        if (nmea_cap < (size_t) have * 164 || text_cap < (size_t) have * line)
+            return fail(GNUAIS_E_ARG, "drain_messages: buffers too small (164 / 512 bytes per pending frame always suffice)");
+        if (int rc = ensure_post_buffers(b, have)) return rc;
+        // lines at a fixed stride, their lengths and offsets, the packed text, two info words, the channel names
+        const size_t need = (size_t) have * line * 2 + (size_t) have * 8 + 256 + N + 256;
+        if (b->d_msg_bytes < need) {
+            if (b->d_msg) (void) hipFree(b->d_msg);
+            b->d_msg = nullptr;
+            b->d_msg_bytes = 0;
+            HIP_TRY(hipMalloc((void **) &b->d_msg, need + need / 4));
+            b->d_msg_bytes = need + need / 4;
+        }
+        char *lines = b->d_msg, *packed = lines + (size_t) have * line;
+        uint32_t *len = reinterpret_cast<uint32_t *>(packed + (size_t) have * line), *off = len + have;
+        uint32_t *info2 = off + have;
+        char *d_chanid = reinterpret_cast<char *>(info2 + 64);
+        if (chanid) HIP_TRY(hipMemcpy(d_chanid, chanid, N, hipMemcpyHostToDevice));
+        if (!b->d_seq[0]) {
+            HIP_TRY(hipMalloc((void **) &b->d_seq[0], N));
+            HIP_TRY(hipMalloc((void **) &b->d_seq[1], N));
+        }
+        HIP_TRY(hipMemcpy(b->d_seq[0], seqnr, N, hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(b->d_seq[1], b->d_seq[0], N, hipMemcpyDeviceToDevice));
+        uint32_t raw[4] = {0, 0, 0, 0}, inf[2] = {0, 0};
+        HIP_TRY(nmea_format_enqueue(b->frames, (int) have, (int) have, b->N, b->d_seq[0], b->d_seq[1], b->d_text,
+                                    b->d_text_bytes, b->nmea_scratch, b->nmea_scratch_bytes, raw, nullptr, 0, 0,
+                                    nullptr, nullptr));
+        HIP_TRY(messages_format_enqueue(b->frames, (int) have, b->N, b->d_seq[0], chanid ? d_chanid : nullptr,
+                                        b->nmea_scratch, b->nmea_scratch_bytes, lines, len, off, packed,
+                                        (size_t) have * line, info2, nullptr));
+        HIP_TRY(hipDeviceSynchronize());
+        HIP_TRY(hipMemcpy(inf, info2, 8, hipMemcpyDeviceToHost));
+        if (raw[3]) return fail(GNUAIS_E_HIP, "drain_messages: a frame record names a channel outside the batch");
+        const size_t nl = (size_t) raw[0] + raw[1];
+        if (nl) HIP_TRY(hipMemcpy(nmea, b->d_text, nl, hipMemcpyDeviceToHost));
+        if (inf[0]) HIP_TRY(hipMemcpy(text, packed, inf[0], hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(seqnr, b->d_seq[1], N, hipMemcpyDeviceToHost));
+        *nmea_len = nl;
+        *text_len = inf[0];
+        if (n_sentences) *n_sentences = (int) raw[2];
+        if (n_lines) *n_lines = (int) inf[1];
+        if (n_frames) *n_frames = (int) have;
+    }
+    HIP_TRY(hipMemset(b->frame_count, 0, sizeof cnt));
+    b->hdlc_calls = 0;
+    if (watchdog)
+        return fail(GNUAIS_E_HIP, "drain_messages: the PLL stage's watchdog fired (device hung or badly oversubscribed)");
+    if (overflow) return fail(GNUAIS_E_OVERFLOW, "drain_messages: frame ring overflowed, frames were dropped");
     return GNUAIS_OK;
 }
 

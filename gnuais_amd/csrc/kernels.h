@@ -128,6 +128,13 @@ hipError_t nmea_slot_info_enqueue(const uint32_t *totals, const uint32_t *ring_c
 // device text -> pinned host text, length taken from info8 on the device; the info words follow it to the host
 hipError_t nmea_text_copy_enqueue(const char *src, const uint32_t *info8_dev, char *dst_pinned, size_t dst_cap,
                                   uint32_t *info8_pinned, int workgroups, hipStream_t s);
+// the stdout lines of protodec_getdata() for the same frames, right after nmea_format_enqueue(n > 0) on the same
+// scratch and stream; lines: n * messages_line_bytes(), len / off: n words; info2 (device): [0] bytes, [1] lines
+size_t messages_line_bytes();
+hipError_t messages_format_enqueue(const struct gnuais_frame *frames, int n, int n_channels, const uint8_t *seq_in,
+                                   const char *chanid_dev, void *scratch, size_t scratch_bytes, char *lines,
+                                   uint32_t *len, uint32_t *off, char *out, size_t out_cap, uint32_t *info2,
+                                   hipStream_t s);
 hipError_t nmea_format(const struct gnuais_frame *frames, int n, int n_channels, const uint8_t *seq_in,
                        uint8_t *seq_out, char *out, size_t out_cap, void *scratch, size_t scratch_bytes,
                        uint32_t *h_info, hipStream_t s);

@@ -282,6 +282,363 @@ __global__ __launch_bounds__(256) void nmea_write_kernel(
     }
 }
 
+// ---- the stdout line of protodec_getdata() (src/protodec.c:934-985), on the device ------------------
+// "ch <id> type <t> mmsi <9 digits>:" + the fields of the per-type decoders (:357-776) + " (!<last
+// sentence>)\n" -- the host formatter (nmea.cpp: describe()) restated for one thread per frame.  The only
+// part that is not integer formatting is printf's %.Nf of a double: done exactly (the double's
+// mantissa times 10^N as a 128-bit integer, shifted, rounded half to even on the exact value -- what
+// glibc prints).
+
+constexpr int MSG_LINE_MAX = 512;               // longest line: type 6 / 8 with the weather report, < 460 bytes
+
+struct LineOut {
+    char *p;
+    int n;
+    __device__ void ch(char c) { if (n < MSG_LINE_MAX) p[n] = c; ++n; }
+    __device__ void str(const char *t) { while (*t) ch(*t++); }
+    // %ld / %d, and %0<width>ld
+    __device__ void dec(long long v, int width = 0)
+    {
+        char t[24];
+        int k = 0;
+        const bool neg = v < 0;
+        unsigned long long u = neg ? 0ull - (unsigned long long) v : (unsigned long long) v;
+        do { t[k++] = (char) ('0' + u % 10ull); u /= 10ull; } while (u);
+        if (neg) ch('-');
+        for (int i = k + (neg ? 1 : 0); i < width; ++i) ch('0');
+        while (k) ch(t[--k]);
+    }
+    // printf("%.<prec>f", d) for |d| < 2^40, prec <= 6
+    __device__ void fixed(double d, int prec)
+    {
+        const unsigned long long bits = (unsigned long long) __double_as_longlong(d);
+        const bool neg = (bits >> 63) != 0;
+        const int ex = (int) ((bits >> 52) & 0x7ffull);
+        unsigned long long m = bits & 0xfffffffffffffull;
+        int e2;
+        if (ex == 0) { e2 = -1074; } else { m |= 1ull << 52; e2 = ex - 1075; }      // |d| = m * 2^e2
+        unsigned long long S = 1;
+        for (int i = 0; i < prec; ++i) S *= 10ull;
+        // P = m * S < 2^73, as hi:lo
+        const unsigned long long a = (m & 0xffffffffull) * S, bq = (m >> 32) * S;
+        unsigned long long lo = a + (bq << 32), hi = (bq >> 32) + (lo < a ? 1ull : 0ull);
+        unsigned long long q;
+        if (e2 >= 0) {                       // an integer already (never for the fields printed here)
+            q = e2 < 11 ? lo << e2 : ~0ull;
+        } else {
+            const int sh = -e2;              // q = round_half_even(P / 2^sh)
+            unsigned long long rem_hi, rem_lo, half_hi, half_lo;
+            if (sh >= 128) {
+                q = 0; rem_hi = hi; rem_lo = lo; half_hi = ~0ull; half_lo = ~0ull;     // P < 2^73 << half
+            } else if (sh >= 64) {
+                const int s2 = sh - 64;
+                q = s2 ? hi >> s2 : hi;
+                rem_hi = s2 ? hi & ((1ull << s2) - 1ull) : 0ull;
+                rem_lo = lo;
+                half_hi = s2 ? 1ull << (s2 - 1) : 0ull;
+                half_lo = s2 ? 0ull : 1ull << 63;
+            } else {
+                q = (lo >> sh) | (hi << (64 - sh));          // hi < 2^9 and sh >= 1: no bits lost for P < 2^73, sh >= 10
+                rem_hi = 0; rem_lo = lo & ((1ull << sh) - 1ull);
+                half_hi = 0; half_lo = 1ull << (sh - 1);
+            }
+            const bool above = rem_hi > half_hi || (rem_hi == half_hi && rem_lo > half_lo);
+            const bool tie = rem_hi == half_hi && rem_lo == half_lo;
+            if (above || (tie && (q & 1ull))) ++q;
+        }
+        if (neg) ch('-');
+        dec((long long) (q / S));
+        if (prec) {
+            ch('.');
+            unsigned long long fr = q % S;
+            char t[8];
+            for (int i = prec - 1; i >= 0; --i) { t[i] = (char) ('0' + fr % 10ull); fr /= 10ull; }
+            for (int i = 0; i < prec; ++i) ch(t[i]);
+        }
+    }
+};
+
+// the frame's payload as the reference's d->rbuffer: bit k, 0 beyond the frame's whole bytes
+struct BitsView {
+    const FrameView &f;
+    int whole;                               // bytes that count (protodec.c:133,150-162)
+    __device__ explicit BitsView(const FrameView &fv) : f(fv)
+    {
+        const int n = fv.nbits();
+        whole = (n < 8 * 53 ? n : 8 * 53) >> 3;
+    }
+    __device__ unsigned byte_at(int k) const { return k < whole ? f.byte(k) : 0u; }
+    // `count` (<= 32) bits from `pos`, MSB first (protodec_henten, protodec.c:205-214)
+    __device__ unsigned long long get(int pos, int count) const
+    {
+        if (pos >= 8 * 64) return 0;
+        const int k = pos >> 3;
+        unsigned long long v = 0;
+#pragma unroll
+        for (int i = 0; i < 5; ++i) v = (v << 8) | byte_at(k + i);
+        return (v >> (40 - (pos & 7) - count)) & ((1ull << count) - 1ull);
+    }
+    __device__ int sget(int pos, int count) const
+    {
+        unsigned long long v = get(pos, count);
+        if ((v >> (count - 1)) & 1ull) v |= ~0ull << count;
+        return (int) v;
+    }
+    // `n` six-bit characters from `pos`, trailing blanks dropped (protodec.c:173-203)
+    __device__ void text(int pos, int n, LineOut &o) const
+    {
+        int last = -1;
+        for (int k = 0; k < n; ++k)
+            if (get(pos + 6 * k, 6) != 32ull && get(pos + 6 * k, 6) != 0ull) last = k;
+        for (int k = 0; k <= last; ++k) {
+            const int v = (int) get(pos + 6 * k, 6);
+            o.ch(v >= 1 && v <= 31 ? (char) (v + 64) : (v >= 32 ? (char) v : ' '));
+        }
+    }
+};
+
+__device__ const char *ifm_name_dev(int fi)    // appid_ifm, protodec.c:220-273
+{
+    switch (fi) {
+    case 0: return "text-telegram"; case 1: return "application-ack"; case 2: return "iai-fi-capab-interrogation";
+    case 3: return "iai-capabi-interrogation"; case 4: return "capability-reply"; case 11: return "tide-weather";
+    case 16: return "vts-targets"; case 17: return "ship-waypoints"; case 18: return "advice-of-waypoints";
+    case 19: return "extended-ship-data"; case 20: return "berthing-data"; case 21: return "weather-obs-report";
+    case 22: return "area-notice-bc"; case 23: return "area-notice-addr"; case 24: return "extended-ship-static";
+    case 25: return "dangerous-cargo-info"; case 26: return "environmental"; case 27: return "route-info-bc";
+    case 28: return "route-info-addr"; case 29: return "text-description-bc"; case 30: return "text-description-addr";
+    case 40: return "persons-on-board";
+    default: return "unknown";
+    }
+}
+
+__device__ void binary_payload_dev(const BitsView &b, int fi, int at, LineOut &o)   // protodec_msg_bin :338-350
+{
+    if (fi == 40) {                              // protodec_msg_40 :279-285
+        o.str(" persons-on-board "); o.dec((int) b.get(at, 13));
+    } else if (fi == 11) {                       // protodec_msg_11 :287-336, its offsets as they are
+        const int lat = (int) b.get(at, 24), lon = (int) b.get(at + 24, 25);
+        const int wind = (int) b.get(at + 40, 7), gust = (int) b.get(at + 47, 7);
+        const int wdir = (int) b.get(at + 54, 9), gdir = (int) b.get(at + 63, 9);
+        const int temp = (int) b.get(at + 72, 11), hum = (int) b.get(at + 83, 7);
+        const int dew = (int) b.get(at + 90, 10), pres = (int) b.get(at + 100, 9) + 800;
+        const int tend = (int) b.get(at + 109, 2), vis = (int) b.get(at + 111, 8);
+        const int level = (int) b.get(at + 119, 9), wave = (int) b.get(at + 124, 8);
+        const int wtemp = (int) b.get(at + 128, 10);
+        o.str(" lat "); o.fixed((double) (float) lat / 60000.0, 6);
+        o.str(" lon "); o.fixed((double) (float) lon / 60000.0, 6);
+        o.str(" wind_speed "); o.dec(wind); o.str("kt wind_gust "); o.dec(gust);
+        o.str("kt wind_dir "); o.dec(wdir); o.str(" wind_gust_dir "); o.dec(gdir);
+        o.str(" air_temp "); o.fixed((double) (float) temp / 10.0 - 60.0, 1);
+        o.str("C rel_humid "); o.dec(hum);
+        o.str("% dew_point "); o.fixed((double) (float) dew / 10.0 - 20.0, 1);
+        o.str("C pressure "); o.dec(pres); o.str(" pressure_tend "); o.dec(tend);
+        o.str(" visib "); o.fixed((double) (float) vis / 10.0, 1);
+        o.str("NM water_level "); o.fixed((double) (float) level / 10.0 - 10.0, 1);
+        o.str("m wave_height "); o.fixed((double) (float) wave / 10.0, 1);
+        o.str("m water_temp "); o.fixed((double) (float) wtemp / 10.0 - 10.0, 1);
+        o.ch('C');
+    }
+}
+
+__device__ void position_fields_dev(int lat, int lon, unsigned course, unsigned sog, int rot, int navstat,
+                                    unsigned heading, LineOut &o)
+{
+    o.str(" lat "); o.fixed((double) (float) lat / 600000.0, 6);
+    o.str(" lon "); o.fixed((double) (float) lon / 600000.0, 6);
+    o.str(" course "); o.fixed((double) (float) (unsigned short) course / 10.0, 0);
+    o.str(" speed "); o.fixed((double) (float) (unsigned short) sog / 10.0, 1);
+    o.str(" rateofturn "); o.dec(rot);
+    o.str(" navstat "); o.dec(navstat);
+    o.str(" heading "); o.dec((int) (unsigned short) heading);
+}
+
+// the fields the reference prints for one frame (the switch at protodec.c:936-982)
+__device__ void describe_dev(const BitsView &b, unsigned type, int padded_len, LineOut &o)
+{
+    switch (type) {
+    case 1: case 2: case 3:                      // protodec_pos :357-402
+        position_fields_dev(b.sget(89, 27), b.sget(61, 28), (unsigned) b.get(116, 12), (unsigned) b.get(50, 10),
+                            (int) (signed char) b.get(40, 8), (int) (signed char) b.get(38, 2),
+                            (unsigned) b.get(128, 9), o);
+        break;
+    case 4: {                                    // protodec_4 :404-441
+        const float lon = (float) ((double) (float) b.sget(79, 28) / 10000.0 / 60.0);
+        const float lat = (float) ((double) (float) b.sget(107, 27) / 10000.0 / 60.0);
+        o.str(" date "); o.dec((long long) b.get(40, 12)); o.ch('-'); o.dec((long long) b.get(52, 4)); o.ch('-');
+        o.dec((long long) b.get(56, 5));
+        o.str(" time "); o.dec((long long) b.get(61, 5), 2); o.ch(':'); o.dec((long long) b.get(66, 6), 2); o.ch(':');
+        o.dec((long long) b.get(72, 6), 2);
+        o.str(" lat "); o.fixed((double) lat, 6); o.str(" lon "); o.fixed((double) lon, 6);
+        break;
+    }
+    case 5: {                                    // protodec_5 :443-519
+        const unsigned A = (unsigned) b.get(240, 9), B = (unsigned) b.get(249, 9);
+        const unsigned char C = (unsigned char) b.get(258, 6), D = (unsigned char) b.get(264, 6);
+        const unsigned char draught = (unsigned char) b.get(294, 8);
+        o.str(" name \""); b.text(112, 20, o); o.str("\" destination \""); b.text(302, 20, o);
+        o.str("\" type "); o.dec((int) b.get(232, 8)); o.str(" length "); o.dec((int) (A + B));
+        o.str(" width "); o.dec(C + D); o.str(" draught "); o.fixed((double) (float) draught / 10.0, 1);
+        break;
+    }
+    case 6: {                                    // protodec_6 :525-542
+        const int dac = (int) b.get(72, 10), fi = (int) b.get(82, 6);
+        o.str(" dst_mmsi "); o.dec((long long) b.get(40, 30), 9); o.str(" seq "); o.dec((int) b.get(38, 2));
+        o.str(" retransmitted "); o.dec((int) b.get(70, 1)); o.str(" appid "); o.dec((int) b.get(72, 16));
+        o.str(" app_dac "); o.dec(dac); o.str(" app_fi "); o.dec(fi);
+        if (dac == 1) {
+            o.ch('('); o.str(ifm_name_dev(fi)); o.ch(')');
+            binary_payload_dev(b, fi, 88, o);
+        }
+        break;
+    }
+    case 7: case 13: {                           // protodec_7_13 :549-567
+        int pos = 40;
+        o.str(" buflen "); o.dec(padded_len); o.str(" pos+32 "); o.dec(pos + 32);
+        for (int i = 0; i < 4 && pos + 32 <= padded_len; pos += 32, ++i) {
+            o.str(" ack "); o.dec(i + 1); o.str(" (to "); o.dec((long long) b.get(pos, 30), 9); o.str(" seq ");
+            o.dec((int) b.get(pos + 30, 2)); o.ch(')');
+        }
+        break;
+    }
+    case 8: {                                    // protodec_8 :573-584
+        const int dac = (int) b.get(40, 10), fi = (int) b.get(50, 6);
+        o.str(" appid "); o.dec((int) b.get(40, 16)); o.str(" app_dac "); o.dec(dac); o.str(" app_fi "); o.dec(fi);
+        if (dac == 1) {
+            o.ch('('); o.str(ifm_name_dev(fi)); o.ch(')');
+            binary_payload_dev(b, fi, 56, o);
+        }
+        break;
+    }
+    case 18:                                     // protodec_18 :586-635 (no turn rate / status in class B)
+        position_fields_dev(b.sget(85, 27), b.sget(57, 28), (unsigned) b.get(112, 12), (unsigned) b.get(46, 10), 0, 15,
+                            (unsigned) b.get(124, 9), o);
+        break;
+    case 19: {                                   // protodec_19 :637-684
+        const unsigned A = (unsigned) b.get(271, 9), B = (unsigned) b.get(280, 9);
+        const unsigned char C = (unsigned char) b.get(289, 6), D = (unsigned char) b.get(295, 6);
+        o.str(" name \""); b.text(143, 20, o); o.str("\" type "); o.dec((int) b.get(263, 8));
+        o.str(" length "); o.dec((int) (A + B)); o.str("  width "); o.dec(C + D);
+        break;
+    }
+    case 20: {                                   // protodec_20 :686-705
+        int pos = 40;
+        for (int i = 0; i < 4 && pos + 30 < padded_len; pos += 30, ++i) {
+            o.str(" reserve "); o.dec(i + 1); o.str(" (ofs "); o.dec((int) b.get(pos, 12)); o.str(" slots ");
+            o.dec((int) b.get(pos + 12, 4)); o.str(" timeout "); o.dec((int) b.get(pos + 16, 3)); o.str(" incr ");
+            o.dec((int) b.get(pos + 19, 11)); o.ch(')');
+        }
+        break;
+    }
+    case 24: {                                   // protodec_24 :707-776
+        const int part = (int) b.get(38, 2);
+        if (part == 0) { o.str(" name \""); b.text(40, 20, o); o.ch('"'); }
+        if (part == 1) {
+            const unsigned A = (unsigned) b.get(132, 9), B = (unsigned) b.get(141, 9);
+            const unsigned char C = (unsigned char) b.get(150, 6), D = (unsigned char) b.get(156, 6);
+            o.str(" callsign \""); b.text(90, 6, o); o.str("\" type "); o.dec((int) b.get(40, 8));
+            o.str(" length "); o.dec((int) (A + B)); o.str(" width "); o.dec(C + D);
+        }
+        break;
+    }
+    default:
+        break;
+    }
+}
+
+// one thread per frame of the print order: its line into lines[j * MSG_LINE_MAX ..], its length into len[j]
+// (0 for frames protodec_getdata() does not accept)
+__global__ __launch_bounds__(128) void message_lines_kernel(
+    const gnuais_frame *__restrict__ frames, const uint32_t *__restrict__ order, const uint32_t *__restrict__ chan,
+    const Tri *__restrict__ tri, const Tri *__restrict__ scan, int n, int n_channels,
+    const uint8_t *__restrict__ seq_in, const char *__restrict__ chanid, char *__restrict__ lines,
+    uint32_t *__restrict__ len)
+{
+    const int j = blockIdx.x * 128 + threadIdx.x;
+    if (j >= n) return;
+    const Tri me = tri[j];
+    const uint32_t ch = chan[j];
+    if (me.bytes == 0 || ch >= (uint32_t) n_channels) { len[j] = 0; return; }
+    const Tri inc = scan[j];
+    const uint32_t h = inc.head;
+    const uint32_t before = (inc.acc - me.acc) - (scan[h].acc - tri[h].acc);
+    const FrameView f = load_frame(frames, order[j]);
+    const BitsView b(f);
+    const Geo g = geometry(f.nbits());
+    LineOut o{lines + (size_t) j * MSG_LINE_MAX, 0};
+    const unsigned type = (unsigned) b.get(0, 6);
+    o.str("ch "); o.ch(chanid ? chanid[ch] : (char) ('A' + ch % 26u));
+    o.str(" type "); o.dec((int) type); o.str(" mmsi "); o.dec((long long) b.get(8, 30), 9); o.ch(':');
+    describe_dev(b, type, f.nbits() + g.fill, o);
+    // protodec.c:934, 984: only the last sentence is shown
+    o.str(" (");
+    {
+        const int part = g.parts;
+        const char seq = (char) ('0' + (seq_in[ch] + before) % 10u);
+        const int n0 = o.n;
+        o.ch('!');
+        o.str("AIVDM,"); o.ch((char) ('0' + g.parts)); o.ch(','); o.ch((char) ('0' + part)); o.ch(',');
+        if (g.parts > 1) { o.ch(seq); o.ch(','); o.ch(','); } else { o.ch(','); o.ch('A'); o.ch(','); }
+        for (int done = (part - 1) * CHARS_PER_SENTENCE; done < g.nchars && done < part * CHARS_PER_SENTENCE; ++done)
+            o.ch(armor(f.six(done)));
+        o.ch(',');
+        o.ch((char) ((g.parts > 1) ? '0' + g.fill : '0'));
+        unsigned x = 0;
+        for (int i = n0 + 1; i < o.n && i < MSG_LINE_MAX; ++i) x ^= (unsigned char) o.p[i];
+        o.ch('*'); o.ch(hexdigit(x >> 4)); o.ch(hexdigit(x & 15u));
+    }
+    o.ch(')'); o.ch('\n');
+    len[j] = (uint32_t) (o.n < MSG_LINE_MAX ? o.n : MSG_LINE_MAX);
+}
+
+// the lines packed back to back: a workgroup takes 64 consecutive lines, gathers them in LDS at their packed
+// offsets (dword loads from the fixed-stride scratch, byte stores into LDS) and stores the piece 16 bytes per lane
+constexpr int PACK_FRAMES = 64;
+__global__ __launch_bounds__(256) void message_pack_kernel(const char *__restrict__ lines, const uint32_t *__restrict__ len,
+                                                           const uint32_t *__restrict__ off, int n, char *__restrict__ out,
+                                                           unsigned long long out_cap, uint32_t *__restrict__ info)
+{
+    __shared__ __attribute__((aligned(16))) char buf[PACK_FRAMES * MSG_LINE_MAX + 32];
+    __shared__ uint32_t s_lines;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int j0 = blockIdx.x * PACK_FRAMES;
+    const int j1 = j0 + PACK_FRAMES < n ? j0 + PACK_FRAMES : n;
+    const uint32_t base = off[j0], shift = base & 15u;
+    const uint32_t end = off[j1 - 1] + len[j1 - 1];
+    if (tid == 0) s_lines = 0;
+    __syncthreads();
+    uint32_t mine = 0;
+    for (int j = j0 + wave; j < j1; j += 4) {
+        const uint32_t l = len[j], o = off[j] - base + shift;
+        const uint32_t *src = reinterpret_cast<const uint32_t *>(lines + (size_t) j * MSG_LINE_MAX);
+        for (uint32_t q = lane; q * 4u < l; q += 64) {
+            const uint32_t v = src[q];
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (q * 4u + k < l) buf[o + q * 4u + k] = (char) (v >> (8 * k));
+        }
+        if (lane == 0 && l) ++mine;
+    }
+    if (mine) atomicAdd(&s_lines, mine);
+    __syncthreads();
+    if (tid == 0) {
+        if (s_lines) atomicAdd(&info[1], s_lines);
+        if (j1 == n) info[0] = end;
+    }
+    const uint32_t total = end - base;
+    const unsigned long long g0 = (unsigned long long) base - shift;
+    const uint32_t units = (shift + total + 15u) >> 4;
+    for (uint32_t u = tid; u < units; u += 256) {
+        const uint32_t lo = u * 16u, hi = lo + 16u;
+        if (lo >= shift && hi <= shift + total && g0 + hi <= out_cap) {
+            *reinterpret_cast<uint4 *>(out + g0 + lo) = *reinterpret_cast<const uint4 *>(buf + lo);
+        } else {
+            for (uint32_t q = lo; q < hi; ++q)
+                if (q >= shift && q < shift + total && g0 + q < out_cap) out[g0 + q] = buf[q];
+        }
+    }
+}
+
 // records gathered into sorted order: one thread moves one 16-byte quarter of a record
 __global__ __launch_bounds__(256) void frames_gather_kernel(const gnuais_frame *__restrict__ frames,
                                                             const uint32_t *__restrict__ order, int n,
@@ -306,7 +663,11 @@ size_t nmea_scratch_bytes(int n, int n_chunks)
     (void) rocprim::radix_sort_pairs(nullptr, sort_tmp, (uint64_t *) nullptr, (uint64_t *) nullptr,
                                      (uint32_t *) nullptr, (uint32_t *) nullptr, m, 0, 64, (hipStream_t) 0);
     (void) rocprim::inclusive_scan(nullptr, scan_tmp, (Tri *) nullptr, (Tri *) nullptr, m, TriOp(), (hipStream_t) 0);
-    const size_t tmp = sort_tmp > scan_tmp ? sort_tmp : scan_tmp;
+    size_t scan_tmp2 = 0;
+    (void) rocprim::exclusive_scan(nullptr, scan_tmp2, (uint32_t *) nullptr, (uint32_t *) nullptr, 0u, m,
+                                   rocprim::plus<uint32_t>(), (hipStream_t) 0);
+    size_t tmp = sort_tmp > scan_tmp ? sort_tmp : scan_tmp;
+    tmp = tmp > scan_tmp2 ? tmp : scan_tmp2;
     // keys x2, idx x2, chan, tri x2, chunk offsets, totals, rocPRIM temp (256-byte slots)
     return 2 * 8 * m + 3 * 4 * m + 2 * sizeof(Tri) * m + 4 * ((size_t) n_chunks + 1) + 256 * 12 + tmp + 64;
 }
@@ -373,6 +734,55 @@ hipError_t nmea_text_copy_enqueue(const char *src, const uint32_t *info8_dev, ch
     return hipGetLastError();
 }
 
+// how nmea_format_enqueue() cuts up its scratch: the message-line pass reads the same arrays
+struct NmeaLayout {
+    uint64_t *keys, *keys2;
+    uint32_t *idx, *idx2, *chan;
+    Tri *tri, *scan;
+    uint32_t *chunk_off, *totals;
+    void *tmp;
+    size_t tmp_bytes;
+};
+static NmeaLayout nmea_layout(void *scratch, size_t scratch_bytes, size_t m, int n_chunks)
+{
+    NmeaLayout l;
+    char *p = static_cast<char *>(scratch);
+    auto take = [&](size_t bytes) { char *q = p; p += (bytes + 255) / 256 * 256; return (void *) q; };
+    l.keys = (uint64_t *) take(8 * m); l.keys2 = (uint64_t *) take(8 * m);
+    l.idx = (uint32_t *) take(4 * m); l.idx2 = (uint32_t *) take(4 * m);
+    l.chan = (uint32_t *) take(4 * m);
+    l.tri = (Tri *) take(sizeof(Tri) * m); l.scan = (Tri *) take(sizeof(Tri) * m);
+    l.chunk_off = (uint32_t *) take(4 * ((size_t) n_chunks + 1));
+    l.totals = (uint32_t *) take(16);
+    l.tmp = p;
+    l.tmp_bytes = scratch_bytes - (size_t) (p - static_cast<char *>(scratch));
+    return l;
+}
+
+// The stdout lines of the same frames, after nmea_format_enqueue(frames, n > 0, ...) on the same scratch and
+// stream (its order, acceptance flags and sequence-digit prefix sums are reused; seq_in is the digit array it was
+// given).  lines: n * 512 bytes, len / off: n words each; info2 (device): [0] bytes, [1] lines.
+size_t messages_line_bytes() { return (size_t) MSG_LINE_MAX; }
+
+hipError_t messages_format_enqueue(const gnuais_frame *frames, int n, int n_channels, const uint8_t *seq_in,
+                                   const char *chanid_dev, void *scratch, size_t scratch_bytes, char *lines,
+                                   uint32_t *len, uint32_t *off, char *out, size_t out_cap, uint32_t *info2,
+                                   hipStream_t s)
+{
+    if (n <= 0) return hipErrorInvalidValue;
+    const NmeaLayout lay = nmea_layout(scratch, scratch_bytes, (size_t) n, 0);
+    hipError_t e;
+    if ((e = hipMemsetAsync(info2, 0, 8, s)) != hipSuccess) return e;
+    hipLaunchKernelGGL(message_lines_kernel, dim3((n + 127) / 128), dim3(128), 0, s, frames, lay.idx2, lay.chan,
+                       lay.tri, lay.scan, n, n_channels, seq_in, chanid_dev, lines, len);
+    size_t t = lay.tmp_bytes;
+    if ((e = rocprim::exclusive_scan(lay.tmp, t, len, off, 0u, (size_t) n, rocprim::plus<uint32_t>(), s)) != hipSuccess)
+        return e;
+    hipLaunchKernelGGL(message_pack_kernel, dim3((n + PACK_FRAMES - 1) / PACK_FRAMES), dim3(256), 0, s, lines, len, off, n, out,
+                       (unsigned long long) out_cap, info2);
+    return hipGetLastError();
+}
+
 // everything of nmea_format() that runs on the device, queued on `s` without waiting for it.
 // n > 0: the host knows the count; the order comes from a radix sort.  n < 0: the ring holds exactly one
 // call, the order AND the count (at most n_max) come from K3's chunk table -- no host value needed.
@@ -387,16 +797,13 @@ hipError_t nmea_format_enqueue(const gnuais_frame *frames, int n, int n_max, int
     if (!by_chunks) { chunks = nullptr; n_chunks = 0; n_max = n; }
     if (scratch_bytes < nmea_scratch_bytes(n_max, n_chunks)) return hipErrorInvalidValue;
     const size_t m = (size_t) n_max;
-    char *p = static_cast<char *>(scratch);
-    auto take = [&](size_t bytes) { char *q = p; p += (bytes + 255) / 256 * 256; return (void *) q; };
-    uint64_t *keys = (uint64_t *) take(8 * m), *keys2 = (uint64_t *) take(8 * m);
-    uint32_t *idx = (uint32_t *) take(4 * m), *idx2 = (uint32_t *) take(4 * m);
-    uint32_t *chan = (uint32_t *) take(4 * m);
-    Tri *tri = (Tri *) take(sizeof(Tri) * m), *scan = (Tri *) take(sizeof(Tri) * m);
-    uint32_t *chunk_off = (uint32_t *) take(4 * ((size_t) n_chunks + 1));
-    uint32_t *totals = (uint32_t *) take(16);
-    void *tmp = p;
-    size_t tmp_bytes = scratch_bytes - (size_t) (p - static_cast<char *>(scratch));
+    const NmeaLayout lay = nmea_layout(scratch, scratch_bytes, m, n_chunks);
+    uint64_t *keys = lay.keys, *keys2 = lay.keys2;
+    uint32_t *idx = lay.idx, *idx2 = lay.idx2, *chan = lay.chan;
+    Tri *tri = lay.tri, *scan = lay.scan;
+    uint32_t *chunk_off = lay.chunk_off, *totals = lay.totals;
+    void *tmp = lay.tmp;
+    const size_t tmp_bytes = lay.tmp_bytes;
     const int grid = (n_max + 255) / 256;
     hipError_t e;
     size_t t = tmp_bytes;

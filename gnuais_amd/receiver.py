@@ -189,6 +189,20 @@ class ReceiverBatch:
         view = np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_uint8)), shape=(ln.value,))
         return (view.tobytes() if copy else view), ns.value, nf.value
 
+    def drain_messages(self, seqnr: np.ndarray, chanid: Optional[bytes] = None):
+        """gnuais_batch_drain_messages(): sentences and stdout lines of everything queued, both formatted
+        on the device -> (nmea bytes, text bytes, sentences, lines, frames)."""
+        assert seqnr.dtype == np.uint8 and seqnr.flags.c_contiguous and len(seqnr) == self.n_channels
+        assert chanid is None or len(chanid) == self.n_channels
+        n = max(self.pending_frames(), 1)
+        nm = np.empty(164 * n, dtype=np.uint8)
+        tx = np.empty(512 * n, dtype=np.uint8)
+        nl, tl, ns, nlines, nf = C.c_size_t(0), C.c_size_t(0), C.c_int(0), C.c_int(0), C.c_int(0)
+        check(self._lib.gnuais_batch_drain_messages(self._h, seqnr.ctypes.data, chanid, nm.ctypes.data, nm.size,
+                                                    C.byref(nl), C.byref(ns), tx.ctypes.data, tx.size, C.byref(tl),
+                                                    C.byref(nlines), C.byref(nf)))
+        return nm[: nl.value].tobytes(), tx[: tl.value].tobytes(), ns.value, nlines.value, nf.value
+
     def drain_frames_nmea(self, seqnr: np.ndarray):
         """Records and device-formatted sentences of the same drained span: (frames, text, sentences)."""
         assert seqnr.dtype == np.uint8 and seqnr.flags.c_contiguous and len(seqnr) == self.n_channels

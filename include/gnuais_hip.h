@@ -217,6 +217,16 @@ int  gnuais_messages_from_frames(const gnuais_frame *frames, int n_frames, uint8
  * 164 bytes per pending frame always suffice). */
 int  gnuais_batch_drain_nmea(gnuais_batch *b, uint8_t *seqnr, char *out, size_t out_cap,
 			     size_t *out_len, int *n_sentences, int *n_frames);
+/* Row f1 complete ON THE DEVICE: the sentences as above AND the stdout lines of
+ * gnuais_messages_from_frames() -- "ch <id> type <t> mmsi <9 digits>:" + the fields of the per-type
+ * decoders (src/protodec.c:357-776) + " (!<last sentence>)\n" -- one thread per frame, printf's %.6f /
+ * %.1f / %.0f done exactly in integer arithmetic; only the two texts cross PCIe.  Consumes the queued
+ * frames like gnuais_batch_drain_frames().  Byte-identical to the host formatter over the drained
+ * records.  chanid[n_channels] or NULL as there.  GNUAIS_E_ARG (nothing consumed) unless nmea_cap >=
+ * 164 and text_cap >= 512 bytes per pending frame (gnuais_batch_pending_frames). */
+int  gnuais_batch_drain_messages(gnuais_batch *b, uint8_t *seqnr, const char *chanid, char *nmea,
+				 size_t nmea_cap, size_t *nmea_len, int *n_sentences, char *text,
+				 size_t text_cap, size_t *text_len, int *n_lines, int *n_frames);
 /* Streaming delivery of the same sentences.  Call once after every gnuais_batch_run(): the frames of
  * the runs since the previous call are taken off at once (the chain moves on to another frame ring);
  * their formatter and the copy of the text into pinned host memory are queued behind the chain with every

@@ -320,3 +320,64 @@ def test_streamed_sentences_with_several_runs_per_call():
     for k, (w, g) in enumerate(zip(want, out)):
         assert g[2] == w[2] and g[1] == w[1], k
         assert g[0] == w[0], k
+
+
+@pytest.mark.gpu
+def test_device_message_lines_match_host_formatter():
+    """gnuais_batch_drain_messages(): the stdout line of every accepted frame formatted on the device
+    (every per-type decoder, %.6f / %.1f / %.0f of the reference's float expressions done in integer
+    arithmetic) == the host formatter's text over the drained records -- which test_stdout_text_* pin to
+    the reference's own printf.  Frames: the golden set (all 24 types, extreme coordinates) and random
+    payloads of every length, through the device deframer; two spans so the digits carry over."""
+    from gnuais_amd import ReceiverBatch, synth, messages_from_frames
+    g = np.load(os.path.join(G, "nmea.npz"))
+    gold = np.frombuffer(np.ascontiguousarray(g["synthetic_frames"]).tobytes(), dtype=FRAME_DTYPE)
+    rnd, n_ch = cases.nmea_frames(seed=91, n_channels=6, n_random=1500)
+    # coordinates whose sixth decimal sits on a rounding boundary: lat / 600000 for many values
+    rng = np.random.default_rng(92)
+    extra = []
+    for k in range(600):
+        bits = rng.integers(0, 2, 53 * 8).astype(np.uint8)
+        t = (1, 2, 3, 18, 4)[k % 5]
+        for i in range(6):
+            bits[i] = (t >> (5 - i)) & 1
+        lat = int(rng.integers(-(1 << 26), 1 << 26)) if k % 4 else int(rng.choice([0, 1, -1, 3, -3, 300000, -300000, 54000000]))
+        pos = {1: 89, 2: 89, 3: 89, 18: 85, 4: 107}[t]
+        for i in range(27):
+            bits[pos + i] = (lat >> (26 - i)) & 1
+        f = np.zeros(1, dtype=FRAME_DTYPE)[0]
+        f["channel"] = k % n_ch
+        f["payload"] = np.packbits(bits)
+        f["nbits"] = 168
+        extra.append(f)
+    allf = list(gold) + list(rnd) + extra
+    streams = [[np.zeros(8, dtype=np.uint8)] for _ in range(n_ch)]
+    for f in allf:
+        body = bytes(f["payload"][: int(f["nbits"]) // 8])
+        if len(body) < 1:
+            continue
+        c = int(f["channel"]) % n_ch
+        streams[c].append(synth.hdlc_frame_bits(body, training_bits=24))
+        streams[c].append(np.zeros(5, dtype=np.uint8))
+    streams = [np.concatenate(s).astype(np.uint8) for s in streams]
+    chanid = b"ABXYZQ"
+    a, b = ReceiverBatch(n_ch, max_len=48000), ReceiverBatch(n_ch, max_len=48000)
+    seq_a, seq_b = np.zeros(n_ch, dtype=np.uint8), np.zeros(n_ch, dtype=np.uint8)
+    types = set()
+    for piece in (0, 1):
+        half = [st[: len(st) // 2] if piece == 0 else st[len(st) // 2:] for st in streams]
+        a.decode_bits(half)
+        b.decode_bits(half)
+        frames = a.drain_frames()
+        want_nm, want_tx = messages_from_frames(frames, seq_a, chanid if piece else None)
+        nm, tx, n_sent, n_lines, n_frames = b.drain_messages(seq_b, chanid if piece else None)
+        assert n_frames == len(frames) > 500
+        assert nm == want_nm and n_sent == want_nm.count(b"\r\n")
+        if tx != want_tx:                             # show the first differing line
+            for x, y in zip(tx.split(b"\n"), want_tx.split(b"\n")):
+                assert x == y
+        assert tx == want_tx and n_lines == want_tx.count(b"\n")
+        assert np.array_equal(seq_a, seq_b) and b.pending_frames() == 0
+        types |= {l.split(b" type ")[1].split(b" ")[0] for l in want_tx.split(b"\n") if b" type " in l}
+    assert types == {str(t).encode() for t in range(1, 25)}
+    assert b"(tide-weather) lat" in want_tx or b"(tide-weather) lat" in tx
