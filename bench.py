@@ -225,6 +225,31 @@ def measure(cfg, args, local, rank, sync, steps, warmup, isolated=True, post=Fal
            "kernel_ms_calls": int(live["calls"])}
 
     if post and cfg["stage_mask"] == 0x1f:
+        # the rest of row f1 from the device: sentences AND the stdout line of every accepted frame
+        # (gnuais_batch_drain_messages), one step's frames, the C call alone into buffers that exist already
+        import ctypes as C
+        b.sync()
+        b.discard_frames(stream)
+        cap = n_ch * 48
+        nmb, txb = np.zeros(164 * cap, dtype=np.uint8), np.zeros(512 * cap, dtype=np.uint8)
+        seq = np.zeros(n_ch, dtype=np.uint8)
+        best = None
+        for _ in range(3):
+            b.run(x, stream=stream, sync=True)
+            nl, tl, ns, nln, nf = C.c_size_t(0), C.c_size_t(0), C.c_int(0), C.c_int(0), C.c_int(0)
+            t0 = time.perf_counter()
+            rc = b._lib.gnuais_batch_drain_messages(b._h, seq.ctypes.data, None, nmb.ctypes.data, nmb.size, C.byref(nl),
+                                                    C.byref(ns), txb.ctypes.data, txb.size, C.byref(tl), C.byref(nln),
+                                                    C.byref(nf))
+            dt = time.perf_counter() - t0
+            if rc == 0 and (best is None or dt < best[0]):
+                best = (dt, nf.value, nln.value, nl.value, tl.value)
+        if best:
+            out["message_lines"] = {"what": "gnuais_batch_drain_messages: NMEA sentences + the stdout line of "
+                                            "protodec_getdata() for one step's frames, formatted on the device, both "
+                                            "texts in host memory", "frames": best[1], "lines": best[2], "ms": best[0] * 1e3,
+                                    "frames_per_s": best[1] / best[0], "nmea_bytes": best[3], "text_bytes": best[4]}
+        del nmb, txb
         # end to end: every step's frames leave the device as NMEA text (formatted on the device, row
         # f1) and arrive in pinned host memory -- gnuais_batch_stream_nmea(), one call per step, the
         # formatter and the copy of step i overlapping the chain of steps i+1..i+3
@@ -309,6 +334,7 @@ def rank_main(rank, local, world, args, sync):
         "kernel_ms_calls": m["kernel_ms_calls"],
         "per_gpu": ranks,
         "end_to_end": m.get("end_to_end"),
+        "message_lines": m.get("message_lines"),
         "roofline": roofline_of(m),
         "note": "the receive path slices the sign of the filter output and never stores the pre-slicer "
                 "floats; gnuais_batch_filter() produces them (bit-exact, tests/test_hip_parity.py)",
