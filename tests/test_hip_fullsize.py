@@ -315,3 +315,41 @@ def test_file_to_frames_through_the_async_host_path(tmp_path):
         assert b.drain_frames().tobytes() == want.tobytes(), chunk
         assert np.array_equal(counters_of(b), o.counters())
         assert pll_of(b) == [o.pll(c) for c in range(n_ch)]
+
+
+# ---------------------------------------------------------------- C3: delivery inside the loop
+
+def test_c3_streamed_delivery_equals_drained_delivery():
+    """The bench's end-to-end loop at full size: twelve C3 calls with gnuais_batch_stream_nmea() after
+    each (asynchronous, pipelined, the order taken from K3's chunk table), against a second batch that
+    drains every call (radix sort on the device) -- the same bytes call by call, and every sentence's
+    checksum recomputed on the host."""
+    from gnuais_amd import tile_channels
+    n_ch, total, calls = 16384, 48000, 12
+    base, _ = synth.make_base_streams(128, total)
+    x = tile_channels(dev(base), n_ch)
+    a, b = batch(n_ch, max_len=total), batch(n_ch, max_len=total)
+    seq = np.zeros(n_ch, dtype=np.uint8)
+    want, got = [], []
+    for i in range(calls):
+        a.run(x)
+        want.append(a.drain_nmea(seq))
+        b.run(x, sync=False)
+        got.append(b.stream_nmea())
+    depth = b.stream_depth
+    for _ in range(depth):
+        got.append(b.stream_nmea())
+    out = got[depth:]
+    assert len(out) == calls
+    for i, (w, g) in enumerate(zip(want, out)):
+        assert g[2] == w[2] > 200000 and g[1] == w[1], i           # frames, sentences
+        assert g[0] == w[0], i
+    lines = out[-1][0].split(b"\r\n")[:-1]
+    assert len(lines) == out[-1][1]
+    body = np.frombuffer(out[-1][0], dtype=np.uint8)
+    for l in lines[:: max(1, len(lines) // 5000)]:                   # a sample of checksums
+        x_ = 0
+        for ch in l[1:l.index(b"*")]:
+            x_ ^= ch
+        assert l.endswith(b"*%02X" % x_)
+    assert body.size == len(out[-1][0])
