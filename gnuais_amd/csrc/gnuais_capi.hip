@@ -103,6 +103,7 @@ struct gnuais_batch {
     char *d_text = nullptr;
     void *nmea_scratch = nullptr;
     char *d_msg = nullptr;          // gnuais_batch_drain_messages: lines, lengths, offsets, packed text
+    uint32_t *d_word = nullptr;     // a few device words for counts read back by the drain-type calls
     size_t d_msg_bytes = 0;
     size_t nmea_scratch_bytes = 0, d_text_bytes = 0;
     // gnuais_batch_stream_nmea: the frame ring exists NRING times (ring 0 is `frames` / `frame_count`
@@ -204,7 +205,7 @@ void gnuais_batch_destroy(gnuais_batch *b)
     }
     void *ptrs[] = {b->hist[0], b->hist[1], b->pll, b->lastbit, b->prev, b->ctl, b->cand,
                     b->frame_count, b->counters, b->maxval[0], b->maxval[1], b->frames, b->d_taps,
-                    b->stage_x, b->d_seq[0], b->d_seq[1], b->d_text, b->nmea_scratch, b->d_msg};
+                    b->stage_x, b->d_seq[0], b->d_seq[1], b->d_text, b->nmea_scratch, b->d_msg, b->d_word};
     for (void *p : ptrs)
         if (p) (void) hipFree(p);
     for (auto &set : b->evr)
@@ -1034,6 +1035,34 @@ int gnuais_batch_drain_messages(gnuais_batch *b, uint8_t *seqnr, const char *cha
     if (watchdog)
         return fail(GNUAIS_E_HIP, "drain_messages: the PLL stage's watchdog fired (device hung or badly oversubscribed)");
     if (overflow) return fail(GNUAIS_E_OVERFLOW, "drain_messages: frame ring overflowed, frames were dropped");
+    return GNUAIS_OK;
+}
+
+// Row f3 on the device: what the queued frames do to the reference's position cache, folded per vessel.
+// Does not consume the frames (call it before a drain).
+int gnuais_batch_fold_vessels(gnuais_batch *b, gnuais_vessel *vessels, int cap, int *n_vessels)
+{
+    if (!b || !n_vessels || cap < 0 || (cap > 0 && !vessels)) return fail(GNUAIS_E_ARG, "fold_vessels: argument");
+    if (b->streaming) return fail(GNUAIS_E_ARG, "fold_vessels: the batch is streaming (gnuais_batch_stream_nmea)");
+    *n_vessels = 0;
+    if (int rc = gnuais_batch_sync(b)) return rc;
+    uint32_t cnt[4] = {0, 0, 0, 0};
+    HIP_TRY(hipMemcpy(cnt, b->frame_count, sizeof cnt, hipMemcpyDeviceToHost));
+    const uint32_t have = std::min<uint32_t>(cnt[0], (uint32_t) b->frame_cap);
+    if (!have) return GNUAIS_OK;
+    if (int rc = ensure_post_buffers(b, have)) return rc;
+    // at most one vessel per frame; the table shares the text buffer (164 bytes per frame >= 120)
+    gnuais_vessel *d_tab = reinterpret_cast<gnuais_vessel *>(b->d_text);
+    const int d_cap = (int) std::min<size_t>(b->d_text_bytes / sizeof(gnuais_vessel), (size_t) have);
+    if (!b->d_word) HIP_TRY(hipMalloc((void **) &b->d_word, 16));
+    HIP_TRY(vessels_fold_enqueue(b->frames, (int) have, b->nmea_scratch, b->nmea_scratch_bytes, d_tab, d_cap,
+                                 b->d_word, nullptr));
+    HIP_TRY(hipDeviceSynchronize());
+    uint32_t nv = 0;
+    HIP_TRY(hipMemcpy(&nv, b->d_word, 4, hipMemcpyDeviceToHost));
+    *n_vessels = (int) nv;
+    if ((int) nv > cap) return fail(GNUAIS_E_OVERFLOW, "fold_vessels: table too small (*n_vessels entries needed)");
+    if (nv) HIP_TRY(hipMemcpy(vessels, d_tab, sizeof(gnuais_vessel) * nv, hipMemcpyDeviceToHost));
     return GNUAIS_OK;
 }
 

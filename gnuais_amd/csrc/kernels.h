@@ -135,6 +135,9 @@ hipError_t messages_format_enqueue(const struct gnuais_frame *frames, int n, int
                                    const char *chanid_dev, void *scratch, size_t scratch_bytes, char *lines,
                                    uint32_t *len, uint32_t *off, char *out, size_t out_cap, uint32_t *info2,
                                    hipStream_t s);
+// the batch's vessel table (gnuais_vessel per MMSI, sorted) folded on the device from the ring's frames
+hipError_t vessels_fold_enqueue(const struct gnuais_frame *frames, int n, void *scratch, size_t scratch_bytes,
+                                struct gnuais_vessel *out, int cap, uint32_t *count_dev, hipStream_t s);
 hipError_t nmea_format(const struct gnuais_frame *frames, int n, int n_channels, const uint8_t *seq_in,
                        uint8_t *seq_out, char *out, size_t out_cap, void *scratch, size_t scratch_bytes,
                        uint32_t *h_info, hipStream_t s);

@@ -639,6 +639,155 @@ __global__ __launch_bounds__(256) void message_pack_kernel(const char *__restric
     }
 }
 
+// ---- the position cache of one batch, folded on the device (cache.c:163-384; nmea.cpp: fold()) --------
+// Every frame that reaches a cache_*() call of the per-type decoders sets whole groups of a vessel's
+// entry (position / static data / name + destination / call sign / persons on board); what the entry
+// holds after the batch is, per group, what the LAST such frame in arrival order wrote.  Arrival order
+// is the print order, so: key = mmsi << 20 | print position, radix sort, one thread per vessel walking
+// its (short) run backwards until every group it can still find has been found.
+enum { VG_POS = 1, VG_STATIC = 2, VG_NAME = 4, VG_CALL = 8, VG_PERSONS = 16 };
+constexpr uint64_t VKEY_NONE = ~0ull;
+
+__device__ __forceinline__ unsigned vessel_groups(const BitsView &b, unsigned type)
+{
+    switch (type) {
+    case 1: case 2: case 3: case 4: case 18: return VG_POS;
+    case 5: return VG_CALL | VG_NAME | VG_STATIC;
+    case 19: return VG_NAME | VG_STATIC;
+    case 24: return b.get(38, 2) == 0 ? VG_NAME : b.get(38, 2) == 1 ? (VG_CALL | VG_STATIC) : 0u;
+    case 6: return (b.get(72, 10) == 1 && b.get(82, 6) == 40) ? VG_PERSONS : 0u;
+    case 8: return (b.get(40, 10) == 1 && b.get(50, 6) == 40) ? VG_PERSONS : 0u;
+    default: return 0u;
+    }
+}
+
+// j = position in print order; frames that touch no cache entry sort to the end
+__global__ __launch_bounds__(256) void vessel_keys_kernel(const gnuais_frame *__restrict__ frames,
+                                                          const uint32_t *__restrict__ order, int n,
+                                                          uint64_t *__restrict__ keys, uint32_t *__restrict__ val)
+{
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= n) return;
+    const FrameView f = load_frame(frames, order[j]);
+    const BitsView b(f);
+    const unsigned type = (unsigned) b.get(0, 6);
+    const unsigned g = (type >= 1 && type <= MAX_TYPE) ? vessel_groups(b, type) : 0u;
+    keys[j] = g ? ((uint64_t) b.get(8, 30) << 20) | (uint64_t) j : VKEY_NONE;
+    val[j] = order[j] ;
+}
+
+__global__ __launch_bounds__(256) void vessel_heads_kernel(const uint64_t *__restrict__ keys, int n,
+                                                           uint32_t *__restrict__ head)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const uint64_t k = keys[i];
+    head[i] = (k != VKEY_NONE && (i == 0 || (keys[i - 1] >> 20) != (k >> 20))) ? 1u : 0u;
+}
+
+__device__ void vessel_text(const BitsView &b, int pos, int nchar, char *dst, int cap)
+{
+    char t[24];
+    LineOut o{t, 0};
+    b.text(pos, nchar, o);
+    const int n = o.n < cap - 1 ? o.n : cap - 1;
+    for (int i = 0; i < cap; ++i) dst[i] = i < n ? t[i] : 0;
+}
+__device__ void vessel_literal(const char *s, char *dst, int cap)
+{
+    int n = 0;
+    while (s[n] && n < cap - 1) { dst[n] = s[n]; ++n; }
+    for (int i = n; i < cap; ++i) dst[i] = 0;
+}
+
+__global__ __launch_bounds__(128) void vessel_fold_kernel(const gnuais_frame *__restrict__ frames,
+                                                          const uint64_t *__restrict__ keys,
+                                                          const uint32_t *__restrict__ val,
+                                                          const uint32_t *__restrict__ head,
+                                                          const uint32_t *__restrict__ hidx, int n,
+                                                          gnuais_vessel *__restrict__ out, int cap,
+                                                          uint32_t *__restrict__ count)
+{
+    const int i = blockIdx.x * 128 + threadIdx.x;
+    if (i >= n || !head[i]) return;
+    const uint32_t slot = hidx[i];                 // vessels before this one
+    atomicMax(count, slot + 1u);
+    if ((int) slot >= cap) return;
+    const uint64_t mm = keys[i] >> 20;
+    int e = i;
+    while (e + 1 < n && (keys[e + 1] >> 20) == mm) ++e;        // the vessel's run: [i, e]
+    gnuais_vessel v;
+    {
+        uint32_t *z = reinterpret_cast<uint32_t *>(&v);
+        for (unsigned q = 0; q < sizeof v / 4; ++q) z[q] = 0;
+    }
+    v.mmsi = (int32_t) mm;                         // cache_get's new entry, cache.c:175-196
+    v.hdg = -1; v.course = -1; v.sog = -1; v.shiptype = -1; v.imo = -1; v.navstat = -1;
+    v.A = v.B = v.C = v.D = -1;
+    v.persons_on_board = -1;
+    unsigned found = 0;
+    for (int k = e; k >= i && found != 31u; --k) {
+        const FrameView f = load_frame(frames, val[k]);
+        const BitsView b(f);
+        const unsigned type = (unsigned) b.get(0, 6);
+        const unsigned todo = vessel_groups(b, type) & ~found;
+        if (!todo) continue;
+        found |= todo;
+        if (todo & VG_POS) {                       // cache_position :204-229
+            long latitude, longitude;
+            int navstat = 0, hdg = 0;
+            unsigned course = 0, sog = 0;
+            if (type == 4) {
+                latitude = b.sget(107, 27); longitude = b.sget(79, 28);
+            } else if (type == 18) {
+                latitude = b.sget(85, 27); longitude = b.sget(57, 28); navstat = 15;
+                hdg = (int) b.get(124, 9); course = (unsigned) b.get(112, 12); sog = (unsigned) b.get(46, 10);
+            } else {
+                latitude = b.sget(89, 27); longitude = b.sget(61, 28); navstat = (int) (signed char) b.get(38, 2);
+                hdg = (int) b.get(128, 9); course = (unsigned) b.get(116, 12); sog = (unsigned) b.get(50, 10);
+            }
+            v.set |= GNUAIS_V_POSITION;
+            v.lat = (float) ((double) (float) latitude / 600000.0);
+            v.lon = (float) ((double) (float) longitude / 600000.0);
+            v.hdg = hdg;
+            v.course = (float) ((double) (float) (unsigned short) course / 10.0);
+            v.sog = (float) ((double) (float) (unsigned short) sog / 10.0);
+            v.navstat = navstat;
+        }
+        if (todo & VG_CALL) {
+            v.set |= GNUAIS_V_CALLSIGN;
+            vessel_text(b, type == 5 ? 70 : 90, 6, v.callsign, (int) sizeof v.callsign);
+        }
+        if (todo & VG_NAME) {
+            v.set |= GNUAIS_V_DATA | GNUAIS_V_NAME;
+            vessel_text(b, type == 5 ? 112 : type == 19 ? 143 : 40, 20, v.name, (int) sizeof v.name);
+            if (type == 5) vessel_text(b, 302, 20, v.destination, (int) sizeof v.destination);
+            else vessel_literal("CLASS B", v.destination, (int) sizeof v.destination);
+        }
+        if (todo & VG_STATIC) {
+            v.set |= GNUAIS_V_DATA | GNUAIS_V_STATIC;
+            if (type == 5) {
+                const unsigned char draught = (unsigned char) b.get(294, 8);
+                v.imo = (int) b.get(40, 30); v.shiptype = (int) b.get(232, 8);
+                v.A = (int) b.get(240, 9); v.B = (int) b.get(249, 9);
+                v.C = (unsigned char) b.get(258, 6); v.D = (unsigned char) b.get(264, 6);
+                v.draught = (float) ((double) draught / 10.0);
+            } else if (type == 19) {
+                v.imo = 0; v.shiptype = (int) b.get(263, 8); v.A = (int) b.get(271, 9); v.B = (int) b.get(280, 9);
+                v.C = (unsigned char) b.get(289, 6); v.D = (unsigned char) b.get(295, 6); v.draught = 0;
+            } else {
+                v.imo = 0; v.shiptype = (int) b.get(40, 8); v.A = (int) b.get(132, 9); v.B = (int) b.get(141, 9);
+                v.C = (unsigned char) b.get(150, 6); v.D = (unsigned char) b.get(156, 6); v.draught = 0;
+            }
+        }
+        if (todo & VG_PERSONS) {                   // protodec_msg_40 :279-285
+            v.set |= GNUAIS_V_PERSONS;
+            v.persons_on_board = (int) b.get(type == 6 ? 88 : 56, 13);
+        }
+    }
+    out[slot] = v;
+}
+
 // records gathered into sorted order: one thread moves one 16-byte quarter of a record
 __global__ __launch_bounds__(256) void frames_gather_kernel(const gnuais_frame *__restrict__ frames,
                                                             const uint32_t *__restrict__ order, int n,
@@ -780,6 +929,37 @@ hipError_t messages_format_enqueue(const gnuais_frame *frames, int n, int n_chan
         return e;
     hipLaunchKernelGGL(message_pack_kernel, dim3((n + PACK_FRAMES - 1) / PACK_FRAMES), dim3(256), 0, s, lines, len, off, n, out,
                        (unsigned long long) out_cap, info2);
+    return hipGetLastError();
+}
+
+// The batch's vessel table (struct cache_ent per MMSI, sorted by MMSI) from the frames of the ring, on the
+// device; *count_dev = vessels found (may exceed cap: then only the first cap were written).
+hipError_t vessels_fold_enqueue(const gnuais_frame *frames, int n, void *scratch, size_t scratch_bytes,
+                                gnuais_vessel *out, int cap, uint32_t *count_dev, hipStream_t s)
+{
+    if (n <= 0) return hipErrorInvalidValue;
+    if (scratch_bytes < nmea_scratch_bytes(n, 0)) return hipErrorInvalidValue;
+    const size_t m = (size_t) n;
+    const NmeaLayout lay = nmea_layout(scratch, scratch_bytes, m, 0);
+    const int grid = (n + 255) / 256;
+    hipError_t e;
+    if ((e = hipMemsetAsync(count_dev, 0, 4, s)) != hipSuccess) return e;
+    // print order (channel, then time), as for the sentences
+    hipLaunchKernelGGL(nmea_keys_kernel, dim3(grid), dim3(256), 0, s, frames, n, lay.keys, lay.idx);
+    size_t t = lay.tmp_bytes;
+    if ((e = rocprim::radix_sort_pairs(lay.tmp, t, lay.keys, lay.keys2, lay.idx, lay.idx2, m, 0, 61, s)) != hipSuccess)
+        return e;
+    // (mmsi, print position) of the frames that touch the cache; ring index as the value
+    hipLaunchKernelGGL(vessel_keys_kernel, dim3(grid), dim3(256), 0, s, frames, lay.idx2, n, lay.keys, lay.idx);
+    t = lay.tmp_bytes;
+    if ((e = rocprim::radix_sort_pairs(lay.tmp, t, lay.keys, lay.keys2, lay.idx, lay.chan, m, 0, 64, s)) != hipSuccess)
+        return e;
+    hipLaunchKernelGGL(vessel_heads_kernel, dim3(grid), dim3(256), 0, s, lay.keys2, n, lay.idx2);
+    t = lay.tmp_bytes;
+    if ((e = rocprim::exclusive_scan(lay.tmp, t, lay.idx2, lay.idx, 0u, m, rocprim::plus<uint32_t>(), s)) != hipSuccess)
+        return e;
+    hipLaunchKernelGGL(vessel_fold_kernel, dim3((n + 127) / 128), dim3(128), 0, s, frames, lay.keys2, lay.chan, lay.idx2,
+                       lay.idx, n, out, cap, count_dev);
     return hipGetLastError();
 }
 

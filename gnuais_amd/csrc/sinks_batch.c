@@ -88,11 +88,54 @@ static int deliver_vessel(const gnuais_vessel *v, int t)
 	return calls;
 }
 
+/* the sink calls of one batch: sentences, stdout lines and the batch's folded vessel entries are there */
+static int deliver_outputs(gnuais_sinks *s, const char *nmea, size_t nmea_len, const char *text, size_t text_len,
+			   const gnuais_vessel *table, int n_v)
+{
+	const int want_nmea = s->serial || s->ipc, want_text = s->text_out != NULL;
+	int i;
+
+	if (want_nmea && nmea_len) {
+		if (s->serial) {                        /* "!AIVDM,...*hh\r\n" x n  (protodec.c:883-885) */
+			size_t off = 0;
+			while (off < nmea_len) {        /* serial_write() takes an int length */
+				size_t n = nmea_len - off > (1u << 30) ? (1u << 30) : nmea_len - off;
+				serial_write(s->serial, (char *) nmea + off, (int) n);
+				s->serial_calls++;
+				off += n;
+			}
+		}
+		if (s->ipc) {                           /* the same without CR LF  (protodec.c:886-888) */
+			size_t n = 0, k;
+			if (!grow(&s->ipcbuf, &s->ipc_cap, nmea_len + 1))
+				return GNUAIS_E_ARG;
+			for (k = 0; k < nmea_len; k++)
+				if (nmea[k] != '\r' && nmea[k] != '\n')
+					s->ipcbuf[n++] = nmea[k];
+			s->ipcbuf[n] = 0;               /* ipc_write() logs the buffer with %s */
+			ipc_write(s->ipc, s->ipcbuf, (int) n);
+			s->ipc_calls++;
+		}
+	}
+	if (want_text && text_len) {
+		fwrite(text, 1, text_len, s->text_out);
+		fflush(s->text_out);                    /* protodec.c:985, once per batch */
+		s->flushes++;
+	}
+	if (s->use_cache && n_v) {
+		const int t = (int) time(NULL);         /* received_t, protodec.c:905 */
+		for (i = 0; i < n_v; i++)
+			s->cache_calls += deliver_vessel(&table[i], t);
+		s->vessels += n_v;
+	}
+	return GNUAIS_OK;
+}
+
 int gnuais_sinks_deliver(gnuais_sinks *s, const gnuais_frame *frames, int n_frames)
 {
 	size_t nmea_len = 0, text_len = 0;
-	int n_sent = 0, n_lines = 0, rc, i;
-	const int want_nmea = s && (s->serial || s->ipc), want_text = s && s->text_out;
+	int n_sent = 0, n_lines = 0, n_v = 0, rc;
+	const int want_text = s && s->text_out;
 
 	if (!s || n_frames < 0 || (n_frames && !frames) || !s->seqnr || s->n_channels <= 0)
 		return GNUAIS_E_ARG;
@@ -111,36 +154,7 @@ int gnuais_sinks_deliver(gnuais_sinks *s, const gnuais_frame *frames, int n_fram
 		return rc;
 	s->frames += n_frames;
 	s->sentences += n_sent;
-	if (want_nmea && nmea_len) {
-		if (s->serial) {                        /* "!AIVDM,...*hh\r\n" x n  (protodec.c:883-885) */
-			size_t off = 0;
-			while (off < nmea_len) {        /* serial_write() takes an int length */
-				size_t n = nmea_len - off > (1u << 30) ? (1u << 30) : nmea_len - off;
-				serial_write(s->serial, s->nmea + off, (int) n);
-				s->serial_calls++;
-				off += n;
-			}
-		}
-		if (s->ipc) {                           /* the same without CR LF  (protodec.c:886-888) */
-			size_t n = 0, k;
-			if (!grow(&s->ipcbuf, &s->ipc_cap, nmea_len + 1))
-				return GNUAIS_E_ARG;
-			for (k = 0; k < nmea_len; k++)
-				if (s->nmea[k] != '\r' && s->nmea[k] != '\n')
-					s->ipcbuf[n++] = s->nmea[k];
-			s->ipcbuf[n] = 0;               /* ipc_write() logs the buffer with %s */
-			ipc_write(s->ipc, s->ipcbuf, (int) n);
-			s->ipc_calls++;
-		}
-	}
-	if (want_text && text_len) {
-		fwrite(s->text, 1, text_len, s->text_out);
-		fflush(s->text_out);                    /* protodec.c:985, once per batch */
-		s->flushes++;
-	}
 	if (s->use_cache) {
-		int n_v = 0;
-		const int t = (int) time(NULL);         /* received_t, protodec.c:905 */
 		if (s->table_cap < n_frames) {
 			gnuais_vessel *q = realloc(s->table, sizeof(gnuais_vessel) * (size_t) n_frames);
 			if (!q)
@@ -151,11 +165,22 @@ int gnuais_sinks_deliver(gnuais_sinks *s, const gnuais_frame *frames, int n_fram
 		rc = gnuais_vessels_from_frames(frames, n_frames, s->table, s->table_cap, &n_v);
 		if (rc != GNUAIS_OK)
 			return rc;
-		for (i = 0; i < n_v; i++)
-			s->cache_calls += deliver_vessel(&s->table[i], t);
-		s->vessels += n_v;
 	}
-	return GNUAIS_OK;
+	return deliver_outputs(s, s->nmea, nmea_len, s->text, text_len, s->table, n_v);
+}
+
+/* The same delivery for a batch whose message layer ran on the device: sentences and stdout lines from
+ * gnuais_batch_drain_messages() (called with s->seqnr and s->chanid), the vessel entries from
+ * gnuais_batch_fold_vessels() -- nothing is formatted or folded on the host. */
+int gnuais_sinks_deliver_formatted(gnuais_sinks *s, int n_frames, int n_sentences, const char *nmea, size_t nmea_len,
+				   const char *text, size_t text_len, const gnuais_vessel *vessels, int n_vessels)
+{
+	if (!s || n_frames < 0 || n_sentences < 0 || (nmea_len && !nmea) || (text_len && !text) ||
+	    n_vessels < 0 || (n_vessels && !vessels))
+		return GNUAIS_E_ARG;
+	s->frames += n_frames;
+	s->sentences += n_sentences;
+	return deliver_outputs(s, nmea, nmea_len, text, text_len, vessels, n_vessels);
 }
 
 void gnuais_sinks_free(gnuais_sinks *s)

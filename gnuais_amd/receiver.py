@@ -189,6 +189,14 @@ class ReceiverBatch:
         view = np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_uint8)), shape=(ln.value,))
         return (view.tobytes() if copy else view), ns.value, nf.value
 
+    def fold_vessels(self) -> np.ndarray:
+        """gnuais_batch_fold_vessels(): the vessel table of the queued frames (gnuais_vessel per MMSI, sorted),
+        folded on the device; the frames stay queued."""
+        out = np.zeros(max(self.pending_frames(), 1), dtype=VESSEL_DTYPE)
+        n = C.c_int(0)
+        check(self._lib.gnuais_batch_fold_vessels(self._h, out.ctypes.data, len(out), C.byref(n)))
+        return out[: n.value].copy()
+
     def drain_messages(self, seqnr: np.ndarray, chanid: Optional[bytes] = None):
         """gnuais_batch_drain_messages(): sentences and stdout lines of everything queued, both formatted
         on the device -> (nmea bytes, text bytes, sentences, lines, frames)."""

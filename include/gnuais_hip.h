@@ -227,6 +227,12 @@ int  gnuais_batch_drain_nmea(gnuais_batch *b, uint8_t *seqnr, char *out, size_t 
 int  gnuais_batch_drain_messages(gnuais_batch *b, uint8_t *seqnr, const char *chanid, char *nmea,
 				 size_t nmea_cap, size_t *nmea_len, int *n_sentences, char *text,
 				 size_t text_cap, size_t *text_len, int *n_lines, int *n_frames);
+/* Row f3 ON THE DEVICE: gnuais_vessels_from_frames() over the queued frames without draining them -- the
+ * batch's position-cache entries (one gnuais_vessel per MMSI seen, sorted by MMSI, exactly what the
+ * per-type decoders' cache_*() calls leave for a fresh cache), folded by a sort on (MMSI, arrival order)
+ * and one thread per vessel.  Call it before the drain that consumes the frames.  *n_vessels = entries;
+ * GNUAIS_E_OVERFLOW (with *n_vessels set) if cap is too small. */
+int  gnuais_batch_fold_vessels(gnuais_batch *b, gnuais_vessel *vessels, int cap, int *n_vessels);
 /* Streaming delivery of the same sentences.  Call once after every gnuais_batch_run(): the frames of
  * the runs since the previous call are taken off at once (the chain moves on to another frame ring);
  * their formatter and the copy of the text into pinned host memory are queued behind the chain with every

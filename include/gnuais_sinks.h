@@ -50,6 +50,12 @@ typedef struct gnuais_sinks {
 
 /* frames: one drained batch (gnuais_batch_drain_frames order).  GNUAIS_OK or GNUAIS_E_ARG. */
 int  gnuais_sinks_deliver(gnuais_sinks *s, const gnuais_frame *frames, int n_frames);
+/* The same sink calls for a batch whose message layer ran on the DEVICE: nmea / text from
+ * gnuais_batch_drain_messages(b, s->seqnr, s->chanid, ...), vessels from gnuais_batch_fold_vessels()
+ * (called before that drain).  Nothing is formatted or folded on the host. */
+int  gnuais_sinks_deliver_formatted(gnuais_sinks *s, int n_frames, int n_sentences, const char *nmea,
+				    size_t nmea_len, const char *text, size_t text_len,
+				    const gnuais_vessel *vessels, int n_vessels);
 void gnuais_sinks_free(gnuais_sinks *s);
 
 #ifdef __cplusplus

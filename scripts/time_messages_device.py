@@ -36,3 +36,15 @@ for it in range(3):
                                          txb.ctypes.data, txb.size, C.byref(tl), C.byref(nlines), C.byref(nf))
     dt = time.perf_counter() - t
     print(f"C call: rc {rc}, {nf.value} frames in {dt*1e3:.1f} ms = {nf.value/dt/1e6:.1f} M frames/s", flush=True)
+# row f3: the batch's vessel table folded on the device (before the drain), the C call alone
+from gnuais_amd import VESSEL_DTYPE
+tab = np.zeros(n, dtype=VESSEL_DTYPE)
+for it in range(3):
+    b.run(x)
+    nv = C.c_int(0)
+    t = time.perf_counter()
+    rc = lib.gnuais_batch_fold_vessels(b._h, tab.ctypes.data, len(tab), C.byref(nv))
+    dt = time.perf_counter() - t
+    pend = b.pending_frames()
+    print(f"fold_vessels: rc {rc}, {pend} frames -> {nv.value} vessels in {dt*1e3:.2f} ms = {pend/dt/1e6:.1f} M frames/s", flush=True)
+    b.discard_frames()

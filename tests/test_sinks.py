@@ -127,3 +127,106 @@ def test_adapter_without_listeners_still_advances_the_sequence_digits(adapter):
     assert s.serial_calls == s.ipc_calls == s.cache_calls == s.flushes == 0
     assert L.gnuais_sinks_deliver(None, fr.ctypes.data, len(fr)) == -1
     L.gnuais_sinks_free(C.byref(s))
+
+
+def _open_sinks(tmp_path, n_ch, tag):
+    libc = C.CDLL(None)
+    libc.fdopen.restype = C.c_void_p
+    libc.fdopen.argtypes = [C.c_int, C.c_char_p]
+    libc.fclose.argtypes = [C.c_void_p]
+    paths = [str(tmp_path / (tag + n)) for n in ("serial", "ipc", "text")]
+    fds = [os.open(p, os.O_RDWR | os.O_CREAT, 0o600) for p in paths]
+    ser, ipc = Serial(fds[0]), Ipc(1)
+    ipc.clientsocket[0] = fds[1]
+    seq = np.zeros(n_ch, dtype=np.uint8)
+    chanid = bytes(ord("A") + c for c in range(n_ch))
+    s = Sinks()
+    s.serial, s.ipc = C.pointer(ser), C.pointer(ipc)
+    s.text_out = libc.fdopen(fds[2], b"w")
+    s.use_cache, s.seqnr, s.chanid, s.n_channels = 1, seq.ctypes.data, chanid, n_ch
+    keep = (ser, ipc, seq, chanid)
+
+    def close():
+        libc.fclose(s.text_out)
+        out = [open(p, "rb").read() for p in paths]
+        os.close(fds[0]); os.close(fds[1])
+        return out
+    return s, seq, chanid, close, keep
+
+
+def test_formatted_delivery_equals_frame_delivery(adapter, tmp_path):
+    """gnuais_sinks_deliver_formatted(): sentences, stdout lines and vessel entries produced elsewhere (here
+    by the host formatter and fold; on a GPU box by the device ones) go through the same sink calls and
+    leave the same bytes and the same cache."""
+    from gnuais_amd import VESSEL_DTYPE, messages_from_frames, vessels_from_frames
+    L, ref = adapter
+    L.gnuais_sinks_deliver_formatted.argtypes = [C.POINTER(Sinks), C.c_int, C.c_int, C.c_char_p, C.c_size_t,
+                                                 C.c_char_p, C.c_size_t, C.c_void_p, C.c_int]
+    fr, n_ch = mixed_traffic()
+    want_nmea, want_seq, want_text = ref.nmea_of_frames(fr, n_ch, stdout=True)
+    want_cache = ref.cache_of_frames(fr, n_ch)
+    s, seq, chanid, close, keep = _open_sinks(tmp_path, n_ch, "f_")
+    ref.lib.ref_cache_enable()
+    scratch = np.zeros(len(fr), dtype=VESSEL_DTYPE)
+    ref.lib.ref_cache_take(scratch.ctypes.data_as(C.c_void_p), 0)
+    cuts = [0, 3, 200, 201, len(fr)]
+    for lo, hi in zip(cuts[:-1], cuts[1:]):
+        part = np.ascontiguousarray(fr[lo:hi])
+        nm, tx = messages_from_frames(part, seq, chanid)
+        tab = vessels_from_frames(part)
+        assert L.gnuais_sinks_deliver_formatted(C.byref(s), len(part), nm.count(b"\r\n"), nm, len(nm), tx, len(tx),
+                                                tab.ctypes.data, len(tab)) == 0
+    n = ref.lib.ref_cache_take(scratch.ctypes.data_as(C.c_void_p), len(scratch))
+    got = close()
+    assert got[0] == want_nmea and got[1] == want_nmea.replace(b"\r\n", b"") and got[2] == want_text
+    assert np.array_equal(seq, want_seq)
+    assert scratch[:n].tobytes() == want_cache.tobytes()
+    assert s.frames == len(fr) and s.serial_calls <= len(cuts) - 1
+    L.gnuais_sinks_free(C.byref(s))
+
+
+@pytest.mark.gpu
+def test_device_message_layer_feeds_the_reference_sinks(adapter, tmp_path):
+    """Row f3 end to end from the device: frames in the HBM ring -> gnuais_batch_fold_vessels() +
+    gnuais_batch_drain_messages() -> gnuais_sinks_deliver_formatted() -> the reference's unchanged
+    serial.c / ipc.c / cache.c / stdout: the same bytes and cache contents as the reference's own
+    per-message path over the same frames."""
+    from gnuais_amd import ReceiverBatch, VESSEL_DTYPE, synth
+    L, ref = adapter
+    L.gnuais_sinks_deliver_formatted.argtypes = [C.POINTER(Sinks), C.c_int, C.c_int, C.c_char_p, C.c_size_t,
+                                                 C.c_char_p, C.c_size_t, C.c_void_p, C.c_int]
+    src, n_ch = mixed_traffic()
+    streams = [[np.zeros(8, dtype=np.uint8)] for _ in range(n_ch)]
+    for f in src:
+        body = bytes(f["payload"][: int(f["nbits"]) // 8])
+        if len(body) < 1:
+            continue
+        streams[int(f["channel"])].append(synth.hdlc_frame_bits(body, training_bits=24))
+        streams[int(f["channel"])].append(np.zeros(5, dtype=np.uint8))
+    streams = [np.concatenate(st).astype(np.uint8) for st in streams]
+    a, b = ReceiverBatch(n_ch, max_len=48000), ReceiverBatch(n_ch, max_len=48000)
+    s, seq, chanid, close, keep = _open_sinks(tmp_path, n_ch, "d_")
+    ref.lib.ref_cache_enable()
+    scratch = np.zeros(len(src) + 8, dtype=VESSEL_DTYPE)
+    ref.lib.ref_cache_take(scratch.ctypes.data_as(C.c_void_p), 0)           # empty the reference's cache
+    all_frames = []
+    for piece in (0, 1):
+        half = [st[: len(st) // 2] if piece == 0 else st[len(st) // 2:] for st in streams]
+        a.decode_bits(half)
+        b.decode_bits(half)
+        all_frames.append(a.drain_frames())
+        tab = b.fold_vessels()
+        nm, tx, n_sent, n_lines, n_frames = b.drain_messages(seq, chanid)
+        assert n_frames == len(all_frames[-1]) > 100
+        assert L.gnuais_sinks_deliver_formatted(C.byref(s), n_frames, n_sent, nm, len(nm), tx, len(tx),
+                                                tab.ctypes.data, len(tab)) == 0
+    got = close()
+    fr = np.concatenate(all_frames)
+    want_nmea, want_seq, want_text = ref.nmea_of_frames(fr, n_ch, stdout=True)
+    assert got[0] == want_nmea and got[1] == want_nmea.replace(b"\r\n", b"") and got[2] == want_text
+    assert np.array_equal(seq, want_seq)
+    # the cache after both batches == the reference's after the same frames one message at a time
+    n = ref.lib.ref_cache_take(scratch.ctypes.data_as(C.c_void_p), len(scratch))
+    want_cache = ref.cache_of_frames(fr, n_ch)
+    assert scratch[:n].tobytes() == want_cache.tobytes()
+    L.gnuais_sinks_free(C.byref(s))

@@ -74,3 +74,36 @@ def test_vessels_random_against_reference(seed, n_mmsi):
     fr, n_ch = cases.vessel_frames(seed=200 + seed, n=900, n_mmsi=n_mmsi)
     want = reference().cache_of_frames(fr, n_ch, pieces=[300, 301])
     assert vessels_from_frames(fr).tobytes() == want.tobytes()
+
+
+@pytest.mark.gpu
+def test_device_fold_equals_host_fold():
+    """gnuais_batch_fold_vessels(): the same table folded on the device from the queued frames (sort on
+    (MMSI, arrival order), one thread per vessel, last writer per field group) == the host fold over the
+    drained records -- which the tests above pin to the reference's cache.  Traffic: the golden frames and
+    random ones over a small MMSI pool, through the device deframer, several channels, two batches."""
+    from gnuais_amd import ReceiverBatch, VESSEL_DTYPE, synth, vessels_from_frames
+    g = np.load(os.path.join(G, "vessels.npz"))
+    gold = as_frames(g["frames"])
+    rnd, n_ch = cases.vessel_frames(seed=73, n_channels=5, n=2500, n_mmsi=300)
+    for span, src in enumerate((list(gold), list(rnd))):
+        streams = [[np.zeros(8, dtype=np.uint8)] for _ in range(n_ch)]
+        for f in src:
+            body = bytes(f["payload"][: int(f["nbits"]) // 8])
+            if len(body) < 1:
+                continue
+            c = int(f["channel"]) % n_ch
+            streams[c].append(synth.hdlc_frame_bits(body, training_bits=24))
+            streams[c].append(np.zeros(5, dtype=np.uint8))
+        streams = [np.concatenate(s).astype(np.uint8) for s in streams]
+        b = ReceiverBatch(n_ch, max_len=48000)
+        b.decode_bits(streams)
+        got = b.fold_vessels()
+        assert b.pending_frames() > 500                       # not consumed
+        frames = b.drain_frames()
+        want = vessels_from_frames(frames)
+        assert len(got) == len(want) > 100
+        for name in VESSEL_DTYPE.names:
+            assert np.array_equal(got[name], want[name]), (span, name)
+        assert got.tobytes() == want.tobytes()
+        assert len(np.unique(want["set"])) >= 6
