@@ -340,6 +340,9 @@ __global__ __launch_bounds__(64) void fir_slice_kernel(
 //
 // Same mapping as K1 (lane = channel, wave = 64 channels x one time segment), but
 // 12 accumulators rotate, so 96 phases (three sign words) are unrolled.
+#ifndef FIR_SIGN_CLAIM
+#define FIR_SIGN_CLAIM "v87"        // the highest VGPR the 12-tap kernel pretends to use (see fir_sign_kernel)
+#endif
 #ifndef FIR_SIGN_FENCE
 #define FIR_SIGN_FENCE 4
 #endif
@@ -390,7 +393,7 @@ __global__ __launch_bounds__(64) void fir_sign_kernel(
     // registers for a wave of each of the stages that run beside us (K2a needs 56).  At seven
     // waves per SIMD this kernel would fill the register file and they would wait for FIR
     // waves to retire before they could even be placed.
-    asm volatile("" ::: "v87");
+    asm volatile("" ::: FIR_SIGN_CLAIM);
 #endif
     static_assert(96 % NC == 0 && NC % 2 == 0, "96 unrolled phases must hold whole turns of the accumulator ring");
     const int lane = threadIdx.x;

@@ -120,7 +120,7 @@ struct gnuais_batch {
     int n_chunks = 0;
     int ring_cur = 0;
     bool streaming = false;
-    hipStream_t s_post = nullptr, s_copy = nullptr;
+    hipStream_t s_post = nullptr, s_copy = nullptr, s_copy_own = nullptr;   // s_copy_own: the one created for it
     hipEvent_t e_fill[NRING] = {}, e_fmt[NRING] = {}, e_txt[NRING] = {};
     char *sd_text[NRING] = {};                  // device text per slot
     size_t sd_text_bytes[NRING] = {};
@@ -130,6 +130,7 @@ struct gnuais_batch {
     int s_stage[NRING] = {};                    // 1: the slot's formatter is queued, its text not handed out yet
     size_t sh_text_want = 0;                    // pinned text buffers grow to this (learnt from the traffic)
     uint32_t *sd_info = nullptr;                // device: [NRING][8], what sh_info receives with the text
+    bool copy_on_k3 = false;                    // experiment: the copy kernel on K3's stream as well
     int copy_wgs = 24;                          // waves of the device -> pinned copy (measured: 16 0.65, 24 0.62, 32 0.64, 64 0.79 ms per C3 step)
     uint8_t *sd_seq[2] = {nullptr, nullptr};    // per-channel sequence digit, carried on the device
     int sd_seq_cur = 0;
@@ -229,8 +230,10 @@ void gnuais_batch_destroy(gnuais_batch *b)
     if (b->sd_info) (void) hipFree(b->sd_info);
     for (auto p : b->sd_seq)
         if (p) (void) hipFree(p);
-    for (hipStream_t st : {b->s_copy})
+    {   // the copy stream may have been replaced by a pool stream (autotune_delivery): destroy the one created for it
+        hipStream_t st = b->s_copy_own ? b->s_copy_own : b->s_copy;
         if (st) (void) hipStreamDestroy(st);
+    }
     for (int q = 0; q < 2; ++q) {
         if (b->pin[q]) (void) hipHostFree(b->pin[q]);
         if (b->dev_in[q]) (void) hipFree(b->dev_in[q]);
@@ -762,6 +765,64 @@ static int ensure_stage(gnuais_batch *b, size_t bytes)
     return GNUAIS_OK;
 }
 
+// The delivery loop (run + stream_nmea) has one more stream to place: the copy kernel's.  Which hardware
+// queue a stream shares is not queryable (see gnuais_batch_autotune); a copy stream that shares its queue with
+// a stage serialises with it (0.62 against 1.5 ms per C3 call).  Times the loop with the copy kernel on each
+// free pool stream and on the stream created for it, keeps the fastest, resets the batch (it stays in
+// streaming mode).
+int gnuais_batch_autotune_delivery(gnuais_batch *b, const int16_t *d_samples, int len, void *stream, float *ms_per_call)
+{
+    if (!b || !d_samples) return fail(GNUAIS_E_ARG, "autotune_delivery: NULL argument");
+    if (int rc = gnuais_batch_sync(b)) return rc;
+    const char *text = nullptr;
+    size_t tl = 0;
+    if (int rc = gnuais_batch_stream_nmea(b, &text, &tl, nullptr, nullptr)) return rc;      // rings, buffers, s_copy
+    if (!b->pipeline) {
+        if (ms_per_call) *ms_per_call = 0.0f;
+        return gnuais_batch_reset(b);
+    }
+    const bool timing = b->timing;
+    b->timing = false;
+    auto quiesce = [&]() -> int {
+        if (int rc = gnuais_batch_sync(b)) return rc;
+        HIP_TRY(hipDeviceSynchronize());
+        return GNUAIS_OK;
+    };
+    auto measure = [&](double &ms, int meas) -> int {
+        const int warm = gnuais_batch::NRING + 2;
+        for (int i = 0; i < warm + meas; ++i) {
+            if (i == warm) {
+                if (int rc = quiesce()) return rc;
+                ms = -now_ms();
+            }
+            if (int rc = gnuais_batch_run(b, d_samples, len, stream)) return rc;
+            const int rc = gnuais_batch_stream_nmea(b, &text, &tl, nullptr, nullptr);
+            if (rc != GNUAIS_OK && rc != GNUAIS_E_OVERFLOW) return rc;
+        }
+        if (int rc = quiesce()) return rc;
+        ms = (ms + now_ms()) / meas;
+        return GNUAIS_OK;
+    };
+    hipStream_t own = b->s_copy_own ? b->s_copy_own : b->s_copy;
+    b->s_copy_own = own;
+    hipStream_t best_s = own;
+    double best = 1e30;
+    for (int cand = -1; cand < gnuais_batch::POOL; ++cand) {
+        hipStream_t st = cand < 0 ? own : b->pool[cand];
+        bool used = false;
+        for (int q = 0; q < 4; ++q) used |= b->s_k[q] == st;
+        if (used || !st) continue;
+        b->s_copy = st;
+        double ms = 0;
+        if (int rc = measure(ms, 12)) return rc;
+        if (ms < best) { best = ms; best_s = st; }
+    }
+    b->s_copy = best_s;
+    b->timing = timing;
+    if (ms_per_call) *ms_per_call = (float) best;
+    return gnuais_batch_reset(b);
+}
+
 int gnuais_batch_run_host(gnuais_batch *b, const int16_t *h_samples, int len)
 {
     if (!b || !h_samples) return fail(GNUAIS_E_ARG, "run_host: NULL argument");
@@ -1137,6 +1198,7 @@ int gnuais_batch_stream_nmea(gnuais_batch *b, const char **text, size_t *len, in
         HIP_TRY(hipMalloc((void **) &b->sd_info, sizeof(uint32_t) * 8 * NR));
         HIP_TRY(hipMemset(b->sd_info, 0, sizeof(uint32_t) * 8 * NR));
         if (const char *v = getenv("GNUAIS_COPY_WGS")) b->copy_wgs = std::max(1, atoi(v));
+        if (const char *v = getenv("GNUAIS_COPY_ON_K3")) b->copy_on_k3 = atoi(v) != 0;
         const size_t need_scratch = nmea_scratch_bytes(b->frame_cap, b->n_chunks);
         if (b->nmea_scratch_bytes < need_scratch) {
             if (b->nmea_scratch) HIP_TRY(hipFree(b->nmea_scratch));
@@ -1235,10 +1297,11 @@ int gnuais_batch_stream_nmea(gnuais_batch *b, const char **text, size_t *len, in
     HIP_TRY(hipMemsetAsync(b->ring_count[c], 0, 16, b->s_post));
     HIP_TRY(hipEventRecord(b->e_fmt[c], b->s_post));          // the ring is free for K3 again
     // (5) the copy has a stream of its own: it runs at PCIe speed beside the next slot's formatter
-    HIP_TRY(hipStreamWaitEvent(b->s_copy, b->e_fmt[c], 0));
+    hipStream_t sc = b->copy_on_k3 ? b->s_post : b->s_copy;
+    if (!b->copy_on_k3) HIP_TRY(hipStreamWaitEvent(sc, b->e_fmt[c], 0));
     HIP_TRY(nmea_text_copy_enqueue(b->sd_text[c], b->sd_info + 8 * c, b->sh_text[c], b->sh_text_bytes[c],
-                                   b->sh_info + 8 * c, b->copy_wgs, b->s_copy));
-    HIP_TRY(hipEventRecord(b->e_txt[c], b->s_copy));
+                                   b->sh_info + 8 * c, b->copy_wgs, sc));
+    HIP_TRY(hipEventRecord(b->e_txt[c], sc));
     b->s_stage[c] = 1;
     b->hdlc_calls = 0;
     b->stream_calls++;

@@ -74,6 +74,7 @@ SYMBOLS = {
     "gnuais_batch_last_timing": (_I, [_P, _P]),
     "gnuais_batch_mean_timing": (_I, [_P, _P, C.POINTER(_I)]),
     "gnuais_batch_autotune": (_I, [_P, _P, _I, _P, C.POINTER(C.c_float)]),
+    "gnuais_batch_autotune_delivery": (_I, [_P, _P, _I, _P, C.POINTER(C.c_float)]),
     "gnuais_batch_set_option": (_I, [_P, C.c_char_p, _I]),
     "gnuais_last_error": (C.c_char_p, []),
     "gnuais_version": (C.c_char_p, []),

@@ -96,6 +96,18 @@ class ReceiverBatch:
                                               C.c_void_p(stream), C.byref(ms)))
         return ms.value
 
+    def autotune_delivery(self, samples, stream: Optional[int] = None) -> float:
+        """gnuais_batch_autotune_delivery(): place the copy stream of stream_nmea() by measurement; resets the
+        batch and leaves it streaming.  Returns the best ms per run + stream_nmea seen."""
+        import torch
+        assert samples.is_cuda and samples.dtype == torch.int16 and samples.is_contiguous()
+        if stream is None:
+            stream = torch.cuda.current_stream(samples.device).cuda_stream
+        ms = C.c_float(0)
+        check(self._lib.gnuais_batch_autotune_delivery(self._h, samples.data_ptr(), int(samples.shape[0]),
+                                                       C.c_void_p(stream), C.byref(ms)))
+        return ms.value
+
     def sync(self):
         check(self._lib.gnuais_batch_sync(self._h))
 

@@ -295,6 +295,12 @@ int  gnuais_batch_set_option(gnuais_batch *b, const char *name, int value);
  * depends on what else the process created before, is not queryable, and matters by up to 1.7x. */
 int  gnuais_batch_autotune(gnuais_batch *b, const int16_t *d_samples, int len, void *stream,
 			   float *ms_per_call);
+/* The same for the delivery loop (gnuais_batch_run + gnuais_batch_stream_nmea): places the stream of the
+ * kernel that copies the text to pinned memory (one more tenant for the few hardware queues: 0.62 or 1.5 ms
+ * per C3 call, by luck of creation order, unless measured).  Call it after gnuais_batch_autotune(), once,
+ * before real work; about 0.2 s; RESETS the batch and leaves it in streaming mode. */
+int  gnuais_batch_autotune_delivery(gnuais_batch *b, const int16_t *d_samples, int len, void *stream,
+				    float *ms_per_call);
 const char *gnuais_last_error(void);
 const char *gnuais_version(void);
 

@@ -303,6 +303,8 @@ def test_streamed_sentences_with_several_runs_per_call():
     x = np.stack([synth.make_stream(call * total, seed=83, channel=c, occupancy=0.9)[0] for c in range(n_ch)], axis=1)
     xd = torch.from_numpy(x).cuda()
     a, b = ReceiverBatch(n_ch, max_len=call), ReceiverBatch(n_ch, max_len=call)
+    b.autotune(xd[:call].contiguous())
+    assert b.autotune_delivery(xd[:call].contiguous()) > 0      # places the copy stream; resets, stays streaming
     seq = np.zeros(n_ch, dtype=np.uint8)
     want, got = [], []
     i = 0
