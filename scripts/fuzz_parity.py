@@ -238,10 +238,22 @@ def deframer_case(seed):
         return "frames differ"
     seq_h = (np.arange(n_ch) % 10).astype(np.uint8)
     seq_d = seq_h.copy()
-    text_h = nmea_from_frames(got_frames, seq_h)
-    text_d, _, nf = b2.drain_nmea(seq_d)
-    if text_h != text_d or nf != len(got_frames) or not np.array_equal(seq_h, seq_d):
-        return f"device NMEA differs from the host formatter ({len(text_d)} vs {len(text_h)} bytes)"
+    if rng.integers(0, 2):
+        text_h = nmea_from_frames(got_frames, seq_h)
+        text_d, _, nf = b2.drain_nmea(seq_d)
+        if text_h != text_d or nf != len(got_frames) or not np.array_equal(seq_h, seq_d):
+            return f"device NMEA differs from the host formatter ({len(text_d)} vs {len(text_h)} bytes)"
+    else:                                                      # sentences + stdout lines + vessel table
+        from gnuais_amd import messages_from_frames, vessels_from_frames
+        chanid = bytes(65 + int(v) for v in rng.integers(0, 26, n_ch)) if rng.integers(0, 2) else None
+        tab_d = b2.fold_vessels()
+        tab_h = vessels_from_frames(got_frames)
+        if tab_d.tobytes() != tab_h.tobytes():
+            return f"device vessel table differs from the host fold ({len(tab_d)} vs {len(tab_h)} entries)"
+        nm_h, tx_h = messages_from_frames(got_frames, seq_h, chanid)
+        nm_d, tx_d, _, _, nf = b2.drain_messages(seq_d, chanid)
+        if nm_h != nm_d or tx_h != tx_d or nf != len(got_frames) or not np.array_equal(seq_h, seq_d):
+            return f"device messages differ from the host formatter ({len(tx_d)} vs {len(tx_h)} bytes of lines)"
     cnt = b.counters()
     if not np.array_equal(np.stack([cnt["receivedframes"], cnt["lostframes"], cnt["lostframes2"]], axis=1),
                           o.counters()):
