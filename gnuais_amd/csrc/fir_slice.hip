@@ -507,9 +507,9 @@ __global__ __launch_bounds__(64) void fir_sign_kernel(
         // inside the unrolled body, moved only at the back edge)
         constexpr int UW = K1S_DIRECT(NC) ? FIR_DIRECT_UNROLL : 3;
         const int nblk = (t1 - t0 + UW * 32 - 1) / (UW * 32);
-        constexpr bool WIDE = K1S_DIRECT(NC) && UW == 4;        // T % 128 == 0: t0's word index is 0 mod 4
+        constexpr bool WIDE = K1S_DIRECT(NC) && (UW == 4 || UW == 2 || UW == 1);   // T % 128 == 0: t0's word index is 0 mod 4
+        uint32_t wq[4] = {0u, 0u, 0u, 0u};                      // the sign words of 128 outputs, stored as one
         for (int b = 0; b < nblk; ++b) {
-            uint32_t wq[UW] = {};
     #pragma unroll
             for (int w3 = 0; w3 < UW; ++w3) {
                 const int obase = (b * UW + w3) * 32;           // outputs obase .. obase+31
@@ -642,21 +642,23 @@ __global__ __launch_bounds__(64) void fir_sign_kernel(
                     amb &= ~bit;
                     if (exact_positive(t0 + obase + pos)) w |= bit; else w &= ~bit;
                 }
-                if constexpr (WIDE) wq[w3] = w;
-                else if (live) sgn[sgn_index((t0 + obase) >> 5, N, cg)] = w;
-            }
-            if constexpr (WIDE) {
-                const int o0 = t0 + b * UW * 32;
-                const int nw = (t1 - o0 + 31) >> 5;             // words of this turn that exist
-                if (live) {
-                    uint32_t *dst = sgn + sgn_index(o0 >> 5, N, cg);
-                    if (nw >= 4) {
-                        *reinterpret_cast<uint4 *>(dst) = make_uint4(wq[0], wq[1], wq[2], wq[3]);
-                    } else {
-    #pragma unroll
-                        for (int k = 0; k < 3; ++k)
-                            if (k < nw) dst[k] = wq[k];
+                if constexpr (WIDE) {
+                    const int wi = b * UW + w3;                 // word of the segment (wave-uniform; static mod 4 for UW = 4)
+                    const int slot = wi & 3;
+                    if (slot == 0) wq[0] = w; else if (slot == 1) wq[1] = w; else if (slot == 2) wq[2] = w; else wq[3] = w;
+                    const bool last = t0 + obase + 32 >= t1;    // the segment's last word
+                    if (live && (slot == 3 || last)) {
+                        uint32_t *dst = sgn + sgn_index(((t0 + obase) >> 5) - slot, N, cg);
+                        if (slot == 3) {
+                            *reinterpret_cast<uint4 *>(dst) = make_uint4(wq[0], wq[1], wq[2], wq[3]);
+                        } else {
+                            dst[0] = wq[0];
+                            if (slot >= 1) dst[1] = wq[1];
+                            if (slot >= 2) dst[2] = wq[2];
+                        }
                     }
+                } else if (live) {
+                    sgn[sgn_index((t0 + obase) >> 5, N, cg)] = w;
                 }
             }
         }
@@ -850,7 +852,11 @@ __global__ __launch_bounds__(64) void fir_sign_kernel(
     }
 }
 
-int launch_fir_sign_quantum(int NC) { return NC == 12 ? 32 * FIR_DIRECT_UNROLL : 96; }
+int launch_fir_sign_quantum(int NC)
+{
+    // the 12-tap kernel stores four sign words at once: segments start on a multiple of 128 outputs
+    return NC == 12 ? ((FIR_DIRECT_UNROLL == 4 || FIR_DIRECT_UNROLL == 2 || FIR_DIRECT_UNROLL == 1) ? 128 : 32 * FIR_DIRECT_UNROLL) : 96;
+}
 
 hipError_t launch_fir_sign(const FirLaunch &a, hipStream_t stream)
 {
