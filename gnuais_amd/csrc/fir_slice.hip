@@ -708,6 +708,7 @@ __global__ __launch_bounds__(64) void fir_sign_kernel(
             eps_w = eps_up * ((float) M * (1.0f / 32768.0f)) + 1e-30f;
         }
 
+        uint32_t wq[4] = {0u, 0u, 0u, 0u};
         // one finished sign word: outputs obase .. obase+31 (the flags of the newest 32 samples)
         auto flush = [&](int obase) {
             const int mb = m0 + NC - 1 + obase;                 // sample of the word's first phase
@@ -737,7 +738,21 @@ __global__ __launch_bounds__(64) void fir_sign_kernel(
                 amb &= ~bit;
                 if (exact_positive(t0 + obase + pos)) w |= bit; else w &= ~bit;
             }
-            if (live) sgn[sgn_index((t0 + obase) >> 5, N, cg)] = w;
+            {   // the sign words of 128 outputs leave as one 16-byte store (T % 128 == 0: t0's word index is 0 mod 4)
+                const int slot = (obase >> 5) & 3;
+                if (slot == 0) wq[0] = w; else if (slot == 1) wq[1] = w; else if (slot == 2) wq[2] = w; else wq[3] = w;
+                const bool last = t0 + obase + 32 >= t1;        // the segment's last word
+                if (live && (slot == 3 || last)) {
+                    uint32_t *dst = sgn + sgn_index(((t0 + obase) >> 5) - slot, N, cg);
+                    if (slot == 3) {
+                        *reinterpret_cast<uint4 *>(dst) = make_uint4(wq[0], wq[1], wq[2], wq[3]);
+                    } else {
+                        dst[0] = wq[0];
+                        if (slot >= 1) dst[1] = wq[1];
+                        if (slot >= 2) dst[2] = wq[2];
+                    }
+                }
+            }
             zor = 0;
         };
 
@@ -855,7 +870,8 @@ __global__ __launch_bounds__(64) void fir_sign_kernel(
 int launch_fir_sign_quantum(int NC)
 {
     // the 12-tap kernel stores four sign words at once: segments start on a multiple of 128 outputs
-    return NC == 12 ? ((FIR_DIRECT_UNROLL == 4 || FIR_DIRECT_UNROLL == 2 || FIR_DIRECT_UNROLL == 1) ? 128 : 32 * FIR_DIRECT_UNROLL) : 96;
+    // (the 48-tap one too, and its unrolled body is three words: 384)
+    return NC == 12 ? ((FIR_DIRECT_UNROLL == 4 || FIR_DIRECT_UNROLL == 2 || FIR_DIRECT_UNROLL == 1) ? 128 : 32 * FIR_DIRECT_UNROLL) : 384;
 }
 
 hipError_t launch_fir_sign(const FirLaunch &a, hipStream_t stream)
