@@ -60,7 +60,15 @@ __device__ __forceinline__ int wave_max_i(int v, int lanes, int lane)
 // NA[EW], CB[EW], E6[EW], SF[EW], PS[EW + 1] (stuffed 0s before word q)
 constexpr int EV_ROWS = (EW + 2) + 4 * EW + (EW + 1);
 
-__global__ __launch_bounds__(64) void hdlc_events_kernel(
+#ifndef EV_WAVES_PER_EU
+#define EV_WAVES_PER_EU 0           // 0: whatever the kernel wants (116 VGPRs); 7 (72 VGPRs) spilt and lost
+#endif
+#if EV_WAVES_PER_EU > 0
+#define EV_OCC __attribute__((amdgpu_waves_per_eu(EV_WAVES_PER_EU, 8)))
+#else
+#define EV_OCC
+#endif
+__global__ __launch_bounds__(64) EV_OCC void hdlc_events_kernel(
     const uint32_t *__restrict__ segbits, const uint32_t *__restrict__ segcnt,
     uint32_t *__restrict__ ctl, uint32_t *__restrict__ cand, uint32_t *__restrict__ cand_first,
     uint32_t *__restrict__ cand_count, int32_t *__restrict__ counters,
