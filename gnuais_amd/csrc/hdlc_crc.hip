@@ -574,7 +574,7 @@ hipError_t launch_hdlc_crc(const HdlcLaunch &a, hipStream_t stream)
 {
     hipLaunchKernelGGL(hdlc_crc_kernel, dim3((unsigned) ((a.N + K3_CH - 1) / K3_CH)), dim3(256), 0,
                        stream, a.cand, a.cand_first, a.cand_count, a.counters,
-                       (uint32_t *) a.frames, a.frame_count, a.frame_cap, a.N, a.K, a.chunks, k3_passes(a.K));
+                       (uint32_t *) a.frames, a.frame_count, a.frame_cap, a.N, a.K, a.chunks, k3_passes(a.K_call > 0 ? a.K_call : a.K));
     return hipGetLastError();
 }
 

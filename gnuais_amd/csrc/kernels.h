@@ -79,7 +79,8 @@ struct HdlcLaunch {
     void *frames;          // gnuais_frame[frame_cap]
     uint32_t *frame_count; // [4]: frames appended, overflow flag, -, PLL watchdog
     uint32_t frame_cap;
-    int N, n_seg, seg_words, K;
+    int N, n_seg, seg_words, K;   // K: slots of a channel's candidate ring
+    int K_call = 0;        // most frame starts one call can have (<= K; 0: K); sizes the chunk table
     int lanes_per_wave;    // channels per wave in K2b (blockDim)
     uint2 *chunks = nullptr;   // optional [blocks of K3][k3_passes(K)]: where each pass of each K3 block put its
                            // frames in the ring (start, count).  (block, pass, position) is the reference's
