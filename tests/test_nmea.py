@@ -383,3 +383,48 @@ def test_device_message_lines_match_host_formatter():
         types |= {l.split(b" type ")[1].split(b" ")[0] for l in want_tx.split(b"\n") if b" type " in l}
     assert types == {str(t).encode() for t in range(1, 25)}
     assert b"(tide-weather) lat" in want_tx or b"(tide-weather) lat" in tx
+
+
+@pytest.mark.gpu
+def test_streamed_delivery_reports_a_ring_overflow_with_its_text():
+    """A call with more CRC-valid frames than `frame_capacity`: the streamed path says so
+    (GNUAIS_E_OVERFLOW) on the call that hands that call's text out -- the text itself holds whole
+    sentences of real frames (K3's chunk counts are clipped to the ring) -- and the calls before and
+    after it are delivered whole."""
+    import ctypes as C
+    import torch
+    from gnuais_amd import ReceiverBatch, lib, synth
+    n_ch, call = 40, 10 * 1280
+    dense = np.stack([synth.make_stream(call, seed=97, channel=c, occupancy=1.0)[0] for c in range(n_ch)], axis=1)
+    quiet = np.stack([synth.make_stream(call, seed=98, channel=c, occupancy=0.02)[0] for c in range(n_ch)], axis=1)
+    xd, xq = torch.from_numpy(dense).cuda(), torch.from_numpy(quiet).cuda()
+    a = ReceiverBatch(n_ch, max_len=call)
+    b = ReceiverBatch(n_ch, max_len=call, frame_capacity=64)
+    plan = [xq, xd, xq, xq]
+    seq = np.zeros(n_ch, dtype=np.uint8)
+    want = []
+    for x in plan:
+        a.run(x)
+        want.append(a.drain_nmea(seq))
+    assert want[1][2] > 64 >= max(want[0][2], want[2][2], want[3][2])
+    depth = b.stream_depth
+    got = []
+    for i in range(len(plan) + depth):
+        if i < len(plan):
+            b.run(plan[i], sync=False)
+        text, ln, ns, nf = C.c_char_p(), C.c_size_t(0), C.c_int(0), C.c_int(0)
+        rc = b._lib.gnuais_batch_stream_nmea(b._h, C.byref(text), C.byref(ln), C.byref(ns), C.byref(nf))
+        got.append((rc, C.string_at(text, ln.value) if ln.value else b"", ns.value, nf.value))
+    out = got[depth:]
+    assert [g[0] for g in out] == [0, lib.E_OVERFLOW, 0, 0]
+    assert out[0][1] == want[0][0] and out[0][3] == want[0][2]
+    assert 0 < out[1][3] <= 64
+    lines = out[1][1].split(b"\r\n")[:-1]
+    assert len(lines) == out[1][2] >= out[1][3] and all(l.startswith(b"!AIVDM,") for l in lines)
+    for l in lines:
+        x_ = 0
+        for ch in l[1:l.index(b"*")]:
+            x_ ^= ch
+        assert l.endswith(b"*%02X" % x_)
+    # the calls after it: all their frames (the sequence digits may differ: the overflowed call accepted fewer)
+    assert out[2][3] == want[2][2] and out[3][3] == want[3][2]
