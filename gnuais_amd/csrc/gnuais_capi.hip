@@ -701,50 +701,59 @@ int gnuais_batch_autotune(gnuais_batch *b, const int16_t *d_samples, int len, vo
         ms = (ms + now_ms()) / meas;
         return GNUAIS_OK;
     };
-    const int order[4] = {0, 3, 2, 1};          // K2a, K3, K2b, K2x
-    int chosen[4] = {-1, -1, -1, -1};
+    const int order[4] = {0, 3, 2, 1};          // the PLL stage first, then K3, K2b, the spare
     double best_all = 0;
-    for (int r = 0; r < 4; ++r) {
-        const int role = order[r];
-        double best = 1e30;
-        int best_s = -1;
-        for (int cand = 0; cand < gnuais_batch::POOL; ++cand) {
-            bool used = false;
-            for (int q = 0; q < r; ++q) used |= chosen[order[q]] == cand;
-            if (used) continue;
-            int trial[4];
-            for (int q = 0; q < 4; ++q) trial[q] = chosen[q];
-            trial[role] = cand;
-            for (int q = r + 1; q < 4; ++q) {   // the roles not decided yet: any distinct free streams
-                for (int f = 0; f < gnuais_batch::POOL; ++f) {
-                    bool taken = false;
-                    for (int t = 0; t < 4; ++t) taken |= trial[t] == f;
-                    if (!taken) { trial[order[q]] = f; break; }
+    auto search = [&](int chosen[4]) -> int {
+        for (int q = 0; q < 4; ++q) chosen[q] = -1;
+        for (int r = 0; r < 4; ++r) {
+            const int role = order[r];
+            double best = 1e30;
+            int best_s = -1;
+            for (int cand = 0; cand < gnuais_batch::POOL; ++cand) {
+                bool used = false;
+                for (int q = 0; q < r; ++q) used |= chosen[order[q]] == cand;
+                if (used) continue;
+                int trial[4];
+                for (int q = 0; q < 4; ++q) trial[q] = chosen[q];
+                trial[role] = cand;
+                for (int q = r + 1; q < 4; ++q) {   // the roles not decided yet: any distinct free streams
+                    for (int f = 0; f < gnuais_batch::POOL; ++f) {
+                        bool taken = false;
+                        for (int t = 0; t < 4; ++t) taken |= trial[t] == f;
+                        if (!taken) { trial[order[q]] = f; break; }
+                    }
                 }
+                for (int q = 0; q < 4; ++q) b->s_k[q] = b->pool[trial[q]];
+                double ms = 0;
+                if (int rc = measure(ms)) return rc;
+                if (ms < best) { best = ms; best_s = cand; }
             }
-            for (int q = 0; q < 4; ++q) b->s_k[q] = b->pool[trial[q]];
-            double ms = 0;
-            if (int rc = measure(ms)) return rc;
-            if (ms < best) { best = ms; best_s = cand; }
+            chosen[role] = best_s;
         }
-        chosen[role] = best_s;
-        best_all = best;
+        return GNUAIS_OK;
+    };
+    // Ten calls per trial are noisy (+-4 %) and a greedy search can follow the noise into a poor
+    // assignment (seen: 0.65 instead of 0.53 ms per call in a third of the runs on one box).  So: two
+    // independent searches, and the default assignment, in a longer head-to-head; the fastest stays.
+    hipStream_t cand_set[3][4];
+    int n_sets = 0;
+    for (int q = 0; q < 4; ++q) cand_set[0][q] = b->s_k_default[q];
+    n_sets = 1;
+    for (int rep = 0; rep < 2; ++rep) {
+        int chosen[4];
+        if (int rc = search(chosen)) return rc;
+        for (int q = 0; q < 4; ++q) cand_set[n_sets][q] = b->pool[chosen[q]];
+        ++n_sets;
     }
-    // ten calls per trial are noisy (+-4 %): keep the search's result only if it beats the default
-    // assignment in a longer head-to-head
-    hipStream_t dflt[4], pick[4];
-    for (int q = 0; q < 4; ++q) {
-        pick[q] = b->pool[chosen[q]];
-        dflt[q] = b->s_k_default[q];
+    int best_set = 0;
+    best_all = 1e30;
+    for (int k = 0; k < n_sets; ++k) {
+        for (int q = 0; q < 4; ++q) b->s_k[q] = cand_set[k][q];
+        double ms = 0;
+        if (int rc = measure(ms, 40)) return rc;
+        if (ms < best_all) { best_all = ms; best_set = k; }
     }
-    double ms_pick = 0, ms_dflt = 0;
-    for (int q = 0; q < 4; ++q) b->s_k[q] = dflt[q];
-    if (int rc = measure(ms_dflt, 40)) return rc;
-    for (int q = 0; q < 4; ++q) b->s_k[q] = pick[q];
-    if (int rc = measure(ms_pick, 40)) return rc;
-    if (ms_dflt <= ms_pick)
-        for (int q = 0; q < 4; ++q) b->s_k[q] = dflt[q];
-    best_all = std::min(ms_dflt, ms_pick);
+    for (int q = 0; q < 4; ++q) b->s_k[q] = cand_set[best_set][q];
     b->timing = timing;
     if (ms_per_call) *ms_per_call = (float) best_all;
     return gnuais_batch_reset(b);

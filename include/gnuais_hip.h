@@ -290,8 +290,8 @@ int  gnuais_batch_mean_timing(gnuais_batch *b, float *ms5, int *n_calls);
  * of stream time), "stage_mask" (experiments: bit 0 = FIR/slicer, bit 1 = PLL/NRZI, bit 3 =
  * deframer, bit 4 = unstuff/CRC; results are wrong unless 0x1f) */
 int  gnuais_batch_set_option(gnuais_batch *b, const char *name, int value);
-/* Optional, once, before real work: time the stage -> stream assignments on `d_samples` (about 0.5 s
- * of pipelined calls) and keep the fastest; RESETS the batch.  Which hardware queue a stream gets
+/* Optional, once, before real work: time the stage -> stream assignments on `d_samples` (about 1.3 s
+ * of pipelined calls: two greedy searches and a longer head-to-head with the default) and keep the fastest; RESETS the batch.  Which hardware queue a stream gets
  * depends on what else the process created before, is not queryable, and matters by up to 1.7x. */
 int  gnuais_batch_autotune(gnuais_batch *b, const int16_t *d_samples, int len, void *stream,
 			   float *ms_per_call);
