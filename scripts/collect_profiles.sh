@@ -23,5 +23,11 @@ rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/c5_pmc_write
 # C2 (256 channels)
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/c2_stats -o bench -- python $R/bench.py --config C2 --no-cpu --steps 100 > $O/c2_bench_under_rocprof.json 2>/dev/null
 find $O -name "*agent_info.csv" -delete
+# the summaries are made here, next to the raw files (the per-dispatch traces are tens of MB and stay behind):
+# copy gpurun_out/<tag>_summary/* into profiles/
+python $R/scripts/summarize_profiles.py $O $TAG $R/gpurun_out/${TAG}_summary > /dev/null
+find $O -name "*kernel_trace.csv" -delete
+find $O -name "*counter_collection.csv" -delete
+find $O -name "*domain_stats.csv" -delete
 ls -R $O | head -40
 cat $O/bench.json | cut -c1-600
