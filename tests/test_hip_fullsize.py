@@ -353,3 +353,39 @@ def test_c3_streamed_delivery_equals_drained_delivery():
             x_ ^= ch
         assert l.endswith(b"*%02X" % x_)
     assert body.size == len(out[-1][0])
+
+
+# ---------------------------------------------------------------- C4: its full size, shard by shard
+
+def test_c4_full_size_shard_by_shard():
+    """BASELINE C4 -- 131072 channels x 48000 samples over 8 GPUs -- is eight independent C3-sized
+    batches (receivers share nothing).  All eight shards of that size, each with input of
+    its own, one after another through the product path on the visible device(s) (shard r on device
+    r % device_count, as `bench.py --gpus 8` places them), every channel of every shard against the
+    oracle: frames, counters, PLL carry.  What an 8-GPU node adds is only that the shards run at once."""
+    import torch
+    from gnuais_amd import tile_channels
+    world, per, total, k = 8, 16384, 48000, 128
+    n_dev = max(1, torch.cuda.device_count())
+    received = 0
+    for r in range(world):
+        lo, hi = shard.shard_range(world * per, world, r)
+        assert hi - lo == per
+        d = r % n_dev
+        torch.cuda.set_device(d)
+        base, _ = synth.make_base_streams(k, total, seed=synth.SEED + 100 + r)
+        xb = tile_channels(dev(base, d), per)
+        b = batch(per, max_len=total, device=d)
+        b.run(xb)
+        frames = b.drain_frames()
+        o = Oracle(per)
+        o.run(xb.cpu().numpy(), threads=host_threads())
+        want = o.frames()
+        assert len(want) > 200000
+        assert frames.tobytes() == want.tobytes(), r
+        assert np.array_equal(counters_of(b), o.counters()), r
+        assert pll_of(b) == [o.pll(c) for c in range(per)], r
+        received += len(frames)
+        del b, o, xb
+    torch.cuda.set_device(0)
+    assert received > 8 * 200000
