@@ -255,7 +255,7 @@ def measure(cfg, args, local, rank, sync, steps, warmup, isolated=True, post=Fal
         # formatter and the copy of step i overlapping the chain of steps i+1..i+3
         b.sync()
         b.autotune_delivery(x, stream)              # the copy stream's place, measured like the stages' (resets)
-        n_e2e = max(8, min(100, steps))
+        n_e2e = 100                                 # its own step count (reported): 20 would mostly time fill and drain
         for _ in range(12):                         # the first use allocates rings, text and scratch buffers
             b.run(x, stream=stream, sync=False)
             b.stream_nmea(copy=False)
