@@ -428,3 +428,48 @@ def test_streamed_delivery_reports_a_ring_overflow_with_its_text():
         assert l.endswith(b"*%02X" % x_)
     # the calls after it: all their frames (the sequence digits may differ: the overflowed call accepted fewer)
     assert out[2][3] == want[2][2] and out[3][3] == want[3][2]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n_ch,call,pipeline", [(1, 2560, 1), (33, 1280, 1), (70, 2560, 0), (5, 77, 1)])
+def test_streamed_delivery_odd_shapes_reset_and_teardown(n_ch, call, pipeline):
+    """Streaming with one channel, a channel count that is no multiple of a K3 block, the pipeline off, and
+    77-sample calls; a reset in the middle (the stream starts afresh, nothing of before is handed out); a
+    batch destroyed with calls in flight."""
+    import torch
+    from gnuais_amd import ReceiverBatch, synth
+    total = call * 14
+    x = np.stack([synth.make_stream(total, seed=101, channel=c, occupancy=0.95)[0] for c in range(n_ch)], axis=1)
+    xd = torch.from_numpy(x).cuda()
+    a, b = ReceiverBatch(n_ch, max_len=call), ReceiverBatch(n_ch, max_len=call)
+    b.set_option("pipeline", pipeline)
+    depth = b.stream_depth
+
+    def both(lo, hi, seq):
+        want, got = [], []
+        for i in range(lo, hi):
+            a.run(xd[i * call:(i + 1) * call])
+            want.append(a.drain_nmea(seq))
+            b.run(xd[i * call:(i + 1) * call], sync=False)
+            got.append(b.stream_nmea())
+        for _ in range(depth):
+            got.append(b.stream_nmea())
+        return want, got[depth:]
+
+    seq = np.zeros(n_ch, dtype=np.uint8)
+    want, out = both(0, 6, seq)
+    assert [(g[0], g[1], g[2]) for g in out] == [(w[0], w[1], w[2]) for w in want]
+    a.reset(); b.reset()
+    seq[:] = 0
+    first = b.stream_nmea()
+    assert first[2] == -1                                   # nothing from before the reset
+    want, out = both(6, 14, seq)
+    got = [first] + out
+    got = [g for g in got if g[2] >= 0]
+    assert [(g[0], g[1], g[2]) for g in got[-len(want):]] == [(w[0], w[1], w[2]) for w in want]
+    if call >= 1280:
+        assert sum(w[2] for w in want) > 0
+    for i in range(3):                                       # leave work in flight
+        b.run(xd[i * call:(i + 1) * call], sync=False)
+        b.stream_nmea()
+    b.close()
