@@ -473,3 +473,33 @@ def test_streamed_delivery_odd_shapes_reset_and_teardown(n_ch, call, pipeline):
         b.run(xd[i * call:(i + 1) * call], sync=False)
         b.stream_nmea()
     b.close()
+
+
+@pytest.mark.gpu
+def test_device_message_layer_edge_cases():
+    """Nothing queued, one channel, too small buffers, a streaming batch: the drain-type device calls say what
+    they must and consume nothing they should not."""
+    import ctypes as C
+    import torch
+    from gnuais_amd import ReceiverBatch, lib, synth
+    b = ReceiverBatch(1, max_len=4 * 1280)
+    seq = np.zeros(1, dtype=np.uint8)
+    assert b.drain_messages(seq) == (b"", b"", 0, 0, 0)
+    assert len(b.fold_vessels()) == 0
+    x = synth.make_stream(4 * 1280, seed=103, channel=0, occupancy=1.0)[0].reshape(-1, 1)
+    b.run(torch.from_numpy(x).cuda())
+    n = b.pending_frames()
+    assert n >= 2
+    nl, tl, ns, nln, nf = C.c_size_t(0), C.c_size_t(0), C.c_int(0), C.c_int(0), C.c_int(0)
+    small = np.zeros(16, dtype=np.uint8)
+    rc = b._lib.gnuais_batch_drain_messages(b._h, seq.ctypes.data, None, small.ctypes.data, small.size, C.byref(nl),
+                                            C.byref(ns), small.ctypes.data, small.size, C.byref(tl), C.byref(nln), C.byref(nf))
+    assert rc == lib.E_ARG and b.pending_frames() == n            # nothing consumed
+    tab = b.fold_vessels()
+    assert b.pending_frames() == n and len(tab) >= 1
+    nm, tx, n_sent, n_lines, n_frames = b.drain_messages(seq)
+    assert n_frames == n and n_sent >= n_lines == tx.count(b"\n") > 0 and b.pending_frames() == 0
+    b.stream_nmea()                                               # now streaming
+    rc = b._lib.gnuais_batch_drain_messages(b._h, seq.ctypes.data, None, small.ctypes.data, small.size, C.byref(nl),
+                                            C.byref(ns), small.ctypes.data, small.size, C.byref(tl), C.byref(nln), C.byref(nf))
+    assert rc == lib.E_ARG and b"streaming" in b._lib.gnuais_last_error()
