@@ -503,3 +503,38 @@ def test_device_message_layer_edge_cases():
     rc = b._lib.gnuais_batch_drain_messages(b._h, seq.ctypes.data, None, small.ctypes.data, small.size, C.byref(nl),
                                             C.byref(ns), small.ctypes.data, small.size, C.byref(tl), C.byref(nln), C.byref(nf))
     assert rc == lib.E_ARG and b"streaming" in b._lib.gnuais_last_error()
+
+
+@pytest.mark.gpu
+def test_streamed_text_larger_than_the_pinned_buffer():
+    """The pinned text buffers start at a fraction of the worst case and grow with the traffic: calls whose
+    text does not fit (long two-sentence frames, a small frame ring) are fetched from the device copy at
+    hand-out time and the buffers grow -- the bytes are the drained path's all the same."""
+    from gnuais_amd import ReceiverBatch, synth
+    rng = np.random.default_rng(107)
+    n_ch = 6
+    a = ReceiverBatch(n_ch, max_len=48000, frame_capacity=4096)
+    b = ReceiverBatch(n_ch, max_len=48000, frame_capacity=4096)
+    seq = np.zeros(n_ch, dtype=np.uint8)
+    want, got = [], []
+    for call in range(5):
+        streams = []
+        for c in range(n_ch):
+            parts = [np.zeros(8, dtype=np.uint8)]
+            for k in range(0 if call == 0 else 600):                # ~3600 frames of 53 bytes: ~0.5 MB of text
+                body = bytearray(rng.integers(0, 256, 53, dtype=np.uint8).tobytes())
+                body[0] = (int(rng.integers(1, 25)) << 2) | (body[0] & 3)
+                parts.append(synth.hdlc_frame_bits(bytes(body), training_bits=24))
+                parts.append(np.zeros(3, dtype=np.uint8))
+            streams.append(np.concatenate(parts).astype(np.uint8))
+        a.decode_bits(streams)
+        want.append(a.drain_nmea(seq))
+        b.decode_bits(streams)
+        got.append(b.stream_nmea())
+    depth = b.stream_depth
+    for _ in range(depth):
+        got.append(b.stream_nmea())
+    out = got[depth:]
+    assert max(len(w[0]) for w in want) > 4096 * 32 + 65536        # larger than the initial pinned buffer
+    for i, (w, g) in enumerate(zip(want, out)):
+        assert g[2] == w[2] and g[1] == w[1] and g[0] == w[0], i
