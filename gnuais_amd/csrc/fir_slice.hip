@@ -390,7 +390,7 @@ __global__ __launch_bounds__(64) void fir_sign_kernel(
 #if FIR_SIGN_FENCE > 0
     if constexpr (NC == 12)
     // Claim 88 VGPRs although the fenced code needs 68: five waves per SIMD then leave 72
-    // registers for a wave of each of the stages that run beside us (K2a needs 56).  At seven
+    // registers for a wave of each of the stages that run beside us (the PLL stage needs 64).  At seven
     // waves per SIMD this kernel would fill the register file and they would wait for FIR
     // waves to retire before they could even be placed.
     asm volatile("" ::: FIR_SIGN_CLAIM);

@@ -2,7 +2,7 @@
 //
 // Owns the per-batch device state (FIR history, PLL phase, deframer state,
 // frame ring) and sequences the kernels of one receiver_run() pass:
-//   K1 fir_slice (+ history carry) -> K2a pll -> K2b hdlc_deframe -> K3 hdlc_crc
+//   K1 fir_slice (+ history carry) -> K2 pll -> K2b hdlc_deframe -> K3 hdlc_crc
 // K1 on the caller's stream, every later stage on an internal stream of its own, chained by
 // events over four sets of hand-off buffers, so that the stages of consecutive calls overlap
 // (DESIGN.md 4.6); `pipeline` = 0 runs them back to back on the caller's stream instead.
@@ -70,23 +70,23 @@ struct gnuais_batch {
     // every hand-off buffer exists NBUF times (index = call % NBUF), so K1 can run up
     // to NBUF-1 calls ahead of the sequential stages
     static constexpr int NBUF = 4;
-    uint32_t *sgn[NBUF] = {};                   // K1 -> K2a
-    uint32_t *pll = nullptr, *lastbit = nullptr, *prev = nullptr;   // receiver.h:38-44, carried by K2a
+    uint32_t *sgn[NBUF] = {};                   // K1 -> K2
+    uint32_t *pll = nullptr, *lastbit = nullptr, *prev = nullptr;   // receiver.h:38-44, carried by K2
     int n_cu = 256;
-    uint32_t *segbits[NBUF] = {};               // K2a -> K2b
+    uint32_t *segbits[NBUF] = {};               // K2 -> K2b
     uint32_t *segcnt[NBUF] = {};
     int n_seg = 0, seg_words = 0;
     // stage pipeline: K1 on the caller's stream and one internal stream per later
     // kernel, so that the short-on-parallelism stages of call i overlap the FIR of
     // call i+1 (and each other).  NBUF = 4 measured best: 3 starves the FIR (1.0 ms per C3 call),
     // 5..8 let it run further ahead and the stages get in each other's way more (0.84).
-    hipStream_t s_k[4] = {nullptr, nullptr, nullptr, nullptr};   // K2a, (spare), K2b, K3 (entries of pool[])
+    hipStream_t s_k[4] = {nullptr, nullptr, nullptr, nullptr};   // K2, (spare), K2b, K3 (entries of pool[])
     hipStream_t s_k_default[4] = {nullptr, nullptr, nullptr, nullptr};
     static constexpr int POOL = 12;
     hipStream_t pool[POOL] = {};                // candidates for gnuais_batch_autotune(): [0..3] the default
                                                 // assignment, [0..7] high priority, [8..11] default priority
     hipEvent_t e_done[5][NBUF] = {};            // e_done[s][k]: stage s of the call using set k is done
-                                                // (0 K1, 1 K2a, 3 K2b, 4 K3)
+                                                // (0 K1, 1 K2, 3 K2b, 4 K3)
     unsigned long long calls = 0, hdlc_calls = 0;   // run calls / K3 launches since the last drain
     bool pipeline = true;
     uint32_t *ctl = nullptr, *cand = nullptr;
@@ -162,7 +162,7 @@ struct gnuais_batch {
     // timing: a ring of per-call event sets so that kernel durations can be read back
     // for every call of a timed region, not just the last one
     static constexpr int TIMING_RING = 64;
-    hipEvent_t evr[TIMING_RING][10] = {};  // 0,1 K1 | 2,6 K2a | 5,7 K2b | 9,4 K3
+    hipEvent_t evr[TIMING_RING][10] = {};  // 0,1 K1 | 2,6 K2 | 5,7 K2b | 9,4 K3
     unsigned long long timed_calls = 0;
     int last_k = 0;
     bool timed_last = false;
@@ -399,9 +399,9 @@ int gnuais_batch_create(gnuais_batch **out, int device, int n_channels, const fl
         // compute pipes round-robin, so in a process with no other streams the 4th stream
         // created here shares its pipe with the caller's (FIR) queue.  With the PLL stage or
         // the deframer there a C3 call takes 0.81-0.83 ms, with K3 there 0.90-0.93 (K3 is the
-        // stage whose completion the host waits on before it reuses a hand-off set), with K2x
-        // 0.87.  Hence: K2x, K2b, K3, and the PLL stage last.  GNUAIS_STREAM_ORDER (four digits,
-        // stage indices 0 = K2a .. 3 = K3 in creation order) overrides, for processes that have
+        // stage whose completion the host waits on before it reuses a hand-off set), with the spare
+        // stream there 0.87.  Hence: the spare, K2b, K3, and the PLL stage last.  GNUAIS_STREAM_ORDER (four digits,
+        // stage indices 0 = K2 .. 3 = K3 in creation order) overrides, for processes that have
         // created streams of their own before.
         const char *order = getenv("GNUAIS_STREAM_ORDER");
         if (!order || strlen(order) != 4) order = "1230";
@@ -649,7 +649,7 @@ int gnuais_batch_run(gnuais_batch *b, const int16_t *d_samples, int len, void *s
             if (int rc = run_fir(b, d_samples, len, nullptr, s0, k)) return rc;
         if (tm) HIP_TRY(hipEventRecord(ev[1], s0));
         if (pl) HIP_TRY(hipEventRecord(b->e_done[0][k], s0));
-        // K2a: this call's sign words -> bit packs segbits[k] (read by K2b of call i-NBUF); in order
+        // K2: this call's sign words -> bit packs segbits[k] (read by K2b of call i-NBUF); in order
         // across calls (it carries the receivers' pll / prev / lastbit)
         PllLaunch p;
         fill_pll(b, p, k, len);
@@ -674,7 +674,7 @@ int gnuais_batch_sync(gnuais_batch *b);
 int gnuais_batch_reset(gnuais_batch *b);
 int gnuais_batch_discard_frames(gnuais_batch *b, void *stream);
 
-// Try the stage -> stream assignments greedily (PLL stage first, then K3, K2b, K2x; each on every
+// Try the stage -> stream assignments greedily (PLL stage first, then K3, K2b, the spare; each on every
 // free candidate stream), timing a few pipelined calls of the caller's own input each, and keep
 // the fastest.  Resets the batch afterwards (the calls advanced every receiver's state).
 int gnuais_batch_autotune(gnuais_batch *b, const int16_t *d_samples, int len, void *stream, float *ms_per_call)
@@ -1477,7 +1477,7 @@ int gnuais_batch_set_timing(gnuais_batch *b, int on)
     return GNUAIS_OK;
 }
 
-// ms[0] K1 fir_slice  [1] K2a pll  [2] K2b hdlc_deframe  [3] K3 hdlc_crc
+// ms[0] K1 fir_slice  [1] K2 pll  [2] K2b hdlc_deframe  [3] K3 hdlc_crc
 // [4] first event to last event of the call
 static int timing_of(gnuais_batch *b, unsigned long long call, float *ms)
 {

@@ -5,7 +5,7 @@
 // protodec_reset() (src/protodec.c:87-100) and for protodec_calculate_crc() /
 // protodec_sdlc_crc() (src/protodec.c:106-167), for a whole batch of channels.
 //
-// K2b -- one lane = one channel walking its own recovered bit stream (K2x's
+// K2b -- one lane = one channel walking its own recovered bit stream (K2's
 // per-segment bit packs) at its own pace.  A wave that is alone on its SIMD issues
 // about one instruction per 5 cycles, so what counts is instructions per channel,
 // i.e. steps x instructions per step.  The five-state machine of the reference is
@@ -109,7 +109,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(7, 8))) void
     do { state = ST_SKURR; nstartsign = 0; antallpreamble = 0; antallenner = 0;        \
          last = 0; bitstuff = 0; bufferpos = 0; } while (0)
 
-    // K2x hands over one bit pack per 2048-sample segment; the word-parallel steps
+    // K2 hands over one bit pack per 2048-sample segment; the word-parallel steps
     // accept any window length, so a pack boundary is just a short window.  A step's
     // window must not wait on HBM/L2 (~1-2 us per dependent load, several hundred
     // steps per channel): the pack of the NEXT segment is fetched into registers

@@ -31,13 +31,13 @@ hipError_t launch_fir_generic(const FirLaunch &a, hipStream_t stream);
 hipError_t launch_fir_history(const int16_t *x, const int16_t *hist_in, int16_t *hist_out,
                               int N, int L, int NT, hipStream_t stream);
 
-// ---- K2a: PLL clock recovery, slice + NRZI (pll_nrzi.hip) --------------------------
+// ---- K2: PLL clock recovery, slice + NRZI (pll_nrzi.hip) --------------------------
 constexpr int PLL_LDS_BYTES = 81 * 1024;   // > half of a CU's LDS: one PLL workgroup per CU
 constexpr int SEG_WORDS = 64;        // segment (one bit pack per channel): 64 sign words
 constexpr int SEG_LEN = SEG_WORDS * 32;    //   = 2048 samples
 constexpr int PACK_STRIDE = 16;      // words reserved per (channel, segment) bit pack: 64 bytes
 // Sign words: word w (samples 32w .. 32w+31, bit 31 = oldest) of channel c.  Four consecutive
-// words of a channel lie side by side, so that K2a fetches 128 samples of a channel with one
+// words of a channel lie side by side, so that K2 fetches 128 samples of a channel with one
 // 16-byte load and a wave's fetch is 1 KB of contiguous memory.
 __host__ __device__ inline size_t sgn_index(int w, int N, int c)
 {
@@ -61,7 +61,7 @@ struct PllLaunch {
     int variant = 0;       // 0: by channel count; 3 / 6: the three- / six-wave form
 };
 hipError_t pll_prepare_device();                                         // once per device, after hipSetDevice
-hipError_t launch_pll(const PllLaunch &a, hipStream_t stream);           // K2a
+hipError_t launch_pll(const PllLaunch &a, hipStream_t stream);           // K2
 
 // ---- K2b: HDLC deframer, K3: CRC-16 + frame delivery (hdlc_crc.hip) ---------
 constexpr int HDLC_CTL_WORDS = 6;

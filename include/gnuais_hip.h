@@ -270,7 +270,7 @@ int  gnuais_vessels_from_frames(const gnuais_frame *frames, int n_frames, gnuais
 int  gnuais_tile_channels(const int16_t *d_base, int n_base, int len, int16_t *d_out,
 			  int n_channels, void *stream);
 /* per-kernel timing of the last run (HIP events recorded on the stream each
- * kernel is launched on), ms[5]: [0] K1 fir_slice  [1] K2a pll  [2] K2b hdlc_deframe
+ * kernel is launched on), ms[5]: [0] K1 fir_slice  [1] K2 pll  [2] K2b hdlc_deframe
  * [3] K3 hdlc_crc  [4] whole call.  Needs gnuais_batch_set_timing(b, 1) before the run. */
 int  gnuais_batch_set_timing(gnuais_batch *b, int on);
 int  gnuais_batch_last_timing(gnuais_batch *b, float *ms5);
