@@ -303,7 +303,12 @@ struct LineOut {
         int k = 0;
         const bool neg = v < 0;
         unsigned long long u = neg ? 0ull - (unsigned long long) v : (unsigned long long) v;
-        do { t[k++] = (char) ('0' + u % 10ull); u /= 10ull; } while (u);
+        if (u <= 0xffffffffull) {           // nearly always: 32-bit division by a constant is a multiply
+            uint32_t w = (uint32_t) u;
+            do { t[k++] = (char) ('0' + w % 10u); w /= 10u; } while (w);
+        } else {
+            do { t[k++] = (char) ('0' + u % 10ull); u /= 10ull; } while (u);
+        }
         if (neg) ch('-');
         for (int i = k + (neg ? 1 : 0); i < width; ++i) ch('0');
         while (k) ch(t[--k]);
@@ -347,12 +352,19 @@ struct LineOut {
             if (above || (tie && (q & 1ull))) ++q;
         }
         if (neg) ch('-');
-        dec((long long) (q / S));
+        unsigned long long ip, fr;
+        if (q <= 0xffffffffull) {           // the fields printed here: 32-bit arithmetic
+            const uint32_t q32 = (uint32_t) q, s32 = (uint32_t) S;
+            ip = q32 / s32; fr = q32 % s32;
+        } else {
+            ip = q / S; fr = q % S;
+        }
+        dec((long long) ip);
         if (prec) {
             ch('.');
-            unsigned long long fr = q % S;
             char t[8];
-            for (int i = prec - 1; i >= 0; --i) { t[i] = (char) ('0' + fr % 10ull); fr /= 10ull; }
+            uint32_t f32 = (uint32_t) fr;                      // < 10^6
+            for (int i = prec - 1; i >= 0; --i) { t[i] = (char) ('0' + f32 % 10u); f32 /= 10u; }
             for (int i = 0; i < prec; ++i) ch(t[i]);
         }
     }
