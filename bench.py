@@ -312,7 +312,7 @@ def rank_main(rank, local, world, args, sync):
     if args.len:
         cfg = dict(cfg, len=args.len)
     want_cpu = rank == 0 and world == 1 and args.cpu and args.config == "C3"
-    m = measure(cfg, args, local, rank, sync, args.steps, args.warmup, post=(rank == 0), keep_input=want_cpu)
+    m = measure(cfg, args, local, rank, sync, args.steps, args.warmup, post=(rank == 0 and args.e2e), keep_input=want_cpu)
     x_cpu, x_wide = m.pop("x_cpu", None), m.pop("x_wide", None)
     per_rank = {"rank": rank, "device": local, "ms_per_step": m["dt_own"] / m["steps"] * 1e3}
     red = sync.reduce(m["dt"], m["msgs"], float(m["n_ch"]) * m["len"] * m["steps"], per_rank)
@@ -377,6 +377,8 @@ def main():
     ap.add_argument("--devices", default="", help="comma list: device of each worker (default 0..N-1); "
                     "repeating a device runs several workers on it")
     ap.add_argument("--no-cpu", dest="cpu", action="store_false")
+    ap.add_argument("--no-e2e", dest="e2e", action="store_false",
+                    help="skip the message-layer legs (message_lines, end_to_end): for profile runs of the chain alone")
     ap.add_argument("--no-others", dest="others", action="store_false",
                     help="skip the brief C2 / C5 measurements of a default single-GPU run")
     args = ap.parse_args()

@@ -382,9 +382,11 @@ __global__ __launch_bounds__(64) void fir_sign_kernel(
     uint32_t *__restrict__ sgn, int *__restrict__ maxval,
     int16_t *__restrict__ hist_out, int *__restrict__ maxval_next,
     const float *__restrict__ te_mem, int N, int L, int T, int d, int NTaps, int NE_rt, float eps_up,
-    int map, FirTaps<NT> taps)
+    int map, FirTaps<NT> taps, unsigned long long *stamps, int n_big, int T2)
 {
     const int NE = NES > 0 ? NES : NE_rt;
+    const int wave_id = (int) (blockIdx.y * gridDim.x + blockIdx.x);
+    if (stamps && threadIdx.x == 0) stamps[2 * wave_id] = wall_clock64();
     const int J0 = (NE - NC) / 2;               // first central tap (10 of 32 for the reference table)
     auto ctap = [&](int q) -> float { return NES > 0 ? taps.te[(NES - NC) / 2 + q] : taps.te[q]; };
 #if FIR_SIGN_FENCE > 0
@@ -410,8 +412,12 @@ __global__ __launch_bounds__(64) void fir_sign_kernel(
     const int cg = bx * 64 + lane;
     const int c = cg < N ? cg : N - 1;
     const bool live = cg < N;
-    const int t0 = by * T;                      // T is a multiple of 96
-    const int t1 = (t0 + T < L) ? t0 + T : L;
+    // Segments of two lengths: the first n_big are T outputs long, the rest T2.  Workgroups are dispatched in
+    // id order, so the short ones are the launch's last: with equal segments the launch ends in a tail of one wave
+    // lifetime (70 us of 410) during which the occupancy falls linearly to zero (scripts/fir_wave_timeline.py).
+    const int t0 = by < n_big ? by * T : n_big * T + (by - n_big) * T2;
+    const int t1e = t0 + (by < n_big ? T : T2);
+    const int t1 = t1e < L ? t1e : L;
     if (t0 >= L) return;
     const int dc = d - J0;                      // y_c[n] = sum_q tc[q] * x[n - dc + q]
 
@@ -865,6 +871,7 @@ __global__ __launch_bounds__(64) void fir_sign_kernel(
         }
         maxval_next[cg] = 0;
     }
+    if (stamps && threadIdx.x == 0) stamps[2 * wave_id + 1] = wall_clock64();
 }
 
 int launch_fir_sign_quantum(int NC)
@@ -879,23 +886,29 @@ hipError_t launch_fir_sign(const FirLaunch &a, hipStream_t stream)
     if (a.dump || a.T % launch_fir_sign_quantum(a.NC) || !a.te_mem || (a.NC != 12 && a.NC != 48) || a.NE < a.NC || (a.NE - a.NC) % 2)
         return hipErrorInvalidValue;
     dim3 grid((a.N + 63) / 64, (a.L + a.T - 1) / a.T), block(64);
+    int n_big = 1 << 30, T2 = a.T;
+    if (a.T2 > 0 && a.T2 < a.T && a.T2 % launch_fir_sign_quantum(a.NC) == 0 && a.n_big < (int) grid.y) {
+        n_big = a.n_big > 0 ? a.n_big : 0;
+        T2 = a.T2;
+        grid.y = n_big + (a.L - n_big * a.T + T2 - 1) / T2;
+    }
     const float eps_up = __builtin_nextafterf(a.eps, INFINITY);
     const int map = (a.map == 1 && grid.x % 8 == 0) ? 1 : 0;
     if (a.NC == 12 && a.NE == 32) {
         FirTaps<32> t;
         for (int j = 0; j < 32; ++j) t.te[j] = a.te[j];
-        hipLaunchKernelGGL((fir_sign_kernel<32, 12, 32>), grid, block, 0, stream, a.x, a.hist, a.sgn, a.maxval,
-                           a.hist_out, a.maxval_next, a.te_mem, a.N, a.L, a.T, a.d, a.NT, a.NE, eps_up, map, t);
+        hipLaunchKernelGGL((fir_sign_kernel<32, 12, 32>), grid, block, a.lds_pad, stream, a.x, a.hist, a.sgn, a.maxval,
+                           a.hist_out, a.maxval_next, a.te_mem, a.N, a.L, a.T, a.d, a.NT, a.NE, eps_up, map, t, a.stamps, n_big, T2);
     } else if (a.NC == 12) {
         FirTaps<12> t;
         for (int j = 0; j < 12; ++j) t.te[j] = a.ctaps[j];
         hipLaunchKernelGGL((fir_sign_kernel<0, 12, 12>), grid, block, 0, stream, a.x, a.hist, a.sgn, a.maxval,
-                           a.hist_out, a.maxval_next, a.te_mem, a.N, a.L, a.T, a.d, a.NT, a.NE, eps_up, map, t);
+                           a.hist_out, a.maxval_next, a.te_mem, a.N, a.L, a.T, a.d, a.NT, a.NE, eps_up, map, t, a.stamps, n_big, T2);
     } else {
         FirTaps<48> t;
         for (int j = 0; j < 48; ++j) t.te[j] = a.ctaps[j];
         hipLaunchKernelGGL((fir_sign_kernel<0, 48, 48>), grid, block, 0, stream, a.x, a.hist, a.sgn, a.maxval,
-                           a.hist_out, a.maxval_next, a.te_mem, a.N, a.L, a.T, a.d, a.NT, a.NE, eps_up, map, t);
+                           a.hist_out, a.maxval_next, a.te_mem, a.N, a.L, a.T, a.d, a.NT, a.NE, eps_up, map, t, a.stamps, n_big, T2);
     }
     return hipGetLastError();
 }

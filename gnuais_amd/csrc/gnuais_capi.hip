@@ -147,6 +147,13 @@ struct gnuais_batch {
     // options
     int fir_T = 512;
     int fir_map = 1;                            // K1s workgroup mapping (fir_slice.hip): XCD-contiguous channel groups
+    int fir_T2 = 128;                           // K1s: segment length of the launch's tail (0: all segments alike)
+    int fir_tail = 0;                           //   how much of the launch, in tenths of a full round of resident waves, takes the short segments
+    int fir_cpl = 1;                            // K1s channels per lane: 1 (fir_slice.hip), 2 or 4 (fir_sign_wide.hip; even / 4-divisible N)
+    unsigned long long *d_stamps = nullptr;     // experiment (fir_stamps): start / end clock of every K1s wave of the last call
+    size_t stamps_waves = 0;
+    int fir_dbg = 0, fir_lds = 0;               // experiments: FirLaunch::dbg / lds_pad
+    int fir_form = 0;                           // fir_sign_wide.hip: bit 0 packed fp32, bit 1 prefetch, bits 4.. rows per group
     int stage_mask = 0x1f;                      // experiments only: bit s = launch stage s
     int fir_variant = 3;            // 3 sign-exact slicer (default when the table allows);
                                     // 0 exact scalar VALU, 1 exact packed, 2 exact MFMA products
@@ -207,7 +214,7 @@ void gnuais_batch_destroy(gnuais_batch *b)
     }
     void *ptrs[] = {b->hist[0], b->hist[1], b->pll, b->lastbit, b->prev, b->ctl, b->cand,
                     b->frame_count, b->counters, b->maxval[0], b->maxval[1], b->frames, b->d_taps,
-                    b->stage_x, b->d_seq[0], b->d_seq[1], b->d_text, b->nmea_scratch, b->d_msg, b->d_word};
+                    b->stage_x, b->d_seq[0], b->d_seq[1], b->d_text, b->nmea_scratch, b->d_msg, b->d_word, b->d_stamps};
     for (void *p : ptrs)
         if (p) (void) hipFree(p);
     for (auto &set : b->evr)
@@ -434,6 +441,8 @@ int gnuais_batch_create(gnuais_batch **out, int device, int n_channels, const fl
         return fail(GNUAIS_E_HIP, "create: device allocation", e);
     }
     if (const char *v = getenv("GNUAIS_FIR_VARIANT")) b->fir_variant = atoi(v);
+    if (const char *v = getenv("GNUAIS_FIR_CPL")) { const int c = atoi(v); if (c == 1 || c == 2 || c == 4) b->fir_cpl = c; }
+    if (const char *v = getenv("GNUAIS_FIR_FORM")) b->fir_form = atoi(v);
     if (const char *v = getenv("GNUAIS_FIR_T")) b->fir_T = std::max(64, atoi(v) / 32 * 32);
     *out = b;
     int rc = gnuais_batch_reset(b);
@@ -490,6 +499,26 @@ int gnuais_batch_set_option(gnuais_batch *b, const char *name, int value)
         b->fir_T = value;
     } else if (!strcmp(name, "fir_map")) {
         b->fir_map = value;
+    } else if (!strcmp(name, "fir_T2")) {
+        if (value < 0 || value % 32) return fail(GNUAIS_E_ARG, "fir_T2 must be a multiple of 32 (0: off)");
+        b->fir_T2 = value;
+    } else if (!strcmp(name, "fir_tail")) {
+        b->fir_tail = value < 0 ? 0 : value;
+    } else if (!strcmp(name, "fir_cpl")) {
+        if (value != 1 && value != 2 && value != 4) return fail(GNUAIS_E_ARG, "fir_cpl must be 1, 2 or 4");
+        b->fir_cpl = value;
+    } else if (!strcmp(name, "fir_form")) {
+        b->fir_form = value;
+    } else if (!strcmp(name, "fir_dbg")) {
+        b->fir_dbg = value;
+    } else if (!strcmp(name, "fir_lds")) {
+        b->fir_lds = value;
+    } else if (!strcmp(name, "fir_stamps")) {
+        if (value && !b->d_stamps) {
+            b->stamps_waves = (size_t) (b->N / 64 + 1) * (size_t) (b->max_len / 128 + 2);
+            HIP_TRY(hipMalloc((void **) &b->d_stamps, b->stamps_waves * 16));
+            HIP_TRY(hipMemset(b->d_stamps, 0, b->stamps_waves * 16));
+        }
     } else if (!strcmp(name, "fir_variant")) {
         if (value < 0 || value > 3) return fail(GNUAIS_E_ARG, "fir_variant must be 0..3");
         b->fir_variant = value;
@@ -538,6 +567,9 @@ static void fill_fir(const gnuais_batch *b, FirLaunch &f, const int16_t *x, int 
         for (int j = 0; j < b->sign_NC; ++j) f.ctaps[j] = b->te[(b->NE - b->sign_NC) / 2 + j];
     f.te_mem = b->d_taps + b->k0;
     f.map = b->fir_map;
+    f.dbg = b->fir_dbg;
+    f.stamps = b->d_stamps;
+    f.lds_pad = b->fir_lds;
 }
 
 static void fill_hdlc(const gnuais_batch *b, HdlcLaunch &h, int k)
@@ -563,7 +595,22 @@ static int run_fir(gnuais_batch *b, const int16_t *x, int len, float *dump, hipS
     if (b->fir_variant == 3 && b->sign_ok && !dump) {
         const int q = launch_fir_sign_quantum(f.NC);        // whole loop turns of the kernel's unrolled body
         f.T = (f.T + q - 1) / q * q;
-        HIP_TRY(launch_fir_sign(f, s));
+        // several adjacent channels per lane (wide typed loads) where the table, the channel count and the
+        // buffer's alignment allow; one channel per lane otherwise
+        const int cpl = (f.NC == 12 && f.NE == 32 && b->fir_cpl > 1 && b->N % b->fir_cpl == 0 &&
+                         ((uintptr_t) x & (uintptr_t) (2 * b->fir_cpl - 1)) == 0) ? b->fir_cpl : 1;
+        // The launch's last round of waves takes short segments (fir_slice.hip: fir_sign_kernel): as many long
+        // segments as leave fir_tail / 10 rounds of resident waves (five per SIMD) of work for the short ones
+        if (f.NC == 12 && b->fir_T2 > 0 && b->fir_tail > 0) {
+            const int groups = (b->N / cpl + 63) / 64, nseg = (len + f.T - 1) / f.T;
+            const int per_round = std::max(1, b->n_cu * 20 / std::max(1, groups));      // long segments one round covers
+            const int tail_segs = (per_round * b->fir_tail + 9) / 10;
+            f.T2 = (b->fir_T2 + q - 1) / q * q;
+            f.n_big = std::max(0, nseg - tail_segs);
+            if (f.T2 >= f.T) f.T2 = 0;
+        }
+        if (cpl > 1) HIP_TRY(launch_fir_sign_wide(f, cpl, b->fir_form, s));
+        else HIP_TRY(launch_fir_sign(f, s));
     } else if (b->NE != 32) {
         HIP_TRY(hipMemsetAsync(b->maxval[b->max_cur ^ 1], 0, sizeof(int) * (size_t) b->N, s));
         HIP_TRY(launch_fir_generic(f, s));
@@ -1468,6 +1515,16 @@ int gnuais_batch_info(const gnuais_batch *b, const char *name, double *value)
 
 int gnuais_batch_n_channels(const gnuais_batch *b) { return b ? b->N : 0; }
 int gnuais_batch_n_taps(const gnuais_batch *b) { return b ? b->NT : 0; }
+
+// experiments only (not in the header): wall-clock (100 MHz) start / end of every K1s wave of the last call
+int gnuais_debug_fir_stamps(gnuais_batch *b, unsigned long long *h_out, size_t max_waves)
+{
+    if (!b || !b->d_stamps || !h_out) return fail(GNUAIS_E_ARG, "debug_fir_stamps: set_option fir_stamps first");
+    if (int rc = set_device(b)) return rc;
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(h_out, b->d_stamps, std::min(max_waves, b->stamps_waves) * 16, hipMemcpyDeviceToHost));
+    return GNUAIS_OK;
+}
 
 int gnuais_batch_set_timing(gnuais_batch *b, int on)
 {

@@ -18,15 +18,20 @@ struct FirLaunch {
     const float *d_taps;   // device copy of all NT taps (generic kernel)
     float te[64];          // trimmed taps (specialised kernel)
     int N, L, T;           // T: outputs per wave, multiple of 32
+    int n_big = 1 << 30, T2 = 0;   // K1s: segments 0 .. n_big-1 are T outputs long, the rest T2 (the launch's tail, see run_fir)
     int NT, NE, d;         // out[n] = sum_j te[j] * x[n - d + j], j < NE
     float eps;             // sign-exact slicer: |central sum| > eps certifies the sign
     int NC;                //   central taps used (12 or 48)
     float ctaps[48];       //   te[(NE-NC)/2 .. +NC)
     const float *te_mem;   //   the NE effective taps in device memory (exact re-evaluation)
+    unsigned long long *stamps = nullptr;   // experiments: [waves][2] wall-clock start / end of every K1s wave
+    int dbg = 0, lds_pad = 0;   // experiments (fir_sign_wide.hip): elimination switches, LDS claimed per wave to cap the occupancy
     int map;               // K1s workgroup -> (channel group, segment) mapping, see fir_sign_kernel
 };
 int launch_fir_sign_quantum(int NC);           // T must be a multiple of this
 hipError_t launch_fir_sign(const FirLaunch &a, hipStream_t stream);
+// K1s with cpl = 2 / 4 adjacent channels per lane (fir_sign_wide.hip): 12 central taps of a 32-tap table only
+hipError_t launch_fir_sign_wide(const FirLaunch &a, int cpl, int form, hipStream_t stream);
 hipError_t launch_fir_generic(const FirLaunch &a, hipStream_t stream);
 hipError_t launch_fir_history(const int16_t *x, const int16_t *hist_in, int16_t *hist_out,
                               int N, int L, int NT, hipStream_t stream);
