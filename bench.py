@@ -223,8 +223,22 @@ def measure(cfg, args, local, rank, sync, steps, warmup, isolated=True, post=Fal
     out = {"n_ch": n_ch, "len": total, "dt": dt, "dt_own": dt_own, "steps": steps, "msgs": float(rx1 - rx0),
            "kernel_ms": {k: float(live[k]) for k in b.KERNELS}, "kernel_ms_isolated": iso,
            "kernel_ms_calls": int(live["calls"])}
+    if post and steps < 100:
+        # beside a short timed region (the driver's 20 steps carry one fill and one drain of the stage pipeline:
+        # a call is about 1.5 ms from its first kernel to its last): the same loop over 200 steps
+        n_ss = 200
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n_ss):
+            step()
+        torch.cuda.synchronize()
+        t_ss = time.perf_counter() - t0
+        out["steady_state"] = {"steps": n_ss, "ms_per_step": t_ss / n_ss * 1e3,
+                               "Msamples_per_s": n_ch * total * n_ss / t_ss / 1e6,
+                               "what": "the timed loop again over 200 steps (not the headline: context for the "
+                                       "fill + drain share of a short region)"}
 
-    if post and cfg["stage_mask"] == 0x1f:
+    if post and args.e2e and cfg["stage_mask"] == 0x1f:
         # the rest of row f1 from the device: sentences AND the stdout line of every accepted frame
         # (gnuais_batch_drain_messages), one step's frames, the C call alone into buffers that exist already
         import ctypes as C
@@ -254,6 +268,7 @@ def measure(cfg, args, local, rank, sync, steps, warmup, isolated=True, post=Fal
         # f1) and arrive in pinned host memory -- gnuais_batch_stream_nmea(), one call per step, the
         # formatter and the copy of step i overlapping the chain of steps i+1..i+3
         b.sync()
+        b.on_overflow = "keep"                     # an overflowed slot still delivers what fitted (counted, reported)
         b.autotune_delivery(x, stream)              # the copy stream's place, measured like the stages' (resets)
         n_e2e = 100                                 # its own step count (reported): 20 would mostly time fill and drain
         for _ in range(12):                         # the first use allocates rings, text and scratch buffers
@@ -278,7 +293,7 @@ def measure(cfg, args, local, rank, sync, steps, warmup, isolated=True, post=Fal
                                      "%d steps later" % depth,
                              "steps": n_e2e, "ms_per_step": t_e2e / n_e2e * 1e3,
                              "delivered_msgs_per_s": frames / t_e2e, "sentences": sent,
-                             "text_bytes_per_step": text / n_e2e,
+                             "text_bytes_per_step": text / n_e2e, "ring_overflows": b.stream_overflows,
                              "Msamples_per_s": n_ch * total * n_e2e / t_e2e / 1e6}
     if keep_input:
         out["x_cpu"] = x[:, : args.cpu_channels].cpu().numpy()
@@ -288,19 +303,127 @@ def measure(cfg, args, local, rank, sync, steps, warmup, isolated=True, post=Fal
     return out
 
 
-def roofline_of(m):
-    """The FIR/slicer launch: 98 % of the chain's algorithmic bytes (every int16 sample read once,
-    SURVEY 8d) and the largest share of its issued instructions."""
+MEASURED_HBM_GBS = 6290.0      # MI355X_MICROARCH.md: float4 copy, 79 % of the 8 TB/s spec
+
+
+def roofline_of(m, ms_per_step=None, traffic=None):
+    """`roofline` of the bench line.  The unit of work is one input sample = 2 algorithmic bytes, a call
+    is N x L of them, and every kernel of the chain works on the same call; `achieved` divides the call's
+    algorithmic bytes by the mean duration of the kernel that takes LONGEST inside the timed region (HIP events on
+    that kernel's own stream) -- the stage that sets the pipeline's period.  `chain` is the same bytes over the
+    driver-visible ms_per_step, `fir` the kernel that actually moves 98 % of them."""
     alg = m["n_ch"] * m["len"] * 2.0
-    ach = alg / (m["kernel_ms"]["fir_slice"] * 1e-3) / 1e9
-    r = {"bound": "hbm", "kernel": "fir_slice", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-         "frac": ach / HBM_PEAK_GBS,
-         # HBM bytes per launch come from separate rocprofv3 --pmc passes (profiles/r02_pmc_traffic.json,
-         # scripts/collect_profiles.sh); they cannot be measured inside this run
-         "traffic": None, "algorithmic_bytes_per_launch": alg}
-    if m["kernel_ms_isolated"]:
-        r["achieved_isolated"] = alg / (m["kernel_ms_isolated"]["fir_slice"] * 1e-3) / 1e9
+    km = {k: v for k, v in m["kernel_ms"].items() if v and v > 0}
+    dom = max(km, key=km.get)
+    ach = alg / (km[dom] * 1e-3) / 1e9
+    r = {"bound": "hbm", "kernel": dom, "kernel_ms": km[dom], "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+         "frac": ach / HBM_PEAK_GBS, "traffic": None, "algorithmic_bytes_per_launch": alg,
+         "why_this_kernel": "largest mean duration of the chain's kernels in the timed region (all of them process "
+                            "the same N x L samples per launch)"}
+    if "fir_slice" in km:
+        f = alg / (km["fir_slice"] * 1e-3) / 1e9
+        r["fir"] = {"kernel": "fir_slice", "kernel_ms": km["fir_slice"], "achieved": f, "frac": f / HBM_PEAK_GBS,
+                    "what": "the FIR/slicer launch: reads every sample once = 98 % of the chain's algorithmic bytes"}
+        if m.get("kernel_ms_isolated"):
+            r["fir"]["achieved_isolated"] = alg / (m["kernel_ms_isolated"]["fir_slice"] * 1e-3) / 1e9
+    if ms_per_step:
+        c = alg / (ms_per_step * 1e-3) / 1e9
+        r["chain"] = {"achieved": c, "frac": c / HBM_PEAK_GBS, "frac_of_measured_peak": c / MEASURED_HBM_GBS,
+                      "measured_peak": MEASURED_HBM_GBS, "ms_per_step": ms_per_step,
+                      "what": "N*L*2 bytes / ms_per_step of this line (whole chain, as the driver clocks it)"}
+    if traffic:
+        r["traffic"] = traffic.get("chain_bytes_per_call")
+        r["traffic_detail"] = traffic
     return r
+
+
+def pmc_traffic(args, config):
+    """HBM bytes per launch from the PMC counters, as MI355X_MICROARCH.md's HBM section prescribes: two separate
+    rocprofv3 passes (--pmc FETCH_SIZE, --pmc WRITE_SIZE, with --kernel-trace only) over a 6-step child run of this
+    same script; both counters are in KiB, FETCH_SIZE is doubled (gfx950 tallies 128-byte requests at 64 bytes)."""
+    import csv
+    import shutil
+    import subprocess
+    import tempfile
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return {"error": "rocprofv3 not found"}
+    child = [sys.executable, os.path.join(ROOT, "bench.py"), "--config", config, "--no-cpu", "--no-others", "--no-e2e",
+             "--no-traffic", "--steps", "6", "--warmup", "1", "--base", str(args.base)]
+    short = (("fir_sign", "fir_slice"), ("fir_slice", "fir_slice"), ("pll3_kernel", "pll"), ("pll_kernel", "pll"),
+             ("hdlc_events", "hdlc_deframe"), ("hdlc_deframe", "hdlc_deframe"), ("hdlc_crc", "hdlc_crc"))
+    env = dict(os.environ, TMPDIR="/tmp")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    res, raw = {}, {}
+    tmp = tempfile.mkdtemp(prefix="gnuais_pmc_", dir="/tmp")
+    try:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            d = os.path.join(tmp, counter)
+            cmd = [exe, "--kernel-trace", "--pmc", counter, "--output-format", "csv", "-d", d, "-o", "pmc", "--"] + child
+            try:
+                subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL,
+                               timeout=240, check=False)
+            except subprocess.TimeoutExpired:
+                return {"error": f"rocprofv3 --pmc {counter} timed out"}
+            acc = {}
+            for dp, _, fs in os.walk(d):
+                for f in fs:
+                    if not f.endswith("counter_collection.csv"):
+                        continue
+                    with open(os.path.join(dp, f)) as fh:
+                        for row in csv.DictReader(fh):
+                            name = next((s_ for pat, s_ in short if pat in row["Kernel_Name"]), None)
+                            if name and row["Counter_Name"] == counter:
+                                acc.setdefault(name, []).append(float(row["Counter_Value"]))
+            if not acc:
+                return {"error": f"no {counter} rows in the rocprofv3 output"}
+            raw[counter] = {k: sum(v) / len(v) for k, v in acc.items()}
+        for k in raw["FETCH_SIZE"]:
+            res[k] = (2.0 * raw["FETCH_SIZE"][k] + raw["WRITE_SIZE"].get(k, 0.0)) * 1024.0
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    return {"bytes_per_launch": res, "chain_bytes_per_call": sum(res.values()), "raw_kib_per_launch": raw,
+            "how": "rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE (separate passes) -- python bench.py --config "
+                   + config + " --no-cpu --no-others --no-e2e --no-traffic --steps 6 --warmup 1, launched by this run; "
+                   "KiB; FETCH_SIZE x 2 (gfx950 correction of MI355X_MICROARCH.md)"}
+
+
+def float_path(args, local, shapes=(("C2", 256, 48000), ("C3", 16384, 48000))):
+    """north_star's pre-slicer floats: gnuais_batch_filter() (the exact K1, bit-identical to filter_run_buf()) on the
+    BASELINE shapes, output [L][N] float32 written to HBM: ms per call, bytes = 2 read + 4 written per sample."""
+    import torch
+    from gnuais_amd import ReceiverBatch, synth, tile_channels
+    import ctypes as C
+    device = torch.device("cuda", local)
+    out = {}
+    for name, n_ch, total in shapes:
+        base, _ = synth.make_base_streams(min(args.base, n_ch), total, seed=synth.SEED)
+        x = tile_channels(torch.from_numpy(base).to(device), n_ch)
+        y = torch.empty((total, n_ch), dtype=torch.float32, device=device)
+        b = ReceiverBatch(n_ch, max_len=total, device=local)
+        stream = torch.cuda.current_stream(device).cuda_stream
+        def call():
+            rc = b._lib.gnuais_batch_filter(b._h, x.data_ptr(), total, y.data_ptr(), C.c_void_p(stream))
+            assert rc == 0
+        for _ in range(3):
+            call()
+        torch.cuda.synchronize()
+        n = 20
+        t0 = time.perf_counter()
+        for _ in range(n):
+            call()
+        torch.cuda.synchronize()
+        ms = (time.perf_counter() - t0) / n * 1e3
+        moved = n_ch * total * 6.0
+        out[name] = {"channels": n_ch, "samples_per_channel": total, "ms": ms, "Msamples_per_s": n_ch * total / ms / 1e3,
+                     "GB_per_s": moved / ms / 1e6, "frac_of_hbm_peak": moved / ms / 1e6 / HBM_PEAK_GBS,
+                     "bytes": "2 read + 4 written per sample"}
+        del b, x, y
+        torch.cuda.empty_cache()
+    out["what"] = ("gnuais_batch_filter(): the exact FIR (strict tap order, separate mul/add), floats bit-identical to "
+                   "filter_run_buf() (tests/test_hip_parity.py, tests/test_hip_fullsize.py), 20 calls back to back")
+    return out
 
 
 def rank_main(rank, local, world, args, sync):
@@ -312,7 +435,7 @@ def rank_main(rank, local, world, args, sync):
     if args.len:
         cfg = dict(cfg, len=args.len)
     want_cpu = rank == 0 and world == 1 and args.cpu and args.config == "C3"
-    m = measure(cfg, args, local, rank, sync, args.steps, args.warmup, post=(rank == 0 and args.e2e), keep_input=want_cpu)
+    m = measure(cfg, args, local, rank, sync, args.steps, args.warmup, post=(rank == 0), keep_input=want_cpu)
     x_cpu, x_wide = m.pop("x_cpu", None), m.pop("x_wide", None)
     per_rank = {"rank": rank, "device": local, "ms_per_step": m["dt_own"] / m["steps"] * 1e3}
     red = sync.reduce(m["dt"], m["msgs"], float(m["n_ch"]) * m["len"] * m["steps"], per_rank)
@@ -336,7 +459,10 @@ def rank_main(rank, local, world, args, sync):
         "per_gpu": ranks,
         "end_to_end": m.get("end_to_end"),
         "message_lines": m.get("message_lines"),
-        "roofline": roofline_of(m),
+        "roofline": roofline_of(m, dt / args.steps * 1e3,
+                                pmc_traffic(args, args.config) if (world == 1 and args.traffic) else None),
+        "float_path": float_path(args, local) if (world == 1 and args.e2e and args.config == "C3") else None,
+        "steady_state": m.get("steady_state"),
         "note": "the receive path slices the sign of the filter output and never stores the pre-slicer "
                 "floats; gnuais_batch_filter() produces them (bit-exact, tests/test_hip_parity.py)",
     }
@@ -350,8 +476,8 @@ def rank_main(rank, local, world, args, sync):
                             "valid_crc_msgs_per_s": o["msgs"] / o["dt"],
                             "x_realtime_channels": v / (CONFIGS[name]["rate"] / 1e6),
                             "kernel_ms": o["kernel_ms"], "kernel_ms_isolated": o["kernel_ms_isolated"],
-                            "dominant_kernel": max(o["kernel_ms_isolated"], key=o["kernel_ms_isolated"].get),
-                            "roofline": roofline_of(o)}
+                            "dominant_kernel": max(o["kernel_ms"], key=o["kernel_ms"].get),
+                            "roofline": roofline_of(o, o["dt"] / o["steps"] * 1e3)}
         out["other_configs"] = others
     if x_cpu is not None:
         out["cpu_baseline"] = cpu_baseline(x_cpu, args.cpu_channels, m["len"], x_wide)
@@ -377,6 +503,8 @@ def main():
     ap.add_argument("--devices", default="", help="comma list: device of each worker (default 0..N-1); "
                     "repeating a device runs several workers on it")
     ap.add_argument("--no-cpu", dest="cpu", action="store_false")
+    ap.add_argument("--no-traffic", dest="traffic", action="store_false",
+                    help="skip the rocprofv3 --pmc child runs that fill roofline.traffic")
     ap.add_argument("--no-e2e", dest="e2e", action="store_false",
                     help="skip the message-layer legs (message_lines, end_to_end): for profile runs of the chain alone")
     ap.add_argument("--no-others", dest="others", action="store_false",

@@ -143,6 +143,7 @@ struct gnuais_batch {
     size_t pin_bytes = 0;
     hipStream_t s_io = nullptr;
     hipEvent_t e_in[2] = {nullptr, nullptr};    // the FIR of the call that used staging pair q is done
+    hipEvent_t e_in_hook = nullptr;             // run_host_async -> run: record this right behind K1
     unsigned long long host_calls = 0;
     // options
     int fir_T = 512;
@@ -264,6 +265,14 @@ int gnuais_batch_create(gnuais_batch **out, int device, int n_channels, const fl
     if (ndev <= 0) return fail(GNUAIS_E_HIP, "create: no HIP device");
     if (device < 0 || device >= ndev) return fail(GNUAIS_E_ARG, "create: device index");
     HIP_TRY(hipSetDevice(device));
+    {   // the PLL stage keeps its position lists and bit packs in LDS (PLL_NEED_LDS, about 116 KB per workgroup) and
+        // is compiled for gfx950's wave and LDS sizes only
+        int lds = 0;
+        if (hipDeviceGetAttribute(&lds, hipDeviceAttributeMaxSharedMemoryPerBlock, device) == hipSuccess &&
+            lds < pll_need_lds())
+            return fail(GNUAIS_E_HIP, "create: the device offers too little LDS per workgroup (gfx950 / MI355X with "
+                                      "160 KB is what this library is built for)");
+    }
     HIP_TRY(pll_prepare_device());              // per device: the PLL stage's LDS reservation
 
     gnuais_batch *b = new gnuais_batch;
@@ -499,6 +508,24 @@ int gnuais_batch_set_option(gnuais_batch *b, const char *name, int value)
         b->fir_T = value;
     } else if (!strcmp(name, "fir_map")) {
         b->fir_map = value;
+    } else if (!strcmp(name, "streaming")) {
+        // 0: leave the streamed delivery (gnuais_batch_stream_nmea / autotune_delivery switch it on): everything in
+        // flight is flushed and DROPPED, K3 goes back to ring 0, the drain-type calls work again.  The rings, texts
+        // and streams stay allocated for the next streaming call.
+        if (value != 0) return fail(GNUAIS_E_ARG, "streaming can only be switched off here (stream_nmea switches it on)");
+        if (b->streaming) {
+            if (int rc = gnuais_batch_sync(b)) return rc;
+            HIP_TRY(hipDeviceSynchronize());
+            for (int q = 0; q < gnuais_batch::NRING; ++q) {
+                if (b->ring_count[q]) HIP_TRY(hipMemset(b->ring_count[q], 0, sizeof(uint32_t) * 4));
+                b->s_stage[q] = 0;
+                b->ring_runs[q] = 0;
+            }
+            b->ring_cur = 0;
+            b->stream_calls = 0;
+            b->hdlc_calls = 0;
+            b->streaming = false;
+        }
     } else if (!strcmp(name, "fir_T2")) {
         if (value < 0 || value % 32) return fail(GNUAIS_E_ARG, "fir_T2 must be a multiple of 32 (0: off)");
         b->fir_T2 = value;
@@ -695,6 +722,10 @@ int gnuais_batch_run(gnuais_batch *b, const int16_t *d_samples, int len, void *s
         if (b->stage_mask & 1)
             if (int rc = run_fir(b, d_samples, len, nullptr, s0, k)) return rc;
         if (tm) HIP_TRY(hipEventRecord(ev[1], s0));
+        if (b->e_in_hook) {                     // run_host_async: its staging pair is free once K1 has read it --
+            HIP_TRY(hipEventRecord(b->e_in_hook, s0));      // also when the whole chain runs on this one stream
+            b->e_in_hook = nullptr;
+        }
         if (pl) HIP_TRY(hipEventRecord(b->e_done[0][k], s0));
         // K2: this call's sign words -> bit packs segbits[k] (read by K2b of call i-NBUF); in order
         // across calls (it carries the receivers' pll / prev / lastbit)
@@ -939,11 +970,14 @@ int gnuais_batch_run_host_async(gnuais_batch *b, const int16_t *h_samples, int l
     if (b->host_calls >= 2) HIP_TRY(hipEventSynchronize(b->e_in[q]));
     memcpy(b->pin[q], h_samples, bytes);
     HIP_TRY(hipMemcpyAsync(b->dev_in[q], b->pin[q], bytes, hipMemcpyHostToDevice, b->s_io));
-    if (int rc = gnuais_batch_run(b, b->dev_in[q], len, b->s_io)) return rc;
-    // K1 is the only reader of the input and runs on s_io itself
-    HIP_TRY(hipEventRecord(b->e_in[q], b->s_io));
-    b->host_calls++;
-    return GNUAIS_OK;
+    b->e_in_hook = b->e_in[q];                  // recorded right behind K1 (run_chain): K1 is the input's only reader
+    const int rc = gnuais_batch_run(b, b->dev_in[q], len, b->s_io);
+    if (b->e_in_hook) {                         // the run failed before its K1: whatever s_io holds (the copy) guards the pair
+        b->e_in_hook = nullptr;
+        (void) hipEventRecord(b->e_in[q], b->s_io);
+    }
+    b->host_calls++;                            // also after a failed run: the copy from pin[q] may still be in flight
+    return rc;
 }
 
 int gnuais_batch_filter(gnuais_batch *b, const int16_t *d_samples, int len, float *d_out,
@@ -1052,6 +1086,10 @@ static int ensure_post_buffers(gnuais_batch *b, uint32_t have)
 static int drain_impl(gnuais_batch *b, gnuais_frame *h_frames, int max_frames, int *n_frames,
                       uint8_t *seqnr, char *out, size_t out_cap, size_t *out_len, int *n_sentences)
 {
+    // a streaming batch spreads its frames over NRING rings that gnuais_batch_stream_nmea() consumes: ring 0 alone
+    // would be a partial view, and clearing its counters would lose frames and error flags
+    if (b->streaming) return fail(GNUAIS_E_STATE, "drain: the batch is streaming (gnuais_batch_stream_nmea); "
+                                                  "set_option(\"streaming\", 0) leaves that mode");
     if (int rc = gnuais_batch_sync(b)) return rc;
     uint32_t cnt[4] = {0, 0, 0, 0};
     HIP_TRY(hipMemcpy(cnt, b->frame_count, sizeof cnt, hipMemcpyDeviceToHost));
@@ -1243,32 +1281,42 @@ int gnuais_batch_stream_nmea(gnuais_batch *b, const char **text, size_t *len, in
     constexpr int NR = gnuais_batch::NRING;
     const size_t N = (size_t) b->N;
     const size_t text_cap = (size_t) b->frame_cap * 164;        // a full ring of two-sentence frames
-    if (!b->streaming) {                        // first use: the other rings, streams, events
+    if (!b->streaming) {                        // first use (or back from set_option("streaming", 0))
         if (int rc = gnuais_batch_sync(b)) return rc;
+        // every object is created only if it does not exist yet: a first use that failed half way (e.g. the pinned
+        // allocation) is repeated by the next call without leaking what the failed one had made
         b->ring[0] = b->frames;
         b->ring_count[0] = b->frame_count;
         for (int q = 1; q < NR; ++q) {
-            HIP_TRY(hipMalloc((void **) &b->ring[q], sizeof(gnuais_frame) * (size_t) b->frame_cap));
-            HIP_TRY(hipMalloc((void **) &b->ring_count[q], sizeof(uint32_t) * 4));
-            HIP_TRY(hipMemset(b->ring_count[q], 0, sizeof(uint32_t) * 4));
+            if (!b->ring[q]) HIP_TRY(hipMalloc((void **) &b->ring[q], sizeof(gnuais_frame) * (size_t) b->frame_cap));
+            if (!b->ring_count[q]) {
+                HIP_TRY(hipMalloc((void **) &b->ring_count[q], sizeof(uint32_t) * 4));
+                HIP_TRY(hipMemset(b->ring_count[q], 0, sizeof(uint32_t) * 4));
+            }
         }
         b->n_chunks = k3_blocks(b->N) * k3_passes(b->cand_K);
+        b->sh_text_want = std::max(b->sh_text_want, ((size_t) b->frame_cap * 32 + 65536) & ~(size_t) 15);
         for (int q = 0; q < NR; ++q) {
-            HIP_TRY(hipMalloc((void **) &b->ring_chunks[q], sizeof(uint2) * (size_t) b->n_chunks));
+            if (!b->ring_chunks[q]) HIP_TRY(hipMalloc((void **) &b->ring_chunks[q], sizeof(uint2) * (size_t) b->n_chunks));
             b->ring_runs[q] = 2;                // whatever ring 0 holds by now came without a table
-            HIP_TRY(hipMalloc((void **) &b->sd_text[q], text_cap));
-            b->sd_text_bytes[q] = text_cap;
-            HIP_TRY(hipEventCreateWithFlags(&b->e_fill[q], hipEventDisableTiming));
-            HIP_TRY(hipEventCreateWithFlags(&b->e_fmt[q], hipEventDisableTiming));
-            HIP_TRY(hipEventCreateWithFlags(&b->e_txt[q], hipEventDisableTiming));
+            if (!b->sd_text[q]) {
+                HIP_TRY(hipMalloc((void **) &b->sd_text[q], text_cap));
+                b->sd_text_bytes[q] = text_cap;
+            }
+            if (!b->e_fill[q]) HIP_TRY(hipEventCreateWithFlags(&b->e_fill[q], hipEventDisableTiming));
+            if (!b->e_fmt[q]) HIP_TRY(hipEventCreateWithFlags(&b->e_fmt[q], hipEventDisableTiming));
+            if (!b->e_txt[q]) HIP_TRY(hipEventCreateWithFlags(&b->e_txt[q], hipEventDisableTiming));
             // pinned text: a fifth of the worst case to begin with (single-sentence frames of average
             // length fill it to about a third); a slot whose text does not fit grows, see (3)
-            b->sh_text_want = ((size_t) b->frame_cap * 32 + 65536) & ~(size_t) 15;
-            HIP_TRY(hipHostMalloc((void **) &b->sh_text[q], b->sh_text_want, hipHostMallocDefault));
-            b->sh_text_bytes[q] = b->sh_text_want;
+            if (!b->sh_text[q]) {
+                HIP_TRY(hipHostMalloc((void **) &b->sh_text[q], b->sh_text_want, hipHostMallocDefault));
+                b->sh_text_bytes[q] = b->sh_text_want;
+            }
         }
-        HIP_TRY(hipMalloc((void **) &b->sd_info, sizeof(uint32_t) * 8 * NR));
-        HIP_TRY(hipMemset(b->sd_info, 0, sizeof(uint32_t) * 8 * NR));
+        if (!b->sd_info) {
+            HIP_TRY(hipMalloc((void **) &b->sd_info, sizeof(uint32_t) * 8 * NR));
+            HIP_TRY(hipMemset(b->sd_info, 0, sizeof(uint32_t) * 8 * NR));
+        }
         if (const char *v = getenv("GNUAIS_COPY_WGS")) b->copy_wgs = std::max(1, atoi(v));
         if (const char *v = getenv("GNUAIS_COPY_ON_K3")) b->copy_on_k3 = atoi(v) != 0;
         const size_t need_scratch = nmea_scratch_bytes(b->frame_cap, b->n_chunks);
@@ -1279,7 +1327,8 @@ int gnuais_batch_stream_nmea(gnuais_batch *b, const char **text, size_t *len, in
             HIP_TRY(hipMalloc(&b->nmea_scratch, need_scratch));
             b->nmea_scratch_bytes = need_scratch;
         }
-        {   // The formatter's kernels go onto K3's stream: they are small, K3's stream is idle most of a call,
+        if (!b->s_copy) {
+            // The formatter's kernels go onto K3's stream: they are small, K3's stream is idle most of a call,
             // and every further stream is one more tenant for the few hardware queues (a formatter stream
             // that shares its queue with a stage serialises with it: 0.8 or 1.5 ms per call, by luck).
             // Only the copy, which lasts as long as PCIe needs, has a stream of its own.
@@ -1287,12 +1336,15 @@ int gnuais_batch_stream_nmea(gnuais_batch *b, const char **text, size_t *len, in
             HIP_TRY(hipDeviceGetStreamPriorityRange(&lo, &hi));
             HIP_TRY(hipStreamCreateWithPriority(&b->s_copy, hipStreamNonBlocking, hi));
         }
-        HIP_TRY(hipHostMalloc((void **) &b->sh_info, sizeof(uint32_t) * 8 * NR, hipHostMallocDefault));
-        memset(b->sh_info, 0, sizeof(uint32_t) * 8 * NR);
-        for (auto &p : b->sd_seq) {
-            HIP_TRY(hipMalloc((void **) &p, N));
-            HIP_TRY(hipMemset(p, 0, N));
+        if (!b->sh_info) {
+            HIP_TRY(hipHostMalloc((void **) &b->sh_info, sizeof(uint32_t) * 8 * NR, hipHostMallocDefault));
+            memset(b->sh_info, 0, sizeof(uint32_t) * 8 * NR);
         }
+        for (auto &p : b->sd_seq)
+            if (!p) {
+                HIP_TRY(hipMalloc((void **) &p, N));
+                HIP_TRY(hipMemset(p, 0, N));
+            }
         HIP_TRY(hipDeviceSynchronize());
         b->streaming = true;
     }
@@ -1383,6 +1435,7 @@ int gnuais_batch_stream_nmea(gnuais_batch *b, const char **text, size_t *len, in
 int gnuais_batch_pending_frames(gnuais_batch *b, int *n_out)
 {
     if (!b || !n_out) return fail(GNUAIS_E_ARG, "pending_frames: argument");
+    if (b->streaming) return fail(GNUAIS_E_STATE, "pending_frames: the batch is streaming (gnuais_batch_stream_nmea)");
     if (int rc = gnuais_batch_sync(b)) return rc;
     uint32_t cnt[4] = {0, 0, 0, 0};
     HIP_TRY(hipMemcpy(cnt, b->frame_count, sizeof cnt, hipMemcpyDeviceToHost));
@@ -1393,6 +1446,7 @@ int gnuais_batch_pending_frames(gnuais_batch *b, int *n_out)
 int gnuais_batch_discard_frames(gnuais_batch *b, void *stream)
 {
     if (!b) return fail(GNUAIS_E_ARG, "discard_frames: NULL batch");
+    if (b->streaming) return fail(GNUAIS_E_STATE, "discard_frames: the batch is streaming (gnuais_batch_stream_nmea)");
     if (int rc = set_device(b)) return rc;
     hipStream_t s = b->pipeline ? b->s_k[3] : (hipStream_t) stream;   // behind the last K3
     HIP_TRY(hipMemsetAsync(b->frame_count, 0, sizeof(uint32_t) * 3, s));

@@ -65,6 +65,7 @@ struct PllLaunch {
     int n_cu;              // compute units of the batch's device
     int variant = 0;       // 0: by channel count; 3 / 6: the three- / six-wave form
 };
+int pll_need_lds();                                                      // bytes of LDS a PLL workgroup cannot do without
 hipError_t pll_prepare_device();                                         // once per device, after hipSetDevice
 hipError_t launch_pll(const PllLaunch &a, hipStream_t stream);           // K2
 

@@ -481,6 +481,8 @@ __global__ __launch_bounds__(64 * PLL_WAVES) __attribute__((amdgpu_waves_per_eu(
 hipError_t pll3_prepare_device();
 hipError_t launch_pll3(const PllLaunch &a, hipStream_t stream);
 
+int pll_need_lds() { return PLL_NEED_LDS; }
+
 hipError_t pll_prepare_device()
 {
     const hipError_t e = pll3_prepare_device();

@@ -14,7 +14,7 @@ from typing import Optional
 import numpy as np
 
 from . import lib as _lib
-from .lib import COUNTERS_DTYPE, FRAME_DTYPE, FSM_DTYPE, PLL_DTYPE, check
+from .lib import COUNTERS_DTYPE, E_OVERFLOW, FRAME_DTYPE, FSM_DTYPE, OK, PLL_DTYPE, GnuaisError, check
 
 
 def _is_torch(x) -> bool:
@@ -40,6 +40,8 @@ class ReceiverBatch:
                                             frame_capacity))
         self.n_channels = n_channels
         self.n_taps = self._lib.gnuais_batch_n_taps(self._h)
+        self.on_overflow = "raise"        # stream_nmea(): "keep" returns an overflowed slot's text and counts it
+        self.stream_overflows = 0
         self.max_len = max_len
         self.device = device
 
@@ -194,12 +196,24 @@ class ReceiverBatch:
         call self.stream_depth calls ago -- frames == -1 while the pipeline fills.  copy=False returns a
         uint8 view of the library's pinned buffer (valid until the next call) instead of bytes."""
         ptr, ln, ns, nf = C.c_void_p(), C.c_size_t(0), C.c_int(0), C.c_int(0)
-        check(self._lib.gnuais_batch_stream_nmea(self._h, C.cast(C.byref(ptr), C.POINTER(C.c_char_p)), C.byref(ln),
-                                                 C.byref(ns), C.byref(nf)))
-        if not ln.value:
-            return (b"" if copy else np.zeros(0, dtype=np.uint8)), ns.value, nf.value
-        view = np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_uint8)), shape=(ln.value,))
-        return (view.tobytes() if copy else view), ns.value, nf.value
+        rc = self._lib.gnuais_batch_stream_nmea(self._h, C.cast(C.byref(ptr), C.POINTER(C.c_char_p)), C.byref(ln),
+                                                C.byref(ns), C.byref(nf))
+        # A slot's LATE error (its frame ring overflowed, a PLL-stage watchdog) comes with that slot's text: the text
+        # that did fit is handed out and the pipeline goes on.  Build the result first, then raise with it attached
+        # (GnuaisError.partial) -- or, for an overflow with on_overflow="keep", return it and count the event.
+        if ln.value:
+            view = np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_uint8)), shape=(ln.value,))
+            res = ((view.tobytes() if copy else view), ns.value, nf.value)
+        else:
+            res = ((b"" if copy else np.zeros(0, dtype=np.uint8)), ns.value, nf.value)
+        if rc != OK:
+            if rc == E_OVERFLOW and self.on_overflow == "keep":
+                self.stream_overflows += 1
+                return res
+            err = GnuaisError(rc, self._lib.gnuais_last_error().decode())
+            err.partial = res
+            raise err
+        return res
 
     def fold_vessels(self) -> np.ndarray:
         """gnuais_batch_fold_vessels(): the vessel table of the queued frames (gnuais_vessel per MMSI, sorted),

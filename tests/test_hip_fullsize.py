@@ -95,6 +95,64 @@ def test_c2_exact_shape_bits_and_state():
     assert np.array_equal(b.maxval(), r["maxval"])
 
 
+# ---------------------------------------------------------------- the pre-slicer floats at BASELINE shapes
+
+@pytest.mark.parametrize("name,n_ch,total,sps,n_check", [("C2", 256, 48000, 5, 256), ("C3", 16384, 48000, 5, 512),
+                                                         ("C5", 16384, 192000, 20, 512)])
+def test_filter_floats_at_baseline_shapes(name, n_ch, total, sps, n_check):
+    """north_star's "pre-slicer filter floats": gnuais_batch_filter() (the exact kernel) at C2's full shape and on 512
+    channels spread over C3 / C5, every float compared with the oracle's filter_run_buf() as a raw 32-bit pattern
+    (tolerance 0; north_star allows 1e-5 relative), plus maxval."""
+    import torch
+    from gnuais_amd import tile_channels
+    k = min(256, n_ch)
+    base, _ = synth.make_base_streams(k, total, sps=sps, seed=73)
+    xb = tile_channels(dev(base), n_ch)
+    kw = dict(taps=params.taps_192k(), pllinc=params.PLLINC_192K) if name == "C5" else {}
+    b = batch(n_ch, max_len=total, **kw)
+    y = b.filter(xb)
+    pick = np.unique(np.linspace(0, n_ch - 1, n_check).astype(np.int64))
+    xs = np.ascontiguousarray(xb[:, torch.from_numpy(pick).to(xb.device)].cpu().numpy())
+    okw = {"taps": params.taps_192k(), "pllinc": params.PLLINC_192K} if name == "C5" else {}
+
+    def part(lo_hi):                                # the oracle's float output is single-threaded: one oracle per slice
+        lo, hi = lo_hi
+        r_ = Oracle(hi - lo, **okw).run(np.ascontiguousarray(xs[:, lo:hi]), want_filtered=True)
+        return r_["filtered"], r_["maxval"]
+    from concurrent.futures import ThreadPoolExecutor
+    nt = max(1, min(host_threads(), len(pick) // 16))
+    cuts = np.linspace(0, len(pick), nt + 1).astype(int)
+    with ThreadPoolExecutor(nt) as ex:
+        parts = list(ex.map(part, zip(cuts[:-1], cuts[1:])))
+    want = np.concatenate([p_[0] for p_ in parts], axis=1)
+    want_max = np.concatenate([p_[1] for p_ in parts])
+    got = y[:, torch.from_numpy(pick).to(y.device)].cpu().numpy()
+    assert got.dtype == np.float32 and want.dtype == np.float32 and got.shape == want.shape
+    assert np.array_equal(got.view(np.uint32), np.ascontiguousarray(want).view(np.uint32))
+    assert np.array_equal(b.maxval()[pick], want_max)
+
+
+@pytest.mark.parametrize("cpl,form", [(2, 0x01), (2, 0x85), (4, 0x85)])
+def test_wide_slicer_equals_the_one_channel_per_lane_kernel_at_c3(cpl, form):
+    """K1s with 2 / 4 adjacent channels per lane (fir_sign_wide.hip, option fir_cpl; typed 16_16 loads or raw packed
+    loads two groups ahead, packed fp32): frames, counters, PLL carry and peaks of C3's 16384 x 48000 equal the default
+    kernel's, two calls (the second ragged, on the carried state)."""
+    from gnuais_amd import tile_channels
+    n_ch, total = 16384, 48000
+    base, _ = synth.make_base_streams(256, total, seed=74)
+    xb = tile_channels(dev(base), n_ch)
+    a, b = batch(n_ch, max_len=total), batch(n_ch, max_len=total)
+    b.set_option("fir_cpl", cpl)
+    b.set_option("fir_form", form)
+    for lo, hi in ((0, total), (777, 23456)):
+        a.run(xb[lo:hi])
+        b.run(xb[lo:hi])
+        assert a.drain_frames().tobytes() == b.drain_frames().tobytes()
+        assert np.array_equal(counters_of(a), counters_of(b)) and pll_of(a) == pll_of(b)
+        assert np.array_equal(a.maxval(), b.maxval())
+        assert np.array_equal(a.history(), b.history())
+
+
 # ---------------------------------------------------------------- C5: full size
 
 def test_c5_full_size():

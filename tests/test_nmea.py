@@ -162,6 +162,56 @@ def test_nmea_of_device_chain_frames():
 
 
 @pytest.mark.gpu
+def test_device_formatters_directly_against_the_golden_text():
+    """The DEVICE formatters pinned to the reference without the host formatter in between: full chain on the GPU,
+    then gnuais_batch_drain_messages() / gnuais_batch_drain_nmea() / the streamed path -- sentences and stdout lines
+    formatted on the device -- against the text the reference itself printed for the same input (nmea.npz), and the
+    golden frames of all 24 message types (sorted into print order, re-sent through the device deframer) against the
+    reference's text for them."""
+    import torch
+    from gnuais_amd import ReceiverBatch, synth
+    g = np.load(os.path.join(G, "nmea.npz"))
+    for name in ("chain_48k", "chain_long"):
+        x = np.load(os.path.join(G, name + ".npz"))["x"]
+        xd = torch.from_numpy(np.ascontiguousarray(x)).cuda()
+        n_ch = x.shape[1]
+        b = ReceiverBatch(n_ch, max_len=x.shape[0])
+        b.run(xd)
+        seq = np.zeros(n_ch, dtype=np.uint8)
+        nm, tx, n_sent, n_lines, n_frames = b.drain_messages(seq)
+        assert nm == g[name + "_text"].tobytes() and tx == g[name + "_stdout"].tobytes()
+        assert np.array_equal(seq, g[name + "_seqnr"]) and n_frames > 0
+        b2 = ReceiverBatch(n_ch, max_len=x.shape[0])
+        b2.run(xd)
+        seq2 = np.zeros(n_ch, dtype=np.uint8)
+        assert b2.drain_nmea(seq2)[0] == g[name + "_text"].tobytes() and np.array_equal(seq2, seq)
+        b3 = ReceiverBatch(n_ch, max_len=x.shape[0])            # streamed: handed out stream_depth calls later
+        b3.run(xd)
+        texts = [b3.stream_nmea()[0] for _ in range(b3.stream_depth + 1)]
+        assert b"".join(texts) == g[name + "_text"].tobytes()
+    # every message type: the golden frames in the reference's print order (stable by channel)
+    gold = np.frombuffer(np.ascontiguousarray(g["synthetic_frames"]).tobytes(), dtype=FRAME_DTYPE)
+    n_ch = int(g["synthetic_nch"][0])
+    keep = gold[(gold["nbits"] >= 8) & (gold["nbits"] % 8 == 0)]
+    keep = keep[np.argsort(keep["channel"], kind="stable")]
+    from gnuais_amd import messages_from_frames
+    want_nm, want_tx = messages_from_frames(keep, np.zeros(n_ch, dtype=np.uint8))     # == reference: test_stdout_text_golden
+    streams = [[np.zeros(8, dtype=np.uint8)] for _ in range(n_ch)]
+    for f in keep:
+        streams[int(f["channel"])].append(synth.hdlc_frame_bits(bytes(f["payload"][: int(f["nbits"]) // 8]), training_bits=24))
+        streams[int(f["channel"])].append(np.zeros(5, dtype=np.uint8))
+    b = ReceiverBatch(n_ch, max_len=48000)
+    b.decode_bits([np.concatenate(s_).astype(np.uint8) for s_ in streams])
+    nm, tx, _, _, n_frames = b.drain_messages(np.zeros(n_ch, dtype=np.uint8))
+    assert n_frames == len(keep) > 500 and nm == want_nm and tx == want_tx
+    # and those lines are the reference's own: the golden stdout holds each of them verbatim
+    ref_lines = set(g["synthetic_stdout"].tobytes().split(b"\n"))
+    body = lambda l: l.split(b" (!AIVDM")[0]                     # the sequence digit differs with the order
+    ref_bodies = {body(l) for l in ref_lines}
+    assert all(body(l) in ref_bodies for l in tx.split(b"\n") if l)
+
+
+@pytest.mark.gpu
 def test_wav_file_to_sentences_end_to_end(tmp_path):
     """f2 + hot path + f1: a stereo WAV of the golden input, read properly, decodes to the golden
     sentences whatever the call size."""
