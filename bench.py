@@ -16,10 +16,11 @@ input resident in HBM.  Workloads (BASELINE.json configs):
 measures the other two briefly and reports them under "other_configs".
 
 Channels shard embarrassingly over GPUs (weak scaling, no data-path collective):
-`--gpus N` starts one worker process per device -- N independent batches, nothing
-shared but a start/stop barrier -- unless the process was launched by
-torch.distributed.run, in which case the ranks it created are used and RCCL
-provides the barrier and the max-over-ranks time.
+`--gpus N` started plainly runs ONE process that drives every device through the library's
+node object (gnuais_node_*: a batch and a host thread per device, merged results);
+`--gpus N --procs` starts one worker process per device instead -- N independent batches,
+nothing shared but a start/stop barrier; launched by torch.distributed.run, the ranks it
+created are used and RCCL provides the barrier and the max-over-ranks time.
 
 Prints ONE JSON line on rank 0.
 """
@@ -484,6 +485,71 @@ def rank_main(rank, local, world, args, sync):
     print(json.dumps(out), flush=True)
 
 
+def node_main(world, args):
+    """--gpus N started plainly: ONE process, the library's node object (gnuais_node_*, gnuais_amd/csrc/node.hip) --
+    a batch and a host thread per device inside the library, 16384 channels per device (weak scaling), every step one
+    gnuais_node_run() over device-resident slabs; nothing is exchanged between devices."""
+    import torch
+    from gnuais_amd import ReceiverNode, params, synth, tile_channels
+    cfg = CONFIGS[args.config]
+    if args.channels:
+        cfg = dict(cfg, channels=args.channels)
+    if args.len:
+        cfg = dict(cfg, len=args.len)
+    devs = [int(d) for d in args.devices.split(",")] if args.devices else list(range(world))
+    devs = [devs[g % len(devs)] for g in range(world)]
+    per, total = cfg["channels"], cfg["len"]
+    kw = dict(taps=params.taps_192k(), pllinc=params.PLLINC_192K) if cfg["wide"] else {}
+    node = ReceiverNode(per * world, devices=devs, max_len=total, **kw)
+    slabs = []
+    for g, (d, first, n) in enumerate(node.shards):
+        base, _ = synth.make_base_streams(min(args.base, n), total, seed=synth.SEED + g, sps=cfg["sps"])
+        with torch.cuda.device(d):
+            slabs.append(tile_channels(torch.from_numpy(base).to(f"cuda:{d}"), n))
+    for d in set(devs):
+        torch.cuda.synchronize(d)
+    node.autotune(slabs)
+    node.set_option("stage_mask", cfg["stage_mask"])
+
+    def step():
+        node.run(slabs)
+        node.discard_frames()
+    for _ in range(args.warmup):
+        step()
+    node.sync()
+    rx0 = node.total_received()
+    for d in set(devs):
+        torch.cuda.synchronize(d)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    node.sync()
+    for d in set(devs):
+        torch.cuda.synchronize(d)
+    dt = time.perf_counter() - t0
+    msgs = node.total_received() - rx0
+    samples = float(per) * world * total * args.steps
+    value = samples / dt / 1e6
+    alg = per * world * total * 2.0
+    c = alg / (dt / args.steps) / 1e9
+    out = {"metric": "Msamples/s demodulated (N-channel batch, " + ("full chain" if cfg["stage_mask"] == 0x1f else "FIR + receiver") + ")",
+           "value": value, "unit": "Msamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+           "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+           "dtype": "f32 FIR on int16 samples; u32 PLL/HDLC/CRC", "data": "synthetic",
+           "config": {"workload": cfg["what"], "channels_per_gpu": per, "samples_per_channel": total,
+                      "parallelism": f"channels in {world} contiguous blocks over device(s) {devs}, one process, one host "
+                                     "thread + batch per device (gnuais_node_*), no collectives"},
+           "valid_crc_msgs_per_s": msgs / dt, "x_realtime_channels": value / (cfg["rate"] / 1e6),
+           "per_gpu": [{"shard": g, "device": d, "first_channel": f, "channels": n} for g, (d, f, n) in enumerate(node.shards)],
+           "roofline": {"bound": "hbm", "kernel": "chain (all devices)", "achieved": c, "peak": HBM_PEAK_GBS * len(set(devs)),
+                        "unit": "GB/s", "frac": c / (HBM_PEAK_GBS * len(set(devs))), "traffic": None,
+                        "algorithmic_bytes_per_launch": alg,
+                        "what": "N*L*2 bytes of all shards / ms_per_step against 8 TB/s per distinct device; per-kernel "
+                                "figures come from the single-GPU line"}}
+    node.close()
+    print(json.dumps(out), flush=True)
+
+
 def _worker(rank, world, args, barrier, queue):
     devs = [int(d) for d in args.devices.split(",")] if args.devices else list(range(world))
     rank_main(rank, devs[rank % len(devs)], world, args, LocalSync(rank, world, barrier, queue))
@@ -502,6 +568,8 @@ def main():
                     help="channels of the batch the single-core CPU baseline runs (about 13 s of CPU work)")
     ap.add_argument("--devices", default="", help="comma list: device of each worker (default 0..N-1); "
                     "repeating a device runs several workers on it")
+    ap.add_argument("--procs", action="store_true",
+                    help="--gpus N as N worker processes (one per device) instead of the in-process node object")
     ap.add_argument("--no-cpu", dest="cpu", action="store_false")
     ap.add_argument("--no-traffic", dest="traffic", action="store_false",
                     help="skip the rocprofv3 --pmc child runs that fill roofline.traffic")
@@ -528,6 +596,9 @@ def main():
     world = max(1, args.gpus)
     if world == 1:
         rank_main(0, 0, 1, args, LocalSync(0, 1, None, None))
+        return
+    if not args.procs:
+        node_main(world, args)                  # one process: the library's node object drives every device
         return
     # one worker process per device (receivers share nothing, src/ais.c:141-147):
     # independent batches and launches, a barrier around the timed region, no process group

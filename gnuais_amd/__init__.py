@@ -15,4 +15,7 @@ def __getattr__(name):
     if name in ("ReceiverBatch", "crc16_batch", "tile_channels", "nmea_from_frames", "messages_from_frames", "range_from_frames", "vessels_from_frames", "VESSEL_DTYPE"):
         from . import receiver
         return getattr(receiver, name)
+    if name == "ReceiverNode":
+        from .shard import ReceiverNode
+        return ReceiverNode
     raise AttributeError(name)

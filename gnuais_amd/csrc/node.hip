@@ -1,0 +1,380 @@
+// node.hip -- the receivers of one node: N channels split into contiguous blocks over the node's GPUs.
+//
+// gnuais creates its receivers one by one and they share nothing (src/ais.c:141-147); the main loop hands every
+// receiver the same interleaved buffer (src/ais.c:237-247).  A node object is that for many devices: device g owns
+// channels [first_g, first_g + n_g) as one gnuais_batch of its own, every device has ONE host thread that issues
+// its copies and launches (hipSetDevice is per thread) on the batch's own streams, and nothing is exchanged
+// between devices -- no collective, no peer copy.  What comes back is merged on the host: frame records with
+// GLOBAL channel numbers in the reference's order (channel, then time), counters per global channel.
+//
+// Built on the public batch ABI only (include/gnuais_hip.h); the HIP runtime is used for the host-buffer split
+// (a strided 2-D copy per device) and nothing else.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string.h>
+
+#include <algorithm>
+#include <condition_variable>
+#include <functional>
+#include <mutex>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "../../include/gnuais_hip.h"
+
+namespace {
+
+struct Worker {
+    std::thread th;
+    std::mutex m;
+    std::condition_variable cv;
+    std::function<int()> job;
+    bool has_job = false, done = true, quit = false;
+    int rc = GNUAIS_OK;
+    std::string err;
+
+    void loop()
+    {
+        for (;;) {
+            std::function<int()> j;
+            {
+                std::unique_lock<std::mutex> l(m);
+                cv.wait(l, [&] { return has_job || quit; });
+                if (quit) return;
+                j = std::move(job);
+                has_job = false;
+            }
+            const int r = j();
+            std::string e = r != GNUAIS_OK ? std::string(gnuais_last_error()) : std::string();   // thread-local text
+            {
+                std::lock_guard<std::mutex> l(m);
+                rc = r;
+                err = std::move(e);
+                done = true;
+            }
+            cv.notify_all();
+        }
+    }
+    void submit(std::function<int()> j)
+    {
+        {
+            std::lock_guard<std::mutex> l(m);
+            job = std::move(j);
+            has_job = true;
+            done = false;
+        }
+        cv.notify_all();
+    }
+    int wait()
+    {
+        std::unique_lock<std::mutex> l(m);
+        cv.wait(l, [&] { return done; });
+        return rc;
+    }
+};
+
+struct Shard {
+    int device = 0, first = 0, n = 0;
+    gnuais_batch *b = nullptr;
+    int16_t *d_in[2] = {nullptr, nullptr};      // run_host: the shard's [len][n] slab, double-buffered
+    hipStream_t s_in = nullptr;
+    hipEvent_t e_free[2] = {nullptr, nullptr};  // the FIR that read d_in[q] is done (recorded behind the run on s_in)
+    unsigned long long host_calls = 0;
+    Worker w;
+};
+
+thread_local std::string g_node_err;
+
+int node_fail(int code, const std::string &what)
+{
+    g_node_err = what;
+    return code;
+}
+
+} // namespace
+
+struct gnuais_node {
+    int N = 0, max_len = 0;
+    std::vector<Shard *> shards;
+    std::vector<gnuais_frame> scratch;
+};
+
+extern "C" {
+
+const char *gnuais_node_last_error(void) { return g_node_err.c_str(); }
+
+static int run_all(gnuais_node *nd, const std::function<int(Shard &)> &f)
+{
+    for (Shard *s : nd->shards) s->w.submit([s, &f] { return f(*s); });
+    int rc = GNUAIS_OK;
+    for (Shard *s : nd->shards) {
+        const int r = s->w.wait();
+        if (r != GNUAIS_OK && rc == GNUAIS_OK) {
+            rc = r;
+            g_node_err = "device " + std::to_string(s->device) + " (channels " + std::to_string(s->first) + ".." +
+                         std::to_string(s->first + s->n - 1) + "): " + s->w.err;
+        }
+    }
+    return rc;
+}
+
+void gnuais_node_destroy(gnuais_node *nd)
+{
+    if (!nd) return;
+    for (Shard *s : nd->shards) {
+        if (s->w.th.joinable()) {
+            s->w.submit([s] {
+                (void) hipSetDevice(s->device);
+                if (s->b) gnuais_batch_destroy(s->b);
+                for (int q = 0; q < 2; ++q) {
+                    if (s->d_in[q]) (void) hipFree(s->d_in[q]);
+                    if (s->e_free[q]) (void) hipEventDestroy(s->e_free[q]);
+                }
+                if (s->s_in) (void) hipStreamDestroy(s->s_in);
+                return GNUAIS_OK;
+            });
+            s->w.wait();
+            {
+                std::lock_guard<std::mutex> l(s->w.m);
+                s->w.quit = true;
+            }
+            s->w.cv.notify_all();
+            s->w.th.join();
+        }
+        delete s;
+    }
+    delete nd;
+}
+
+int gnuais_node_create(gnuais_node **out, const int *devices, int n_devices, int n_channels, const float *taps,
+                       int n_taps, unsigned pllinc, int max_len, int frame_capacity_per_device)
+{
+    if (!out) return node_fail(GNUAIS_E_ARG, "node_create: out is NULL");
+    *out = nullptr;
+    if (n_channels <= 0 || max_len <= 0) return node_fail(GNUAIS_E_ARG, "node_create: n_channels / max_len");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return node_fail(GNUAIS_E_HIP, "node_create: no HIP device");
+    std::vector<int> devs;
+    if (devices && n_devices > 0) devs.assign(devices, devices + n_devices);
+    else for (int d = 0; d < ndev; ++d) devs.push_back(d);            // NULL / 0: every visible device
+    for (int d : devs)
+        if (d < 0 || d >= ndev) return node_fail(GNUAIS_E_ARG, "node_create: device index out of range");
+    const int G = (int) std::min<size_t>(devs.size(), (size_t) n_channels);
+    gnuais_node *nd = new gnuais_node;
+    nd->N = n_channels;
+    nd->max_len = max_len;
+    for (int g = 0; g < G; ++g) {
+        // contiguous blocks, SURVEY 8e: device g owns [g*N/G, (g+1)*N/G)
+        const int lo = (int) ((long long) n_channels * g / G), hi = (int) ((long long) n_channels * (g + 1) / G);
+        Shard *s = new Shard;
+        s->device = devs[g];
+        s->first = lo;
+        s->n = hi - lo;
+        s->w.th = std::thread([s] { s->w.loop(); });
+        nd->shards.push_back(s);
+    }
+    const int rc = run_all(nd, [&](Shard &s) {
+        return gnuais_batch_create(&s.b, s.device, s.n, taps, n_taps, pllinc, max_len, frame_capacity_per_device);
+    });
+    if (rc != GNUAIS_OK) {
+        const std::string keep = g_node_err;
+        gnuais_node_destroy(nd);
+        return node_fail(rc, keep);
+    }
+    *out = nd;
+    return GNUAIS_OK;
+}
+
+int gnuais_node_n_devices(const gnuais_node *nd) { return nd ? (int) nd->shards.size() : 0; }
+int gnuais_node_n_channels(const gnuais_node *nd) { return nd ? nd->N : 0; }
+
+int gnuais_node_shard(const gnuais_node *nd, int i, int *device, int *first_channel, int *n_channels,
+                      gnuais_batch **batch)
+{
+    if (!nd || i < 0 || i >= (int) nd->shards.size()) return node_fail(GNUAIS_E_ARG, "node_shard: index");
+    const Shard *s = nd->shards[i];
+    if (device) *device = s->device;
+    if (first_channel) *first_channel = s->first;
+    if (n_channels) *n_channels = s->n;
+    if (batch) *batch = s->b;
+    return GNUAIS_OK;
+}
+
+int gnuais_node_reset(gnuais_node *nd)
+{
+    if (!nd) return node_fail(GNUAIS_E_ARG, "node_reset: NULL");
+    return run_all(nd, [](Shard &s) { return gnuais_batch_reset(s.b); });
+}
+
+int gnuais_node_run(gnuais_node *nd, const int16_t *const *d_samples, int len, void *const *streams)
+{
+    if (!nd || !d_samples) return node_fail(GNUAIS_E_ARG, "node_run: NULL argument");
+    if (len <= 0 || len > nd->max_len) return node_fail(GNUAIS_E_ARG, "node_run: len out of range");
+    std::vector<Shard *> &sh = nd->shards;
+    return run_all(nd, [&](Shard &s) {
+        const size_t i = (size_t) (std::find(sh.begin(), sh.end(), &s) - sh.begin());
+        return gnuais_batch_run(s.b, d_samples[i], len, streams ? streams[i] : nullptr);
+    });
+}
+
+int gnuais_node_run_host(gnuais_node *nd, const int16_t *h_samples, int len)
+{
+    if (!nd || !h_samples) return node_fail(GNUAIS_E_ARG, "node_run_host: NULL argument");
+    if (len <= 0 || len > nd->max_len) return node_fail(GNUAIS_E_ARG, "node_run_host: len out of range");
+    const int N = nd->N, max_len = nd->max_len;
+    return run_all(nd, [=](Shard &s) -> int {
+        if (hipSetDevice(s.device) != hipSuccess) return node_fail(GNUAIS_E_HIP, "node_run_host: hipSetDevice");
+        if (!s.s_in) {
+            if (hipStreamCreateWithFlags(&s.s_in, hipStreamNonBlocking) != hipSuccess)
+                return node_fail(GNUAIS_E_HIP, "node_run_host: stream");
+            for (int q = 0; q < 2; ++q) {
+                if (hipMalloc((void **) &s.d_in[q], sizeof(int16_t) * (size_t) max_len * (size_t) s.n) != hipSuccess ||
+                    hipEventCreateWithFlags(&s.e_free[q], hipEventDisableTiming) != hipSuccess)
+                    return node_fail(GNUAIS_E_HIP, "node_run_host: staging allocation");
+            }
+        }
+        const int q = (int) (s.host_calls & 1);
+        if (s.host_calls >= 2 && hipEventSynchronize(s.e_free[q]) != hipSuccess)
+            return node_fail(GNUAIS_E_HIP, "node_run_host: wait for the staging slab");
+        // the shard's columns of the interleaved buffer: a strided 2-D copy, rows of n channels out of N
+        if (hipMemcpy2DAsync(s.d_in[q], sizeof(int16_t) * (size_t) s.n, h_samples + s.first,
+                             sizeof(int16_t) * (size_t) N, sizeof(int16_t) * (size_t) s.n, (size_t) len,
+                             hipMemcpyHostToDevice, s.s_in) != hipSuccess)
+            return node_fail(GNUAIS_E_HIP, "node_run_host: host -> device copy");
+        const int rc = gnuais_batch_run(s.b, s.d_in[q], len, s.s_in);
+        (void) hipEventRecord(s.e_free[q], s.s_in);
+        s.host_calls++;
+        // the caller's buffer is borrowed for the call only (src/ais.c:216 reuses it): the copy out of it must be done
+        if (hipStreamSynchronize(s.s_in) != hipSuccess && rc == GNUAIS_OK)
+            return node_fail(GNUAIS_E_HIP, "node_run_host: copy");
+        return rc;
+    });
+}
+
+int gnuais_node_sync(gnuais_node *nd)
+{
+    if (!nd) return node_fail(GNUAIS_E_ARG, "node_sync: NULL");
+    return run_all(nd, [](Shard &s) { return gnuais_batch_sync(s.b); });
+}
+
+int gnuais_node_pending_frames(gnuais_node *nd, int *n_out)
+{
+    if (!nd || !n_out) return node_fail(GNUAIS_E_ARG, "node_pending_frames: argument");
+    std::vector<int> n(nd->shards.size(), 0);
+    std::vector<Shard *> &sh = nd->shards;
+    const int rc = run_all(nd, [&](Shard &s) {
+        const size_t i = (size_t) (std::find(sh.begin(), sh.end(), &s) - sh.begin());
+        return gnuais_batch_pending_frames(s.b, &n[i]);
+    });
+    long long t = 0;
+    for (int v : n) t += v;
+    *n_out = (int) std::min<long long>(t, 0x7fffffff);
+    return rc;
+}
+
+int gnuais_node_drain_frames(gnuais_node *nd, gnuais_frame *h_out, int max, int *n_out)
+{
+    if (!nd || !h_out || !n_out || max < 0) return node_fail(GNUAIS_E_ARG, "node_drain_frames: argument");
+    *n_out = 0;
+    int total = 0;
+    if (int rc = gnuais_node_pending_frames(nd, &total)) return rc;
+    if (total > max) return node_fail(GNUAIS_E_ARG, "node_drain_frames: frame buffer too small");
+    // every device drains into its own part of the output, concurrently; a shard's records come in the reference's
+    // order (channel, then time) with LOCAL channel numbers, so the parts only have to be laid end to end -- shards
+    // own ascending channel blocks -- and renumbered
+    std::vector<Shard *> &sh = nd->shards;
+    std::vector<int> cnt(sh.size(), 0), off(sh.size(), 0);
+    {
+        std::vector<int> pend(sh.size(), 0);
+        const int rc = run_all(nd, [&](Shard &s) {
+            const size_t i = (size_t) (std::find(sh.begin(), sh.end(), &s) - sh.begin());
+            return gnuais_batch_pending_frames(s.b, &pend[i]);
+        });
+        if (rc) return rc;
+        int o = 0;
+        for (size_t i = 0; i < sh.size(); ++i) { off[i] = o; o += pend[i]; }
+        if (o > max) return node_fail(GNUAIS_E_ARG, "node_drain_frames: frame buffer too small");
+        cnt = pend;
+    }
+    const int rc = run_all(nd, [&](Shard &s) {
+        const size_t i = (size_t) (std::find(sh.begin(), sh.end(), &s) - sh.begin());
+        int got = 0;
+        const int r = gnuais_batch_drain_frames(s.b, h_out + off[i], cnt[i], &got);
+        for (int k = 0; k < got; ++k) h_out[off[i] + k].channel += (uint32_t) s.first;
+        cnt[i] = got;
+        return r;
+    });
+    // close gaps if a device delivered fewer than it had announced (it cannot deliver more)
+    int w = 0;
+    for (size_t i = 0; i < sh.size(); ++i) {
+        if (off[i] != w && cnt[i] > 0) memmove(h_out + w, h_out + off[i], sizeof(gnuais_frame) * (size_t) cnt[i]);
+        w += cnt[i];
+    }
+    *n_out = w;
+    return rc;              // GNUAIS_E_OVERFLOW of a device is reported with what was drained
+}
+
+int gnuais_node_discard_frames(gnuais_node *nd)
+{
+    if (!nd) return node_fail(GNUAIS_E_ARG, "node_discard_frames: NULL");
+    return run_all(nd, [](Shard &s) { return gnuais_batch_discard_frames(s.b, nullptr); });
+}
+
+int gnuais_node_counters(gnuais_node *nd, gnuais_counters *h_out)
+{
+    if (!nd || !h_out) return node_fail(GNUAIS_E_ARG, "node_counters: argument");
+    return run_all(nd, [&](Shard &s) { return gnuais_batch_counters(s.b, h_out + s.first); });
+}
+
+int gnuais_node_total_received(gnuais_node *nd, long long *total)
+{
+    if (!nd || !total) return node_fail(GNUAIS_E_ARG, "node_total_received: argument");
+    std::vector<Shard *> &sh = nd->shards;
+    std::vector<long long> t(sh.size(), 0);
+    const int rc = run_all(nd, [&](Shard &s) {
+        const size_t i = (size_t) (std::find(sh.begin(), sh.end(), &s) - sh.begin());
+        return gnuais_batch_total_received(s.b, &t[i]);
+    });
+    *total = 0;
+    for (long long v : t) *total += v;
+    return rc;
+}
+
+int gnuais_node_maxval(gnuais_node *nd, int16_t *h_out)
+{
+    if (!nd || !h_out) return node_fail(GNUAIS_E_ARG, "node_maxval: argument");
+    return run_all(nd, [&](Shard &s) { return gnuais_batch_maxval(s.b, h_out + s.first); });
+}
+
+int gnuais_node_pll_state(gnuais_node *nd, gnuais_pll_state *h_out)
+{
+    if (!nd || !h_out) return node_fail(GNUAIS_E_ARG, "node_pll_state: argument");
+    return run_all(nd, [&](Shard &s) { return gnuais_batch_pll_state(s.b, h_out + s.first); });
+}
+
+int gnuais_node_set_option(gnuais_node *nd, const char *name, int value)
+{
+    if (!nd || !name) return node_fail(GNUAIS_E_ARG, "node_set_option: argument");
+    return run_all(nd, [&](Shard &s) { return gnuais_batch_set_option(s.b, name, value); });
+}
+
+int gnuais_node_autotune(gnuais_node *nd, const int16_t *const *d_samples, int len, void *const *streams,
+                         float *best_ms_max)
+{
+    if (!nd || !d_samples) return node_fail(GNUAIS_E_ARG, "node_autotune: argument");
+    std::vector<Shard *> &sh = nd->shards;
+    std::vector<float> ms(sh.size(), 0.0f);
+    // one device after the other: the measurement of one batch must not see another batch's host thread at work
+    int rc = GNUAIS_OK;
+    for (size_t i = 0; i < sh.size() && rc == GNUAIS_OK; ++i) {
+        Shard *s = sh[i];
+        s->w.submit([&, s, i] { return gnuais_batch_autotune(s->b, d_samples[i], len, streams ? streams[i] : nullptr, &ms[i]); });
+        rc = s->w.wait();
+        if (rc != GNUAIS_OK) g_node_err = s->w.err;
+    }
+    if (best_ms_max) *best_ms_max = *std::max_element(ms.begin(), ms.end());
+    return rc;
+}
+
+} // extern "C"

@@ -76,6 +76,25 @@ SYMBOLS = {
     "gnuais_batch_autotune": (_I, [_P, _P, _I, _P, C.POINTER(C.c_float)]),
     "gnuais_batch_autotune_delivery": (_I, [_P, _P, _I, _P, C.POINTER(C.c_float)]),
     "gnuais_batch_set_option": (_I, [_P, C.c_char_p, _I]),
+    "gnuais_node_create": (_I, [C.POINTER(_P), _P, _I, _I, _P, _I, _U, _I, _I]),
+    "gnuais_node_destroy": (None, [_P]),
+    "gnuais_node_reset": (_I, [_P]),
+    "gnuais_node_n_devices": (_I, [_P]),
+    "gnuais_node_n_channels": (_I, [_P]),
+    "gnuais_node_shard": (_I, [_P, _I, C.POINTER(_I), C.POINTER(_I), C.POINTER(_I), C.POINTER(_P)]),
+    "gnuais_node_run_host": (_I, [_P, _P, _I]),
+    "gnuais_node_run": (_I, [_P, _P, _I, _P]),
+    "gnuais_node_sync": (_I, [_P]),
+    "gnuais_node_pending_frames": (_I, [_P, C.POINTER(_I)]),
+    "gnuais_node_drain_frames": (_I, [_P, _P, _I, C.POINTER(_I)]),
+    "gnuais_node_discard_frames": (_I, [_P]),
+    "gnuais_node_counters": (_I, [_P, _P]),
+    "gnuais_node_total_received": (_I, [_P, C.POINTER(C.c_longlong)]),
+    "gnuais_node_maxval": (_I, [_P, _P]),
+    "gnuais_node_pll_state": (_I, [_P, _P]),
+    "gnuais_node_set_option": (_I, [_P, C.c_char_p, _I]),
+    "gnuais_node_autotune": (_I, [_P, _P, _I, _P, C.POINTER(C.c_float)]),
+    "gnuais_node_last_error": (C.c_char_p, []),
     "gnuais_last_error": (C.c_char_p, []),
     "gnuais_version": (C.c_char_p, []),
 }

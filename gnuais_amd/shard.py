@@ -23,3 +23,114 @@ def reduce_bench(dist, device, seconds: float, msgs: float, samples: float):
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dist.all_reduce(s, op=dist.ReduceOp.SUM)
     return float(t.item()), float(s[0].item()), float(s[1].item())
+
+
+class ReceiverNode:
+    """ctypes face of the node object (include/gnuais_hip.h: gnuais_node_*; gnuais_amd/csrc/node.hip): N channels in
+    contiguous blocks over `devices`, one batch and one host thread per device inside the library, results merged in
+    the reference's order with global channel numbers.  The product path of BASELINE's C4."""
+
+    def __init__(self, n_channels: int, devices=None, taps=None, pllinc: int = 0, max_len: int = 48000,
+                 frame_capacity: int = 0):
+        import ctypes as C
+        import numpy as np
+        from .lib import check, load
+        self._C, self._np, self._check = C, np, check
+        self._lib = load()
+        self._h = C.c_void_p()
+        dv = None if devices is None else np.ascontiguousarray(devices, dtype=np.int32)
+        tp = None if taps is None else np.ascontiguousarray(taps, dtype=np.float32)
+        rc = self._lib.gnuais_node_create(C.byref(self._h), None if dv is None else dv.ctypes.data,
+                                          0 if dv is None else len(dv), n_channels,
+                                          None if tp is None else tp.ctypes.data, 0 if tp is None else len(tp),
+                                          pllinc, max_len, frame_capacity)
+        self._raise(rc)
+        self.n_channels, self.max_len = n_channels, max_len
+        self.shards = []
+        for i in range(self._lib.gnuais_node_n_devices(self._h)):
+            d, f, n = C.c_int(), C.c_int(), C.c_int()
+            self._lib.gnuais_node_shard(self._h, i, C.byref(d), C.byref(f), C.byref(n), None)
+            self.shards.append((d.value, f.value, n.value))
+
+    def _raise(self, rc, allow=()):
+        if rc != 0 and rc not in allow:
+            from .lib import GnuaisError
+            raise GnuaisError(rc, self._lib.gnuais_node_last_error().decode())
+        return rc
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.gnuais_node_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def run_host(self, samples):
+        x = self._np.ascontiguousarray(samples, dtype=self._np.int16)
+        assert x.ndim == 2 and x.shape[1] == self.n_channels
+        self._raise(self._lib.gnuais_node_run_host(self._h, x.ctypes.data, int(x.shape[0])))
+
+    def run(self, slabs, streams=None):
+        """slabs: one CUDA/HIP int16 tensor [len][n_i] per shard, each on its shard's device."""
+        C = self._C
+        assert len(slabs) == len(self.shards)
+        ln = int(slabs[0].shape[0])
+        for t, (d, f, n) in zip(slabs, self.shards):
+            assert t.is_cuda and t.is_contiguous() and t.shape == (ln, n) and t.device.index == d
+        ptrs = (C.c_void_p * len(slabs))(*[t.data_ptr() for t in slabs])
+        st = None if streams is None else (C.c_void_p * len(slabs))(*streams)
+        self._raise(self._lib.gnuais_node_run(self._h, ptrs, ln, st))
+
+    def autotune(self, slabs, streams=None) -> float:
+        C = self._C
+        ptrs = (C.c_void_p * len(slabs))(*[t.data_ptr() for t in slabs])
+        st = None if streams is None else (C.c_void_p * len(slabs))(*streams)
+        ms = C.c_float(0)
+        self._raise(self._lib.gnuais_node_autotune(self._h, ptrs, int(slabs[0].shape[0]), st, C.byref(ms)))
+        return ms.value
+
+    def sync(self):
+        self._raise(self._lib.gnuais_node_sync(self._h))
+
+    def set_option(self, name: str, value: int):
+        self._raise(self._lib.gnuais_node_set_option(self._h, name.encode(), int(value)))
+
+    def reset(self):
+        self._raise(self._lib.gnuais_node_reset(self._h))
+
+    def pending_frames(self) -> int:
+        n = self._C.c_int()
+        self._raise(self._lib.gnuais_node_pending_frames(self._h, self._C.byref(n)))
+        return n.value
+
+    def discard_frames(self):
+        self._raise(self._lib.gnuais_node_discard_frames(self._h))
+
+    def drain_frames(self):
+        from .lib import FRAME_DTYPE
+        out = self._np.zeros(max(self.pending_frames(), 1), dtype=FRAME_DTYPE)
+        got = self._C.c_int()
+        self._raise(self._lib.gnuais_node_drain_frames(self._h, out.ctypes.data, len(out), self._C.byref(got)))
+        return out[: got.value].copy()
+
+    def counters(self):
+        from .lib import COUNTERS_DTYPE
+        out = self._np.zeros(self.n_channels, dtype=COUNTERS_DTYPE)
+        self._raise(self._lib.gnuais_node_counters(self._h, out.ctypes.data))
+        return out
+
+    def total_received(self) -> int:
+        t = self._C.c_longlong()
+        self._raise(self._lib.gnuais_node_total_received(self._h, self._C.byref(t)))
+        return t.value
+
+    def maxval(self):
+        out = self._np.zeros(self.n_channels, dtype=self._np.int16)
+        self._raise(self._lib.gnuais_node_maxval(self._h, out.ctypes.data))
+        return out
+
+    def pll_state(self):
+        from .lib import PLL_DTYPE
+        out = self._np.zeros(self.n_channels, dtype=PLL_DTYPE)
+        self._raise(self._lib.gnuais_node_pll_state(self._h, out.ctypes.data))
+        return out

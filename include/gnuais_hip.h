@@ -304,6 +304,46 @@ int  gnuais_batch_autotune_delivery(gnuais_batch *b, const int16_t *d_samples, i
 const char *gnuais_last_error(void);
 const char *gnuais_version(void);
 
+/* ---- the receivers of one NODE: N channels over several GPUs (src/ais.c:141-147, 237-247) ----------
+ * gnuais creates its receivers one by one and they share nothing; the main loop hands every receiver the same
+ * interleaved buffer.  A node is that over the node's devices: device g owns the contiguous channel block
+ * [g*N/G, (g+1)*N/G) as a gnuais_batch of its own, one host thread per device issues that device's copies and
+ * launches, nothing is exchanged between devices (no collective).  Results are merged on the host: frame records
+ * carry GLOBAL channel numbers and come in the reference's order (channel, then time).
+ * devices / n_devices: HIP device indices, one shard each (an index may repeat: several shards on one device);
+ *   NULL / 0 = every visible device.  The other arguments as gnuais_batch_create(), per shard. */
+typedef struct gnuais_node gnuais_node;
+int  gnuais_node_create(gnuais_node **out, const int *devices, int n_devices, int n_channels, const float *taps,
+			int n_taps, unsigned pllinc, int max_len, int frame_capacity_per_device);
+void gnuais_node_destroy(gnuais_node *nd);
+int  gnuais_node_reset(gnuais_node *nd);
+int  gnuais_node_n_devices(const gnuais_node *nd);      /* shards */
+int  gnuais_node_n_channels(const gnuais_node *nd);
+/* shard i: its device, first global channel, channel count and batch (for the per-batch calls above) */
+int  gnuais_node_shard(const gnuais_node *nd, int i, int *device, int *first_channel, int *n_channels,
+		       gnuais_batch **batch);
+/* receiver_run() for all N channels from ONE host buffer, interleaved int16 [len][N] as src/ais.c:216 holds it:
+ * every device's thread copies its columns (a strided 2-D copy) and queues its chain; the call returns when
+ * the buffer may be reused.  Results after gnuais_node_sync(). */
+int  gnuais_node_run_host(gnuais_node *nd, const int16_t *h_samples, int len);
+/* the same with the samples already on the devices: d_samples[i] = shard i's DEVICE slab, interleaved
+ * int16 [len][n_channels of shard i]; streams[i] (or NULL) as in gnuais_batch_run().  Asynchronous. */
+int  gnuais_node_run(gnuais_node *nd, const int16_t *const *d_samples, int len, void *const *streams);
+int  gnuais_node_sync(gnuais_node *nd);
+/* merged results: records of every device, channel = global index, reference order (channel, then time) */
+int  gnuais_node_pending_frames(gnuais_node *nd, int *n_out);
+int  gnuais_node_drain_frames(gnuais_node *nd, gnuais_frame *h_out, int max, int *n_out);
+int  gnuais_node_discard_frames(gnuais_node *nd);
+int  gnuais_node_counters(gnuais_node *nd, gnuais_counters *h_out /* [n_channels] */);
+int  gnuais_node_total_received(gnuais_node *nd, long long *total);
+int  gnuais_node_maxval(gnuais_node *nd, int16_t *h_out /* [n_channels] */);
+int  gnuais_node_pll_state(gnuais_node *nd, gnuais_pll_state *h_out /* [n_channels] */);
+int  gnuais_node_set_option(gnuais_node *nd, const char *name, int value);      /* on every shard */
+/* gnuais_batch_autotune() on every shard, one after the other; *best_ms_max = the slowest shard's best */
+int  gnuais_node_autotune(gnuais_node *nd, const int16_t *const *d_samples, int len, void *const *streams,
+			  float *best_ms_max);
+const char *gnuais_node_last_error(void);   /* of the calling thread: which device failed and why */
+
 #ifdef __cplusplus
 }
 #endif

@@ -303,6 +303,69 @@ def test_shards_over_devices_from_host_threads():
     assert [s for p in out for s in p[2]] == [o.pll(c) for c in range(n_ch)]
 
 
+def test_node_object_equals_one_unsharded_batch(tmp_path):
+    """Row e as a product: gnuais_node_* (gnuais_amd/csrc/node.hip) -- 1000 channels in four contiguous blocks (on the
+    visible devices, repeated if there are fewer than four), one host thread per shard inside the library, fed from
+    ONE interleaved host buffer and, in a second pass, from device slabs -- against a single unsharded batch: the
+    merged records (global channel numbers, reference order), counters, PLL carry and peaks are byte-equal, over
+    three ragged calls."""
+    import torch
+    from gnuais_amd import ReceiverNode
+    n_ch, total = 1000, 9 * 1280
+    x = np.stack([synth.make_stream(total, seed=75, channel=c % 97, occupancy=0.8)[0] for c in range(n_ch)], axis=1)
+    nd = torch.cuda.device_count()
+    devices = [g % nd for g in range(4)]
+    one = batch(n_ch, max_len=total)
+    node = ReceiverNode(n_ch, devices=devices, max_len=total)
+    assert [(f, n) for _, f, n in node.shards] == [(0, 250), (250, 250), (500, 250), (750, 250)]
+    for mode in ("host", "device"):
+        for lo, hi in ((0, 4000), (4000, 4001), (4001, total)):
+            one.run(dev(x[lo:hi]))
+            if mode == "host":
+                buf = x[lo:hi].copy()
+                node.run_host(buf)
+                buf[:] = 0                                      # borrowed for the call only
+            else:
+                node.run([dev(x[lo:hi, f:f + n], d) for d, f, n in node.shards])
+            node.sync()
+            want, got = one.drain_frames(), node.drain_frames()
+            assert got.tobytes() == want.tobytes()
+            assert node.pending_frames() == 0
+            assert node.counters().tobytes() == one.counters().tobytes()
+            assert node.pll_state().tobytes() == one.pll_state().tobytes()
+            assert np.array_equal(node.maxval(), one.maxval())
+        assert node.total_received() == one.total_received() > 1000
+        one.reset()
+        node.reset()
+    # argument errors name the call; a device index that does not exist is refused
+    from gnuais_amd.lib import GnuaisError
+    with pytest.raises(GnuaisError):
+        ReceiverNode(64, devices=[nd + 7])
+    with pytest.raises(GnuaisError):
+        node.run_host(np.zeros((total + 1, n_ch), dtype=np.int16))
+
+
+def test_node_example_program(tmp_path):
+    """examples/node_decode.c -- the 40-line C program of the node API -- builds against include/gnuais_hip.h and
+    decodes a raw 64-channel file on whatever devices exist: as many frames as the oracle finds."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = tmp_path / "node_decode"
+    subprocess.check_call(["gcc", "-O2", "-I" + os.path.join(root, "include"), os.path.join(root, "examples", "node_decode.c"),
+                           "-L" + os.path.join(root, "gnuais_amd"), "-lgnuais_hip",
+                           "-Wl,-rpath," + os.path.join(root, "gnuais_amd"), "-o", str(exe)])
+    n_ch, total = 64, 8 * 1280
+    x = np.stack([synth.make_stream(total, seed=76, channel=c, occupancy=0.9)[0] for c in range(n_ch)], axis=1)
+    raw = tmp_path / "in.raw"
+    x.astype("<i2").tofile(raw)
+    p = subprocess.run([str(exe), str(n_ch), "4096", str(raw)], capture_output=True, timeout=300)
+    assert p.returncode == 0, p.stderr.decode()
+    o = Oracle(n_ch)
+    o.run(x)
+    lines = p.stdout.decode().splitlines()
+    assert len(lines) == len(o.frames()) > 300
+    assert p.stderr.decode().splitlines()[-1] == f"{len(lines)} frames drained, {len(lines)} received in all"
+
+
 def test_bench_two_workers_prints_n_gpus_2():
     """`bench.py --gpus 2` without torch.distributed.run: one worker process per device (both on
     device 0 when only one is visible), n_gpus 2 and a whole-job value in the line."""
@@ -311,13 +374,14 @@ def test_bench_two_workers_prints_n_gpus_2():
     import torch
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     devs = "0,1" if torch.cuda.device_count() >= 2 else "0,0"
-    out = subprocess.check_output([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--devices", devs,
-                                   "--steps", "6", "--warmup", "2", "--channels", "2048", "--len", "9600",
-                                   "--base", "64", "--no-cpu"], timeout=600)
-    line = json.loads(out.decode().strip().splitlines()[-1])
-    assert line["n_gpus"] == 2 and len(line["per_gpu"]) == 2
-    assert line["value"] > 0 and line["valid_crc_msgs_per_s"] > 0
-    assert abs(line["value"] - 2 * 2048 * 9600 * 6 / (line["ms_per_step"] * 6e-3) / 1e6) < 1e-6 * line["value"]
+    for mode in (["--procs"], []):                          # worker processes; the in-process node object
+        out = subprocess.check_output([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--devices", devs,
+                                       "--steps", "6", "--warmup", "2", "--channels", "2048", "--len", "9600",
+                                       "--base", "64", "--no-cpu"] + mode, timeout=600)
+        line = json.loads(out.decode().strip().splitlines()[-1])
+        assert line["n_gpus"] == 2 and len(line["per_gpu"]) == 2
+        assert line["value"] > 0 and line["valid_crc_msgs_per_s"] > 0
+        assert abs(line["value"] - 2 * 2048 * 9600 * 6 / (line["ms_per_step"] * 6e-3) / 1e6) < 1e-6 * line["value"]
 
 
 # ---------------------------------------------------------------- the drop-in with the reference's message layer
