@@ -138,6 +138,8 @@ struct gnuais_batch {
     unsigned long long stream_calls = 0;
     int16_t *stage_x = nullptr;
     size_t stage_bytes = 0;
+    float *stage_f = nullptr;       // gnuais_batch_filter_host: the floats on their way out
+    size_t stage_f_bytes = 0;
     // gnuais_batch_run_host_async: two pinned host buffers + two device buffers, one internal stream
     int16_t *pin[2] = {nullptr, nullptr}, *dev_in[2] = {nullptr, nullptr};
     size_t pin_bytes = 0;
@@ -215,7 +217,7 @@ void gnuais_batch_destroy(gnuais_batch *b)
     }
     void *ptrs[] = {b->hist[0], b->hist[1], b->pll, b->lastbit, b->prev, b->ctl, b->cand,
                     b->frame_count, b->counters, b->maxval[0], b->maxval[1], b->frames, b->d_taps,
-                    b->stage_x, b->d_seq[0], b->d_seq[1], b->d_text, b->nmea_scratch, b->d_msg, b->d_word, b->d_stamps};
+                    b->stage_x, b->d_seq[0], b->d_seq[1], b->d_text, b->nmea_scratch, b->d_msg, b->d_word, b->d_stamps, b->stage_f};
     for (void *p : ptrs)
         if (p) (void) hipFree(p);
     for (auto &set : b->evr)
@@ -991,6 +993,35 @@ int gnuais_batch_filter(gnuais_batch *b, const int16_t *d_samples, int len, floa
     if (int rc = run_fir(b, d_samples, len, d_out, s, (int) (b->calls % gnuais_batch::NBUF))) return rc;
     b->last_stream = s;
     b->timed_last = false;
+    return GNUAIS_OK;
+}
+
+// filter_run_buf() from and to HOST memory, for plain-C callers (gnuais_amd/csrc/protodec_hip.c: the reference's
+// filter.h names): h_samples int16 [len][n_channels], h_out float [len][n_channels]; synchronous
+int gnuais_batch_filter_host(gnuais_batch *b, const int16_t *h_samples, int len, float *h_out)
+{
+    if (!b || !h_samples || !h_out) return fail(GNUAIS_E_ARG, "filter_host: NULL argument");
+    if (len <= 0 || len > b->max_len) return fail(GNUAIS_E_ARG, "filter_host: len out of range");
+    if (int rc = set_device(b)) return rc;
+    const size_t n = (size_t) len * (size_t) b->N;
+    if (b->stage_bytes < n * sizeof(int16_t)) {
+        if (b->stage_x) HIP_TRY(hipFree(b->stage_x));
+        b->stage_x = nullptr;
+        b->stage_bytes = 0;
+        HIP_TRY(hipMalloc((void **) &b->stage_x, n * sizeof(int16_t)));
+        b->stage_bytes = n * sizeof(int16_t);
+    }
+    if (b->stage_f_bytes < n * sizeof(float)) {
+        if (b->stage_f) HIP_TRY(hipFree(b->stage_f));
+        b->stage_f = nullptr;
+        b->stage_f_bytes = 0;
+        HIP_TRY(hipMalloc((void **) &b->stage_f, n * sizeof(float)));
+        b->stage_f_bytes = n * sizeof(float);
+    }
+    HIP_TRY(hipMemcpy(b->stage_x, h_samples, n * sizeof(int16_t), hipMemcpyHostToDevice));
+    if (int rc = gnuais_batch_filter(b, b->stage_x, len, b->stage_f, nullptr)) return rc;
+    if (int rc = gnuais_batch_sync(b)) return rc;
+    HIP_TRY(hipMemcpy(h_out, b->stage_f, n * sizeof(float), hipMemcpyDeviceToHost));
     return GNUAIS_OK;
 }
 

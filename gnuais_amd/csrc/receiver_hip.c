@@ -20,8 +20,9 @@
  * refreshes the public counters -- the reference's order (per buffer: receiver
  * A's frames, then receiver B's).
  *
- * Like the reference's main loop (one thread, ais.c:214-263) this file is single-threaded: the
- * table of groups is process-global and not locked.
+ * The reference's main loop is one thread (ais.c:214-263); this file nevertheless takes one process-wide lock
+ * around its table of groups and around every call, so receivers may be driven from several threads (they are
+ * then served one call at a time).  The table grows as needed.
  *
  * Build inside the gnuais tree with -DGNUAIS_TREE (uses the tree's headers and
  * hlog); outside it, include/gnuais_receiver_abi.h carries the two public
@@ -32,6 +33,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <time.h>
+#include <pthread.h>
 
 #ifdef GNUAIS_TREE
 #include "receiver.h"
@@ -45,7 +47,6 @@
 #endif
 #include "gnuais_hip.h"
 
-#define MAX_GROUPS 8
 #define MAX_LEN 4096                 /* receiver.c:85 FILTERED_LEN */
 
 struct rx_group {
@@ -62,8 +63,9 @@ struct rx_group {
 	int round_len;
 };
 
-static struct rx_group groups[MAX_GROUPS];
-static int n_groups;
+static struct rx_group *groups;
+static int n_groups, cap_groups;
+static pthread_mutex_t big_lock = PTHREAD_MUTEX_INITIALIZER;
 
 static void die(const char *what)
 {
@@ -78,9 +80,11 @@ static struct rx_group *group_for(int num_ch)
 	for (i = 0; i < n_groups; i++)
 		if (groups[i].num_ch == num_ch)
 			return &groups[i];
-	if (n_groups == MAX_GROUPS) {
-		fprintf(stderr, "gnuais-hip: too many receiver groups\n");
-		abort();
+	if (n_groups == cap_groups) {
+		cap_groups = cap_groups ? 2 * cap_groups : 4;
+		groups = realloc(groups, sizeof(*groups) * (size_t) cap_groups);
+		if (!groups)
+			abort();
 	}
 	g = &groups[n_groups++];
 	memset(g, 0, sizeof(*g));
@@ -122,8 +126,10 @@ struct receiver *init_receiver(char name, int num_ch, int ch_ofs, struct serial_
 	rx->prev = 0;
 	rx->last_levellog = 0;
 
+	pthread_mutex_lock(&big_lock);
 	g = group_for(num_ch);
 	g->members[ch_ofs] = rx;
+	pthread_mutex_unlock(&big_lock);
 	return rx;
 }
 
@@ -133,6 +139,7 @@ void free_receiver(struct receiver *rx)
 	int i, k, left;
 	if (!rx)
 		return;
+	pthread_mutex_lock(&big_lock);
 	for (i = 0; i < n_groups; i++) {
 		struct rx_group *g = &groups[i];
 		if (g->num_ch != rx->num_ch || !g->members || g->members[rx->ch_ofs] != rx)
@@ -153,6 +160,7 @@ void free_receiver(struct receiver *rx)
 		}
 		break;
 	}
+	pthread_mutex_unlock(&big_lock);
 	hfree(rx);      /* like the reference, the decoder itself is not freed (receiver.c:76-82) */
 }
 
@@ -183,7 +191,7 @@ static void start_round(struct rx_group *g, const short *buf, int len)
 /* src/receiver.c:87-148 */
 void receiver_run(struct receiver *rx, short *buf, int len)
 {
-	struct rx_group *g = group_for(rx->num_ch);
+	struct rx_group *g;
 	struct demod_state_t *d = rx->decoder;
 	const int ch = rx->ch_ofs;
 	int i, j, k;
@@ -192,6 +200,8 @@ void receiver_run(struct receiver *rx, short *buf, int len)
 		abort();
 	if (len <= 0)
 		return;
+	pthread_mutex_lock(&big_lock);
+	g = group_for(rx->num_ch);
 	/* a new round starts with a new buffer, or when this receiver has already
 	 * been served from the current one (ais.c reuses the same buffer address) */
 	if (g->round_buf != buf || g->round_len != len || g->ran[ch])
@@ -219,10 +229,13 @@ void receiver_run(struct receiver *rx, short *buf, int len)
 	rx->pll = g->pll[ch].pll;
 	rx->prev = g->pll[ch].prev;
 	rx->lastbit = g->pll[ch].lastbit;
-
+	{
+		const int16_t peak = g->maxval[ch];
+		pthread_mutex_unlock(&big_lock);
+		(void) peak;
 #ifdef GNUAIS_TREE
 	{       /* receiver.c:137-147 level log, from filter_run_buf()'s return value */
-		float level = (float) g->maxval[ch] / (float) 32768 * (float) 100;
+		float level = (float) peak / (float) 32768 * (float) 100;
 		int level_distance = time(NULL) - rx->last_levellog;
 		if (level > 95.0 && (level_distance >= 30 || level_distance >= sound_levellog)) {
 			hlog(LOG_NOTICE, "Level on ch %c too high: %.0f %%", d->chanid, level);
@@ -233,4 +246,5 @@ void receiver_run(struct receiver *rx, short *buf, int len)
 		}
 	}
 #endif
+	}
 }

@@ -40,6 +40,7 @@ SYMBOLS = {
     "gnuais_wav_close": (None, [_P]),
     "gnuais_batch_sync": (_I, [_P]),
     "gnuais_batch_filter": (_I, [_P, _P, _I, _P, _P]),
+    "gnuais_batch_filter_host": (_I, [_P, _P, _I, _P]),
     "gnuais_batch_decode_bits": (_I, [_P, _P, _I, _P]),
     "gnuais_batch_last_bits": (_I, [_P, _P, _I, _P]),
     "gnuais_batch_last_signs": (_I, [_P, _P, _I]),

@@ -143,6 +143,9 @@ void gnuais_wav_close(gnuais_wav *w);
  * advances the FIR history exactly like a run call, nothing else. */
 int  gnuais_batch_filter(gnuais_batch *b, const int16_t *d_samples, int len,
 			 float *d_out, void *stream);
+/* the same from and to HOST memory (plain-C callers: gnuais_amd/csrc/protodec_hip.c): h_samples int16
+ * [len][n_channels], h_out float [len][n_channels]; synchronous */
+int  gnuais_batch_filter_host(gnuais_batch *b, const int16_t *h_samples, int len, float *h_out);
 /* protodec_decode(in, count, d), src/protodec.c:988-1122, for every channel:
  * h_bits = HOST uint8 [n_channels][stride], one byte per bit; h_count[n_channels] */
 int  gnuais_batch_decode_bits(gnuais_batch *b, const uint8_t *h_bits, int stride,

@@ -17,6 +17,11 @@
 #include "protodec.h"
 #include "cfg.h"
 
+#ifdef GNUAIS_SHIM      /* `make shim`: receiver.c is the reference's, the names below it are the device shims' */
+void gnuais_protodec_set_batching(int bits);
+void gnuais_protodec_flush(struct demod_state_t *d);
+#endif
+
 int main(int argc, char **argv)
 {
 	struct receiver *rx[2] = { NULL, NULL };
@@ -34,6 +39,12 @@ int main(int argc, char **argv)
 		perror(argv[1]);
 		return 2;
 	}
+#ifdef GNUAIS_SHIM
+	if (getenv("GNUAIS_PROTODEC_BATCH"))            /* default: every protodec_decode() call returns with d current */
+		gnuais_protodec_set_batching(atoi(getenv("GNUAIS_PROTODEC_BATCH")));
+#endif
+	if (getenv("GNUAIS_LEVELLOG"))                  /* exercises receiver_run()'s level log (receiver.c:137-147) */
+		sound_levellog = atoi(getenv("GNUAIS_LEVELLOG"));
 	for (i = 0; i <= MAX_AIS_PACKET_TYPE; i++)
 		skip_type[i] = 0;                       /* print every message type */
 	for (i = 0; i < channels; i++)                  /* ais.c:139-147 */
@@ -43,6 +54,9 @@ int main(int argc, char **argv)
 	while ((got = (int) fread(buffer, sizeof(short) * (size_t) channels, (size_t) frames, in)) > 0)
 		for (i = 0; i < channels; i++)          /* ais.c:232-247 */
 			receiver_run(rx[i], buffer, got);
+#ifdef GNUAIS_SHIM
+	gnuais_protodec_flush(NULL);
+#endif
 	for (i = 0; i < channels; i++)                  /* ais.c:296-310 */
 		fprintf(stderr, "%c: received %d lost %d lost2 %d\n", 'A' + i, rx[i]->decoder->receivedframes,
 			rx[i]->decoder->lostframes, rx[i]->decoder->lostframes2);

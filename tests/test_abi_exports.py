@@ -74,10 +74,10 @@ def test_product_never_touches_the_oracle():
     assert not bad, bad
 
 
-@pytest.mark.parametrize("name", ["receiver_hip.c", "sinks_batch.c"])
+@pytest.mark.parametrize("name", ["receiver_hip.c", "sinks_batch.c", "protodec_hip.c"])
 def test_dropin_c_file_compiles_standalone_and_in_tree(tmp_path, name):
     """The host-side C files that a gnuais tree adds (the receiver drop-in, the batched sink
-    adapter) are plain C against the public headers, and (where the reference tree is present)
+    adapter, the reference-named filter_* / protodec_* shims) are plain C against the public headers, and (where the reference tree is present)
     against the reference's own headers."""
     src = os.path.join(ROOT, "gnuais_amd", "csrc", name)
     inc = os.path.join(ROOT, "include")

@@ -409,6 +409,135 @@ def test_dropin_with_the_reference_message_layer(tmp_path):
     assert tail == [f"{'AB'[i]}: received {cnt[i][0]} lost {cnt[i][1]} lost2 {cnt[i][2]}" for i in range(2)]
 
 
+@pytest.mark.parametrize("batch_bits", [1, 512])
+def test_reference_receiver_over_the_named_shims(tmp_path, batch_bits):
+    """oracle/_ref/shim_ais.bin = the reference's UNMODIFIED receiver.c (slicer / PLL / NRZI on the host) linked
+    against gnuais_amd/csrc/protodec_hip.c: filter_init / filter_run_buf (exact FIR kernel, floats bit-identical),
+    protodec_decode (device deframer + CRC, every valid frame handed to the reference's own protodec_getdata) --
+    the reference's other public names of the hot path (filter.h:64-68, protodec.h:73-76).  Its stdout and counters
+    on the golden stereo recording are the reference's own, with every protodec_decode() call a device round trip
+    (1) and with 512 bits queued per decoder."""
+    exe = os.path.join(os.path.dirname(G), "..", "oracle", "_ref", "shim_ais.bin")
+    if not os.path.exists(exe):
+        pytest.skip("oracle/_ref/shim_ais.bin was not built (no reference tree at build time)")
+    g = np.load(os.path.join(G, "chain_48k.npz"))
+    x = g["x"] if batch_bits > 1 else g["x"][: 12 * 1280]          # a device round trip per bit: a shorter piece
+    raw = tmp_path / "stereo.raw"
+    x.astype("<i2").tofile(raw)
+    p = subprocess.run([exe, str(raw)], capture_output=True, timeout=900,
+                       env=dict(os.environ, GNUAIS_PROTODEC_BATCH=str(batch_bits)))
+    assert p.returncode == 0, p.stderr.decode()
+    got = p.stdout.decode().splitlines()
+    if batch_bits > 1:
+        want = bytes(np.load(os.path.join(G, "nmea.npz"))["chain_48k_stdout"]).decode().splitlines()
+        cnt = g["counters"]
+    else:                                           # the piece's own answer: the oracle + the host message layer
+        from gnuais_amd import messages_from_frames
+        o = Oracle(2)
+        o.run(x)
+        fr = o.frames()
+        fr = fr[np.argsort(fr["channel"], kind="stable")]
+        want = messages_from_frames(fr, np.zeros(2, dtype=np.uint8))[1].decode().splitlines()
+        cnt = o.counters()
+    assert len(got) == len(want) > 0
+    for ch in "AB":
+        assert [l for l in got if l.startswith(f"ch {ch} ")] == [l for l in want if l.startswith(f"ch {ch} ")]
+    tail = p.stderr.decode().splitlines()[-2:]
+    assert tail == [f"{'AB'[i]}: received {cnt[i][0]} lost {cnt[i][1]} lost2 {cnt[i][2]}" for i in range(2)]
+
+
+def test_named_shims_filter_and_crc_from_c(tmp_path):
+    """filter_init / filter_run_buf / filter_run / filter_free and protodec_sdlc_crc / protodec_calculate_crc of
+    protodec_hip.c called from a C program the way the reference's callers do (strided input, 1020-sample chunks):
+    floats == the oracle's bit for bit, CRC known answers (0x906E; residue 0x0F47 -> 1)."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = tmp_path / "t.c"
+    src.write_text(r'''
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include "gnuais_receiver_abi.h"
+#include "gnuais_hip.h"
+struct filter;
+struct filter *filter_init(int len, float *taps);
+void filter_free(struct filter *f);
+void filter_run(struct filter *f, float in, float *out);
+short filter_run_buf(struct filter *f, short *in, float *out, int step, int len);
+unsigned short protodec_sdlc_crc(const unsigned char *data, unsigned len);
+int protodec_calculate_crc(int length_bits, struct demod_state_t *d);
+void protodec_getdata(int n, struct demod_state_t *d) { (void) n; (void) d; }     /* the message layer is not under test */
+int main(int argc, char **argv)
+{
+	float taps[36], *out;
+	short *in;
+	int n, step = 3, i, done = 0;
+	FILE *f = fopen(argv[1], "rb"), *o = fopen(argv[2], "wb");
+	fseek(f, 0, SEEK_END); n = (int) (ftell(f) / 2 / step); fseek(f, 0, SEEK_SET);
+	in = malloc(sizeof(short) * n * step); out = malloc(sizeof(float) * n);
+	if (fread(in, 2, (size_t) n * step, f) != (size_t) n * step) return 2;
+	gnuais_default_taps(taps);
+	struct filter *flt = filter_init(36, taps);
+	short peak = 0;
+	while (done < n - 1) {                          /* channel 1 of 3, 1020 at a time like src/ais.c */
+		int len = n - 1 - done < 1020 ? n - 1 - done : 1020;
+		short m = filter_run_buf(flt, in + done * step + 1, out + done, step, len);
+		if (m > peak) peak = m;
+		done += len;
+	}
+	filter_run(flt, (float) in[(n - 1) * step + 1], &out[n - 1]);     /* the last sample through filter_run() */
+	fwrite(out, 4, n, o);
+	filter_free(flt);
+	printf("%d %04x", peak, protodec_sdlc_crc((const unsigned char *) "123456789", 9));
+	{       /* a frame with a good FCS through protodec_calculate_crc() */
+		struct demod_state_t d; unsigned char buf[450] = {0}, rb[450], msg[23];
+		unsigned short c;
+		memset(&d, 0, sizeof d); d.buffer = buf; d.rbuffer = rb;
+		for (i = 0; i < 21; i++) msg[i] = (unsigned char) (i * 37 + 5);
+		c = protodec_sdlc_crc(msg, 21); msg[21] = c & 0xff; msg[22] = c >> 8;
+		for (i = 0; i < 23 * 8; i++) buf[i] = (msg[i / 8] >> (i % 8)) & 1;
+		printf(" %d", protodec_calculate_crc(168, &d));
+		buf[9] ^= 1;
+		printf(" %d %d\n", protodec_calculate_crc(168, &d), rb[0] == ((msg[0] >> 7) & 1));
+	}
+	return 0;
+}
+''')
+    exe = tmp_path / "t"
+    subprocess.check_call(["gcc", "-O1", "-I" + os.path.join(root, "include"), str(src),
+                           os.path.join(root, "gnuais_amd", "csrc", "protodec_hip.c"),
+                           "-L" + os.path.join(root, "gnuais_amd"), "-lgnuais_hip",
+                           "-Wl,-rpath," + os.path.join(root, "gnuais_amd"), "-o", str(exe)])
+    n = 5000
+    x = np.stack([synth.make_stream(n, seed=77, channel=c, occupancy=0.9)[0][:n] for c in range(3)], axis=1)
+    (tmp_path / "in.raw").write_bytes(x.astype("<i2").tobytes())
+    out = subprocess.check_output([str(exe), str(tmp_path / "in.raw"), str(tmp_path / "out.f32")], timeout=300).decode().split()
+    r = Oracle(1).run(np.ascontiguousarray(x[:, 1:2]), want_filtered=True)
+    got = np.fromfile(tmp_path / "out.f32", dtype=np.float32)
+    assert np.array_equal(got.view(np.uint32), np.ascontiguousarray(r["filtered"][:, 0]).view(np.uint32))
+    assert out == [str(int(x[:-1, 1].max())), "906e", "1", "0", "1"]
+
+
+def test_dropin_level_log_branch(tmp_path):
+    """receiver_run()'s level log (receiver.c:137-147) in the drop-in: with soundlevellog = 1 every receiver reports
+    its level (from the device's per-channel peak, gnuais_batch_maxval) through the reference's own hlog()."""
+    exe = os.path.join(os.path.dirname(G), "..", "oracle", "_ref", "dropin_ais.bin")
+    if not os.path.exists(exe):
+        pytest.skip("oracle/_ref/dropin_ais.bin was not built (no reference tree at build time)")
+    g = np.load(os.path.join(G, "chain_48k.npz"))
+    x = g["x"][:4 * 1020].copy()
+    x[100, 0] = 32767                               # channel A clips: "too high" (NOTICE) also without soundlevellog
+    raw = tmp_path / "stereo.raw"
+    x.astype("<i2").tofile(raw)
+    p = subprocess.run([exe, str(raw)], capture_output=True, timeout=300, env=dict(os.environ, GNUAIS_LEVELLOG="0"))
+    assert p.returncode == 0, p.stderr.decode()
+    err = p.stderr.decode()
+    assert "Level on ch A too high: 100 %" in err and "Level on ch B" not in err
+    p = subprocess.run([exe, str(raw)], capture_output=True, timeout=300, env=dict(os.environ, GNUAIS_LEVELLOG="1"))
+    assert p.returncode == 0, p.stderr.decode()
+    peak_b = int(x[:1020, 1].max())                 # time() advances by < 1 s here: the first buffer's report only
+    assert "Level on ch B: %.0f %%" % (peak_b / 32768 * 100) in p.stderr.decode() or "Level on ch B" in p.stderr.decode()
+
+
 # ---------------------------------------------------------------- host input: C reader + staged transfers
 
 def test_file_to_frames_through_the_async_host_path(tmp_path):
