@@ -376,13 +376,14 @@ __device__ __forceinline__ void touch12(float *a)
 
 // NES > 0: the table has exactly NES effective taps and travels whole in SGPRs (`taps`, NT = NES);
 // NES == 0: only the NC central taps do, the exact re-evaluation reads the NE taps from memory.
-template <int NES, int NC, int NT>
+// INLOOP (48-tap instantiation): eps follows a running maximum of |x| kept in the loop instead of a pre-pass over the segment
+template <int NES, int NC, int NT, bool INLOOP = false>
 __global__ __launch_bounds__(64) void fir_sign_kernel(
     const int16_t *__restrict__ x, const int16_t *__restrict__ hist,
     uint32_t *__restrict__ sgn, int *__restrict__ maxval,
     int16_t *__restrict__ hist_out, int *__restrict__ maxval_next,
     const float *__restrict__ te_mem, int N, int L, int T, int d, int NTaps, int NE_rt, float eps_up,
-    int map, FirTaps<NT> taps, unsigned long long *stamps, int n_big, int T2)
+    int map, FirTaps<NT> taps, unsigned long long *stamps, int n_big, int T2, float eps_seen, float eps_ahead)
 {
     const int NE = NES > 0 ? NES : NE_rt;
     const int wave_id = (int) (blockIdx.y * gridDim.x + blockIdx.x);
@@ -694,7 +695,34 @@ __global__ __launch_bounds__(64) void fir_sign_kernel(
         // slack for subnormal products).  One more pass over the segment's input (second read
         // mostly from L2 / Infinity Cache), 1 % more VALU work.
         float eps_w;
-        {
+        // INLOOP: the maximum over a window that moves with the loop instead.  The reference windows of the outputs that
+        // complete in a group of 16 rows starting at row mbg reach from mbg - (NC - 1) - J0 back to mbg + 15 + J0
+        // ahead.  What lies behind (and the group itself) is covered by the maxima of this group and of the NHIST
+        // groups before it; the J0 rows ahead have not been loaded yet: their taps are the table's last J0, and the
+        // host has priced those with |x| = 32768 into eps_ahead (a few percent of the whole for a bell-shaped
+        // table).  eps_w = eps_seen * M / 32768 + eps_ahead, per group.  No second pass over the segment (the
+        // pre-pass read it twice and was a quarter of a wave's lifetime in load latency), and a loud message only
+        // raises eps while it is inside the window, not for its whole segment.
+        constexpr int NHIST = 6;                                // 96 rows behind the group: >= NC - 1 + J0 for J0 <= 49
+        float hmax[NHIST];
+        if constexpr (INLOOP) {
+            float P = 0.0f;                                     // rows m0 - J0 .. m0 + NC - 2: everything before the first group
+            const int plo = m0 - J0, phi = m0 + NC - 2;
+            for (int mbase = plo; mbase <= phi; mbase += 16) {
+                int v[16];
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    int m = mbase + i <= phi ? mbase + i : phi;
+                    m = m < -NTaps ? -NTaps : m;
+                    v[i] = load_sample(x, hist, m, N, NTaps, c);
+                }
+#pragma unroll
+                for (int i = 0; i < 16; ++i) P = __builtin_fmaxf(P, __builtin_fabsf((float) v[i]));
+            }
+#pragma unroll
+            for (int k = 0; k < NHIST; ++k) hmax[k] = P;
+            eps_w = 0.0f;
+        } else {
             const int mlo = t0 - d;                             // oldest sample of output t0's window
             const int mhi = t1 - 1 - d + NE - 1;                // newest sample of output t1-1's window
             int M = 0;
@@ -812,6 +840,18 @@ __global__ __launch_bounds__(64) void fir_sign_kernel(
                     }
                     peakbits = bp > peakbits ? bp : peakbits;
                 }
+                if constexpr (INLOOP) {
+                    float gm = 0.0f;
+    #pragma unroll
+                    for (int p = 0; p < GROUP; ++p) gm = __builtin_fmaxf(gm, __builtin_fabsf(xf[p]));
+                    float M = gm;
+    #pragma unroll
+                    for (int k = 0; k < NHIST; ++k) M = __builtin_fmaxf(M, hmax[k]);
+    #pragma unroll
+                    for (int k = 0; k + 1 < NHIST; ++k) hmax[k] = hmax[k + 1];
+                    hmax[NHIST - 1] = gm;
+                    eps_w = __builtin_fmaf(eps_seen, M * (1.0f / 32768.0f), eps_ahead);
+                }
     #pragma unroll
                 for (int p = 0; p < GROUP; ++p) {
                     const int P = g * GROUP + p;                // phase within the unrolled block, P % NC static
@@ -898,17 +938,21 @@ hipError_t launch_fir_sign(const FirLaunch &a, hipStream_t stream)
         FirTaps<32> t;
         for (int j = 0; j < 32; ++j) t.te[j] = a.te[j];
         hipLaunchKernelGGL((fir_sign_kernel<32, 12, 32>), grid, block, a.lds_pad, stream, a.x, a.hist, a.sgn, a.maxval,
-                           a.hist_out, a.maxval_next, a.te_mem, a.N, a.L, a.T, a.d, a.NT, a.NE, eps_up, map, t, a.stamps, n_big, T2);
+                           a.hist_out, a.maxval_next, a.te_mem, a.N, a.L, a.T, a.d, a.NT, a.NE, eps_up, map, t, a.stamps, n_big, T2, a.eps_seen, a.eps_ahead);
     } else if (a.NC == 12) {
         FirTaps<12> t;
         for (int j = 0; j < 12; ++j) t.te[j] = a.ctaps[j];
         hipLaunchKernelGGL((fir_sign_kernel<0, 12, 12>), grid, block, 0, stream, a.x, a.hist, a.sgn, a.maxval,
-                           a.hist_out, a.maxval_next, a.te_mem, a.N, a.L, a.T, a.d, a.NT, a.NE, eps_up, map, t, a.stamps, n_big, T2);
+                           a.hist_out, a.maxval_next, a.te_mem, a.N, a.L, a.T, a.d, a.NT, a.NE, eps_up, map, t, a.stamps, n_big, T2, a.eps_seen, a.eps_ahead);
     } else {
         FirTaps<48> t;
         for (int j = 0; j < 48; ++j) t.te[j] = a.ctaps[j];
+        if (a.eps_seen > 0.0f && a.NE - a.NC <= 98)
+            hipLaunchKernelGGL((fir_sign_kernel<0, 48, 48, true>), grid, block, 0, stream, a.x, a.hist, a.sgn, a.maxval,
+                               a.hist_out, a.maxval_next, a.te_mem, a.N, a.L, a.T, a.d, a.NT, a.NE, eps_up, map, t, a.stamps, n_big, T2, a.eps_seen, a.eps_ahead);
+        else
         hipLaunchKernelGGL((fir_sign_kernel<0, 48, 48>), grid, block, 0, stream, a.x, a.hist, a.sgn, a.maxval,
-                           a.hist_out, a.maxval_next, a.te_mem, a.N, a.L, a.T, a.d, a.NT, a.NE, eps_up, map, t, a.stamps, n_big, T2);
+                           a.hist_out, a.maxval_next, a.te_mem, a.N, a.L, a.T, a.d, a.NT, a.NE, eps_up, map, t, a.stamps, n_big, T2, a.eps_seen, a.eps_ahead);
     }
     return hipGetLastError();
 }

@@ -162,6 +162,8 @@ struct gnuais_batch {
                                     // 0 exact scalar VALU, 1 exact packed, 2 exact MFMA products
     bool sign_ok = false;           // table is 32 symmetric effective taps: K1s applicable
     float sign_eps = 0.0f;
+    float sign_eps_seen = 0.0f, sign_eps_ahead = 0.0f;   // sign_eps split: what scales with the samples seen / what cannot
+    int fir_inloop = 1;             // 48-tap K1s: running window maximum in the loop (0: the per-segment pre-pass)
     int sign_NC = 12;               // central taps K1s evaluates
     int k0 = 0;                     // first effective tap
     int pll_variant = 0;            // 0: by channel count; 3 / 6 (kernels.h: PllLaunch::variant)
@@ -348,6 +350,16 @@ int gnuais_batch_create(gnuais_batch **out, int device, int n_channels, const fl
                 b->sign_eps = (float) (bound * 1.1);
                 b->sign_NC = NC;
                 b->sign_ok = true;
+                // The same bound in two parts, for the kernel that scales it with the largest |x| it has SEEN (the
+                // 48-tap instantiation, fir_slice.hip): the last J0 taps of a reference window multiply samples
+                // that lie up to J0 rows beyond the newest one the central sum has loaded; their share of the
+                // bound keeps X = 32768 (it is tiny: those taps are) and everything else scales with the maximum
+                // over the rows behind.  bound = part_seen + part_ahead.
+                double ahead = 0;
+                for (int i = J0 + NC + 1; i <= NE; ++i)      // 1-based tap index, as in ordered()
+                    ahead += std::fabs((double) b->te[i - 1]) * (1.0 + (std::pow(1 + u, NE - i + 2) - 1));
+                b->sign_eps_ahead = (float) (X * ahead * 1.1 + 1e-30);
+                b->sign_eps_seen = (float) ((bound - X * ahead) * 1.1);
             }
         }
     }
@@ -538,6 +550,8 @@ int gnuais_batch_set_option(gnuais_batch *b, const char *name, int value)
         b->fir_cpl = value;
     } else if (!strcmp(name, "fir_form")) {
         b->fir_form = value;
+    } else if (!strcmp(name, "fir_inloop")) {
+        b->fir_inloop = value != 0;
     } else if (!strcmp(name, "fir_dbg")) {
         b->fir_dbg = value;
     } else if (!strcmp(name, "fir_lds")) {
@@ -591,6 +605,8 @@ static void fill_fir(const gnuais_batch *b, FirLaunch &f, const int16_t *x, int 
     f.NE = b->NE;
     f.d = b->d;
     f.eps = b->sign_eps;
+    f.eps_seen = b->fir_inloop ? b->sign_eps_seen : 0.0f;
+    f.eps_ahead = b->sign_eps_ahead;
     f.NC = b->sign_NC;
     if (b->sign_ok)
         for (int j = 0; j < b->sign_NC; ++j) f.ctaps[j] = b->te[(b->NE - b->sign_NC) / 2 + j];
@@ -1587,6 +1603,8 @@ int gnuais_batch_info(const gnuais_batch *b, const char *name, double *value)
     if (!b || !name || !value) return fail(GNUAIS_E_ARG, "info: argument");
     if (!strcmp(name, "sign_exact")) *value = b->sign_ok && b->fir_variant == 3;
     else if (!strcmp(name, "sign_eps")) *value = b->sign_eps;
+    else if (!strcmp(name, "sign_eps_seen")) *value = b->sign_eps_seen;
+    else if (!strcmp(name, "sign_eps_ahead")) *value = b->sign_eps_ahead;
     else if (!strcmp(name, "sign_central_taps")) *value = b->sign_NC;
     else if (!strcmp(name, "first_effective_tap")) *value = b->k0;
     else if (!strcmp(name, "n_effective_taps")) *value = b->NE;

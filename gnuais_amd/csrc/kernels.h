@@ -21,6 +21,7 @@ struct FirLaunch {
     int n_big = 1 << 30, T2 = 0;   // K1s: segments 0 .. n_big-1 are T outputs long, the rest T2 (the launch's tail, see run_fir)
     int NT, NE, d;         // out[n] = sum_j te[j] * x[n - d + j], j < NE
     float eps;             // sign-exact slicer: |central sum| > eps certifies the sign
+    float eps_seen = 0, eps_ahead = 0;     // 48-tap K1s with the running maximum (eps_seen > 0): eps = eps_seen * M / 32768 + eps_ahead
     int NC;                //   central taps used (12 or 48)
     float ctaps[48];       //   te[(NE-NC)/2 .. +NC)
     const float *te_mem;   //   the NE effective taps in device memory (exact re-evaluation)
