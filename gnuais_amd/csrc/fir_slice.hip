@@ -352,6 +352,10 @@ __global__ __launch_bounds__(64) void fir_slice_kernel(
 #ifndef FIR_TYPED_LOADS_48
 #define FIR_TYPED_LOADS_48 1
 #endif
+// 48-tap instantiation: ask for the next group's rows before working on this group's (16 registers)
+#ifndef FIR_PREFETCH_48
+#define FIR_PREFETCH_48 0       // measured: 5.10 ms either way (C5 FIR alone) -- the kernel is not waiting for its loads
+#endif
 // words per loop turn of the direct form; with 4 a lane stores its four sign words of 128 outputs as ONE
 // 16-byte store (sgn_index() keeps them adjacent): a wave's store covers 1 KB densely instead of four
 // stores of 4 bytes in every 16 (PMC: 0.30 GB of write traffic per C3 call for 0.10 GB of sign words)
@@ -378,7 +382,7 @@ __device__ __forceinline__ void touch12(float *a)
 // NES == 0: only the NC central taps do, the exact re-evaluation reads the NE taps from memory.
 // INLOOP (48-tap instantiation): eps follows a running maximum of |x| kept in the loop instead of a pre-pass over the segment
 template <int NES, int NC, int NT, bool INLOOP = false>
-__global__ __launch_bounds__(64) void fir_sign_kernel(
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NC == 48 ? 4 : 1))) void fir_sign_kernel(
     const int16_t *__restrict__ x, const int16_t *__restrict__ hist,
     uint32_t *__restrict__ sgn, int *__restrict__ maxval,
     int16_t *__restrict__ hist_out, int *__restrict__ maxval_next,
@@ -793,6 +797,36 @@ __global__ __launch_bounds__(64) void fir_sign_kernel(
         // whole words, also for a last word that ends inside its first half: flush()'s silence test
         // needs all 32 samples of the word in zor (the phases past t1 are masked out)
         const int ngroups = (t1 - t0 + 31) / 32 * 2;
+        // rows mbx .. mbx + GROUP - 1 of the lane's channel as floats
+        auto load_group48 = [&](int mbx, float *dst) {
+            if ((mbx >= 0) && (mbx + GROUP - 1 < L)) {
+#if FIR_TYPED_LOADS_48
+                // typed buffer loads as in the 12-tap path, but with the row in the VECTOR offset (one
+                // two-operand add per load): this instantiation has no SGPRs to spare for 16 row offsets
+                // -- with them it lost 6.8 vs 6.6 ms -- and still sheds the 64-bit address add and the
+                // int -> float convert
+                const int voff0 = coff + (int) ((uint32_t) (mbx - row0) * rowbytes);
+    #pragma unroll
+                for (int p = 0; p < GROUP; ++p)
+                    dst[p] = fir_load_format_f32(rsrc_f, voff0 + (int) ((uint32_t) p * rowbytes), 0, 0);
+#else
+                const int16_t *row = x + (size_t) mbx * (size_t) N + c;
+    #pragma unroll
+                for (int p = 0; p < GROUP; ++p) dst[p] = (float) (int) row[(size_t) p * (size_t) N];
+#endif
+            } else {
+    #pragma unroll
+                for (int p = 0; p < GROUP; ++p) {
+                    int m = mbx + p;
+                    m = (m < L) ? m : L - 1;
+                    dst[p] = (float) load_sample(x, hist, m, N, NTaps, c);
+                }
+            }
+        };
+#if FIR_PREFETCH_48
+        float xn[GROUP];
+        load_group48(m0 + NC - 1, xn);
+#endif
         for (int b = 0; b * NG < ngroups; ++b) {
     #pragma unroll
             for (int g = 0; g < NG; ++g) {
@@ -802,29 +836,17 @@ __global__ __launch_bounds__(64) void fir_sign_kernel(
                 float xf[GROUP];                                // the group's samples as floats (exact)
                 const int mb = m0 + NC - 1 + gbase;             // sample of the group's first phase
                 const bool interior = (mb >= 0) && (mb + GROUP - 1 < L);
-                if (interior) {
-#if FIR_TYPED_LOADS_48
-                    // typed buffer loads as in the 12-tap path, but with the row in the VECTOR offset (one
-                    // two-operand add per load): this instantiation has no SGPRs to spare for 16 row offsets
-                    // -- with them it lost 6.8 vs 6.6 ms -- and still sheds the 64-bit address add and the
-                    // int -> float convert
-                    const int voff0 = coff + (int) ((uint32_t) (mb - row0) * rowbytes);
+#if FIR_PREFETCH_48
+                // the rows of this group were asked for one group ago; the next group's go out now, before this
+                // group's 880 instructions, so that a wave's loads are in flight while it computes (four waves per
+                // SIMD do not cover a load's latency for each other when each of them waits at the same point)
     #pragma unroll
-                    for (int p = 0; p < GROUP; ++p)
-                        xf[p] = fir_load_format_f32(rsrc_f, voff0 + (int) ((uint32_t) p * rowbytes), 0, 0);
+                for (int p = 0; p < GROUP; ++p) xf[p] = xn[p];
+                if (gi + 1 < ngroups) load_group48(mb + GROUP, xn);
+                __builtin_amdgcn_sched_barrier(0);
 #else
-                    const int16_t *row = x + (size_t) mb * (size_t) N + c;
-    #pragma unroll
-                    for (int p = 0; p < GROUP; ++p) xf[p] = (float) (int) row[(size_t) p * (size_t) N];
+                load_group48(mb, xf);
 #endif
-                } else {
-    #pragma unroll
-                    for (int p = 0; p < GROUP; ++p) {
-                        int m = mb + p;
-                        m = (m < L) ? m : L - 1;
-                        xf[p] = (float) load_sample(x, hist, m, N, NTaps, c);
-                    }
-                }
                 {   // filter.c:118-119 peak, on the float bit patterns (see the 12-tap path)
                     int bp = 0;
                     if (interior) {
