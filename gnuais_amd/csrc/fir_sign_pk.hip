@@ -1,0 +1,416 @@
+// fir_sign_pk.hip -- K1s in transposed form on register PAIRS (gfx950): v_pk_fma_f32 does two of the slicer's
+// multiply-adds for the issue cost of one.
+//
+// Same contract as fir_sign_kernel (fir_slice.hip): the sign-exact slicer standing in for filter_run_buf() + the
+// `out > 0` test of receiver_run() (gnuais src/filter.c:106-143, src/receiver.c:109-111,126); bit-identical sign
+// words, peak and history carry.  What changes is how y_c, the sum over the NC central taps, is formed.
+//
+// Measured on this chip (scripts/ubench/valu_rate.hip, four waves per SIMD): v_fmac_f32 with the tap in an SGPR --
+// what the scalar kernels issue -- costs 2.0 ns per wave-instruction per SIMD, v_pk_fma_f32 with the taps in an SGPR
+// PAIR 2.1 ns for two multiply-adds, with or without op_sel swizzles on its operands.  The 48-tap kernel is bound by
+// exactly that (48 x 2.0 ns + flags = 106 ns per sample and wave = the 5.1 ms it takes for C5), the 12-tap kernel
+// spends half of its issue time there.
+//
+// Transposed form: sample x_i adds tc[q] * x_i to output o = i - q, q = 0 .. NC-1; the NC outputs in flight are a ring
+// of NC accumulators, here NC/2 register pairs (slots a, a+1 with a even).  Samples are taken two at a time (x_P, x_P+1
+// in one register pair, P even), each pair of samples is 2 x NC/2 packed instructions:
+//   slot pair a, k = (P - a) mod NC (even):
+//     acc[a:a+1] += { tc[k],   tc[k-1] } * { x_P,   x_P   }        "odd" tap pair  O(k)
+//     acc[a:a+1] += { tc[k+1], tc[k]   } * { x_P+1, x_P+1 }        reversed "even" tap pair E(k) = { tc[k], tc[k+1] }
+// The table is bitwise symmetric (tc[q] = tc[NC-1-q]), so E(NC-2-k) = reverse(E(k)) and O(NC-k) = reverse(O(k)): only
+// NC/4 even and NC/4 + 1 odd pairs exist (NC + 2 SGPRs), the other half is the same registers with the halves
+// swapped by op_sel; the sample broadcast is op_sel too.  After the first instruction group slot P+1 is complete (its
+// last term was tc[NC-1] * x_P): it is read and cleared; after the second, slot P+2.  Every accumulator receives its
+// NC products in sample order, one fused rounding each -- the arithmetic of the scalar transposed form, so the host's
+// bound for it (ordered sum of NC fused terms, gnuais_capi.hip) carries over unchanged.
+//
+// Everything around the sum (typed loads, flags through v_alignbit_b32, the silence test, the exact ordered NE-tap
+// re-evaluation of uncertified samples, the running window maximum that scales eps for long tables, peak, carry) is
+// that of fir_sign_kernel's grouped branch.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <math.h>
+#include <utility>
+#include "kernels.h"
+
+namespace gnuais {
+
+namespace {
+
+typedef float pk_f2 __attribute__((ext_vector_type(2)));
+typedef int pk_v4i __attribute__((ext_vector_type(4)));
+extern "C" __device__ float pk_load_format_f32(pk_v4i rsrc, int voffset, int soffset, int aux)
+    __asm("llvm.amdgcn.raw.buffer.load.format.f32");
+
+__device__ __forceinline__ int pk_load_sample(const int16_t *__restrict__ x, const int16_t *__restrict__ hist,
+                                              int m, int N, int NT, int c)
+{
+    const int16_t *p = (m >= 0) ? (x + (size_t) m * (size_t) N + c) : (hist + (size_t) (NT + m) * (size_t) N + c);
+    return (int) *p;
+}
+
+template <int I> struct PkIc { static constexpr int value = I; };
+template <class F, int... Is>
+__device__ __forceinline__ void pk_expand(F &&f, std::integer_sequence<int, Is...>) { (f(PkIc<Is>{}), ...); }
+template <class F, int... Is>
+__device__ __forceinline__ void pk_expand_void(F &&f, std::integer_sequence<int, Is...>) { (f(PkIc<Is>{}), ...); }
+template <class F, int... Is>
+__device__ __forceinline__ bool pk_expand_and(F &&f, std::integer_sequence<int, Is...>) { return (f(PkIc<Is>{}) && ...); }
+
+template <int NC>
+struct PkTaps {
+    pk_f2 E[NC / 4];            // E[j] = { tc[2j], tc[2j+1] },   j < NC/4
+    pk_f2 O[NC / 4 + 1];        // O[j] = { tc[2j], tc[2j-1] },   j <= NC/4, tc[-1] = tc[NC-1]
+};
+template <int NES> struct PkExact { float te[NES > 0 ? NES : 1]; };
+
+// the next group's rows are requested before this group's steps run
+#ifndef PK_PREFETCH_12
+#define PK_PREFETCH_12 1
+#endif
+#ifndef PK_PREFETCH_48
+#define PK_PREFETCH_48 0
+#endif
+#ifndef PK_WARM_BATCH
+#define PK_WARM_BATCH 8
+#endif
+#include "fir_sign_pk_asm.inc"       // generated: the pair steps as fixed-register instruction streams (scripts/gen_fir_pk_asm.py)
+
+// NES > 0: the table's NES effective taps travel in SGPRs for the exact re-evaluation (reference table: 32);
+// NES == 0: they are read from te_mem.  INLOOP: eps follows a running window maximum (long tables).
+template <int NES, int NC, bool INLOOP>
+__device__ __forceinline__ void fir_sign_pk_body(
+    const int16_t *__restrict__ x, const int16_t *__restrict__ hist,
+    uint32_t *__restrict__ sgn, int *__restrict__ maxval,
+    int16_t *__restrict__ hist_out, int *__restrict__ maxval_next,
+    const float *__restrict__ te_mem, int N, int L, int T, int d, int NTaps, int NE_rt, float eps_up,
+    float eps_seen, float eps_ahead, int map, PkTaps<NC> tp, PkExact<NES> ex)
+{
+    static_assert(NC % 4 == 0 && 48 % NC == 0, "48 unrolled phases must hold whole turns of the accumulator ring");
+    constexpr int GROUP = 16, UNROLL = 48, NG = UNROLL / GROUP, NP = NC / 2;
+    const int NE = NES > 0 ? NES : NE_rt;
+    const int J0 = (NE - NC) / 2;
+    const int lane = threadIdx.x;
+    int bx = (int) blockIdx.x, by = (int) blockIdx.y;
+    if (map == 1) {                             // XCD-contiguous channel groups, as in fir_sign_kernel
+        const int G = (int) gridDim.x, id = by * G + bx, per = G >> 3;
+        bx = (id & 7) * per + (id >> 3) % per;
+        by = (id >> 3) / per;
+    }
+    const int cg = bx * 64 + lane;
+    const int c = cg < N ? cg : N - 1;
+    const bool live = cg < N;
+    const int t0 = by * T;                      // T is a multiple of 384 (whole unrolled turns, whole 16-byte sign stores)
+    const int t1 = (t0 + T < L) ? t0 + T : L;
+    if (t0 >= L) return;
+    const int dc = d - J0;                      // y_c[n] = sum_q tc[q] * x[n - dc + q]
+    const int m0 = t0 - dc;                     // local sample i <-> row m0 + i; output o completes with sample o + NC - 1
+
+    auto exact_positive = [&](int n) __attribute__((always_inline)) -> bool {  // filter.h:40-49 order
+        float sum = 0.0f;
+        if constexpr (NES > 0) {
+#pragma unroll
+            for (int j = 0; j < NES; ++j) {
+                const float xs = (float) pk_load_sample(x, hist, n - d + j, N, NTaps, c);
+                sum = sum + ex.te[j] * xs;
+            }
+            return sum > 0.0f;
+        }
+        for (int j0 = 0; j0 < NE; j0 += 8) {        // eight loads in flight: this rare path must not set the kernel's register count
+            int xs[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int jj = j0 + j < NE ? j0 + j : NE - 1;
+                xs[j] = pk_load_sample(x, hist, n - d + jj, N, NTaps, c);
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                if (j0 + j < NE) sum = sum + te_mem[j0 + j] * (float) xs[j];
+        }
+        return sum > 0.0f;
+    };
+    auto all_zero = [&](int m_first, int count) __attribute__((always_inline)) -> bool {
+        uint32_t o = 0;
+        for (int i = 0; i < count; ++i) {
+            int m = m_first + i;
+            m = m < -NTaps ? -NTaps : (m > L - 1 ? L - 1 : m);
+            o |= (uint32_t) pk_load_sample(x, hist, m, N, NTaps, c);
+        }
+        return o == 0;
+    };
+
+    const int row0 = m0 > 0 ? m0 : 0;
+    const uint32_t rowbytes = (uint32_t) N * 2u;
+    const unsigned long long span = (unsigned long long) (L - row0) * rowbytes;
+    const unsigned long long xbase = (unsigned long long) (x + (size_t) row0 * (size_t) N);
+    const pk_v4i rsrc_f = {(int) (xbase & 0xffffffffull), (int) ((xbase >> 32) & 0xffffull),
+                           (int) (span > 0xffffffffull ? 0xffffffffull : span), 0x13004};     // R | SSCALED | 16
+    const int coff = c * 2;
+
+    // The accumulator ring (and, for 48 taps, the odd tap pairs) sits in fixed registers above PK_VGPR_BASE, outside
+    // the compiler's budget; everything that touches it is one of the generated instruction streams.
+    (void) NP;
+    if constexpr (NC == 12) asm volatile(PK12_ZERO ::: PK12_CLOBBERS);
+    else {
+        asm volatile(PK48_ZERO ::: PK48_CLOBBERS);
+        pk48_load_o(tp);
+    }
+    // warm-up: samples i = 0 .. NC-2 (ring phase i + 1); nothing they complete is an output of this segment.  The loads
+    // of up to eight steps go out together (the steps are volatile asm: a load issued between two of them would be
+    // waited for there, one round trip per step)
+    {
+        constexpr int NW = (NC - 2) / 2;                        // full pair steps after the half step of sample 0
+        pk_f2 w0;
+        w0[0] = 0.0f;
+        w0[1] = (float) pk_load_sample(x, hist, m0, N, NTaps, c);
+        auto batch = [&](auto B0) __attribute__((always_inline)) {
+            constexpr int s0 = decltype(B0)::value * PK_WARM_BATCH;
+            constexpr int n = NW - s0 < PK_WARM_BATCH ? NW - s0 : PK_WARM_BATCH;
+            pk_f2 w[n];
+#pragma unroll
+            for (int k = 0; k < n; ++k) {
+                const int P = 2 + 2 * (s0 + k);                 // phases P, P+1 = samples P-1, P
+                w[k][0] = (float) pk_load_sample(x, hist, m0 + P - 1, N, NTaps, c);
+                w[k][1] = (float) pk_load_sample(x, hist, m0 + P, N, NTaps, c);
+            }
+            if constexpr (s0 == 0) {
+                if constexpr (NC == 12) pk12_warm<0, true>(w0, tp); else pk48_warm<0, true>(w0, tp);   // phase 0 is empty, phase 1 = sample 0
+            }
+            auto warm = [&](auto S) __attribute__((always_inline)) {
+                constexpr int k = decltype(S)::value;
+                constexpr int P = 2 + 2 * (s0 + k);
+                if constexpr (NC == 12) pk12_warm<P, false>(w[k], tp); else pk48_warm<P, false>(w[k], tp);
+            };
+            pk_expand(warm, std::make_integer_sequence<int, n>{});
+        };
+        pk_expand(batch, std::make_integer_sequence<int, (NW + PK_WARM_BATCH - 1) / PK_WARM_BATCH>{});
+    }
+
+    int peakbits = 0;
+    uint32_t neg = 0, amb = 0, zor = 0;
+    bool zprev_known = false, zprev = false;
+    float eps_w = eps_up;
+    constexpr int NHIST = 6;                    // see fir_sign_kernel: 96 rows behind a group cover NC - 1 + J0 for J0 <= 49
+    float hmax[NHIST];
+    if constexpr (INLOOP) {
+        float Pm = 0.0f;
+        const int plo = m0 - J0, phi = m0 + NC - 2;
+        for (int mbase = plo; mbase <= phi; mbase += 16) {
+            int v[16];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                int m = mbase + i <= phi ? mbase + i : phi;
+                m = m < -NTaps ? -NTaps : m;
+                v[i] = pk_load_sample(x, hist, m, N, NTaps, c);
+            }
+#pragma unroll
+            for (int i = 0; i < 16; ++i) Pm = __builtin_fmaxf(Pm, __builtin_fabsf((float) v[i]));
+        }
+#pragma unroll
+        for (int k = 0; k < NHIST; ++k) hmax[k] = Pm;
+    }
+
+    uint32_t wq[4] = {0u, 0u, 0u, 0u};
+    auto flush = [&](int obase) __attribute__((always_inline)) {               // one finished sign word: outputs obase .. obase+31
+        const int mb = m0 + NC - 1 + obase;
+        uint32_t w = ~neg;
+        const int valid = t1 - (t0 + obase);
+        if (valid < 32) {
+            w &= ~0u << (32 - valid);
+            amb &= ~0u << (32 - valid);
+        }
+        bool zc_known = false, zc = false;
+        if (__popc(amb) >= 8) {                 // a silent stretch?  (fir_sign_kernel)
+            zc = zor == 0;
+            zc_known = true;
+            const int before = J0 + NC - 1;
+            if (zc && ((before <= 32 && zprev_known) ? zprev : all_zero(mb - before, before)) && all_zero(mb + 32, J0)) {
+                w &= ~amb;
+                amb = 0;
+            }
+        }
+        zprev_known = zc_known;
+        zprev = zc;
+        while (amb) {
+            const int pos = __clz((int) amb);
+            const uint32_t bit = 0x80000000u >> pos;
+            amb &= ~bit;
+            if (exact_positive(t0 + obase + pos)) w |= bit; else w &= ~bit;
+        }
+        const int slot = (obase >> 5) & 3;
+        if (slot == 0) wq[0] = w; else if (slot == 1) wq[1] = w; else if (slot == 2) wq[2] = w; else wq[3] = w;
+        const bool last = t0 + obase + 32 >= t1;
+        if (live && (slot == 3 || last)) {
+            uint32_t *dst = sgn + sgn_index(((t0 + obase) >> 5) - slot, N, cg);
+            if (slot == 3) {
+                *reinterpret_cast<uint4 *>(dst) = make_uint4(wq[0], wq[1], wq[2], wq[3]);
+            } else {
+                dst[0] = wq[0];
+                if (slot >= 1) dst[1] = wq[1];
+                if (slot >= 2) dst[2] = wq[2];
+            }
+        }
+        zor = 0;
+    };
+
+    const int ngroups = (t1 - t0 + 31) / 32 * 2;
+    // rows mbx .. mbx + GROUP - 1 as floats; rows past the call are clamped (their outputs are masked), rows before it
+    // come from the history
+    auto load_group = [&](int mbx, pk_f2 *dst) __attribute__((always_inline)) {
+        if ((mbx >= 0) && (mbx + GROUP - 1 < L)) {
+            const int voff0 = coff + (int) ((uint32_t) (mbx - row0) * rowbytes);
+#pragma unroll
+            for (int p = 0; p < GROUP; ++p)
+                dst[p / 2][p % 2] = pk_load_format_f32(rsrc_f, voff0 + (int) ((uint32_t) p * rowbytes), 0, 0);
+        } else {
+            // typed loads here as well (no 64-bit address arithmetic: this path must not set the register count):
+            // the row is wave-uniform, so history or input is a scalar select of the descriptor
+            const unsigned long long hbase = (unsigned long long) hist;
+#pragma unroll
+            for (int p = 0; p < GROUP; ++p) {
+                const int m = mbx + p;
+                const bool h = m < 0;
+                const int mm = m < L ? m : L - 1;
+                const pk_v4i r = {h ? (int) (hbase & 0xffffffffull) : rsrc_f[0], h ? (int) ((hbase >> 32) & 0xffffull) : rsrc_f[1],
+                                  h ? (int) ((uint32_t) NTaps * rowbytes) : rsrc_f[2], 0x13004};
+                dst[p / 2][p % 2] = pk_load_format_f32(r, coff, (int) ((uint32_t) (h ? NTaps + m : mm - row0) * rowbytes), 0);
+            }
+        }
+    };
+    constexpr bool PF = NC == 12 ? (PK_PREFETCH_12 != 0) : (PK_PREFETCH_48 != 0);
+    pk_f2 xn[GROUP / 2];
+    if constexpr (PF) load_group(m0 + NC - 1, xn);
+    for (int b = 0; b * NG < ngroups; ++b) {
+        auto group = [&](auto GI) __attribute__((always_inline)) -> bool {
+            constexpr int g = decltype(GI)::value;
+            const int gi = b * NG + g;
+            if (gi >= ngroups) return false;
+            const int gbase = gi * GROUP;                           // outputs gbase .. gbase + 15
+            const int mb = m0 + NC - 1 + gbase;                     // row of the group's first phase
+            const bool interior = (mb >= 0) && (mb + GROUP - 1 < L);
+            pk_f2 xp[GROUP / 2];                                    // the group's rows as floats (exact), two to a register pair
+            if constexpr (PF) {
+            // this group's rows were asked for one group ago; the next group's go out now, ahead of this group's steps
+#pragma unroll
+            for (int p = 0; p < GROUP / 2; ++p) xp[p] = xn[p];
+            if (gi + 1 < ngroups) load_group(mb + GROUP, xn);
+            } else {
+                load_group(mb, xp);
+            }
+            {   // filter.c:118-119 peak, on the float bit patterns
+                int bp = 0;
+                if (interior) {
+#pragma unroll
+                    for (int p = 0; p < GROUP; ++p) bp = __float_as_int(xp[p / 2][p % 2]) > bp ? __float_as_int(xp[p / 2][p % 2]) : bp;
+                } else {
+#pragma unroll
+                    for (int p = 0; p < GROUP; ++p) {
+                        const int m = mb + p;
+                        const int v = (m >= 0 && m < L) ? __float_as_int(xp[p / 2][p % 2]) : 0;
+                        bp = v > bp ? v : bp;
+                    }
+                }
+                peakbits = bp > peakbits ? bp : peakbits;
+            }
+            if constexpr (INLOOP) {
+                float gm = 0.0f;
+#pragma unroll
+                for (int p = 0; p < GROUP; ++p) gm = __builtin_fmaxf(gm, __builtin_fabsf(xp[p / 2][p % 2]));
+                float M = gm;
+#pragma unroll
+                for (int k = 0; k < NHIST; ++k) M = __builtin_fmaxf(M, hmax[k]);
+#pragma unroll
+                for (int k = 0; k + 1 < NHIST; ++k) hmax[k] = hmax[k + 1];
+                hmax[NHIST - 1] = gm;
+                eps_w = __builtin_fmaf(eps_seen, M * (1.0f / 32768.0f), eps_ahead);
+            }
+            auto pairs = [&](auto S) __attribute__((always_inline)) {
+                constexpr int s = decltype(S)::value;
+                constexpr int P = (g * GROUP + 2 * s) % NC;
+                if constexpr (NC == 12) pk12_step<P>(neg, amb, xp[s], eps_w, tp);
+                else pk48_step<P>(neg, amb, xp[s], eps_w, tp);
+            };
+            pk_expand_void(pairs, std::make_integer_sequence<int, GROUP / 2>{});
+            if (amb != 0) {
+#pragma unroll
+                for (int p = 0; p < GROUP; ++p) zor |= __float_as_uint(xp[p / 2][p % 2]);
+            } else {
+                zor |= 1u;
+            }
+            if (gi & 1) flush(gbase - 16);
+            return true;
+        };
+        if (!pk_expand_and(group, std::make_integer_sequence<int, NG>{})) break;
+    }
+
+    int peak = (int) __int_as_float(peakbits);
+    if (t1 == L) {                              // the last dc-NC+1 samples of the call
+        const int shift = dc - NC + 1;
+        for (int n = (L - shift > 0 ? L - shift : 0); n < L; ++n) {
+            const int v = (int) x[(size_t) n * (size_t) N + c];
+            peak = v > peak ? v : peak;
+        }
+    }
+    if (live && peak > 0) atomicMax(&maxval[cg], peak);
+    if (t1 == L && live) {                      // carry for the next call (filter.c:129-134 restated)
+        for (int k = 0; k < NTaps; ++k) {
+            const int m = L - NTaps + k;
+            hist_out[(size_t) k * (size_t) N + cg] =
+                (m >= 0) ? x[(size_t) m * (size_t) N + cg] : hist[(size_t) (NTaps + m) * (size_t) N + cg];
+        }
+        maxval_next[cg] = 0;
+    }
+}
+
+// the attribute wants a literal: one kernel per instantiation; the compiler's VGPR budget ends GAP registers below the ring
+#define PK_KERNEL(NAME, NCV, INL, BASE)                                                                              \
+    __global__ __launch_bounds__(64) __attribute__((amdgpu_num_vgpr(BASE))) void NAME(                                \
+        const int16_t *__restrict__ x, const int16_t *__restrict__ hist, uint32_t *__restrict__ sgn,                 \
+        int *__restrict__ maxval, int16_t *__restrict__ hist_out, int *__restrict__ maxval_next,                     \
+        const float *__restrict__ te_mem, int N, int L, int T, int d, int NTaps, int NE_rt, float eps_up,            \
+        float eps_seen, float eps_ahead, int map, PkTaps<NCV> tp, PkExact<0> ex)                                     \
+    {                                                                                                                 \
+        fir_sign_pk_body<0, NCV, INL>(x, hist, sgn, maxval, hist_out, maxval_next, te_mem, N, L, T, d, NTaps, NE_rt,  \
+                                      eps_up, eps_seen, eps_ahead, map, tp, ex);                                      \
+    }
+PK_KERNEL(fir_sign_pk12_kernel, 12, false, PK12_VGPR_BUDGET)
+PK_KERNEL(fir_sign_pk48_kernel, 48, true, PK48_VGPR_BUDGET)
+#undef PK_KERNEL
+
+} // namespace
+
+int launch_fir_sign_pk_quantum() { return 384; }
+
+// NC = 12 with the reference's 32 effective taps, or NC = 48 (any symmetric table of up to 146 effective taps)
+hipError_t launch_fir_sign_pk(const FirLaunch &a, hipStream_t stream)
+{
+    if (a.dump || a.T % 384 || (a.NC != 12 && a.NC != 48) || a.NE < a.NC || (a.NE - a.NC) % 2 || !a.te_mem ||
+        (a.NC == 12 && a.NE != 32) || (a.NC == 48 && (a.NE - a.NC > 98 || a.eps_seen <= 0.0f)))
+        return hipErrorInvalidValue;
+    dim3 grid((a.N + 63) / 64, (a.L + a.T - 1) / a.T), block(64);
+    const float eps_up = __builtin_nextafterf(a.eps_pk > 0.0f ? a.eps_pk : a.eps, INFINITY);
+    const int map = (a.map == 1 && grid.x % 8 == 0) ? 1 : 0;
+    if (a.NC == 12) {
+        PkTaps<12> tp;
+        PkExact<0> ex;
+        ex.te[0] = 0.0f;
+        auto tc = [&](int q) { return a.ctaps[((q % 12) + 12) % 12]; };
+        for (int j = 0; j < 3; ++j) tp.E[j] = pk_f2{tc(2 * j), tc(2 * j + 1)};
+        for (int j = 0; j <= 3; ++j) tp.O[j] = pk_f2{tc(2 * j), tc(2 * j - 1)};
+        hipLaunchKernelGGL(fir_sign_pk12_kernel, grid, block, 0, stream, a.x, a.hist, a.sgn, a.maxval,
+                           a.hist_out, a.maxval_next, a.te_mem, a.N, a.L, a.T, a.d, a.NT, a.NE, eps_up, 0.0f, 0.0f, map, tp, ex);
+    } else {
+        PkTaps<48> tp;
+        PkExact<0> ex;
+        auto tc = [&](int q) { return a.ctaps[((q % 48) + 48) % 48]; };
+        for (int j = 0; j < 12; ++j) tp.E[j] = pk_f2{tc(2 * j), tc(2 * j + 1)};
+        for (int j = 0; j <= 12; ++j) tp.O[j] = pk_f2{tc(2 * j), tc(2 * j - 1)};
+        ex.te[0] = 0.0f;
+        hipLaunchKernelGGL(fir_sign_pk48_kernel, grid, block, 0, stream, a.x, a.hist, a.sgn, a.maxval,
+                           a.hist_out, a.maxval_next, a.te_mem, a.N, a.L, a.T, a.d, a.NT, a.NE, eps_up, a.eps_seen,
+                           a.eps_ahead, map, tp, ex);
+    }
+    return hipGetLastError();
+}
+
+} // namespace gnuais

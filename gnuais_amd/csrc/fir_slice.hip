@@ -353,6 +353,9 @@ __global__ __launch_bounds__(64) void fir_slice_kernel(
 #define FIR_TYPED_LOADS_48 1
 #endif
 // 48-tap instantiation: ask for the next group's rows before working on this group's (16 registers)
+#ifndef FIR_VTAPS_48
+#define FIR_VTAPS_48 0       // measured: 5.14 ms with the taps in VGPRs against 5.10 (C5 FIR alone); the isolated rates do not carry over
+#endif
 #ifndef FIR_PREFETCH_48
 #define FIR_PREFETCH_48 0       // measured: 5.10 ms either way (C5 FIR alone) -- the kernel is not waiting for its loads
 #endif
@@ -681,6 +684,18 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NC == 48 ? 4
         // 16 samples are 31 KB, and a word is flushed after every second group.
         constexpr int GROUP = 16;
         constexpr int UNROLL = NC;
+        // The central taps in VECTOR registers (FIR_VTAPS_48): v_fmac_f32 with its multiplier in an SGPR issues at
+        // 2.0 ns per wave-instruction and SIMD, with all three operands in VGPRs at 1.1 (four waves per SIMD; 1.4-1.5
+        // with three or five) -- scripts/ubench/valu_rate.hip.  The 48-tap kernel is 48 of them per sample.  The empty
+        // asm hides that the value is wave-uniform, or the compiler would move it back into SGPRs.
+        float vtap[NC / 2];
+#pragma unroll
+        for (int q = 0; q < NC / 2; ++q) {
+            vtap[q] = ctap(q);
+#if FIR_VTAPS_48
+            asm volatile("" : "+v"(vtap[q]));
+#endif
+        }
         constexpr int NG = UNROLL / GROUP;
         static_assert(UNROLL % NC == 0 && UNROLL % GROUP == 0, "whole ring turns, whole groups");
         // Two flag bits per sample, each gathered with ONE v_alignbit_b32 (shift the word
@@ -886,8 +901,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NC == 48 ? 4
                         // term instead of two (inside the host's bound, which is taken for mul + add)
                         const int s0 = (P + NC - 1 - q) % NC;
                         const int s1 = (P + q) % NC;
-                        if (q == 0) acc[s0] = ctap(q) * xs; else acc[s0] = __builtin_fmaf(ctap(q), xs, acc[s0]);
-                        acc[s1] = __builtin_fmaf(ctap(q), xs, acc[s1]);
+                        if (q == 0) acc[s0] = vtap[q] * xs; else acc[s0] = __builtin_fmaf(vtap[q], xs, acc[s0]);
+                        acc[s1] = __builtin_fmaf(vtap[q], xs, acc[s1]);
                     }
                     const float y = acc[P % NC];                // y_c of output gbase + p
                     neg = __builtin_amdgcn_alignbit(neg, __float_as_uint(y), 31);

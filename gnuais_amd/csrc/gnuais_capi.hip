@@ -162,6 +162,9 @@ struct gnuais_batch {
                                     // 0 exact scalar VALU, 1 exact packed, 2 exact MFMA products
     bool sign_ok = false;           // table is 32 symmetric effective taps: K1s applicable
     float sign_eps = 0.0f;
+    float sign_eps_pk = 0.0f;       // the same for the packed transposed kernel's order of operations
+    int fir_pk = -1;                // K1s on register pairs (fir_sign_pk.hip): 1 where the table allows, 0 never, -1 where it is
+                                    // faster: the 48-tap sum (C5: 4.3 against 5.1 ms), not the 12-tap one (0.47 against 0.42-0.45)
     float sign_eps_seen = 0.0f, sign_eps_ahead = 0.0f;   // sign_eps split: what scales with the samples seen / what cannot
     int fir_inloop = 1;             // 48-tap K1s: running window maximum in the loop (0: the per-segment pre-pass)
     int sign_NC = 12;               // central taps K1s evaluates
@@ -348,6 +351,7 @@ int gnuais_batch_create(gnuais_batch **out, int device, int n_channels, const fl
             const double bound = X * (ordered(0, NE) + central + sum_out) + 1e-30;
             if (std::isfinite(bound) && bound < 2.0) {
                 b->sign_eps = (float) (bound * 1.1);
+                b->sign_eps_pk = (float) ((X * (ordered(0, NE) + ordered(J0, NC) + sum_out) + 1e-30) * 1.1);   // transposed sum (fir_sign_pk.hip)
                 b->sign_NC = NC;
                 b->sign_ok = true;
                 // The same bound in two parts, for the kernel that scales it with the largest |x| it has SEEN (the
@@ -464,6 +468,7 @@ int gnuais_batch_create(gnuais_batch **out, int device, int n_channels, const fl
         return fail(GNUAIS_E_HIP, "create: device allocation", e);
     }
     if (const char *v = getenv("GNUAIS_FIR_VARIANT")) b->fir_variant = atoi(v);
+    if (const char *v = getenv("GNUAIS_FIR_PK")) b->fir_pk = atoi(v) < 0 ? -1 : (atoi(v) != 0);
     if (const char *v = getenv("GNUAIS_FIR_CPL")) { const int c = atoi(v); if (c == 1 || c == 2 || c == 4) b->fir_cpl = c; }
     if (const char *v = getenv("GNUAIS_FIR_FORM")) b->fir_form = atoi(v);
     if (const char *v = getenv("GNUAIS_FIR_T")) b->fir_T = std::max(64, atoi(v) / 32 * 32);
@@ -550,6 +555,8 @@ int gnuais_batch_set_option(gnuais_batch *b, const char *name, int value)
         b->fir_cpl = value;
     } else if (!strcmp(name, "fir_form")) {
         b->fir_form = value;
+    } else if (!strcmp(name, "fir_pk")) {
+        b->fir_pk = value < 0 ? -1 : (value != 0);
     } else if (!strcmp(name, "fir_inloop")) {
         b->fir_inloop = value != 0;
     } else if (!strcmp(name, "fir_dbg")) {
@@ -605,6 +612,7 @@ static void fill_fir(const gnuais_batch *b, FirLaunch &f, const int16_t *x, int 
     f.NE = b->NE;
     f.d = b->d;
     f.eps = b->sign_eps;
+    f.eps_pk = b->sign_eps_pk;
     f.eps_seen = b->fir_inloop ? b->sign_eps_seen : 0.0f;
     f.eps_ahead = b->sign_eps_ahead;
     f.NC = b->sign_NC;
@@ -642,6 +650,16 @@ static int run_fir(gnuais_batch *b, const int16_t *x, int len, float *dump, hipS
         f.T = (f.T + q - 1) / q * q;
         // several adjacent channels per lane (wide typed loads) where the table, the channel count and the
         // buffer's alignment allow; one channel per lane otherwise
+        if ((b->fir_pk == 1 || (b->fir_pk < 0 && f.NC == 48)) &&
+            ((f.NC == 12 && f.NE == 32) || (f.NC == 48 && f.NE - f.NC <= 98 && f.eps_seen > 0.0f))) {
+            const int qp = launch_fir_sign_pk_quantum();
+            f.T = (b->fir_T + qp - 1) / qp * qp;
+            HIP_TRY(launch_fir_sign_pk(f, s));
+            b->hist_cur ^= 1;
+            b->max_last = b->max_cur;
+            b->max_cur ^= 1;
+            return GNUAIS_OK;
+        }
         const int cpl = (f.NC == 12 && f.NE == 32 && b->fir_cpl > 1 && b->N % b->fir_cpl == 0 &&
                          ((uintptr_t) x & (uintptr_t) (2 * b->fir_cpl - 1)) == 0) ? b->fir_cpl : 1;
         // The launch's last round of waves takes short segments (fir_slice.hip: fir_sign_kernel): as many long

@@ -21,6 +21,7 @@ struct FirLaunch {
     int n_big = 1 << 30, T2 = 0;   // K1s: segments 0 .. n_big-1 are T outputs long, the rest T2 (the launch's tail, see run_fir)
     int NT, NE, d;         // out[n] = sum_j te[j] * x[n - d + j], j < NE
     float eps;             // sign-exact slicer: |central sum| > eps certifies the sign
+    float eps_pk = 0;      // fir_sign_pk.hip, 12 taps: the bound for the transposed fused sum (the direct form's is eps)
     float eps_seen = 0, eps_ahead = 0;     // 48-tap K1s with the running maximum (eps_seen > 0): eps = eps_seen * M / 32768 + eps_ahead
     int NC;                //   central taps used (12 or 48)
     float ctaps[48];       //   te[(NE-NC)/2 .. +NC)
@@ -33,6 +34,9 @@ int launch_fir_sign_quantum(int NC);           // T must be a multiple of this
 hipError_t launch_fir_sign(const FirLaunch &a, hipStream_t stream);
 // K1s with cpl = 2 / 4 adjacent channels per lane (fir_sign_wide.hip): 12 central taps of a 32-tap table only
 hipError_t launch_fir_sign_wide(const FirLaunch &a, int cpl, int form, hipStream_t stream);
+// K1s in transposed form on register pairs (fir_sign_pk.hip): NC 12 (32-tap table) or 48
+int launch_fir_sign_pk_quantum();
+hipError_t launch_fir_sign_pk(const FirLaunch &a, hipStream_t stream);
 hipError_t launch_fir_generic(const FirLaunch &a, hipStream_t stream);
 hipError_t launch_fir_history(const int16_t *x, const int16_t *hist_in, int16_t *hist_out,
                               int N, int L, int NT, hipStream_t stream);

@@ -1,0 +1,1 @@
+./scripts/ubench/valu_rate.bin 2>&1 | grep -E "stream" 

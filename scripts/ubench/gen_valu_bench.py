@@ -44,6 +44,29 @@ modes["k1s_fma_4samples"] = ["s_mov_b32 s20, 0x3f000000"] + kf
 # H: 32 x v_pk_fma
 modes["pk_fma32"] = [f"v_pk_fma_f32 v[{100+2*i}:{101+2*i}], v[{100+2*i}:{101+2*i}], %1, %1" for i in range(32)]
 
+# the transposed FIR on register PAIRS: acc pair += tap pair (VGPR or SGPR pair, halves swapped by op_sel) x one sample
+# broadcast from either half of a sample pair (op_sel / op_sel_hi on the sample operand)
+modes["pk_fma_acc_vtap"] = [f"v_pk_fma_f32 v[{100+2*i}:{101+2*i}], v[{170+2*(i%4)}:{171+2*(i%4)}], v[164:165], v[{100+2*i}:{101+2*i}] op_sel_hi:[1,0,1]" for i in range(32)]
+modes["pk_fma_acc_vtap_swz"] = [f"v_pk_fma_f32 v[{100+2*i}:{101+2*i}], v[{170+2*(i%4)}:{171+2*(i%4)}], v[164:165], v[{100+2*i}:{101+2*i}] op_sel:[{i%2},1,0] op_sel_hi:[{1-i%2},1,1]" for i in range(32)]
+modes["pk_fma_acc_stap"] = ["s_mov_b32 s20, 0x3f000000", "s_mov_b32 s21, 0x3f100000"] + [f"v_pk_fma_f32 v[{100+2*i}:{101+2*i}], s[20:21], v[164:165], v[{100+2*i}:{101+2*i}] op_sel_hi:[1,0,1]" for i in range(32)]
+modes["pk_fma_acc_stap_swz"] = ["s_mov_b32 s20, 0x3f000000", "s_mov_b32 s21, 0x3f100000"] + [f"v_pk_fma_f32 v[{100+2*i}:{101+2*i}], s[20:21], v[164:165], v[{100+2*i}:{101+2*i}] op_sel:[1,1,0] op_sel_hi:[0,1,1]" for i in range(32)]
+modes["fmac32_vtap"] = [f"v_fmac_f32 v{100+i}, v{170+i%8}, v{164+i%2}" for i in range(32)]
+
+# the packed transposed 12-tap stream of fir_sign_pk.hip, 12 samples (six pair steps), registers renamed
+modes["pk12_stream_12samples"] = ["s_mov_b32 s%d, 0x3f000000" % r for r in range(20, 34)] + ['v_pk_fma_f32 v[74:75], s[28:29], v[152:153], v[74:75] op_sel:[1,0,0] op_sel_hi:[0,0,1]', 'v_pk_fma_f32 v[76:77], s[30:31], v[152:153], v[76:77] op_sel:[1,0,0] op_sel_hi:[0,0,1]', 'v_pk_fma_f32 v[72:73], s[26:27], v[152:153], v[72:73] op_sel:[0,0,0] op_sel_hi:[1,0,1]', 'v_pk_fma_f32 v[78:79], s[32:33], v[152:153], v[78:79] op_sel:[0,0,0] op_sel_hi:[1,0,1]', 'v_pk_fma_f32 v[80:81], s[30:31], v[152:153], v[80:81] op_sel:[0,0,0] op_sel_hi:[1,0,1]', 'v_pk_fma_f32 v[82:83], s[28:29], v[152:153], v[82:83] op_sel:[0,0,0] op_sel_hi:[1,0,1]', 'v_sub_f32 v84, |v73|, v154', 'v_alignbit_b32 v151, v151, v84, 31', 'v_alignbit_b32 v150, v150, v73, 31', 'v_mov_b32 v73, 0', 'v_pk_fma_f32 v[74:75], s[20:21], v[152:153], v[74:75] op_sel:[0,1,0] op_sel_hi:[1,1,1]', 'v_pk_fma_f32 v[76:77], s[22:23], v[152:153], v[76:77] op_sel:[0,1,0] op_sel_hi:[1,1,1]', 'v_pk_fma_f32 v[78:79], s[24:25], v[152:153], v[78:79] op_sel:[0,1,0] op_sel_hi:[1,1,1]', 'v_pk_fma_f32 v[80:81], s[24:25], v[152:153], v[80:81] op_sel:[1,1,0] op_sel_hi:[0,1,1]', 'v_pk_fma_f32 v[82:83], s[22:23], v[152:153], v[82:83] op_sel:[1,1,0] op_sel_hi:[0,1,1]', 'v_pk_fma_f32 v[72:73], s[20:21], v[152:153], v[72:73] op_sel:[1,1,0] op_sel_hi:[0,1,1]', 'v_sub_f32 v84, |v74|, v154', 'v_alignbit_b32 v151, v151, v84, 31', 'v_alignbit_b32 v150, v150, v74, 31', 'v_mov_b32 v74, 0', 'v_pk_fma_f32 v[76:77], s[28:29], v[152:153], v[76:77] op_sel:[1,0,0] op_sel_hi:[0,0,1]', 'v_pk_fma_f32 v[78:79], s[30:31], v[152:153], v[78:79] op_sel:[1,0,0] op_sel_hi:[0,0,1]', 'v_pk_fma_f32 v[74:75], s[26:27], v[152:153], v[74:75] op_sel:[0,0,0] op_sel_hi:[1,0,1]', 'v_pk_fma_f32 v[80:81], s[32:33], v[152:153], v[80:81] op_sel:[0,0,0] op_sel_hi:[1,0,1]', 'v_pk_fma_f32 v[82:83], s[30:31], v[152:153], v[82:83] op_sel:[0,0,0] op_sel_hi:[1,0,1]', 'v_pk_fma_f32 v[72:73], s[28:29], v[152:153], v[72:73] op_sel:[0,0,0] op_sel_hi:[1,0,1]', 'v_sub_f32 v84, |v75|, v154', 'v_alignbit_b32 v151, v151, v84, 31', 'v_alignbit_b32 v150, v150, v75, 31', 'v_mov_b32 v75, 0', 'v_pk_fma_f32 v[76:77], s[20:21], v[152:153], v[76:77] op_sel:[0,1,0] op_sel_hi:[1,1,1]', 'v_pk_fma_f32 v[78:79], s[22:23], v[152:153], v[78:79] op_sel:[0,1,0] op_sel_hi:[1,1,1]', 'v_pk_fma_f32 v[80:81], s[24:25], v[152:153], v[80:81] op_sel:[0,1,0] op_sel_hi:[1,1,1]', 'v_pk_fma_f32 v[82:83], s[24:25], v[152:153], v[82:83] op_sel:[1,1,0] op_sel_hi:[0,1,1]', 'v_pk_fma_f32 v[72:73], s[22:23], v[152:153], v[72:73] op_sel:[1,1,0] op_sel_hi:[0,1,1]', 'v_pk_fma_f32 v[74:75], s[20:21], v[152:153], v[74:75] op_sel:[1,1,0] op_sel_hi:[0,1,1]', 'v_sub_f32 v84, |v76|, v154', 'v_alignbit_b32 v151, v151, v84, 31', 'v_alignbit_b32 v150, v150, v76, 31', 'v_mov_b32 v76, 0', 'v_pk_fma_f32 v[78:79], s[28:29], v[152:153], v[78:79] op_sel:[1,0,0] op_sel_hi:[0,0,1]', 'v_pk_fma_f32 v[80:81], s[30:31], v[152:153], v[80:81] op_sel:[1,0,0] op_sel_hi:[0,0,1]', 'v_pk_fma_f32 v[76:77], s[26:27], v[152:153], v[76:77] op_sel:[0,0,0] op_sel_hi:[1,0,1]', 'v_pk_fma_f32 v[82:83], s[32:33], v[152:153], v[82:83] op_sel:[0,0,0] op_sel_hi:[1,0,1]', 'v_pk_fma_f32 v[72:73], s[30:31], v[152:153], v[72:73] op_sel:[0,0,0] op_sel_hi:[1,0,1]', 'v_pk_fma_f32 v[74:75], s[28:29], v[152:153], v[74:75] op_sel:[0,0,0] op_sel_hi:[1,0,1]', 'v_sub_f32 v84, |v77|, v154', 'v_alignbit_b32 v151, v151, v84, 31', 'v_alignbit_b32 v150, v150, v77, 31', 'v_mov_b32 v77, 0', 'v_pk_fma_f32 v[78:79], s[20:21], v[152:153], v[78:79] op_sel:[0,1,0] op_sel_hi:[1,1,1]', 'v_pk_fma_f32 v[80:81], s[22:23], v[152:153], v[80:81] op_sel:[0,1,0] op_sel_hi:[1,1,1]', 'v_pk_fma_f32 v[82:83], s[24:25], v[152:153], v[82:83] op_sel:[0,1,0] op_sel_hi:[1,1,1]', 'v_pk_fma_f32 v[72:73], s[24:25], v[152:153], v[72:73] op_sel:[1,1,0] op_sel_hi:[0,1,1]', 'v_pk_fma_f32 v[74:75], s[22:23], v[152:153], v[74:75] op_sel:[1,1,0] op_sel_hi:[0,1,1]', 'v_pk_fma_f32 v[76:77], s[20:21], v[152:153], v[76:77] op_sel:[1,1,0] op_sel_hi:[0,1,1]', 'v_sub_f32 v84, |v78|, v154', 'v_alignbit_b32 v151, v151, v84, 31', 'v_alignbit_b32 v150, v150, v78, 31', 'v_mov_b32 v78, 0', 'v_pk_fma_f32 v[80:81], s[28:29], v[152:153], v[80:81] op_sel:[1,0,0] op_sel_hi:[0,0,1]', 'v_pk_fma_f32 v[82:83], s[30:31], v[152:153], v[82:83] op_sel:[1,0,0] op_sel_hi:[0,0,1]', 'v_pk_fma_f32 v[78:79], s[26:27], v[152:153], v[78:79] op_sel:[0,0,0] op_sel_hi:[1,0,1]', 'v_pk_fma_f32 v[72:73], s[32:33], v[152:153], v[72:73] op_sel:[0,0,0] op_sel_hi:[1,0,1]', 'v_pk_fma_f32 v[74:75], s[30:31], v[152:153], v[74:75] op_sel:[0,0,0] op_sel_hi:[1,0,1]', 'v_pk_fma_f32 v[76:77], s[28:29], v[152:153], v[76:77] op_sel:[0,0,0] op_sel_hi:[1,0,1]', 'v_sub_f32 v84, |v79|, v154', 'v_alignbit_b32 v151, v151, v84, 31', 'v_alignbit_b32 v150, v150, v79, 31', 'v_mov_b32 v79, 0', 'v_pk_fma_f32 v[80:81], s[20:21], v[152:153], v[80:81] op_sel:[0,1,0] op_sel_hi:[1,1,1]', 'v_pk_fma_f32 v[82:83], s[22:23], v[152:153], v[82:83] op_sel:[0,1,0] op_sel_hi:[1,1,1]', 'v_pk_fma_f32 v[72:73], s[24:25], v[152:153], v[72:73] op_sel:[0,1,0] op_sel_hi:[1,1,1]', 'v_pk_fma_f32 v[74:75], s[24:25], v[152:153], v[74:75] op_sel:[1,1,0] op_sel_hi:[0,1,1]', 'v_pk_fma_f32 v[76:77], s[22:23], v[152:153], v[76:77] op_sel:[1,1,0] op_sel_hi:[0,1,1]', 'v_pk_fma_f32 v[78:79], s[20:21], v[152:153], v[78:79] op_sel:[1,1,0] op_sel_hi:[0,1,1]', 'v_sub_f32 v84, |v80|, v154', 'v_alignbit_b32 v151, v151, v84, 31', 'v_alignbit_b32 v150, v150, v80, 31', 'v_mov_b32 v80, 0', 'v_pk_fma_f32 v[82:83], s[28:29], v[152:153], v[82:83] op_sel:[1,0,0] op_sel_hi:[0,0,1]', 'v_pk_fma_f32 v[72:73], s[30:31], v[152:153], v[72:73] op_sel:[1,0,0] op_sel_hi:[0,0,1]', 'v_pk_fma_f32 v[80:81], s[26:27], v[152:153], v[80:81] op_sel:[0,0,0] op_sel_hi:[1,0,1]', 'v_pk_fma_f32 v[74:75], s[32:33], v[152:153], v[74:75] op_sel:[0,0,0] op_sel_hi:[1,0,1]', 'v_pk_fma_f32 v[76:77], s[30:31], v[152:153], v[76:77] op_sel:[0,0,0] op_sel_hi:[1,0,1]', 'v_pk_fma_f32 v[78:79], s[28:29], v[152:153], v[78:79] op_sel:[0,0,0] op_sel_hi:[1,0,1]', 'v_sub_f32 v84, |v81|, v154', 'v_alignbit_b32 v151, v151, v84, 31', 'v_alignbit_b32 v150, v150, v81, 31', 'v_mov_b32 v81, 0', 'v_pk_fma_f32 v[82:83], s[20:21], v[152:153], v[82:83] op_sel:[0,1,0] op_sel_hi:[1,1,1]', 'v_pk_fma_f32 v[72:73], s[22:23], v[152:153], v[72:73] op_sel:[0,1,0] op_sel_hi:[1,1,1]', 'v_pk_fma_f32 v[74:75], s[24:25], v[152:153], v[74:75] op_sel:[0,1,0] op_sel_hi:[1,1,1]', 'v_pk_fma_f32 v[76:77], s[24:25], v[152:153], v[76:77] op_sel:[1,1,0] op_sel_hi:[0,1,1]', 'v_pk_fma_f32 v[78:79], s[22:23], v[152:153], v[78:79] op_sel:[1,1,0] op_sel_hi:[0,1,1]', 'v_pk_fma_f32 v[80:81], s[20:21], v[152:153], v[80:81] op_sel:[1,1,0] op_sel_hi:[0,1,1]', 'v_sub_f32 v84, |v82|, v154', 'v_alignbit_b32 v151, v151, v84, 31', 'v_alignbit_b32 v150, v150, v82, 31', 'v_mov_b32 v82, 0', 'v_pk_fma_f32 v[72:73], s[28:29], v[152:153], v[72:73] op_sel:[1,0,0] op_sel_hi:[0,0,1]', 'v_pk_fma_f32 v[74:75], s[30:31], v[152:153], v[74:75] op_sel:[1,0,0] op_sel_hi:[0,0,1]', 'v_pk_fma_f32 v[82:83], s[26:27], v[152:153], v[82:83] op_sel:[0,0,0] op_sel_hi:[1,0,1]', 'v_pk_fma_f32 v[76:77], s[32:33], v[152:153], v[76:77] op_sel:[0,0,0] op_sel_hi:[1,0,1]', 'v_pk_fma_f32 v[78:79], s[30:31], v[152:153], v[78:79] op_sel:[0,0,0] op_sel_hi:[1,0,1]', 'v_pk_fma_f32 v[80:81], s[28:29], v[152:153], v[80:81] op_sel:[0,0,0] op_sel_hi:[1,0,1]', 'v_sub_f32 v84, |v83|, v154', 'v_alignbit_b32 v151, v151, v84, 31', 'v_alignbit_b32 v150, v150, v83, 31', 'v_mov_b32 v83, 0', 'v_pk_fma_f32 v[72:73], s[20:21], v[152:153], v[72:73] op_sel:[0,1,0] op_sel_hi:[1,1,1]', 'v_pk_fma_f32 v[74:75], s[22:23], v[152:153], v[74:75] op_sel:[0,1,0] op_sel_hi:[1,1,1]', 'v_pk_fma_f32 v[76:77], s[24:25], v[152:153], v[76:77] op_sel:[0,1,0] op_sel_hi:[1,1,1]', 'v_pk_fma_f32 v[78:79], s[24:25], v[152:153], v[78:79] op_sel:[1,1,0] op_sel_hi:[0,1,1]', 'v_pk_fma_f32 v[80:81], s[22:23], v[152:153], v[80:81] op_sel:[1,1,0] op_sel_hi:[0,1,1]', 'v_pk_fma_f32 v[82:83], s[20:21], v[152:153], v[82:83] op_sel:[1,1,0] op_sel_hi:[0,1,1]', 'v_sub_f32 v84, |v72|, v154', 'v_alignbit_b32 v151, v151, v84, 31', 'v_alignbit_b32 v150, v150, v72, 31', 'v_mov_b32 v72, 0']
+# the scalar direct-form stream of fir_sign_kernel per sample: 6 adds, 1 mul + 5 fmac with SGPR taps, |y|-eps, two alignbits, max3 every other sample
+sc = []
+for smp in range(12):
+    for q in range(6):
+        sc.append(f"v_add_f32 v{140+q}, v{100+(smp+q)%32}, v{100+(smp+11-q)%32}")
+    sc.append("v_mul_f32 v146, s20, v140")
+    for q in range(1, 6):
+        sc.append(f"v_fmac_f32 v146, s{20+q}, v{140+q}")
+    sc.append("v_sub_f32 v147, |v146|, v154")
+    sc.append("v_alignbit_b32 v151, v151, v147, 31")
+    sc.append("v_alignbit_b32 v150, v150, v146, 31")
+    if smp % 2: sc.append(f"v_max3_i32 v148, v148, v{100+smp}, v{101+smp}")
+modes["scalar12_stream_12samples"] = ["s_mov_b32 s%d, 0x3f000000" % r for r in range(20, 26)] + sc
 # integer / bit ops used by the PLL core
 modes["bfi32"] = [f"v_bfi_b32 v{100+i}, v{100+i}, %0, %0" for i in range(32)]
 modes["bfe32"] = [f"v_bfe_i32 v{100+i}, v{100+i}, 3, 1" for i in range(32)]
@@ -87,7 +110,7 @@ for k, (name, ins) in enumerate(modes.items()):
   f32x2 bb = {{b, b}};
   if ((int) (threadIdx.x & 63) >= lim) return;
   for (int it = 0; it < iters; ++it)
-    asm volatile("{body}" :: "v"(b), "v"(bb) : {clob(100, 180)}, "vcc", "s20", "s21", "s22", "s23");
+    asm volatile("{body}" :: "v"(b), "v"(bb) : {clob(72, 180)}, "vcc", "s20","s21","s22","s23","s24","s25","s26","s27","s28","s29","s30","s31","s32","s33");
   out[blockIdx.x * blockDim.x + threadIdx.x] = b;
 }}''')
 src.append('typedef void (*kern_t)(float*, int, float, int);')
@@ -95,7 +118,7 @@ src.append('int main() { float *d; (void) hipMalloc(&d, 8192 * 256 * 4); const i
 src.append('  kern_t ks[] = {' + ",".join(f"k{k}" for k in range(len(names))) + '};')
 src.append('  const char *nm[] = {' + ",".join(f'"{n}"' for n in names) + '};')
 src.append('  const int ninstr[] = {' + ",".join(str(len(modes[n])) for n in names) + '};')
-src.append('''  for (int lim = 64; lim >= 16; lim /= 2) for (int wps = 1; wps <= 4; wps *= 4) for (int m = 0; m < (int)(sizeof(ks)/sizeof(ks[0])); ++m) {
+src.append('''  for (int lim = 64; lim >= 64; lim /= 2) for (int wps = 1; wps <= 5; ++wps) for (int m = 0; m < (int)(sizeof(ks)/sizeof(ks[0])); ++m) {
     hipEvent_t e0, e1; (void) hipEventCreate(&e0); (void) hipEventCreate(&e1);
     hipLaunchKernelGGL(ks[m], dim3(256 * wps), dim3(256), 0, 0, d, 10, 1.0f, lim);
     (void) hipEventRecord(e0);

@@ -3,6 +3,7 @@ loads, and exports every symbol include/gnuais_hip.h declares.  No compute."""
 import os
 import re
 import subprocess
+import sys
 
 import numpy as np
 import pytest
@@ -105,3 +106,13 @@ def test_public_struct_layout_matches_reference_sizes():
                                "-o", os.path.join(d, "s")])
         out = subprocess.check_output([os.path.join(d, "s")]).decode().split()
     assert out == ["56", "144"]
+
+
+def test_packed_fir_keeps_its_ring_out_of_the_compilers_registers():
+    """fir_sign_pk.hip holds its accumulator ring in fixed VGPRs above what the compiler uses for the rest of the kernel;
+    amdgpu_num_vgpr is only a hint, so the generated ISA is scanned: no compiler-generated instruction may name a
+    register of the ring (scripts/check_pk_registers.py; a violation shows up as rare wrong signs, not as a crash)."""
+    if not os.path.exists("/opt/rocm/bin/hipcc"):
+        pytest.skip("no hipcc")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "check_pk_registers.py")], capture_output=True, timeout=600)
+    assert r.returncode == 0, r.stdout.decode() + r.stderr.decode()
