@@ -571,6 +571,96 @@ extern "C" int gnuais_vessels_from_frames(const gnuais_frame *frames, int n_fram
     return GNUAIS_OK;
 }
 
+// The MySQL sink's statements for a batch, reduced to the calls that leave something (include/gnuais_hip.h).  Every
+// argument is formed as the reference forms it at its call site (protodec.c:383-388, 430-433, 510-514, 612-617, 670-674,
+// 737-738, 768-771): float expressions in double, narrowed at the call.
+extern "C" int gnuais_sql_plan_from_frames(const gnuais_frame *frames, int n_frames, gnuais_sql_call *out, int cap, int *n_out)
+{
+    if (n_frames < 0 || (n_frames > 0 && !frames) || !out || cap < 0 || !n_out) return GNUAIS_E_ARG;
+    struct Rec { int mmsi, kind, order; gnuais_sql_call c; };
+    std::vector<Rec> recs;
+    auto add = [&](const gnuais_sql_call &c, int order) { recs.push_back(Rec{c.mmsi, c.kind, order, c}); };
+    for (int k = 0; k < n_frames; ++k) {
+        const gnuais_frame &f = frames[k];
+        if (f.nbits > MAX_NBITS) return GNUAIS_E_ARG;
+        const Bits b(f, (int) f.nbits);
+        const unsigned type = (unsigned) b.get(0, 6);
+        if (type < 1 || type > MAX_TYPE) continue;
+        gnuais_sql_call c;
+        memset(&c, 0, sizeof c);
+        c.mmsi = (int) b.get(8, 30);
+        auto pos = [&](long lat, long lon, int hdg, unsigned course, unsigned sog) {
+            c.kind = GNUAIS_SQL_POSITION;
+            c.lat = (float) ((float) lat / 600000.0);
+            c.lon = (float) ((float) lon / 600000.0);
+            c.hdg = (float) hdg;
+            c.course = (float) ((float) (unsigned short) course / 10.0);
+            c.sog = (float) ((float) (unsigned short) sog / 10.0);
+            add(c, 2 * k);
+        };
+        auto datab = [&](int A, int B, int C_, int D, int order) {
+            gnuais_sql_call e = c;
+            e.kind = GNUAIS_SQL_VESSELDATAB;
+            e.A = A; e.B = B; e.C = C_; e.D = D;
+            add(e, order);
+        };
+        auto vname = [&](const std::string &name, const std::string &dest, int order) {
+            gnuais_sql_call e = c;
+            e.kind = GNUAIS_SQL_VESSELNAME;
+            put(e.name, sizeof e.name, name);
+            put(e.destination, sizeof e.destination, dest);
+            add(e, order);
+        };
+        switch (type) {
+        case 1: case 2: case 3:
+            pos(b.sget(89, 27), b.sget(61, 28), (int) b.get(128, 9), (unsigned) b.get(116, 12), (unsigned) b.get(50, 10));
+            break;
+        case 18:
+            pos(b.sget(85, 27), b.sget(57, 28), (int) b.get(124, 9), (unsigned) b.get(112, 12), (unsigned) b.get(46, 10));
+            break;
+        case 4:
+            c.kind = GNUAIS_SQL_BASESTATION;
+            c.lat = (float) ((float) b.sget(107, 27) / 600000.0);
+            c.lon = (float) ((float) b.sget(79, 28) / 600000.0);
+            add(c, 2 * k);
+            break;
+        case 5: {
+            const unsigned char draught = (unsigned char) b.get(294, 8);
+            c.kind = GNUAIS_SQL_VESSELDATA;
+            put(c.name, sizeof c.name, b.text(112, 20));
+            put(c.destination, sizeof c.destination, b.text(302, 20));
+            c.draught = (float) ((float) draught / 10.0);
+            c.A = (int) b.get(240, 9); c.B = (int) b.get(249, 9);
+            c.C = (unsigned char) b.get(258, 6); c.D = (unsigned char) b.get(264, 6);
+            add(c, 2 * k);
+            break;
+        }
+        case 19:                                     // name first, then the dimensions (protodec.c:671-673)
+            vname(b.text(143, 20), "CLASS B", 2 * k);
+            datab((int) b.get(271, 9), (int) b.get(280, 9), (unsigned char) b.get(289, 6), (unsigned char) b.get(295, 6), 2 * k + 1);
+            break;
+        case 24:
+            if (b.get(38, 2) == 0) vname(b.text(40, 20), "CLASS B", 2 * k);
+            if (b.get(38, 2) == 1)
+                datab((int) b.get(132, 9), (int) b.get(141, 9), (unsigned char) b.get(150, 6), (unsigned char) b.get(156, 6), 2 * k);
+            break;
+        default: break;
+        }
+    }
+    // per (vessel, kind) the last call; survivors in arrival order
+    std::stable_sort(recs.begin(), recs.end(), [](const Rec &a, const Rec &b_) {
+        return a.mmsi != b_.mmsi ? a.mmsi < b_.mmsi : (a.kind != b_.kind ? a.kind < b_.kind : a.order < b_.order);
+    });
+    std::vector<Rec> keep;
+    for (size_t i2 = 0; i2 < recs.size(); ++i2)
+        if (i2 + 1 == recs.size() || recs[i2 + 1].mmsi != recs[i2].mmsi || recs[i2 + 1].kind != recs[i2].kind) keep.push_back(recs[i2]);
+    std::sort(keep.begin(), keep.end(), [](const Rec &a, const Rec &b_) { return a.order < b_.order; });
+    *n_out = (int) keep.size();
+    if ((int) keep.size() > cap) return GNUAIS_E_OVERFLOW;
+    for (size_t i2 = 0; i2 < keep.size(); ++i2) out[i2] = keep[i2].c;
+    return GNUAIS_OK;
+}
+
 extern "C" int gnuais_nmea_from_frames(const gnuais_frame *frames, int n_frames, uint8_t *seqnr,
                                        int n_channels, char *out, size_t out_cap, size_t *out_len,
                                        int *n_sentences)

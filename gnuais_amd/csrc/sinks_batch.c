@@ -183,10 +183,88 @@ int gnuais_sinks_deliver_formatted(gnuais_sinks *s, int n_frames, int n_sentence
 	return deliver_outputs(s, nmea, nmea_len, text, text_len, vessels, n_vessels);
 }
 
+/* src/out_mysql.h:37-45 */
+extern int myout_ais_position(struct mysql_state_t *my, time_t tid, int mmsi, float lat, float lon, float hdg,
+			      float course, float sog);
+extern int myout_ais_basestation(struct mysql_state_t *my, time_t tid, int mmsi, float lat, float lon);
+extern int myout_ais_vesseldata(struct mysql_state_t *my, time_t tid, int mmsi, char *name, char *destination,
+				float draught, int A, int B, int C, int D);
+extern int myout_ais_vesseldatab(struct mysql_state_t *my, time_t tid, int mmsi, int A, int B, int C, int D);
+extern int myout_ais_vesselname(struct mysql_state_t *my, time_t tid, int mmsi, const char *name,
+				const char *destination);
+extern int myout_nmea(struct mysql_state_t *my, time_t tid, char *nmea);
+
+int gnuais_sinks_deliver_mysql(gnuais_sinks *s, struct mysql_state_t *my, long t, const gnuais_frame *frames,
+			       int n_frames, const char *nmea, size_t nmea_len, long counts[2])
+{
+	int n = 0, i, rc;
+	size_t off = 0;
+
+	if (!s || !my || n_frames < 0 || (n_frames && !frames) || (nmea_len && !nmea))
+		return GNUAIS_E_ARG;
+	if (s->sql_cap < 2 * n_frames + 1) {            /* a type 19 message is two calls */
+		gnuais_sql_call *q = realloc(s->sql, sizeof(gnuais_sql_call) * (size_t) (2 * n_frames + 1));
+		if (!q)
+			return GNUAIS_E_ARG;
+		s->sql = q;
+		s->sql_cap = 2 * n_frames + 1;
+	}
+	rc = gnuais_sql_plan_from_frames(frames, n_frames, s->sql, s->sql_cap, &n);
+	if (rc != GNUAIS_OK)
+		return rc;
+	for (i = 0; i < n; i++) {
+		gnuais_sql_call *c = &s->sql[i];
+		switch (c->kind) {
+		case GNUAIS_SQL_POSITION:
+			myout_ais_position(my, (time_t) t, c->mmsi, c->lat, c->lon, c->hdg, c->course, c->sog);
+			break;
+		case GNUAIS_SQL_BASESTATION:
+			myout_ais_basestation(my, (time_t) t, c->mmsi, c->lat, c->lon);
+			break;
+		case GNUAIS_SQL_VESSELDATA:
+			myout_ais_vesseldata(my, (time_t) t, c->mmsi, c->name, c->destination, c->draught, c->A, c->B,
+					     c->C, c->D);
+			break;
+		case GNUAIS_SQL_VESSELDATAB:
+			myout_ais_vesseldatab(my, (time_t) t, c->mmsi, c->A, c->B, c->C, c->D);
+			break;
+		case GNUAIS_SQL_VESSELNAME:
+			myout_ais_vesselname(my, (time_t) t, c->mmsi, c->name, c->destination);
+			break;
+		default:
+			break;
+		}
+	}
+	if (counts)
+		counts[0] += n;
+	/* the sentence log: myout_nmea() gets d->nmea, the sentence without '!' and CR LF (protodec.c:891-892) */
+	while (off < nmea_len) {
+		char line[128];
+		size_t e = off, len;
+		while (e < nmea_len && nmea[e] != '\r' && nmea[e] != '\n')
+			e++;
+		len = e - off;
+		if (len > 1 && nmea[off] == '!' && len - 1 < sizeof line) {
+			memcpy(line, nmea + off + 1, len - 1);
+			line[len - 1] = 0;
+			myout_nmea(my, (time_t) t, line);
+			if (counts)
+				counts[1]++;
+		}
+		while (e < nmea_len && (nmea[e] == '\r' || nmea[e] == '\n'))
+			e++;
+		off = e;
+	}
+	return GNUAIS_OK;
+}
+
 void gnuais_sinks_free(gnuais_sinks *s)
 {
 	if (!s)
 		return;
+	free(s->sql);
+	s->sql = NULL;
+	s->sql_cap = 0;
 	free(s->nmea);
 	free(s->text);
 	free(s->ipcbuf);

@@ -70,6 +70,7 @@ SYMBOLS = {
                                             C.POINTER(_I)]),
     "gnuais_range_from_frames": (_I, [_P, _I, _I, C.c_float, C.c_float, _P]),
     "gnuais_vessels_from_frames": (_I, [_P, _I, _P, _I, C.POINTER(_I)]),
+    "gnuais_sql_plan_from_frames": (_I, [_P, _I, _P, _I, C.POINTER(_I)]),
     "gnuais_tile_channels": (_I, [_P, _I, _I, _P, _I, _P]),
     "gnuais_batch_set_timing": (_I, [_P, _I]),
     "gnuais_batch_last_timing": (_I, [_P, _P]),

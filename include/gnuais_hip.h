@@ -307,6 +307,26 @@ int  gnuais_batch_autotune_delivery(gnuais_batch *b, const int16_t *d_samples, i
 const char *gnuais_last_error(void);
 const char *gnuais_version(void);
 
+/* ---- the MySQL sink behind a batch (src/out_mysql.c:174-297, called from src/protodec.c:383,430,510,612,670,737,768,891) ----
+ * Every myout_ais_*() call is "UPDATE <table> SET <this call's columns> WHERE mmsi, else INSERT": per table and vessel
+ * only the LAST call of each kind leaves anything in the database.  gnuais_sql_plan_from_frames() walks a batch of frame
+ * records in arrival order and returns those surviving calls -- kind, mmsi and the argument values the reference's
+ * decoders would pass, bit for bit -- in their original relative order: the same final rows with <= 5 statements per
+ * vessel and batch instead of one or two per message.  (The per-sentence myout_nmea() log rows are not reduced: one per
+ * sentence of gnuais_nmea_from_frames().)  Host code. */
+#define GNUAIS_SQL_POSITION    1   /* myout_ais_position(my, t, mmsi, lat, lon, hdg, course, sog)            types 1-3, 18 */
+#define GNUAIS_SQL_BASESTATION 2   /* myout_ais_basestation(my, t, mmsi, lat, lon)                            type 4        */
+#define GNUAIS_SQL_VESSELDATA  3   /* myout_ais_vesseldata(my, t, mmsi, name, destination, draught, A, B, C, D) type 5      */
+#define GNUAIS_SQL_VESSELDATAB 4   /* myout_ais_vesseldatab(my, t, mmsi, A, B, C, D)                          types 19, 24B */
+#define GNUAIS_SQL_VESSELNAME  5   /* myout_ais_vesselname(my, t, mmsi, name, destination)                    types 19, 24A */
+typedef struct gnuais_sql_call {
+	int32_t kind, mmsi;
+	float   lat, lon, hdg, course, sog, draught;
+	int32_t A, B, C, D;
+	char    name[24], destination[24];
+} gnuais_sql_call;
+int  gnuais_sql_plan_from_frames(const gnuais_frame *frames, int n_frames, gnuais_sql_call *out, int cap, int *n_out);
+
 /* ---- the receivers of one NODE: N channels over several GPUs (src/ais.c:141-147, 237-247) ----------
  * gnuais creates its receivers one by one and they share nothing; the main loop hands every receiver the same
  * interleaved buffer.  A node is that over the node's devices: device g owns the contiguous channel block

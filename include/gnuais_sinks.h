@@ -12,8 +12,10 @@
  *   1 fwrite + 1 fflush                           for all stdout lines of the batch,
  *   <= 3 cache_*() calls per VESSEL seen in the batch (position, static data, persons)
  *                                                 instead of one per message.
- * The MySQL sink (src/out_mysql.c) is per-message SQL by construction and is not batched here:
- * the drop-in of receiver_hip.c keeps serving it through the reference's own protodec_getdata().
+ * The MySQL sink (src/out_mysql.c) gets a front of its own, gnuais_sinks_deliver_mysql(): its statements are
+ * "UPDATE ... WHERE mmsi, else INSERT" per vessel and table, so only the last call of each kind per vessel and batch
+ * is issued (gnuais_sql_plan_from_frames), plus the per-sentence myout_nmea() log rows.  The JSON uplink
+ * (src/out_json.c) reads the position cache (cache_rotate) and is thereby served by the cache front above.
  *
  * Host C above libgnuais_hip.so (gnuais_amd/csrc/sinks_batch.c); links against the gnuais tree's
  * serial.o / ipc.o / cache.o.
@@ -46,6 +48,8 @@ typedef struct gnuais_sinks {
 	size_t nmea_cap, text_cap, ipc_cap;
 	gnuais_vessel *table;
 	int table_cap;
+	gnuais_sql_call *sql;
+	int sql_cap;
 } gnuais_sinks;
 
 /* frames: one drained batch (gnuais_batch_drain_frames order).  GNUAIS_OK or GNUAIS_E_ARG. */
@@ -56,6 +60,13 @@ int  gnuais_sinks_deliver(gnuais_sinks *s, const gnuais_frame *frames, int n_fra
 int  gnuais_sinks_deliver_formatted(gnuais_sinks *s, int n_frames, int n_sentences, const char *nmea,
 				    size_t nmea_len, const char *text, size_t text_len,
 				    const gnuais_vessel *vessels, int n_vessels);
+/* The reference's own myout_ais_*() / myout_nmea() (src/out_mysql.h:37-45, unchanged) for one batch: the surviving
+ * calls of gnuais_sql_plan_from_frames() in arrival order, then one myout_nmea() per sentence of `nmea` (the batch's
+ * "!AIVDM...\r\n" text; NULL: none).  t = received_t (src/protodec.c:905).  counts[0] += vessel-table calls,
+ * counts[1] += myout_nmea calls.  Scratch comes from `s` (may be a zeroed struct). */
+struct mysql_state_t;           /* src/out_mysql.h:29-35 */
+int  gnuais_sinks_deliver_mysql(gnuais_sinks *s, struct mysql_state_t *my, long t, const gnuais_frame *frames,
+				int n_frames, const char *nmea, size_t nmea_len, long counts[2]);
 void gnuais_sinks_free(gnuais_sinks *s);
 
 #ifdef __cplusplus

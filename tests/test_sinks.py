@@ -37,7 +37,10 @@ class Sinks(C.Structure):                        # include/gnuais_sinks.h
                 ("flushes", C.c_long),
                 ("nmea", C.c_void_p), ("text", C.c_void_p), ("ipcbuf", C.c_void_p),
                 ("nmea_cap", C.c_size_t), ("text_cap", C.c_size_t), ("ipc_cap", C.c_size_t),
-                ("table", C.c_void_p), ("table_cap", C.c_int)]
+                ("table", C.c_void_p), ("table_cap", C.c_int), ("sql", C.c_void_p), ("sql_cap", C.c_int)]
+
+
+Sinks2 = Sinks
 
 
 @pytest.fixture(scope="module")
@@ -182,6 +185,123 @@ def test_formatted_delivery_equals_frame_delivery(adapter, tmp_path):
     assert np.array_equal(seq, want_seq)
     assert scratch[:n].tobytes() == want_cache.tobytes()
     assert s.frames == len(fr) and s.serial_calls <= len(cuts) - 1
+    L.gnuais_sinks_free(C.byref(s))
+
+
+MYSQL_STUB = r'''
+/* test stub of the MySQL sink's API (src/out_mysql.h:37-45): writes every call down, in the format of the
+ * reference-side log (oracle/ref_shim.c) */
+#include <stdio.h>
+#include <stdlib.h>
+#include <stdarg.h>
+#include <time.h>
+struct mysql_state_t;
+static char *g; static size_t gn, gc;
+static void lg(const char *fmt, ...)
+{
+	va_list ap; int n;
+	if (gn + 512 > gc) { gc = gc * 2 + 65536; g = realloc(g, gc); }
+	va_start(ap, fmt); n = vsnprintf(g + gn, 512, fmt, ap); va_end(ap);
+	if (n > 0) gn += (size_t) (n < 512 ? n : 511);
+}
+int myout_ais_position(struct mysql_state_t *m, time_t t, int mmsi, float lat, float lon, float hdg, float course, float sog)
+{ lg("position %d %.9g %.9g %.9g %.9g %.9g\n", mmsi, lat, lon, hdg, course, sog); return 0; }
+int myout_ais_basestation(struct mysql_state_t *m, time_t t, int mmsi, float lat, float lon)
+{ lg("basestation %d %.9g %.9g\n", mmsi, lat, lon); return 0; }
+int myout_ais_vesseldata(struct mysql_state_t *m, time_t t, int mmsi, char *name, char *destination, float draught, int A, int B, int C, int D)
+{ lg("vesseldata %d %.9g %d %d %d %d |%s|%s|\n", mmsi, draught, A, B, C, D, name, destination); return 0; }
+int myout_ais_vesseldatab(struct mysql_state_t *m, time_t t, int mmsi, int A, int B, int C, int D)
+{ lg("vesseldatab %d %d %d %d %d\n", mmsi, A, B, C, D); return 0; }
+int myout_ais_vesselname(struct mysql_state_t *m, time_t t, int mmsi, const char *name, const char *destination)
+{ lg("vesselname %d |%s|%s|\n", mmsi, name, destination); return 0; }
+int myout_nmea(struct mysql_state_t *m, time_t t, char *nmea)
+{ lg("nmea %s\n", nmea); return 0; }
+const char *stub_log(void) { return g; }
+size_t stub_log_bytes(void) { return gn; }
+'''
+
+
+def sql_state(log: bytes):
+    """What the statements of a call log leave in the database: every myout_ais_*() call is UPDATE-else-INSERT of its own
+    columns WHERE mmsi (src/out_mysql.c:174-283); myout_nmea() appends a row (:286-297)."""
+    tables = {"ais_position": {}, "ais_basestation": {}, "ais_vesseldata": {}}
+    nmea, calls = [], 0
+    for line in log.decode("latin-1").splitlines():
+        kind, _, rest = line.partition(" ")
+        if kind == "nmea":
+            nmea.append(rest)
+            continue
+        calls += 1
+        head, *strs = rest.split("|")
+        v = head.split()
+        mmsi = int(v[0])
+        if kind == "position":
+            tables["ais_position"].setdefault(mmsi, {}).update(dict(zip(("lat", "lon", "hdg", "course", "sog"), v[1:6])))
+        elif kind == "basestation":
+            tables["ais_basestation"].setdefault(mmsi, {}).update(dict(zip(("lat", "lon"), v[1:3])))
+        elif kind == "vesseldata":
+            tables["ais_vesseldata"].setdefault(mmsi, {}).update(dict(zip(("draught", "A", "B", "C", "D"), v[1:6]),
+                                                                    name=strs[0], destination=strs[1]))
+        elif kind == "vesseldatab":
+            tables["ais_vesseldata"].setdefault(mmsi, {}).update(dict(zip(("A", "B", "C", "D"), v[1:5])))
+        elif kind == "vesselname":
+            tables["ais_vesseldata"].setdefault(mmsi, {}).update(name=strs[0], destination=strs[1])
+        else:
+            raise AssertionError(line)
+    return tables, nmea, calls
+
+
+def test_mysql_front_leaves_the_rows_of_the_per_message_path(tmp_path):
+    """gnuais_sinks_deliver_mysql(): per batch only the last myout_ais_*() call of each kind per vessel (the statements are
+    UPDATE ... WHERE mmsi, else INSERT) and one myout_nmea() per sentence.  The reference's own protodec_getdata() is run
+    over the same frames with its MySQL sink switched on and its myout_*() calls written down (--wrap in oracle/_ref);
+    both call logs are applied to a model of the three tables: identical rows (argument values as printed with nine
+    significant digits, i.e. bit for bit), identical sentence log, and far fewer statements."""
+    from gnuais_amd import lib, nmea_from_frames
+    ref = reference()
+    fr, n_ch = mixed_traffic()
+    ref.lib.ref_sql_bytes.restype = C.c_size_t
+    ref.lib.ref_sql_ptr.restype = C.c_void_p
+    ref.lib.ref_mysql_enable(1)
+    try:
+        ref.lib.ref_sql_clear()
+        ref.nmea_of_frames(fr, n_ch, stdout=True)
+        want_log = C.string_at(ref.lib.ref_sql_ptr(), ref.lib.ref_sql_bytes())
+    finally:
+        ref.lib.ref_mysql_enable(0)
+    (tmp_path / "stub.c").write_text(MYSQL_STUB)
+    so = str(tmp_path / "libsinks_my.so")
+    subprocess.check_call(["gcc", "-std=gnu11", "-w", "-shared", "-fPIC", "-Wl,-Bsymbolic-functions", "-I",
+                           os.path.join(ROOT, "include"), os.path.join(ROOT, "gnuais_amd", "csrc", "sinks_batch.c"),
+                           str(tmp_path / "stub.c"), "-o", so])
+    C.CDLL(REF_SO, mode=C.RTLD_GLOBAL)
+    C.CDLL(lib.LIB_PATH, mode=C.RTLD_GLOBAL)
+    L = C.CDLL(so)
+    L.gnuais_sinks_deliver_mysql.argtypes = [C.POINTER(Sinks2), C.c_void_p, C.c_long, C.c_void_p, C.c_int, C.c_char_p,
+                                             C.c_size_t, C.POINTER(C.c_long)]
+    L.stub_log.restype = C.c_void_p
+    L.stub_log_bytes.restype = C.c_size_t
+    s = Sinks2()
+    counts = (C.c_long * 2)(0, 0)
+    seq = np.zeros(n_ch, dtype=np.uint8)
+    cuts = [0, 1, 2, 150, 151, 600, len(fr)]
+    for lo, hi in zip(cuts[:-1], cuts[1:]):
+        part = np.ascontiguousarray(fr[lo:hi])
+        text = nmea_from_frames(part, seq)
+        assert L.gnuais_sinks_deliver_mysql(C.byref(s), C.c_void_p(16), 1234, part.ctypes.data, len(part), text, len(text), counts) == 0
+    got_log = C.string_at(L.stub_log(), L.stub_log_bytes())
+    want_tables, want_nmea, want_calls = sql_state(want_log)
+    got_tables, got_nmea, got_calls = sql_state(got_log)
+    assert got_tables == want_tables and sum(len(t) for t in want_tables.values()) > 100
+    assert got_nmea == want_nmea and len(want_nmea) == counts[1] > 900
+    assert counts[0] == got_calls < want_calls              # fewer statements already with six small batches of 120 vessels
+    # one batch: exactly one call per (vessel, kind)
+    from gnuais_amd.lib import load
+    plan = np.zeros(2 * len(fr) + 1, dtype=np.dtype([("kind", "<i4"), ("mmsi", "<i4"), ("f", "<f4", (6,)), ("abcd", "<i4", (4,)), ("name", "S24"), ("destination", "S24")]))
+    n = C.c_int(0)
+    assert load().gnuais_sql_plan_from_frames(fr.ctypes.data, len(fr), plan.ctypes.data, len(plan), C.byref(n)) == 0
+    keys = list(zip(plan["mmsi"][: n.value].tolist(), plan["kind"][: n.value].tolist()))
+    assert len(keys) == len(set(keys)) and n.value < 0.75 * want_calls
     L.gnuais_sinks_free(C.byref(s))
 
 
