@@ -258,10 +258,10 @@ __device__ __forceinline__ void fir_sign_pk_body(
     // come from the history
     auto load_group = [&](int mbx, pk_f2 *dst) __attribute__((always_inline)) {
         if ((mbx >= 0) && (mbx + GROUP - 1 < L)) {
-            const int voff0 = coff + (int) ((uint32_t) (mbx - row0) * rowbytes);
+            // the row in the SCALAR offset (the taps no longer occupy the SGPRs): no vector add per load
 #pragma unroll
             for (int p = 0; p < GROUP; ++p)
-                dst[p / 2][p % 2] = pk_load_format_f32(rsrc_f, voff0 + (int) ((uint32_t) p * rowbytes), 0, 0);
+                dst[p / 2][p % 2] = pk_load_format_f32(rsrc_f, coff, (int) ((uint32_t) (mbx - row0 + p) * rowbytes), 0);
         } else {
             // typed loads here as well (no 64-bit address arithmetic: this path must not set the register count):
             // the row is wave-uniform, so history or input is a scalar select of the descriptor
@@ -312,6 +312,7 @@ __device__ __forceinline__ void fir_sign_pk_body(
                 }
                 peakbits = bp > peakbits ? bp : peakbits;
             }
+            float gmax_group = 0.0f;
             if constexpr (INLOOP) {
                 float gm = 0.0f;
 #pragma unroll
@@ -322,6 +323,7 @@ __device__ __forceinline__ void fir_sign_pk_body(
 #pragma unroll
                 for (int k = 0; k + 1 < NHIST; ++k) hmax[k] = hmax[k + 1];
                 hmax[NHIST - 1] = gm;
+                gmax_group = gm;
                 eps_w = __builtin_fmaf(eps_seen, M * (1.0f / 32768.0f), eps_ahead);
             }
             auto pairs = [&](auto S) __attribute__((always_inline)) {
@@ -331,7 +333,9 @@ __device__ __forceinline__ void fir_sign_pk_body(
                 else pk48_step<P>(neg, amb, xp[s], eps_w, tp);
             };
             pk_expand_void(pairs, std::make_integer_sequence<int, GROUP / 2>{});
-            if (amb != 0) {
+            if constexpr (INLOOP) {
+                zor |= __float_as_uint(gmax_group);                 // all sixteen are 0 exactly when their largest |x| is
+            } else if (amb != 0) {
 #pragma unroll
                 for (int p = 0; p < GROUP; ++p) zor |= __float_as_uint(xp[p / 2][p % 2]);
             } else {

@@ -653,7 +653,9 @@ static int run_fir(gnuais_batch *b, const int16_t *x, int len, float *dump, hipS
         if ((b->fir_pk == 1 || (b->fir_pk < 0 && f.NC == 48)) &&
             ((f.NC == 12 && f.NE == 32) || (f.NC == 48 && f.NE - f.NC <= 98 && f.eps_seen > 0.0f))) {
             const int qp = launch_fir_sign_pk_quantum();
-            f.T = (b->fir_T + qp - 1) / qp * qp;
+            // 48 taps: a segment's warm-up is 47 pair steps' worth of samples; longer segments (there are plenty of
+            // waves: 16384 x 192000 is 32000 segments of 1536) halve its share
+            f.T = ((f.NC == 48 && b->fir_T <= 768 ? 1536 : b->fir_T) + qp - 1) / qp * qp;
             HIP_TRY(launch_fir_sign_pk(f, s));
             b->hist_cur ^= 1;
             b->max_last = b->max_cur;
