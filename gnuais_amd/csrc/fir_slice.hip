@@ -353,6 +353,9 @@ __global__ __launch_bounds__(64) void fir_slice_kernel(
 #define FIR_TYPED_LOADS_48 1
 #endif
 // 48-tap instantiation: ask for the next group's rows before working on this group's (16 registers)
+#ifndef FIR_VTAPS_12
+#define FIR_VTAPS_12 0
+#endif
 #ifndef FIR_VTAPS_48
 #define FIR_VTAPS_48 0       // measured: 5.14 ms with the taps in VGPRs against 5.10 (C5 FIR alone); the isolated rates do not carry over
 #endif
@@ -582,6 +585,15 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NC == 48 ? 4
                 //   amb  collects the sign bit of |y_c| - eps_up, eps_up = nextafter(eps): set
                 //        exactly when |y_c| <= eps (a - b is negative or -0 iff a < b).
                 uint32_t neg = 0, amb = 0;
+                // FIR_VTAPS_12: the direct form's taps in vector registers (see FIR_VTAPS_48 below for the rates)
+                float dtap[NC / 2];
+    #pragma unroll
+                for (int q = 0; q < NC / 2; ++q) {
+                    dtap[q] = ctap(q);
+#if FIR_VTAPS_12
+                    asm volatile("" : "+v"(dtap[q]));
+#endif
+                }
     #pragma unroll
                 for (int p = 0; p < 32; ++p) {
                     const int P = w3 * 32 + p;                  // phase 0..95, P % 12 static
@@ -598,9 +610,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NC == 48 ? 4
                         // y_c only has to stay within the certified distance of the exact central sum,
                         // so its products are FUSED into the accumulation (one rounding per term instead
                         // of two: inside the host's bound, which is taken for mul + add)
-                        y = ctap(0) * (xb(0) + xb(NC - 1));
+                        y = dtap[0] * (xb(0) + xb(NC - 1));
     #pragma unroll
-                        for (int q = 1; q < NC / 2; ++q) y = __builtin_fmaf(ctap(q), xb(q) + xb(NC - 1 - q), y);
+                        for (int q = 1; q < NC / 2; ++q) y = __builtin_fmaf(dtap[q], xb(q) + xb(NC - 1 - q), y);
                         (void) P;
                     } else {
                         const float xs = xf[p];
@@ -614,6 +626,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NC == 48 ? 4
                         }
                         y = acc[P % NC];                    // y_c of output obase + p
                     }
+#ifdef FIR_PAD
+                    // experiment: FIR_PAD extra VALU instructions per sample (does the pipeline's period follow the
+                    // chain's instruction count?)
+    #pragma unroll
+                    for (int pd = 0; pd < FIR_PAD; ++pd) asm volatile("v_mov_b32 %0, %0" : "+v"(peakbits));
+#endif
                     neg = __builtin_amdgcn_alignbit(neg, __float_as_uint(y), 31);
                     amb = __builtin_amdgcn_alignbit(amb, __float_as_uint(__builtin_fabsf(y) - eps_up), 31);
     #if FIR_SIGN_FENCE > 0

@@ -84,10 +84,15 @@ constexpr int PLL_STRIP = BLK_LEN + 12;    // bytes per lane and slot: the posit
 #define PLL_SLOTS_N 6
 #endif
 constexpr int PLL_SLOTS = PLL_SLOTS_N;   // block slots between scanner, recurrence and togglers
-constexpr int PLL_AHEAD = 2;         // blocks of sign words the scanner has in flight
+#ifndef SCAN_EXP
+#define SCAN_EXP 0
+#endif
+#ifndef PLL_AHEAD_N
+#define PLL_AHEAD_N 2
+#endif
+constexpr int PLL_AHEAD = PLL_AHEAD_N;         // blocks of sign words the scanner has in flight
 constexpr int PLL_SLOT_BYTES = 64 * PLL_STRIP + 64 * 4 + 64 + 64 * 4;     // strips, counts, rows, slices before the block
 constexpr int PLL_PACKW = PACK_STRIDE + 1;   // words per lane and pack buffer: the pack + its bit count
-constexpr int PLL_WAVES = 6;
 constexpr int PLL_LUT_BYTES = 2048;
 constexpr int PLL_FLAG_WORDS = 16 + 2 * 64 + 4 * 64;  // counters, the sign before / after the call per lane, bit counts of four segments
 constexpr int PLL_NEED_LDS = PLL_LUT_BYTES + PLL_SLOTS * PLL_SLOT_BYTES + 2 * PLL_PACKW * 64 * 4 + PLL_FLAG_WORDS * 4;
@@ -213,7 +218,9 @@ __host__ __device__ inline int n_seg_cap(int L)
 //   2 x PLL_PACKW x 64 words        pack buffers (toggle words per lane)
 //   PLL_FLAG_WORDS                  hand-over counters; sign before / after the call per lane; the bit
 //                                   counts of four segments per lane
-__global__ __launch_bounds__(64 * PLL_WAVES) __attribute__((amdgpu_waves_per_eu(7, 8))) void pll_kernel(
+// NSC scanners and NTG togglers: 2 (even / odd blocks) or 1 (every block) of each; six waves down to four
+template <int NSC, int NTG>
+__global__ __launch_bounds__(64 * (2 + NSC + NTG)) __attribute__((amdgpu_waves_per_eu(7, 8))) void pll_kernel(
     const uint4 *__restrict__ sgn4, uint32_t *__restrict__ pllst, uint32_t *__restrict__ prevst,
     uint32_t *__restrict__ lastbit, uint32_t *__restrict__ segbits, uint32_t *__restrict__ segcnt,
     uint32_t *__restrict__ watchdog, int N, int L, int n_seg_alloc, uint32_t pllinc)
@@ -225,7 +232,9 @@ __global__ __launch_bounds__(64 * PLL_WAVES) __attribute__((amdgpu_waves_per_eu(
     uint32_t *flag = pack + 2 * PLL_PACKW * 64;
     uint32_t *sign0 = flag + 16, *sign1 = flag + 16 + 64;      // level before the call's first / at its last sample
     uint32_t *nbuf = flag + 16 + 128;                          // [4][64]: bits of segment s at (s & 3)
-    const int lane = threadIdx.x & 63, role = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63;
+    // wave -> role: 0 recurrence, 1 scanner, 2 writer, 3 toggler, then the second toggler (4) and scanner (5) if any
+    const int wv = threadIdx.x >> 6, role = wv < 4 ? wv : (wv == 4 && NTG == 2 ? 4 : 5);
     const int cg = blockIdx.x * 64 + lane;
     const int c = cg < N ? cg : N - 1;
     const bool live = cg < N;
@@ -234,16 +243,16 @@ __global__ __launch_bounds__(64 * PLL_WAVES) __attribute__((amdgpu_waves_per_eu(
     // flag[0] blocks scanned, [1] blocks the recurrence has finished, [2] segments whose bit count it has
     // published, [3] packs written, [4] scanners done, [5] / [6] the next block the even / odd toggler takes,
     // [7] / [8] blocks scanned by the even / odd scanner (last block + 1)
-    if (threadIdx.x < 16) flag[threadIdx.x] = threadIdx.x == 6 ? 1u : 0u;
+    if (threadIdx.x < 16) flag[threadIdx.x] = (NTG == 2 && threadIdx.x == 6) ? 1u : 0u;
     if (role == 0) sign0[lane] = prevst[c] & 1u;               // receiver.h:44 prev, before the scanner rewrites it
-    for (int v = threadIdx.x; v < 256; v += 64 * PLL_WAVES) {
+    for (int v = threadIdx.x; v < 256; v += 64 * (2 + NSC + NTG)) {
         uint64_t e = 0;
         int n = 0;
         for (int b = 7; b >= 0; --b)
             if (v & (1 << b)) e |= (uint64_t) (7 - b) << (8 * n++);
         lut[v] = e;
     }
-    for (int q = threadIdx.x; q < 2 * PLL_PACKW * 64; q += 64 * PLL_WAVES) pack[q] = 0;
+    for (int q = threadIdx.x; q < 2 * PLL_PACKW * 64; q += 64 * (2 + NSC + NTG)) pack[q] = 0;
     __syncthreads();
     const unsigned long long t_start = wall_clock64();
     // nothing here may spin forever: a wave that waits longer than this gives up (200 ms; the waves
@@ -256,19 +265,20 @@ __global__ __launch_bounds__(64 * PLL_WAVES) __attribute__((amdgpu_waves_per_eu(
     };
 
     if (role == 1 || role == 5) {                 // ---- the scanners: even / odd blocks ----
-        const int w = role == 1 ? 0 : 1;
+        const int w = role == 1 ? 0 : 1;                           // (role 5 exists with NSC == 2 only)
         const uint4 *__restrict__ src = sgn4 + c;                  // piece i of this lane: src[i * N]
         // a block's lists depend on the sign before its first sample only: the newest bit of the block before
         auto last_word = [&](int b) -> uint32_t {                  // word 8 b - 1 (any valid word when there is none)
+            if (NSC == 1) return 0;                                // a lone scanner carries the bit itself
             const int quad = (b >= 1 && b < n_blk) ? b * BLK_QUADS - 1 : 0;
             return reinterpret_cast<const uint32_t *>(src + (size_t) quad * (size_t) N)[3];
         };
-        const int n_own = (n_blk - w + 1) / 2;                     // blocks w, w + 2, ...
+        const int n_own = (n_blk - w + NSC - 1) / NSC;             // blocks w, w + NSC, ...
         uint4 q[PLL_AHEAD][BLK_QUADS];
         uint32_t pw[PLL_AHEAD];
 #pragma unroll
         for (int j = 0; j < PLL_AHEAD; ++j) {
-            const int b = j < n_own ? w + 2 * j : w;
+            const int b = j < n_own ? w + NSC * j : w;
 #pragma unroll
             for (int h = 0; h < BLK_QUADS; ++h) q[j][h] = src[(size_t) ((b < n_blk ? b : 0) * BLK_QUADS + h) * (size_t) N];
             pw[j] = last_word(b);
@@ -279,7 +289,7 @@ __global__ __launch_bounds__(64 * PLL_WAVES) __attribute__((amdgpu_waves_per_eu(
         for (int i0 = 0; i0 < n_own && !dead; i0 += PLL_AHEAD) {
 #pragma unroll
             for (int j = 0; j < PLL_AHEAD; ++j) {
-                const int i = i0 + j, b = w + 2 * i;
+                const int i = i0 + j, b = w + NSC * i;
                 uint32_t S[4 * BLK_QUADS];
 #pragma unroll
                 for (int h = 0; h < BLK_QUADS; ++h) {
@@ -288,7 +298,7 @@ __global__ __launch_bounds__(64 * PLL_WAVES) __attribute__((amdgpu_waves_per_eu(
                 const uint32_t pword = pw[j];
                 {   // loads are unconditional (past the end: an early block again), so that the compiler
                     // counts them and waits for exactly the oldest
-                    const int nb = b + 2 * PLL_AHEAD;
+                    const int nb = b + NSC * PLL_AHEAD;
                     const int lb = nb < n_blk ? nb : (w < n_blk ? w : 0);
 #pragma unroll
                     for (int h = 0; h < BLK_QUADS; ++h) q[j][h] = src[(size_t) (lb * BLK_QUADS + h) * (size_t) N];
@@ -297,7 +307,7 @@ __global__ __launch_bounds__(64 * PLL_WAVES) __attribute__((amdgpu_waves_per_eu(
                 if (i < n_own && !dead) {
                     while (b - seen >= PLL_SLOTS && !dead) {       // slot b % PLL_SLOTS still in use?
                         const int t0 = __builtin_amdgcn_readfirstlane((int) lds_flag_load(flag + 5));
-                        const int t1 = __builtin_amdgcn_readfirstlane((int) lds_flag_load(flag + 6));
+                        const int t1 = NTG == 2 ? __builtin_amdgcn_readfirstlane((int) lds_flag_load(flag + 6)) : t0;
                         seen = t0 < t1 ? t0 : t1;              // every block before this one has been toggled
                         if (b - seen >= PLL_SLOTS) {
                             if (expired()) dead = true;
@@ -305,7 +315,7 @@ __global__ __launch_bounds__(64 * PLL_WAVES) __attribute__((amdgpu_waves_per_eu(
                         }
                     }
                     if (!dead) {
-                        prev = b == 0 ? sign0[lane] : (pword & 1u);
+                        if (NSC == 2) prev = b == 0 ? sign0[lane] : (pword & 1u);
                         uint8_t *slot = slots + (b % PLL_SLOTS) * PLL_SLOT_BYTES;
                         uint32_t cur = (uint32_t) (slot - lds) + (uint32_t) (lane * PLL_STRIP);   // LDS address
                         const uint32_t cur0 = cur;
@@ -324,25 +334,38 @@ __global__ __launch_bounds__(64 * PLL_WAVES) __attribute__((amdgpu_waves_per_eu(
                             }
                             uint64_t ent[4];
 #pragma unroll
-                            for (int y = 0; y < 4; ++y) ent[y] = lut[(d >> (24 - 8 * y)) & 0xffu];
+                            for (int y = 0; y < 4; ++y)
+#if SCAN_EXP & 2
+                                ent[y] = (uint64_t) d * 0x0101010101ull;
+#else
+                                ent[y] = lut[(d >> (24 - 8 * y)) & 0xffu];
+#endif
 #pragma unroll
                             for (int y = 0; y < 4; ++y) {
                                 const uint32_t base = 0x01010101u * (uint32_t) (32 * w8 + 8 * y);
                                 const uint64_t e = ent[y] + (((uint64_t) base << 32) | base);
+#if SCAN_EXP & 1
+                                asm volatile("ds_write_b64 %0, %1" :: "v"(cur & ~7u), "v"(e) : "memory");
+#else
                                 asm volatile("ds_write_b64 %0, %1" :: "v"(cur), "v"(e) : "memory");   // any byte address
+#endif
                                 cur += (uint32_t) __popc((d >> (24 - 8 * y)) & 0xffu);
                             }
                         }
                         const uint32_t cnt = cur - cur0;
                         reinterpret_cast<uint32_t *>(slot + 64 * PLL_STRIP)[lane] = cnt;
+#if SCAN_EXP & 4
+                        const uint32_t ng = 24;
+#else
                         const uint32_t ng = wave_max((cnt + 3u) >> 2);
+#endif
                         if (lane == 0) reinterpret_cast<uint32_t *>(slot + 64 * PLL_STRIP + 256)[0] = ng;
                         lds_flag_store(flag + 7 + w, (uint32_t) (b + 1));
                     }
                 }
             }
         }
-        if (((n_blk - 1) & 1) == w) {                              // this scanner had the call's last block
+        if (((n_blk - 1) % NSC) == w) {                              // this scanner had the call's last block
             sign1[lane] = prev;
             lds_flag_store(flag + 4, 1u);
             if (live && !dead) prevst[cg] = prev;
@@ -362,7 +385,7 @@ __global__ __launch_bounds__(64 * PLL_WAVES) __attribute__((amdgpu_waves_per_eu(
             for (;;) {
                 const int pub = __builtin_amdgcn_readfirstlane((int) lds_flag_load(flag + 2));
                 const int t0 = __builtin_amdgcn_readfirstlane((int) lds_flag_load(flag + 5));
-                const int t1 = __builtin_amdgcn_readfirstlane((int) lds_flag_load(flag + 6));
+                const int t1 = NTG == 2 ? __builtin_amdgcn_readfirstlane((int) lds_flag_load(flag + 6)) : t0;
                 if (pub >= s + 1 && t0 >= b1 && t1 >= b1) break;
                 if (expired()) return;
                 __builtin_amdgcn_s_sleep(16);
@@ -405,7 +428,7 @@ __global__ __launch_bounds__(64 * PLL_WAVES) __attribute__((amdgpu_waves_per_eu(
     if (role >= 3) {                              // ---- the togglers: even / odd blocks ----
         const int w = role - 3;
         int done = 0, drained = 0;
-        for (int b = w; b < n_blk; b += 2) {
+        for (int b = w; b < n_blk; b += NTG) {
             const int s = b / SEG_BLKS;
             while (drained < s - 1) {                          // pack buffer s & 1 was segment s-2's
                 drained = __builtin_amdgcn_readfirstlane((int) lds_flag_load(flag + 3));
@@ -429,7 +452,7 @@ __global__ __launch_bounds__(64 * PLL_WAVES) __attribute__((amdgpu_waves_per_eu(
             const uint32_t pb = (uint32_t) (reinterpret_cast<uint8_t *>(pack) - lds) +
                                 (uint32_t) (((s & 1) * PLL_PACKW * 64 + lane) * 4);   // LDS address of this lane's pack word 0
             if (ng) pll_toggle_rows(cnt, (uint32_t) (slot - lds) + (uint32_t) (lane * PLL_STRIP), ng, base, pb);
-            lds_flag_store(flag + 5 + w, (uint32_t) (b + 2));
+            lds_flag_store(flag + 5 + w, (uint32_t) (b + NTG));
         }
         lds_flag_store(flag + 5 + w, 0x7fffffffu);
         return;
@@ -450,7 +473,7 @@ __global__ __launch_bounds__(64 * PLL_WAVES) __attribute__((amdgpu_waves_per_eu(
         for (int b = s * SEG_BLKS; b < b1 && !dead; ++b) {
             seen = 0;
             while (seen < b + 1 && !dead) {                    // scanned by the scanner of its parity
-                seen = __builtin_amdgcn_readfirstlane((int) lds_flag_load(flag + 7 + (b & 1)));
+                seen = __builtin_amdgcn_readfirstlane((int) lds_flag_load(flag + 7 + (b % NSC)));
                 if (seen < b + 1) {
                     if (expired()) dead = true;
                     __builtin_amdgcn_s_sleep(1);
@@ -487,7 +510,13 @@ hipError_t pll_prepare_device()
 {
     const hipError_t e = pll3_prepare_device();
     if (e != hipSuccess) return e;
-    return hipFuncSetAttribute((const void *) pll_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    const void *forms[] = {(const void *) pll_kernel<1, 1>, (const void *) pll_kernel<2, 1>, (const void *) pll_kernel<1, 2>,
+                           (const void *) pll_kernel<2, 2>};
+    for (const void *f : forms) {
+        const hipError_t ef = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (ef != hipSuccess) return ef;
+    }
+    return hipSuccess;
 }
 
 // Which form: the six-wave workgroup finishes a call a quarter sooner (0.31 against 0.41 ms per 48 000 samples)
@@ -499,15 +528,23 @@ hipError_t launch_pll(const PllLaunch &a, hipStream_t stream)
 {
     const int n_cu = a.n_cu > 0 ? a.n_cu : 256;
     const int groups = (a.N + 63) / 64;
-    const int variant = a.variant == 3 || a.variant == 6 ? a.variant : (2 * groups <= n_cu ? 6 : 3);
-    if (variant == 3) return launch_pll3(a, stream);
+    const int variant = a.variant == 3 || a.variant == 4 || a.variant == 6 || a.variant == 32 || a.variant == 51 || a.variant == 52
+                            ? a.variant : (2 * groups <= n_cu ? 6 : 3);
+    if (variant == 3 || variant == 32) return launch_pll3(a, stream);
     // one workgroup per CU while the channel groups fit one round; beyond that share the CUs evenly
     const int per_cu = (groups + n_cu - 1) / n_cu;
     const int lds = per_cu <= 1 ? std::max(PLL_NEED_LDS, PLL_LDS_BYTES)
                                 : std::max(PLL_NEED_LDS, (160 * 1024 / per_cu) & ~1023);
     if (lds > 160 * 1024) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(pll_kernel, dim3(groups), dim3(64 * PLL_WAVES), lds, stream, (const uint4 *) a.sgn, a.pll,
-                       a.prev, a.lastbit, a.segbits, a.segcnt, a.watchdog, a.N, a.L, a.n_seg, a.pllinc);
+#define PLL_FORM(NSC, NTG)                                                                                     \
+    hipLaunchKernelGGL((pll_kernel<NSC, NTG>), dim3(groups), dim3(64 * (2 + NSC + NTG)), lds, stream,             \
+                       (const uint4 *) a.sgn, a.pll, a.prev, a.lastbit, a.segbits, a.segcnt, a.watchdog, a.N, a.L, \
+                       a.n_seg, a.pllinc)
+    if (variant == 4) PLL_FORM(1, 1);
+    else if (variant == 51) PLL_FORM(2, 1);          // measurement forms: which of the two is short of a wave
+    else if (variant == 52) PLL_FORM(1, 2);
+    else PLL_FORM(2, 2);
+#undef PLL_FORM
     return hipGetLastError();
 }
 

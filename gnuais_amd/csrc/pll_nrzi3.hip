@@ -78,10 +78,12 @@ constexpr int SEG_BLKS = SEG_LEN / BLK_LEN;
 constexpr int PLL_STRIP = BLK_LEN + 12;    // bytes per lane and slot: the positions + an 8-byte store's overhang +
                                      // the recurrence's read-ahead; 67 dwords (odd): lanes hit different banks
 constexpr int PLL_SLOTS = 4;         // block slots between scanner and recurrence
-constexpr int PLL_AHEAD = 2;         // blocks of sign words the scanner has in flight
+#ifndef PLL_AHEAD_N
+#define PLL_AHEAD_N 2
+#endif
+constexpr int PLL_AHEAD = PLL_AHEAD_N;         // blocks of sign words the scanner has in flight
 constexpr int PLL_SLOT_BYTES = 64 * PLL_STRIP + 64 * 4 + 64;     // strips, counts, rows
 constexpr int PLL_PACKW = PACK_STRIDE + 1;   // words per lane and pack buffer: the pack + its bit count
-constexpr int PLL_WAVES = 3;
 constexpr int PLL_LUT_BYTES = 2048;
 constexpr int PLL_FLAG_WORDS = 16 + 2 * 64;  // counters, then the sign before / after the call per lane
 constexpr int PLL_NEED_LDS = PLL_LUT_BYTES + PLL_SLOTS * PLL_SLOT_BYTES + 2 * PLL_PACKW * 64 * 4 + PLL_FLAG_WORDS * 4;
@@ -169,7 +171,9 @@ __host__ __device__ inline int n_seg_cap(int L)
 //   PLL_SLOTS x PLL_SLOT_BYTES      block slots: 64 strips of PLL_STRIP bytes, cnt[64], rows
 //   2 x PLL_PACKW x 64 words        pack buffers (toggle words + bit count per lane)
 //   PLL_FLAG_WORDS                  hand-over counters; sign before / after the call per lane
-__global__ __launch_bounds__(64 * PLL_WAVES) __attribute__((amdgpu_waves_per_eu(7, 8))) void pll3_kernel(
+// NSC scanners: 1 (three waves) or 2 (four waves: even / odd blocks, six block slots instead of four)
+template <int NSC>
+__global__ __launch_bounds__(64 * (2 + NSC)) __attribute__((amdgpu_waves_per_eu(7, 8))) void pll3_kernel(
     const uint4 *__restrict__ sgn4, uint32_t *__restrict__ pllst, uint32_t *__restrict__ prevst,
     uint32_t *__restrict__ lastbit, uint32_t *__restrict__ segbits, uint32_t *__restrict__ segcnt,
     uint32_t *__restrict__ watchdog, int N, int L, int n_seg_alloc, uint32_t pllinc)
@@ -177,7 +181,8 @@ __global__ __launch_bounds__(64 * PLL_WAVES) __attribute__((amdgpu_waves_per_eu(
     extern __shared__ uint8_t lds[];
     uint64_t *lut = reinterpret_cast<uint64_t *>(lds);
     uint8_t *slots = lds + PLL_LUT_BYTES;
-    uint32_t *pack = reinterpret_cast<uint32_t *>(slots + PLL_SLOTS * PLL_SLOT_BYTES);    // [2][PLL_PACKW][64]
+    constexpr int SLOTS = NSC == 2 ? PLL_SLOTS + 2 : PLL_SLOTS;
+    uint32_t *pack = reinterpret_cast<uint32_t *>(slots + SLOTS * PLL_SLOT_BYTES);    // [2][PLL_PACKW][64]
     uint32_t *flag = pack + 2 * PLL_PACKW * 64;
     uint32_t *sign0 = flag + 16, *sign1 = flag + 16 + 64;      // level before the call's first / at its last sample
     const int lane = threadIdx.x & 63, role = threadIdx.x >> 6;
@@ -186,17 +191,18 @@ __global__ __launch_bounds__(64 * PLL_WAVES) __attribute__((amdgpu_waves_per_eu(
     const bool live = cg < N;
     const int n_seg = n_seg_cap(L);
     const int n_blk = (L + BLK_LEN - 1) / BLK_LEN;
-    // flag[0] blocks scanned, [1] blocks consumed, [2] segments finished, [3] packs written, [4] scanner done
+    // flag[1] blocks consumed, [2] segments finished, [3] packs written, [4] scanners done, [5] / [6] blocks scanned by
+    // the first / second scanner (last block + 1)
     if (threadIdx.x < 16) flag[threadIdx.x] = 0;
     if (role == 0) sign0[lane] = prevst[c] & 1u;               // receiver.h:44 prev, before the scanner rewrites it
-    for (int v = threadIdx.x; v < 256; v += 64 * PLL_WAVES) {
+    for (int v = threadIdx.x; v < 256; v += 64 * (2 + NSC)) {
         uint64_t e = 0;
         int n = 0;
         for (int b = 7; b >= 0; --b)
             if (v & (1 << b)) e |= (uint64_t) (7 - b) << (8 * n++);
         lut[v] = e;
     }
-    for (int q = threadIdx.x; q < 2 * PLL_PACKW * 64; q += 64 * PLL_WAVES) pack[q] = 0;
+    for (int q = threadIdx.x; q < 2 * PLL_PACKW * 64; q += 64 * (2 + NSC)) pack[q] = 0;
     __syncthreads();
     const unsigned long long t_start = wall_clock64();
     // nothing here may spin forever: a wave that waits longer than this gives up (200 ms; the waves
@@ -208,64 +214,79 @@ __global__ __launch_bounds__(64 * PLL_WAVES) __attribute__((amdgpu_waves_per_eu(
         return true;
     };
 
-    if (role == 1) {                              // ---- the scanner ----
+    if (role == 1 || role == 3) {                 // ---- the scanner(s): every block, or even / odd blocks ----
+        const int w = role == 1 ? 0 : 1;                           // (role 3 exists with NSC == 2 only)
         const uint4 *__restrict__ src = sgn4 + c;                  // piece i of this lane: src[i * N]
-        uint32_t prev = sign0[lane];
+        // a block's lists depend on the sign before its first sample only: the newest bit of the block before
+        auto last_word = [&](int b) -> uint32_t {                  // word 8 b - 1 (any valid word when there is none)
+            if (NSC == 1) return 0;                                // a lone scanner carries the bit itself
+            const int quad = (b >= 1 && b < n_blk) ? b * BLK_QUADS - 1 : 0;
+            return reinterpret_cast<const uint32_t *>(src + (size_t) quad * (size_t) N)[3];
+        };
+        const int n_own = (n_blk - w + NSC - 1) / NSC;             // blocks w, w + NSC, ...
         uint4 q[PLL_AHEAD][BLK_QUADS];
+        uint32_t pw[PLL_AHEAD];
 #pragma unroll
-        for (int j = 0; j < PLL_AHEAD; ++j)
+        for (int j = 0; j < PLL_AHEAD; ++j) {
+            const int b = j < n_own ? w + NSC * j : w;
 #pragma unroll
-            for (int h = 0; h < BLK_QUADS; ++h)
-                q[j][h] = src[(size_t) ((j < n_blk ? j : 0) * BLK_QUADS + h) * (size_t) N];
+            for (int h = 0; h < BLK_QUADS; ++h) q[j][h] = src[(size_t) ((b < n_blk ? b : 0) * BLK_QUADS + h) * (size_t) N];
+            pw[j] = last_word(b);
+        }
         int seen = 0;
         bool dead = false;
-        for (int b0 = 0; b0 < n_blk && !dead; b0 += PLL_AHEAD) {
+        uint32_t prev = sign0[lane];
+        for (int i0 = 0; i0 < n_own && !dead; i0 += PLL_AHEAD) {
 #pragma unroll
             for (int j = 0; j < PLL_AHEAD; ++j) {
-                const int b = b0 + j;
+                const int i = i0 + j, b = w + NSC * i;
                 uint32_t S[4 * BLK_QUADS];
 #pragma unroll
                 for (int h = 0; h < BLK_QUADS; ++h) {
                     S[4 * h] = q[j][h].x; S[4 * h + 1] = q[j][h].y; S[4 * h + 2] = q[j][h].z; S[4 * h + 3] = q[j][h].w;
                 }
-                {   // loads are unconditional (past the end: block 0 again), so that the compiler
+                const uint32_t pword = pw[j];
+                {   // loads are unconditional (past the end: an early block again), so that the compiler
                     // counts them and waits for exactly the oldest
-                    const int nb = b + PLL_AHEAD;
+                    const int nb = b + NSC * PLL_AHEAD;
+                    const int lb = nb < n_blk ? nb : (w < n_blk ? w : 0);
 #pragma unroll
-                    for (int h = 0; h < BLK_QUADS; ++h)
-                        q[j][h] = src[(size_t) ((nb < n_blk ? nb : 0) * BLK_QUADS + h) * (size_t) N];
+                    for (int h = 0; h < BLK_QUADS; ++h) q[j][h] = src[(size_t) (lb * BLK_QUADS + h) * (size_t) N];
+                    pw[j] = last_word(lb);
                 }
-                if (b < n_blk && !dead) {
-                    while (b - seen >= PLL_SLOTS && !dead) {       // slot b % PLL_SLOTS still in use?
-                        seen = __builtin_amdgcn_readfirstlane((int) lds_flag_load(flag + 1));
-                        if (b - seen >= PLL_SLOTS) {
+                if (i < n_own && !dead) {
+                    while (b - seen >= SLOTS && !dead) {       // slot b % SLOTS still in use?
+                        seen = __builtin_amdgcn_readfirstlane((int) lds_flag_load(flag + 1));   // blocks consumed
+                        if (b - seen >= SLOTS) {
                             if (expired()) dead = true;
                             __builtin_amdgcn_s_sleep(2);
                         }
                     }
                     if (!dead) {
-                        uint8_t *slot = slots + (b % PLL_SLOTS) * PLL_SLOT_BYTES;
+                        if (NSC == 2) prev = b == 0 ? sign0[lane] : (pword & 1u);
+                        uint8_t *slot = slots + (b % SLOTS) * PLL_SLOT_BYTES;
                         uint32_t cur = (uint32_t) (slot - lds) + (uint32_t) (lane * PLL_STRIP);   // LDS address
                         const uint32_t cur0 = cur;
                         const int nv = L - b * BLK_LEN;            // valid samples of this block (>= 1)
 #pragma unroll
-                        for (int w = 0; w < 4 * BLK_QUADS; ++w) {
-                            const int k = nv - 32 * w;             // valid samples of this word
-                            uint32_t d = S[w] ^ ((S[w] >> 1) | (prev << 31));      // receiver.c:113
+                        for (int w8 = 0; w8 < 4 * BLK_QUADS; ++w8) {
+                            const int k = nv - 32 * w8;            // valid samples of this word
+                            uint32_t d = S[w8] ^ ((S[w8] >> 1) | (prev << 31));      // receiver.c:113
                             if (k <= 0) {
                                 d = 0;
                             } else if (k < 32) {
                                 d &= ~0u << (32 - k);
-                                prev = (S[w] >> (32 - k)) & 1u;
+                                prev = (S[w8] >> (32 - k)) & 1u;
                             } else {
-                                prev = S[w] & 1u;
+                                prev = S[w8] & 1u;
                             }
                             uint64_t ent[4];
 #pragma unroll
-                            for (int y = 0; y < 4; ++y) ent[y] = lut[(d >> (24 - 8 * y)) & 0xffu];
+                            for (int y = 0; y < 4; ++y)
+                                ent[y] = lut[(d >> (24 - 8 * y)) & 0xffu];
 #pragma unroll
                             for (int y = 0; y < 4; ++y) {
-                                const uint32_t base = 0x01010101u * (uint32_t) (32 * w + 8 * y);
+                                const uint32_t base = 0x01010101u * (uint32_t) (32 * w8 + 8 * y);
                                 const uint64_t e = ent[y] + (((uint64_t) base << 32) | base);
                                 asm volatile("ds_write_b64 %0, %1" :: "v"(cur), "v"(e) : "memory");   // any byte address
                                 cur += (uint32_t) __popc((d >> (24 - 8 * y)) & 0xffu);
@@ -275,14 +296,16 @@ __global__ __launch_bounds__(64 * PLL_WAVES) __attribute__((amdgpu_waves_per_eu(
                         reinterpret_cast<uint32_t *>(slot + 64 * PLL_STRIP)[lane] = cnt;
                         const uint32_t ng = wave_max((cnt + 3u) >> 2);
                         if (lane == 0) reinterpret_cast<uint32_t *>(slot + 64 * PLL_STRIP + 256)[0] = ng;
-                        lds_flag_store(flag + 0, (uint32_t) (b + 1));
+                        lds_flag_store(flag + 5 + w, (uint32_t) (b + 1));
                     }
                 }
             }
         }
-        sign1[lane] = prev;
-        lds_flag_store(flag + 4, 1u);
-        if (live && !dead) prevst[cg] = prev;
+        if (((n_blk - 1) % NSC) == w) {                              // this scanner had the call's last block
+            sign1[lane] = prev;
+            lds_flag_store(flag + 4, 1u);
+            if (live && !dead) prevst[cg] = prev;
+        }
         return;
     }
 
@@ -357,15 +380,16 @@ __global__ __launch_bounds__(64 * PLL_WAVES) __attribute__((amdgpu_waves_per_eu(
                             (uint32_t) (((s & 1) * PLL_PACKW * 64 + lane) * 4);   // LDS address of this lane's pack word 0
         const int b1 = (s + 1) * SEG_BLKS < n_blk ? (s + 1) * SEG_BLKS : n_blk;
         for (int b = s * SEG_BLKS; b < b1 && !dead; ++b) {
+            seen = 0;
             while (seen < b + 1 && !dead) {
-                seen = __builtin_amdgcn_readfirstlane((int) lds_flag_load(flag + 0));
+                seen = __builtin_amdgcn_readfirstlane((int) lds_flag_load(flag + 5 + (b % NSC)));
                 if (seen < b + 1) {
                     if (expired()) dead = true;
                     __builtin_amdgcn_s_sleep(1);
                 }
             }
             if (dead) break;
-            const uint8_t *slot = slots + (b % PLL_SLOTS) * PLL_SLOT_BYTES;
+            const uint8_t *slot = slots + (b % SLOTS) * PLL_SLOT_BYTES;
             const uint32_t cnt = reinterpret_cast<const uint32_t *>(slot + 64 * PLL_STRIP)[lane];
             const uint32_t ng = (uint32_t) __builtin_amdgcn_readfirstlane(
                 (int) reinterpret_cast<const uint32_t *>(slot + 64 * PLL_STRIP + 256)[0]);
@@ -386,7 +410,9 @@ __global__ __launch_bounds__(64 * PLL_WAVES) __attribute__((amdgpu_waves_per_eu(
 
 hipError_t pll3_prepare_device()
 {
-    return hipFuncSetAttribute((const void *) pll3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    const hipError_t e = hipFuncSetAttribute((const void *) pll3_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) return e;
+    return hipFuncSetAttribute((const void *) pll3_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
 }
 
 hipError_t launch_pll3(const PllLaunch &a, hipStream_t stream)
@@ -394,11 +420,16 @@ hipError_t launch_pll3(const PllLaunch &a, hipStream_t stream)
     // one workgroup per CU while the channel groups fit one round; beyond that share the CUs evenly
     const int n_cu = a.n_cu > 0 ? a.n_cu : 256;
     const int groups = (a.N + 63) / 64, per_cu = (groups + n_cu - 1) / n_cu;
-    const int lds = per_cu <= 1 ? std::max(PLL_NEED_LDS, PLL_LDS_BYTES)
-                                : std::max(PLL_NEED_LDS, (160 * 1024 / per_cu) & ~1023);
+    const int nsc = a.variant == 32 ? 2 : 1;
+    const int need = PLL_NEED_LDS + (nsc == 2 ? 2 * PLL_SLOT_BYTES : 0);
+    const int lds = per_cu <= 1 ? std::max(need, PLL_LDS_BYTES) : std::max(need, (160 * 1024 / per_cu) & ~1023);
     if (lds > 160 * 1024) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(pll3_kernel, dim3(groups), dim3(64 * PLL_WAVES), lds, stream, (const uint4 *) a.sgn, a.pll,
-                       a.prev, a.lastbit, a.segbits, a.segcnt, a.watchdog, a.N, a.L, a.n_seg, a.pllinc);
+    if (nsc == 2)
+        hipLaunchKernelGGL(pll3_kernel<2>, dim3(groups), dim3(64 * 4), lds, stream, (const uint4 *) a.sgn, a.pll,
+                           a.prev, a.lastbit, a.segbits, a.segcnt, a.watchdog, a.N, a.L, a.n_seg, a.pllinc);
+    else
+        hipLaunchKernelGGL(pll3_kernel<1>, dim3(groups), dim3(64 * 3), lds, stream, (const uint4 *) a.sgn, a.pll,
+                           a.prev, a.lastbit, a.segbits, a.segcnt, a.watchdog, a.N, a.L, a.n_seg, a.pllinc);
     return hipGetLastError();
 }
 

@@ -286,7 +286,9 @@ int  gnuais_batch_mean_timing(gnuais_batch *b, float *ms5, int *n_calls);
  * 1 = its v_pk build, 2 = its MFMA-product build), "fir_map" (1 = workgroups of one XCD
  * walk neighbouring channel groups, the default; 0 = plain blockIdx order), "pipeline",
  * "pll_variant" (0 = by channel count, the default: the six-wave PLL workgroup where fewer channel
- * groups than half the CUs leave the chip room, the three-wave one otherwise; 3 / 6 force one),
+ * groups than half the CUs leave the chip room, the three-wave one otherwise; 3 / 6 force one;
+ * measurement forms, all bit-exact: 32 = three waves + a second scanner, 4 = one scanner / short
+ * recurrence / one toggler / writer, 51 / 52 = the six-wave form less one toggler / one scanner),
  * "hdlc_variant" (1 = the event-driven deframer, the default; 0 = the bit-serial one),
  * "hdlc_lpw" (channels per wave in the bit-serial deframer, 1..64), "timing_stride" (with
  * set_timing on, time every n-th call only: the event records of a timed call cost ~0.05 ms

@@ -176,7 +176,7 @@ def run_both(x, chunks, n_ch, taps=None, pllinc=0, fir_T=None, pll_variant=0):
     return o, b
 
 
-@pytest.mark.parametrize("pll_variant", [3, 6])
+@pytest.mark.parametrize("pll_variant", [3, 32, 4, 51, 52, 6])
 def test_chain_vs_oracle_ragged_chunks(pll_variant):
     n_ch, total = 70, 30 * 1280
     x = np.stack([synth.make_stream(total, seed=31, channel=c,
@@ -188,7 +188,7 @@ def test_chain_vs_oracle_ragged_chunks(pll_variant):
     assert o.counters()[:, 0].sum() > 300
 
 
-@pytest.mark.parametrize("pll_variant", [3, 6])
+@pytest.mark.parametrize("pll_variant", [3, 32, 4, 51, 52, 6])
 def test_chain_vs_oracle_noise_only_and_extremes(pll_variant):
     rng = np.random.default_rng(33)
     total = 40000
