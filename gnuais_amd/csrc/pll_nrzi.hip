@@ -334,17 +334,12 @@ __global__ __launch_bounds__(64 * (2 + NSC + NTG)) __attribute__((amdgpu_waves_p
                             }
                             uint64_t ent[4];
 #pragma unroll
-                            for (int y = 0; y < 4; ++y)
-#if SCAN_EXP & 2
-                                ent[y] = (uint64_t) d * 0x0101010101ull;
-#else
-                                ent[y] = lut[(d >> (24 - 8 * y)) & 0xffu];
-#endif
+                            for (int y = 0; y < 4; ++y) ent[y] = lut[(d >> (24 - 8 * y)) & 0xffu];
 #pragma unroll
                             for (int y = 0; y < 4; ++y) {
                                 const uint32_t base = 0x01010101u * (uint32_t) (32 * w8 + 8 * y);
                                 const uint64_t e = ent[y] + (((uint64_t) base << 32) | base);
-#if SCAN_EXP & 1
+#if SCAN_EXP            // timing experiment only (wrong lists): what the unaligned stores cost
                                 asm volatile("ds_write_b64 %0, %1" :: "v"(cur & ~7u), "v"(e) : "memory");
 #else
                                 asm volatile("ds_write_b64 %0, %1" :: "v"(cur), "v"(e) : "memory");   // any byte address
@@ -354,11 +349,7 @@ __global__ __launch_bounds__(64 * (2 + NSC + NTG)) __attribute__((amdgpu_waves_p
                         }
                         const uint32_t cnt = cur - cur0;
                         reinterpret_cast<uint32_t *>(slot + 64 * PLL_STRIP)[lane] = cnt;
-#if SCAN_EXP & 4
-                        const uint32_t ng = 24;
-#else
                         const uint32_t ng = wave_max((cnt + 3u) >> 2);
-#endif
                         if (lane == 0) reinterpret_cast<uint32_t *>(slot + 64 * PLL_STRIP + 256)[0] = ng;
                         lds_flag_store(flag + 7 + w, (uint32_t) (b + 1));
                     }

@@ -1,0 +1,2 @@
+cd $GRAFT_REPO_ROOT
+timeout 120 scripts/ubench/pll_step6.bin
