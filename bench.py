@@ -276,19 +276,24 @@ def measure(cfg, args, local, rank, sync, steps, warmup, isolated=True, post=Fal
             b.run(x, stream=stream, sync=False)
             b.stream_nmea(copy=False)
         torch.cuda.synchronize()
-        frames = text = sent = 0
-        t0 = time.perf_counter()
         depth = b.stream_depth
-        for i in range(n_e2e + depth):              # `depth` more calls deliver what is in flight
-            if i < n_e2e:
-                b.run(x, stream=stream, sync=False)
-            tx, ns, nf = b.stream_nmea(copy=False)
-            if i >= depth:
-                frames += nf
-                sent += ns
-                text += len(tx)
-        torch.cuda.synchronize()
-        t_e2e = time.perf_counter() - t0
+
+        def delivery_loop():
+            torch.cuda.synchronize()
+            frames = text = sent = 0
+            t0 = time.perf_counter()
+            for i in range(n_e2e + depth):          # `depth` more calls deliver what is in flight
+                if i < n_e2e:
+                    b.run(x, stream=stream, sync=False)
+                tx, ns, nf = b.stream_nmea(copy=False)
+                if i >= depth:
+                    frames += nf
+                    sent += ns
+                    text += len(tx)
+            torch.cuda.synchronize()
+            return time.perf_counter() - t0, frames, sent, text
+
+        t_e2e, frames, sent, text = delivery_loop()
         out["end_to_end"] = {"what": "run + gnuais_batch_stream_nmea every step: chain, NMEA sentences formatted on the "
                                      "device in the reference's order, text into pinned host memory, handed out "
                                      "%d steps later" % depth,
@@ -296,6 +301,17 @@ def measure(cfg, args, local, rank, sync, steps, warmup, isolated=True, post=Fal
                              "delivered_msgs_per_s": frames / t_e2e, "sentences": sent,
                              "text_bytes_per_step": text / n_e2e, "ring_overflows": b.stream_overflows,
                              "Msamples_per_s": n_ch * total * n_e2e / t_e2e / 1e6}
+        # the same loop with the position cache carried on the device (row f3): every step's frames are folded into
+        # the table behind their formatter
+        b.vessel_table_enable(1 << 16)
+        for _ in range(4):
+            b.run(x, stream=stream, sync=False)
+            b.stream_nmea(copy=False)
+        t_tab, frames_t, _, _ = delivery_loop()
+        out["end_to_end"]["with_vessel_table"] = {
+            "what": "the same loop with gnuais_batch_vessel_table_enable(): sentences to the host + every frame folded "
+                    "into the position cache kept on the device", "ms_per_step": t_tab / n_e2e * 1e3,
+            "delivered_msgs_per_s": frames_t / t_tab, "vessels": int(len(b.vessel_table()))}
     if keep_input:
         out["x_cpu"] = x[:, : args.cpu_channels].cpu().numpy()
         out["x_wide"] = np.ascontiguousarray(x.cpu().numpy())

@@ -105,6 +105,11 @@ struct gnuais_batch {
     void *nmea_scratch = nullptr;
     char *d_msg = nullptr;          // gnuais_batch_drain_messages: lines, lengths, offsets, packed text
     uint32_t *d_word = nullptr;     // a few device words for counts read back by the drain-type calls
+    // the vessel table carried on the device (gnuais_batch_vessel_table_*): one allocation, per-frame slot scratch
+    void *vt = nullptr;
+    uint32_t *vt_fslot = nullptr;
+    uint32_t vt_slots = 0;
+    int vt_capacity = 0;
     size_t d_msg_bytes = 0;
     size_t nmea_scratch_bytes = 0, d_text_bytes = 0;
     // gnuais_batch_stream_nmea: the frame ring exists NRING times (ring 0 is `frames` / `frame_count`
@@ -222,7 +227,7 @@ void gnuais_batch_destroy(gnuais_batch *b)
     }
     void *ptrs[] = {b->hist[0], b->hist[1], b->pll, b->lastbit, b->prev, b->ctl, b->cand,
                     b->frame_count, b->counters, b->maxval[0], b->maxval[1], b->frames, b->d_taps,
-                    b->stage_x, b->d_seq[0], b->d_seq[1], b->d_text, b->nmea_scratch, b->d_msg, b->d_word, b->d_stamps, b->stage_f};
+                    b->stage_x, b->d_seq[0], b->d_seq[1], b->d_text, b->nmea_scratch, b->d_msg, b->d_word, b->d_stamps, b->stage_f, b->vt, b->vt_fslot};
     for (void *p : ptrs)
         if (p) (void) hipFree(p);
     for (auto &set : b->evr)
@@ -1304,6 +1309,67 @@ int gnuais_batch_fold_vessels(gnuais_batch *b, gnuais_vessel *vessels, int cap, 
     return GNUAIS_OK;
 }
 
+// ---- row f3, carried: the position cache kept on the device from batch to batch ------------------------------------
+int gnuais_batch_vessel_table_enable(gnuais_batch *b, int capacity)
+{
+    if (!b || capacity < 1 || capacity > (1 << 24)) return fail(GNUAIS_E_ARG, "vessel_table_enable: capacity 1 .. 2^24");
+    if (int rc = gnuais_batch_sync(b)) return rc;
+    if (b->s_post) HIP_TRY(hipStreamSynchronize(b->s_post));
+    uint32_t slots = 1024;
+    while (slots < 2u * (uint32_t) capacity) slots <<= 1;        // at most half full: short probe sequences
+    if (b->vt) HIP_TRY(hipFree(b->vt));
+    b->vt = nullptr;
+    b->vt_slots = 0;
+    HIP_TRY(hipMalloc(&b->vt, vessel_table_bytes(slots)));
+    HIP_TRY(hipMemset(b->vt, 0, vessel_table_bytes(slots)));
+    if (!b->vt_fslot) HIP_TRY(hipMalloc((void **) &b->vt_fslot, sizeof(uint32_t) * (size_t) b->frame_cap));
+    b->vt_slots = slots;
+    b->vt_capacity = capacity;
+    return GNUAIS_OK;
+}
+
+int gnuais_batch_vessel_table_clear(gnuais_batch *b)
+{
+    if (!b || !b->vt) return fail(GNUAIS_E_STATE, "vessel_table_clear: no table (gnuais_batch_vessel_table_enable)");
+    if (int rc = gnuais_batch_sync(b)) return rc;
+    if (b->s_post) HIP_TRY(hipStreamSynchronize(b->s_post));
+    HIP_TRY(hipMemset(b->vt, 0, vessel_table_bytes(b->vt_slots)));
+    return GNUAIS_OK;
+}
+
+// drain-type use: the queued frames into the table (they stay queued)
+int gnuais_batch_vessel_table_update(gnuais_batch *b)
+{
+    if (!b || !b->vt) return fail(GNUAIS_E_STATE, "vessel_table_update: no table (gnuais_batch_vessel_table_enable)");
+    if (b->streaming) return fail(GNUAIS_E_STATE, "vessel_table_update: a streaming batch updates its table by itself");
+    if (int rc = gnuais_batch_sync(b)) return rc;             // a drain-type call: waits for the chain like the drains do
+    hipStream_t s = b->pipeline ? b->s_k[3] : b->last_stream;
+    HIP_TRY(vessel_table_update_enqueue(b->frames, b->frame_count, b->frame_cap, b->vt, b->vt_slots, b->vt_fslot, s));
+    return GNUAIS_OK;
+}
+
+int gnuais_batch_vessel_table(gnuais_batch *b, gnuais_vessel *vessels, int cap, int *n_vessels)
+{
+    if (!b || !n_vessels || cap < 0 || (cap > 0 && !vessels)) return fail(GNUAIS_E_ARG, "vessel_table: argument");
+    *n_vessels = 0;
+    if (!b->vt) return fail(GNUAIS_E_STATE, "vessel_table: no table (gnuais_batch_vessel_table_enable)");
+    if (int rc = set_device(b)) return rc;
+    hipStream_t s = b->streaming ? b->s_post : (b->pipeline ? b->s_k[3] : b->last_stream);
+    uint32_t info[4] = {0, 0, 0, 0};
+    int n = 0;
+    HIP_TRY(vessel_table_fetch(b->vt, b->vt_slots, vessels, cap, &n, info, s));
+    *n_vessels = n;
+    if (info[1] || (int) info[0] > b->vt_capacity) {
+        char msg[160];
+        snprintf(msg, sizeof msg, "vessel_table: more vessels than the table was enabled for (%u seen%s, capacity %d)",
+                 info[0], info[1] ? ", some dropped" : "", b->vt_capacity);
+        return fail(GNUAIS_E_OVERFLOW, msg);
+    }
+    if (n > cap) return fail(GNUAIS_E_OVERFLOW, "vessel_table: output too small (*n_vessels entries needed)");
+    std::sort(vessels, vessels + n, [](const gnuais_vessel &x, const gnuais_vessel &y) { return x.mmsi < y.mmsi; });
+    return GNUAIS_OK;
+}
+
 int gnuais_batch_drain_frames(gnuais_batch *b, gnuais_frame *h_out, int max, int *n_out)
 {
     if (!b || !n_out || (max > 0 && !h_out)) return fail(GNUAIS_E_ARG, "drain_frames: argument");
@@ -1484,6 +1550,10 @@ int gnuais_batch_stream_nmea(gnuais_batch *b, const char **text, size_t *len, in
             b->sd_seq_cur ^= 1;
         }
     }
+    // the span's frames into the carried vessel table, behind the formatter and before the ring is handed back
+    if (b->vt && runs >= 1)
+        HIP_TRY(vessel_table_update_enqueue(b->ring[c], b->ring_count[c], b->frame_cap, b->vt, b->vt_slots, b->vt_fslot,
+                                            b->s_post));
     HIP_TRY(nmea_slot_info_enqueue(totals, b->ring_count[c], b->sd_info + 8 * c, b->s_post));
     HIP_TRY(hipMemsetAsync(b->ring_count[c], 0, 16, b->s_post));
     HIP_TRY(hipEventRecord(b->e_fmt[c], b->s_post));          // the ring is free for K3 again

@@ -150,6 +150,13 @@ hipError_t messages_format_enqueue(const struct gnuais_frame *frames, int n, int
 // the batch's vessel table (gnuais_vessel per MMSI, sorted) folded on the device from the ring's frames
 hipError_t vessels_fold_enqueue(const struct gnuais_frame *frames, int n, void *scratch, size_t scratch_bytes,
                                 struct gnuais_vessel *out, int cap, uint32_t *count_dev, hipStream_t s);
+// the vessel table carried on the device from batch to batch (one allocation of vessel_table_bytes(slots), zeroed;
+// slots a power of two)
+size_t vessel_table_bytes(uint32_t slots);
+hipError_t vessel_table_update_enqueue(const struct gnuais_frame *frames, const uint32_t *count, int n_max, void *table,
+                                       uint32_t slots, uint32_t *fslot, hipStream_t s);
+hipError_t vessel_table_fetch(const void *table, uint32_t slots, struct gnuais_vessel *h_out, int max, int *n_out,
+                              uint32_t h_info[4], hipStream_t s);
 hipError_t nmea_format(const struct gnuais_frame *frames, int n, int n_channels, const uint8_t *seq_in,
                        uint8_t *seq_out, char *out, size_t out_cap, void *scratch, size_t scratch_bytes,
                        uint32_t *h_info, hipStream_t s);

@@ -21,6 +21,7 @@
 // HBM-bound byte shuffling: 64 B read + ~50 B written per frame.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <vector>
 
 #include <cstring>
 #include <rocprim/device/device_radix_sort.hpp>
@@ -712,6 +713,62 @@ __device__ void vessel_literal(const char *s, char *dst, int cap)
     for (int i = n; i < cap; ++i) dst[i] = 0;
 }
 
+// what the frame's cache_*() calls write, for the groups in `todo` (the frame's own groups or a subset)
+__device__ void vessel_write_groups(gnuais_vessel &v, const BitsView &b, unsigned type, unsigned todo)
+{
+    if (todo & VG_POS) {                       // cache_position :204-229
+        long latitude, longitude;
+        int navstat = 0, hdg = 0;
+        unsigned course = 0, sog = 0;
+        if (type == 4) {
+            latitude = b.sget(107, 27); longitude = b.sget(79, 28);
+        } else if (type == 18) {
+            latitude = b.sget(85, 27); longitude = b.sget(57, 28); navstat = 15;
+            hdg = (int) b.get(124, 9); course = (unsigned) b.get(112, 12); sog = (unsigned) b.get(46, 10);
+        } else {
+            latitude = b.sget(89, 27); longitude = b.sget(61, 28); navstat = (int) (signed char) b.get(38, 2);
+            hdg = (int) b.get(128, 9); course = (unsigned) b.get(116, 12); sog = (unsigned) b.get(50, 10);
+        }
+        v.set |= GNUAIS_V_POSITION;
+        v.lat = (float) ((double) (float) latitude / 600000.0);
+        v.lon = (float) ((double) (float) longitude / 600000.0);
+        v.hdg = hdg;
+        v.course = (float) ((double) (float) (unsigned short) course / 10.0);
+        v.sog = (float) ((double) (float) (unsigned short) sog / 10.0);
+        v.navstat = navstat;
+    }
+    if (todo & VG_CALL) {
+        v.set |= GNUAIS_V_CALLSIGN;
+        vessel_text(b, type == 5 ? 70 : 90, 6, v.callsign, (int) sizeof v.callsign);
+    }
+    if (todo & VG_NAME) {
+        v.set |= GNUAIS_V_DATA | GNUAIS_V_NAME;
+        vessel_text(b, type == 5 ? 112 : type == 19 ? 143 : 40, 20, v.name, (int) sizeof v.name);
+        if (type == 5) vessel_text(b, 302, 20, v.destination, (int) sizeof v.destination);
+        else vessel_literal("CLASS B", v.destination, (int) sizeof v.destination);
+    }
+    if (todo & VG_STATIC) {
+        v.set |= GNUAIS_V_DATA | GNUAIS_V_STATIC;
+        if (type == 5) {
+            const unsigned char draught = (unsigned char) b.get(294, 8);
+            v.imo = (int) b.get(40, 30); v.shiptype = (int) b.get(232, 8);
+            v.A = (int) b.get(240, 9); v.B = (int) b.get(249, 9);
+            v.C = (unsigned char) b.get(258, 6); v.D = (unsigned char) b.get(264, 6);
+            v.draught = (float) ((double) draught / 10.0);
+        } else if (type == 19) {
+            v.imo = 0; v.shiptype = (int) b.get(263, 8); v.A = (int) b.get(271, 9); v.B = (int) b.get(280, 9);
+            v.C = (unsigned char) b.get(289, 6); v.D = (unsigned char) b.get(295, 6); v.draught = 0;
+        } else {
+            v.imo = 0; v.shiptype = (int) b.get(40, 8); v.A = (int) b.get(132, 9); v.B = (int) b.get(141, 9);
+            v.C = (unsigned char) b.get(150, 6); v.D = (unsigned char) b.get(156, 6); v.draught = 0;
+        }
+    }
+    if (todo & VG_PERSONS) {                   // protodec_msg_40 :279-285
+        v.set |= GNUAIS_V_PERSONS;
+        v.persons_on_board = (int) b.get(type == 6 ? 88 : 56, 13);
+    }
+}
+
 __global__ __launch_bounds__(128) void vessel_fold_kernel(const gnuais_frame *__restrict__ frames,
                                                           const uint64_t *__restrict__ keys,
                                                           const uint32_t *__restrict__ val,
@@ -745,59 +802,120 @@ __global__ __launch_bounds__(128) void vessel_fold_kernel(const gnuais_frame *__
         const unsigned todo = vessel_groups(b, type) & ~found;
         if (!todo) continue;
         found |= todo;
-        if (todo & VG_POS) {                       // cache_position :204-229
-            long latitude, longitude;
-            int navstat = 0, hdg = 0;
-            unsigned course = 0, sog = 0;
-            if (type == 4) {
-                latitude = b.sget(107, 27); longitude = b.sget(79, 28);
-            } else if (type == 18) {
-                latitude = b.sget(85, 27); longitude = b.sget(57, 28); navstat = 15;
-                hdg = (int) b.get(124, 9); course = (unsigned) b.get(112, 12); sog = (unsigned) b.get(46, 10);
-            } else {
-                latitude = b.sget(89, 27); longitude = b.sget(61, 28); navstat = (int) (signed char) b.get(38, 2);
-                hdg = (int) b.get(128, 9); course = (unsigned) b.get(116, 12); sog = (unsigned) b.get(50, 10);
-            }
-            v.set |= GNUAIS_V_POSITION;
-            v.lat = (float) ((double) (float) latitude / 600000.0);
-            v.lon = (float) ((double) (float) longitude / 600000.0);
-            v.hdg = hdg;
-            v.course = (float) ((double) (float) (unsigned short) course / 10.0);
-            v.sog = (float) ((double) (float) (unsigned short) sog / 10.0);
-            v.navstat = navstat;
-        }
-        if (todo & VG_CALL) {
-            v.set |= GNUAIS_V_CALLSIGN;
-            vessel_text(b, type == 5 ? 70 : 90, 6, v.callsign, (int) sizeof v.callsign);
-        }
-        if (todo & VG_NAME) {
-            v.set |= GNUAIS_V_DATA | GNUAIS_V_NAME;
-            vessel_text(b, type == 5 ? 112 : type == 19 ? 143 : 40, 20, v.name, (int) sizeof v.name);
-            if (type == 5) vessel_text(b, 302, 20, v.destination, (int) sizeof v.destination);
-            else vessel_literal("CLASS B", v.destination, (int) sizeof v.destination);
-        }
-        if (todo & VG_STATIC) {
-            v.set |= GNUAIS_V_DATA | GNUAIS_V_STATIC;
-            if (type == 5) {
-                const unsigned char draught = (unsigned char) b.get(294, 8);
-                v.imo = (int) b.get(40, 30); v.shiptype = (int) b.get(232, 8);
-                v.A = (int) b.get(240, 9); v.B = (int) b.get(249, 9);
-                v.C = (unsigned char) b.get(258, 6); v.D = (unsigned char) b.get(264, 6);
-                v.draught = (float) ((double) draught / 10.0);
-            } else if (type == 19) {
-                v.imo = 0; v.shiptype = (int) b.get(263, 8); v.A = (int) b.get(271, 9); v.B = (int) b.get(280, 9);
-                v.C = (unsigned char) b.get(289, 6); v.D = (unsigned char) b.get(295, 6); v.draught = 0;
-            } else {
-                v.imo = 0; v.shiptype = (int) b.get(40, 8); v.A = (int) b.get(132, 9); v.B = (int) b.get(141, 9);
-                v.C = (unsigned char) b.get(150, 6); v.D = (unsigned char) b.get(156, 6); v.draught = 0;
-            }
-        }
-        if (todo & VG_PERSONS) {                   // protodec_msg_40 :279-285
-            v.set |= GNUAIS_V_PERSONS;
-            v.persons_on_board = (int) b.get(type == 6 ? 88 : 56, 13);
-        }
+        vessel_write_groups(v, b, type, todo);
     }
     out[slot] = v;
+}
+
+// ---- the position cache CARRIED on the device from batch to batch (cache.c:163-384 across calls) --------
+// An open-addressing table keyed by MMSI (slot key = mmsi + 1, 0 = free; linear probing, nothing is ever
+// removed -- the reference's cache only expires entries by age, from another thread).  A span of frames is
+// folded into it without any sort: what an entry holds afterwards is, per group, what the LAST frame of the
+// span in arrival order wrote, and arrival order inside a span is the print order (channel, then the 37-bit
+// time stamp), which every record carries.  So: pass 1, every frame finds or creates its vessel's slot and
+// raises the slot's stamp of each group it writes to its own (atomicMax); pass 2, the frame whose stamp
+// stands writes the group (distinct groups = distinct fields, one writer each) and clears the stamp.
+constexpr uint32_t VT_NONE = 0xffffffffu;
+
+__device__ __forceinline__ void vessel_fresh(gnuais_vessel &v, int32_t mmsi)      // cache_get's new entry, cache.c:175-196
+{
+    uint32_t *z = reinterpret_cast<uint32_t *>(&v);
+    for (unsigned q = 0; q < sizeof v / 4; ++q) z[q] = 0;
+    v.mmsi = mmsi;
+    v.hdg = -1; v.course = -1; v.sog = -1; v.shiptype = -1; v.imo = -1; v.navstat = -1;
+    v.A = v.B = v.C = v.D = -1;
+    v.persons_on_board = -1;
+}
+
+__device__ __forceinline__ unsigned long long vessel_stamp(const gnuais_frame *f)
+{
+    const uint2 h = *reinterpret_cast<const uint2 *>(f);
+    const uint32_t hi = (reinterpret_cast<const uint32_t *>(f)[15] >> 9) & 31u;
+    return (((unsigned long long) h.x << 37) | ((unsigned long long) hi << 32) | h.y) + 1ull;
+}
+
+// info: [0] slots in use, [1] a frame found no slot (table full), [2] frames seen
+__global__ __launch_bounds__(256) void vtable_stamp_kernel(const gnuais_frame *__restrict__ frames,
+                                                           const uint32_t *__restrict__ count, uint32_t n_max,
+                                                           uint32_t *__restrict__ keys, uint32_t mask,
+                                                           gnuais_vessel *__restrict__ ent,
+                                                           unsigned long long *__restrict__ stamps,
+                                                           uint32_t *__restrict__ fslot, uint32_t *__restrict__ info)
+{
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    const uint32_t n = count[0] < n_max ? count[0] : n_max;
+    if (i >= n) return;
+    if (i == 0) atomicAdd(info + 2, n);
+    const FrameView f = load_frame(frames, i);
+    const BitsView b(f);
+    const unsigned type = (unsigned) b.get(0, 6);
+    const unsigned g = (type >= 1 && type <= MAX_TYPE) ? vessel_groups(b, type) : 0u;
+    uint32_t slot = VT_NONE;
+    if (g) {
+        const uint32_t mmsi = (uint32_t) b.get(8, 30), want = mmsi + 1u;
+        uint32_t h = (mmsi * 2654435761u) >> 7 & mask;
+        for (uint32_t probes = 0; probes <= mask; ++probes, h = (h + 1u) & mask) {
+            uint32_t k = __hip_atomic_load(keys + h, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (k == 0u) {
+                k = atomicCAS(keys + h, 0u, want);
+                if (k == 0u) {                     // this thread made the entry: cache_get's defaults
+                    gnuais_vessel v;
+                    vessel_fresh(v, (int32_t) mmsi);
+                    ent[h] = v;
+                    atomicAdd(info + 0, 1u);
+                    k = want;
+                }
+            }
+            if (k == want) { slot = h; break; }
+        }
+        if (slot == VT_NONE) atomicOr(info + 1, 1u);
+        else {
+            const unsigned long long st = vessel_stamp(frames + i);
+            for (unsigned gi = 0; gi < 5; ++gi)
+                if (g >> gi & 1u) atomicMax(stamps + (size_t) slot * 5 + gi, st);
+        }
+    }
+    fslot[i] = slot;
+}
+
+__global__ __launch_bounds__(256) void vtable_apply_kernel(const gnuais_frame *__restrict__ frames,
+                                                           const uint32_t *__restrict__ count, uint32_t n_max,
+                                                           gnuais_vessel *__restrict__ ent,
+                                                           unsigned long long *__restrict__ stamps,
+                                                           const uint32_t *__restrict__ fslot)
+{
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    const uint32_t n = count[0] < n_max ? count[0] : n_max;
+    if (i >= n) return;
+    const uint32_t slot = fslot[i];
+    if (slot == VT_NONE) return;
+    const unsigned long long st = vessel_stamp(frames + i);
+    unsigned win = 0;
+    for (unsigned gi = 0; gi < 5; ++gi)
+        if (stamps[(size_t) slot * 5 + gi] == st) win |= 1u << gi;
+    if (!win) return;
+    const FrameView f = load_frame(frames, i);
+    const BitsView b(f);
+    const unsigned type = (unsigned) b.get(0, 6);
+    win &= vessel_groups(b, type);                 // (a stamp is the frame's own: this only guards the reads below)
+    gnuais_vessel t;
+    t.set = 0;
+    vessel_write_groups(t, b, type, win);
+    gnuais_vessel *e = ent + slot;
+    if (win & VG_POS) {
+        e->lat = t.lat; e->lon = t.lon; e->hdg = t.hdg; e->course = t.course; e->sog = t.sog; e->navstat = t.navstat;
+    }
+    if (win & VG_CALL)
+        for (unsigned q = 0; q < sizeof t.callsign; ++q) e->callsign[q] = t.callsign[q];
+    if (win & VG_NAME)
+        for (unsigned q = 0; q < sizeof t.name; ++q) { e->name[q] = t.name[q]; e->destination[q] = t.destination[q]; }
+    if (win & VG_STATIC) {
+        e->imo = t.imo; e->shiptype = t.shiptype; e->A = t.A; e->B = t.B; e->C = t.C; e->D = t.D; e->draught = t.draught;
+    }
+    if (win & VG_PERSONS) e->persons_on_board = t.persons_on_board;
+    atomicOr(&e->set, t.set);
+    for (unsigned gi = 0; gi < 5; ++gi)
+        if (win >> gi & 1u) stamps[(size_t) slot * 5 + gi] = 0ull;
 }
 
 // records gathered into sorted order: one thread moves one 16-byte quarter of a record
@@ -973,6 +1091,66 @@ hipError_t vessels_fold_enqueue(const gnuais_frame *frames, int n, void *scratch
     hipLaunchKernelGGL(vessel_fold_kernel, dim3((n + 127) / 128), dim3(128), 0, s, frames, lay.keys2, lay.chan, lay.idx2,
                        lay.idx, n, out, cap, count_dev);
     return hipGetLastError();
+}
+
+static_assert(sizeof(((gnuais_vessel *) 0)->name) == sizeof(((gnuais_vessel *) 0)->destination), "copied together");
+
+size_t vessel_table_bytes(uint32_t slots)
+{
+    return (size_t) slots * (4 + sizeof(gnuais_vessel) + 5 * 8) + 64;
+}
+
+// the table's arrays inside one allocation of vessel_table_bytes(slots): stamps, entries, keys, info
+static void vessel_table_layout(void *mem, uint32_t slots, unsigned long long **stamps, gnuais_vessel **ent,
+                                uint32_t **keys, uint32_t **info)
+{
+    char *p = static_cast<char *>(mem);
+    *stamps = (unsigned long long *) p; p += (size_t) slots * 5 * 8;
+    *ent = (gnuais_vessel *) p; p += (size_t) slots * sizeof(gnuais_vessel);
+    *keys = (uint32_t *) p; p += (size_t) slots * 4;
+    *info = (uint32_t *) p;
+}
+
+// Folds the ring's frames (count[0] of them, at most n_max; the count is read on the device) into the table.
+// fslot: n_max words of scratch.  Queued on `s`; nothing is waited for.
+hipError_t vessel_table_update_enqueue(const gnuais_frame *frames, const uint32_t *count, int n_max, void *table,
+                                       uint32_t slots, uint32_t *fslot, hipStream_t s)
+{
+    if (n_max <= 0 || !slots || (slots & (slots - 1))) return hipErrorInvalidValue;
+    unsigned long long *stamps; gnuais_vessel *ent; uint32_t *keys, *info;
+    vessel_table_layout(table, slots, &stamps, &ent, &keys, &info);
+    const int grid = (n_max + 255) / 256;
+    hipLaunchKernelGGL(vtable_stamp_kernel, dim3(grid), dim3(256), 0, s, frames, count, (uint32_t) n_max, keys, slots - 1u,
+                       ent, stamps, fslot, info);
+    hipLaunchKernelGGL(vtable_apply_kernel, dim3(grid), dim3(256), 0, s, frames, count, (uint32_t) n_max, ent, stamps, fslot);
+    return hipGetLastError();
+}
+
+// The table's entries (unsorted, `max` at most) and its info words to the host; the stream is waited for.
+hipError_t vessel_table_fetch(const void *table, uint32_t slots, gnuais_vessel *h_out, int max, int *n_out,
+                              uint32_t h_info[4], hipStream_t s)
+{
+    unsigned long long *stamps; gnuais_vessel *ent; uint32_t *keys, *info;
+    vessel_table_layout(const_cast<void *>(table), slots, &stamps, &ent, &keys, &info);
+    hipError_t e;
+    if ((e = hipStreamSynchronize(s)) != hipSuccess) return e;
+    if ((e = hipMemcpy(h_info, info, 16, hipMemcpyDeviceToHost)) != hipSuccess) return e;
+    *n_out = (int) h_info[0];
+    if ((int) h_info[0] > max) return hipSuccess;               // the caller reports the size needed
+    std::vector<uint32_t> k(slots);
+    if ((e = hipMemcpy(k.data(), keys, (size_t) slots * 4, hipMemcpyDeviceToHost)) != hipSuccess) return e;
+    int n = 0;
+    for (uint32_t h = 0; h < slots; ) {              // runs of occupied slots, one copy each
+        if (!k[h]) { ++h; continue; }
+        uint32_t h1 = h;
+        while (h1 < slots && k[h1]) ++h1;
+        if ((e = hipMemcpy(h_out + n, ent + h, (size_t) (h1 - h) * sizeof(gnuais_vessel), hipMemcpyDeviceToHost)) != hipSuccess)
+            return e;
+        n += (int) (h1 - h);
+        h = h1;
+    }
+    *n_out = n;
+    return hipSuccess;
 }
 
 // everything of nmea_format() that runs on the device, queued on `s` without waiting for it.

@@ -87,6 +87,9 @@ constexpr int PLL_SLOTS = PLL_SLOTS_N;   // block slots between scanner, recurre
 #ifndef SCAN_EXP
 #define SCAN_EXP 0
 #endif
+#ifndef PLL_SCAN_PRIO
+#define PLL_SCAN_PRIO 0
+#endif
 #ifndef PLL_AHEAD_N
 #define PLL_AHEAD_N 2
 #endif
@@ -265,6 +268,9 @@ __global__ __launch_bounds__(64 * (2 + NSC + NTG)) __attribute__((amdgpu_waves_p
     };
 
     if (role == 1 || role == 5) {                 // ---- the scanners: even / odd blocks ----
+#if PLL_SCAN_PRIO
+        __builtin_amdgcn_s_setprio(PLL_SCAN_PRIO);
+#endif
         const int w = role == 1 ? 0 : 1;                           // (role 5 exists with NSC == 2 only)
         const uint4 *__restrict__ src = sgn4 + c;                  // piece i of this lane: src[i * N]
         // a block's lists depend on the sign before its first sample only: the newest bit of the block before

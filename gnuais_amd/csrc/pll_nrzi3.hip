@@ -78,6 +78,9 @@ constexpr int SEG_BLKS = SEG_LEN / BLK_LEN;
 constexpr int PLL_STRIP = BLK_LEN + 12;    // bytes per lane and slot: the positions + an 8-byte store's overhang +
                                      // the recurrence's read-ahead; 67 dwords (odd): lanes hit different banks
 constexpr int PLL_SLOTS = 4;         // block slots between scanner and recurrence
+#ifndef PLL_SCAN_PRIO
+#define PLL_SCAN_PRIO 0
+#endif
 #ifndef PLL_AHEAD_N
 #define PLL_AHEAD_N 2
 #endif
@@ -215,6 +218,9 @@ __global__ __launch_bounds__(64 * (2 + NSC)) __attribute__((amdgpu_waves_per_eu(
     };
 
     if (role == 1 || role == 3) {                 // ---- the scanner(s): every block, or even / odd blocks ----
+#if PLL_SCAN_PRIO
+        __builtin_amdgcn_s_setprio(PLL_SCAN_PRIO);
+#endif
         const int w = role == 1 ? 0 : 1;                           // (role 3 exists with NSC == 2 only)
         const uint4 *__restrict__ src = sgn4 + c;                  // piece i of this lane: src[i * N]
         // a block's lists depend on the sign before its first sample only: the newest bit of the block before

@@ -65,6 +65,10 @@ SYMBOLS = {
     "gnuais_batch_drain_messages": (_I, [_P, _P, _P, _P, C.c_size_t, C.POINTER(C.c_size_t), C.POINTER(_I), _P, C.c_size_t,
                                          C.POINTER(C.c_size_t), C.POINTER(_I), C.POINTER(_I)]),
     "gnuais_batch_fold_vessels": (_I, [_P, _P, _I, C.POINTER(_I)]),
+    "gnuais_batch_vessel_table_enable": (_I, [_P, _I]),
+    "gnuais_batch_vessel_table_update": (_I, [_P]),
+    "gnuais_batch_vessel_table": (_I, [_P, _P, _I, C.POINTER(_I)]),
+    "gnuais_batch_vessel_table_clear": (_I, [_P]),
     "gnuais_batch_stream_nmea": (_I, [_P, C.POINTER(C.c_char_p), C.POINTER(C.c_size_t), C.POINTER(_I), C.POINTER(_I)]),
     "gnuais_batch_drain_frames_nmea": (_I, [_P, _P, _I, C.POINTER(_I), _P, _P, C.c_size_t, C.POINTER(C.c_size_t),
                                             C.POINTER(_I)]),

@@ -223,6 +223,27 @@ class ReceiverBatch:
         check(self._lib.gnuais_batch_fold_vessels(self._h, out.ctypes.data, len(out), C.byref(n)))
         return out[: n.value].copy()
 
+    def vessel_table_enable(self, capacity: int) -> None:
+        """gnuais_batch_vessel_table_enable(): an empty position cache for `capacity` vessels, carried on the device
+        from batch to batch; stream_nmea() folds every span it takes off into it from now on."""
+        check(self._lib.gnuais_batch_vessel_table_enable(self._h, capacity))
+        self._vt_capacity = capacity
+
+    def vessel_table_update(self) -> None:
+        """gnuais_batch_vessel_table_update(): the queued frames into the carried table (drain-type use: call it
+        before the drain that consumes them)."""
+        check(self._lib.gnuais_batch_vessel_table_update(self._h))
+
+    def vessel_table(self) -> np.ndarray:
+        """gnuais_batch_vessel_table(): the carried table, sorted by MMSI."""
+        out = np.zeros(max(getattr(self, "_vt_capacity", 1), 1), dtype=VESSEL_DTYPE)
+        n = C.c_int(0)
+        check(self._lib.gnuais_batch_vessel_table(self._h, out.ctypes.data, len(out), C.byref(n)))
+        return out[: n.value].copy()
+
+    def vessel_table_clear(self) -> None:
+        check(self._lib.gnuais_batch_vessel_table_clear(self._h))
+
     def drain_messages(self, seqnr: np.ndarray, chanid: Optional[bytes] = None):
         """gnuais_batch_drain_messages(): sentences and stdout lines of everything queued, both formatted
         on the device -> (nmea bytes, text bytes, sentences, lines, frames)."""

@@ -236,6 +236,21 @@ int  gnuais_batch_drain_messages(gnuais_batch *b, uint8_t *seqnr, const char *ch
  * and one thread per vessel.  Call it before the drain that consumes the frames.  *n_vessels = entries;
  * GNUAIS_E_OVERFLOW (with *n_vessels set) if cap is too small. */
 int  gnuais_batch_fold_vessels(gnuais_batch *b, gnuais_vessel *vessels, int cap, int *n_vessels);
+/* Row f3, CARRIED: the reference keeps one position cache for the whole run (src/cache.c:163-384) and every
+ * decoder call updates it; this is that cache kept in device memory from batch to batch.
+ * gnuais_batch_vessel_table_enable(capacity) makes an empty table for `capacity` vessels (a hash table keyed by MMSI,
+ * twice as many slots).  From then on every gnuais_batch_stream_nmea() call also folds the frames it takes off
+ * into the table, queued behind their formatter (two small kernels, no sort, nothing waited for).  A drain-type
+ * caller calls gnuais_batch_vessel_table_update() before the drain that consumes the frames: the queued
+ * frames are folded (and stay queued); once per span of frames, or a frame is applied twice (harmless for the
+ * result: the fold is idempotent per span).  gnuais_batch_vessel_table() waits for what has been queued and
+ * returns the entries sorted by MMSI: byte for byte what gnuais_vessels_from_frames() leaves when it is fed the
+ * same spans one after another.  GNUAIS_E_OVERFLOW (with *n_vessels set) when `cap` is too small or more vessels
+ * were seen than the table was enabled for.  _clear() empties the table. */
+int  gnuais_batch_vessel_table_enable(gnuais_batch *b, int capacity);
+int  gnuais_batch_vessel_table_update(gnuais_batch *b);
+int  gnuais_batch_vessel_table(gnuais_batch *b, gnuais_vessel *vessels, int cap, int *n_vessels);
+int  gnuais_batch_vessel_table_clear(gnuais_batch *b);
 /* Streaming delivery of the same sentences.  Call once after every gnuais_batch_run(): the frames of
  * the runs since the previous call are taken off at once (the chain moves on to another frame ring);
  * their formatter and the copy of the text into pinned host memory are queued behind the chain with every

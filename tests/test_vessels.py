@@ -107,3 +107,97 @@ def test_device_fold_equals_host_fold():
             assert np.array_equal(got[name], want[name]), (span, name)
         assert got.tobytes() == want.tobytes()
         assert len(np.unique(want["set"])) >= 6
+
+
+def _vessel_traffic(seed, n_ch, n, n_mmsi):
+    """bit streams per channel carrying `n` random cache-touching frames over a small MMSI pool"""
+    from gnuais_amd import synth
+    rnd, _ = cases.vessel_frames(seed=seed, n_channels=n_ch, n=n, n_mmsi=n_mmsi)
+    streams = [[np.zeros(8, dtype=np.uint8)] for _ in range(n_ch)]
+    for f in rnd:
+        body = bytes(f["payload"][: int(f["nbits"]) // 8])
+        if len(body) < 1:
+            continue
+        c = int(f["channel"]) % n_ch
+        streams[c].append(synth.hdlc_frame_bits(body, training_bits=24))
+        streams[c].append(np.zeros(5, dtype=np.uint8))
+    return [np.concatenate(s).astype(np.uint8) for s in streams]
+
+
+@pytest.mark.gpu
+def test_carried_table_equals_the_host_fold_span_by_span():
+    """gnuais_batch_vessel_table_*(): the position cache kept on the device across batches (hash table by MMSI, two
+    passes per span: stamps by atomicMax, the standing stamp writes its group) == gnuais_vessels_from_frames() fed
+    the same spans one after another -- which the CPU tests above pin to the reference's cache.  Drain-type use:
+    update() before every drain; the table is read after every span, cleared, and filled again."""
+    from gnuais_amd import ReceiverBatch, VESSEL_DTYPE, vessels_from_frames
+    n_ch = 7
+    b = ReceiverBatch(n_ch, max_len=48000)
+    b.vessel_table_enable(2000)
+    want = np.zeros(0, dtype=VESSEL_DTYPE)
+    for span, (seed, n_mmsi) in enumerate(((5, 40), (6, 300), (7, 300), (8, 700))):
+        b.decode_bits(_vessel_traffic(seed, n_ch, 1800, n_mmsi))
+        b.vessel_table_update()
+        frames = b.drain_frames()
+        assert len(frames) > 1000
+        want = vessels_from_frames(frames, want)
+        got = b.vessel_table()
+        assert len(got) == len(want)
+        for name in VESSEL_DTYPE.names:
+            assert np.array_equal(got[name], want[name]), (span, name)
+        assert got.tobytes() == want.tobytes()
+    assert len(want) > 600 and len(np.unique(want["set"])) >= 6
+    b.vessel_table_clear()
+    assert len(b.vessel_table()) == 0
+    b.decode_bits(_vessel_traffic(9, n_ch, 500, 50))
+    b.vessel_table_update()
+    assert b.vessel_table().tobytes() == vessels_from_frames(b.drain_frames()).tobytes()
+
+
+@pytest.mark.gpu
+def test_carried_table_overflow_is_reported():
+    from gnuais_amd import ReceiverBatch
+    from gnuais_amd.lib import GnuaisError
+    b = ReceiverBatch(4, max_len=48000)
+    b.vessel_table_enable(100)
+    b.decode_bits(_vessel_traffic(11, 4, 3000, 2500))
+    b.vessel_table_update()
+    with pytest.raises(GnuaisError) as e:
+        b.vessel_table()
+    assert e.value.code == -3 and "more vessels" in str(e.value)
+
+
+@pytest.mark.gpu
+def test_streamed_delivery_carries_the_table_on_the_device():
+    """A streaming batch (run + gnuais_batch_stream_nmea per call) with the table enabled folds every span into it
+    behind the span's formatter, no host round trip: after call i the table == the host fold over the frames a
+    second, drain-type batch drained for calls 0..i.  Sample-domain input, mixed message types over 200 MMSIs."""
+    import torch
+    from gnuais_amd import ReceiverBatch, VESSEL_DTYPE, synth, vessels_from_frames
+    n_ch, call, n_calls = 96, 2 * 1280, 8
+    pool, _ = cases.vessel_frames(seed=31, n_channels=1, n=4000, n_mmsi=200)
+    bodies = [bytes(f["payload"][: int(f["nbits"]) // 8]) for f in pool if int(f["nbits"]) >= 8]
+
+    def payloads(rng, slot):
+        return bodies[int(rng.integers(0, len(bodies)))] if rng.random() < 0.8 else None
+
+    x = np.stack([synth.make_stream(call * n_calls, seed=33, channel=c, payloads=payloads)[0] for c in range(n_ch)], axis=1)
+    xd = torch.from_numpy(x).cuda()
+    a, b = ReceiverBatch(n_ch, max_len=call), ReceiverBatch(n_ch, max_len=call)
+    b.vessel_table_enable(500)
+    want = np.zeros(0, dtype=VESSEL_DTYPE)
+    total = 0
+    for i in range(n_calls):
+        a.run(xd[i * call:(i + 1) * call])
+        fr = a.drain_frames()
+        total += len(fr)
+        want = vessels_from_frames(fr, want)
+        b.run(xd[i * call:(i + 1) * call], sync=False)
+        b.stream_nmea()
+        if i in (0, 3, n_calls - 1):
+            got = b.vessel_table()
+            assert got.tobytes() == want.tobytes(), i
+    for _ in range(b.stream_depth):
+        b.stream_nmea()
+    assert b.vessel_table().tobytes() == want.tobytes()
+    assert total > 300 and len(want) > 100 and len(np.unique(want["set"])) >= 5
