@@ -78,6 +78,9 @@ constexpr int SEG_BLKS = SEG_LEN / BLK_LEN;
 constexpr int PLL_STRIP = BLK_LEN + 12;    // bytes per lane and slot: the positions + an 8-byte store's overhang +
                                      // the recurrence's read-ahead; 67 dwords (odd): lanes hit different banks
 constexpr int PLL_SLOTS = 4;         // block slots between scanner and recurrence
+#ifndef PLL3_LONE_SCANNER
+#define PLL3_LONE_SCANNER 1
+#endif
 #ifndef PLL_SCAN_PRIO
 #define PLL_SCAN_PRIO 3     // the scanner beside five FIR waves on its SIMD: in-pipeline PLL 0.52 -> 0.50 ms (C3), period -1 %
 #endif
@@ -217,7 +220,88 @@ __global__ __launch_bounds__(64 * (2 + NSC)) __attribute__((amdgpu_waves_per_eu(
         return true;
     };
 
-    if (role == 1 || role == 3) {                 // ---- the scanner(s): every block, or even / odd blocks ----
+    if (NSC == 1 && PLL3_LONE_SCANNER && role == 1) {   // ---- the lone scanner: every block, the sign carried in a register ----
+#if PLL_SCAN_PRIO
+        __builtin_amdgcn_s_setprio(PLL_SCAN_PRIO);
+#endif
+        const uint4 *__restrict__ src = sgn4 + c;                  // piece i of this lane: src[i * N]
+        uint32_t prev = sign0[lane];
+        uint4 q[PLL_AHEAD][BLK_QUADS];
+#pragma unroll
+        for (int j = 0; j < PLL_AHEAD; ++j)
+#pragma unroll
+            for (int h = 0; h < BLK_QUADS; ++h)
+                q[j][h] = src[(size_t) ((j < n_blk ? j : 0) * BLK_QUADS + h) * (size_t) N];
+        int seen = 0;
+        bool dead = false;
+        for (int b0 = 0; b0 < n_blk && !dead; b0 += PLL_AHEAD) {
+#pragma unroll
+            for (int j = 0; j < PLL_AHEAD; ++j) {
+                const int b = b0 + j;
+                uint32_t S[4 * BLK_QUADS];
+#pragma unroll
+                for (int h = 0; h < BLK_QUADS; ++h) {
+                    S[4 * h] = q[j][h].x; S[4 * h + 1] = q[j][h].y; S[4 * h + 2] = q[j][h].z; S[4 * h + 3] = q[j][h].w;
+                }
+                {   // loads are unconditional (past the end: block 0 again), so that the compiler
+                    // counts them and waits for exactly the oldest
+                    const int nb = b + PLL_AHEAD;
+#pragma unroll
+                    for (int h = 0; h < BLK_QUADS; ++h)
+                        q[j][h] = src[(size_t) ((nb < n_blk ? nb : 0) * BLK_QUADS + h) * (size_t) N];
+                }
+                if (b < n_blk && !dead) {
+                    while (b - seen >= SLOTS && !dead) {       // slot b % SLOTS still in use?
+                        seen = __builtin_amdgcn_readfirstlane((int) lds_flag_load(flag + 1));
+                        if (b - seen >= SLOTS) {
+                            if (expired()) dead = true;
+                            __builtin_amdgcn_s_sleep(2);
+                        }
+                    }
+                    if (!dead) {
+                        uint8_t *slot = slots + (b % SLOTS) * PLL_SLOT_BYTES;
+                        uint32_t cur = (uint32_t) (slot - lds) + (uint32_t) (lane * PLL_STRIP);   // LDS address
+                        const uint32_t cur0 = cur;
+                        const int nv = L - b * BLK_LEN;            // valid samples of this block (>= 1)
+#pragma unroll
+                        for (int w = 0; w < 4 * BLK_QUADS; ++w) {
+                            const int k = nv - 32 * w;             // valid samples of this word
+                            uint32_t d = S[w] ^ ((S[w] >> 1) | (prev << 31));      // receiver.c:113
+                            if (k <= 0) {
+                                d = 0;
+                            } else if (k < 32) {
+                                d &= ~0u << (32 - k);
+                                prev = (S[w] >> (32 - k)) & 1u;
+                            } else {
+                                prev = S[w] & 1u;
+                            }
+                            uint64_t ent[4];
+#pragma unroll
+                            for (int y = 0; y < 4; ++y) ent[y] = lut[(d >> (24 - 8 * y)) & 0xffu];
+#pragma unroll
+                            for (int y = 0; y < 4; ++y) {
+                                const uint32_t base = 0x01010101u * (uint32_t) (32 * w + 8 * y);
+                                const uint64_t e = ent[y] + (((uint64_t) base << 32) | base);
+                                asm volatile("ds_write_b64 %0, %1" :: "v"(cur), "v"(e) : "memory");   // any byte address
+                                cur += (uint32_t) __popc((d >> (24 - 8 * y)) & 0xffu);
+                            }
+                        }
+                        const uint32_t cnt = cur - cur0;
+                        reinterpret_cast<uint32_t *>(slot + 64 * PLL_STRIP)[lane] = cnt;
+                        const uint32_t ng = wave_max((cnt + 3u) >> 2);
+                        if (lane == 0) reinterpret_cast<uint32_t *>(slot + 64 * PLL_STRIP + 256)[0] = ng;
+                        lds_flag_store(flag + 5, (uint32_t) (b + 1));
+                    }
+                }
+            }
+        }
+        sign1[lane] = prev;
+        lds_flag_store(flag + 4, 1u);
+        if (live && !dead) prevst[cg] = prev;
+        return;
+    }
+
+    if ((NSC == 2 || !PLL3_LONE_SCANNER) && (role == 1 || role == 3)) {   // ---- two scanners: even / odd blocks (or the same code for one) ----
 #if PLL_SCAN_PRIO
         __builtin_amdgcn_s_setprio(PLL_SCAN_PRIO);
 #endif
@@ -386,7 +470,7 @@ __global__ __launch_bounds__(64 * (2 + NSC)) __attribute__((amdgpu_waves_per_eu(
                             (uint32_t) (((s & 1) * PLL_PACKW * 64 + lane) * 4);   // LDS address of this lane's pack word 0
         const int b1 = (s + 1) * SEG_BLKS < n_blk ? (s + 1) * SEG_BLKS : n_blk;
         for (int b = s * SEG_BLKS; b < b1 && !dead; ++b) {
-            seen = 0;
+            if (NSC == 2) seen = 0;                            // (the other scanner's counter: nothing known yet)
             while (seen < b + 1 && !dead) {
                 seen = __builtin_amdgcn_readfirstlane((int) lds_flag_load(flag + 5 + (b % NSC)));
                 if (seen < b + 1) {
