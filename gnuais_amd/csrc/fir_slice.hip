@@ -393,11 +393,20 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NC == 48 ? 4
     uint32_t *__restrict__ sgn, int *__restrict__ maxval,
     int16_t *__restrict__ hist_out, int *__restrict__ maxval_next,
     const float *__restrict__ te_mem, int N, int L, int T, int d, int NTaps, int NE_rt, float eps_up,
-    int map, FirTaps<NT> taps, unsigned long long *stamps, int n_big, int T2, float eps_seen, float eps_ahead)
+    int map, FirTaps<NT> taps, unsigned long long *stamps, int n_big, int T2, float eps_seen, float eps_ahead,
+    int gx, int gy)
 {
     const int NE = NES > 0 ? NES : NE_rt;
     const int wave_id = (int) (blockIdx.y * gridDim.x + blockIdx.x);
     if (stamps && threadIdx.x == 0) stamps[2 * wave_id] = wall_clock64();
+    // (gx, gy) = the logical grid: channel groups x segments.  Launched with exactly that grid a workgroup does one
+    // item.  Launched with FEWER workgroups (a one-dimensional grid, option fir_persist = workgroups per SIMD) each
+    // takes the items id, id + gridDim.x, ...: measured, bit-exact, slower (C3: FIR 0.53 instead of 0.46 ms inside the
+    // pipeline, period 0.53 instead of 0.51 with five per SIMD; four: 0.56) -- the hardware's own placement of 24 000
+    // short-lived workgroups balances the launch better than a static split, and resident waves that never leave give
+    // the other stages' workgroups no turn.  Kept as an option for that measurement.
+    const int items = gx * gy, stride = (int) (gridDim.x * gridDim.y);
+    auto work = [&](const int item) {
     const int J0 = (NE - NC) / 2;               // first central tap (10 of 32 for the reference table)
     auto ctap = [&](int q) -> float { return NES > 0 ? taps.te[(NES - NC) / 2 + q] : taps.te[q]; };
 #if FIR_SIGN_FENCE > 0
@@ -414,9 +423,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NC == 48 ? 4
     // round-robin over the 8 XCDs.  map 0: id = segment * groups + group, so an XCD works on every
     // 8th channel group (its 128-byte pieces of a sample row are 1 KB apart); map 1: every XCD takes
     // a contiguous eighth of the channel groups (4 KB of each row for 16384 channels).
-    int bx = (int) blockIdx.x, by = (int) blockIdx.y;
+    int bx = item % gx, by = item / gx;
     if (map == 1) {
-        const int G = (int) gridDim.x, id = by * G + bx, per = G >> 3;
+        const int G = gx, id = item, per = G >> 3;
         bx = (id & 7) * per + (id >> 3) % per;
         by = (id >> 3) / per;
     }
@@ -966,6 +975,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NC == 48 ? 4
         }
         maxval_next[cg] = 0;
     }
+    };
+    for (int item = wave_id; item < items; item += stride) work(item);
     if (stamps && threadIdx.x == 0) stamps[2 * wave_id + 1] = wall_clock64();
 }
 
@@ -989,25 +1000,27 @@ hipError_t launch_fir_sign(const FirLaunch &a, hipStream_t stream)
     }
     const float eps_up = __builtin_nextafterf(a.eps, INFINITY);
     const int map = (a.map == 1 && grid.x % 8 == 0) ? 1 : 0;
+    const int gx = (int) grid.x, gy = (int) grid.y;
+    if (a.persist > 0 && (long) gx * gy > a.persist) grid = dim3((a.persist + 7) & ~7);   // a multiple of 8: a workgroup's items stay on its XCD
     if (a.NC == 12 && a.NE == 32) {
         FirTaps<32> t;
         for (int j = 0; j < 32; ++j) t.te[j] = a.te[j];
         hipLaunchKernelGGL((fir_sign_kernel<32, 12, 32>), grid, block, a.lds_pad, stream, a.x, a.hist, a.sgn, a.maxval,
-                           a.hist_out, a.maxval_next, a.te_mem, a.N, a.L, a.T, a.d, a.NT, a.NE, eps_up, map, t, a.stamps, n_big, T2, a.eps_seen, a.eps_ahead);
+                           a.hist_out, a.maxval_next, a.te_mem, a.N, a.L, a.T, a.d, a.NT, a.NE, eps_up, map, t, a.stamps, n_big, T2, a.eps_seen, a.eps_ahead, gx, gy);
     } else if (a.NC == 12) {
         FirTaps<12> t;
         for (int j = 0; j < 12; ++j) t.te[j] = a.ctaps[j];
         hipLaunchKernelGGL((fir_sign_kernel<0, 12, 12>), grid, block, 0, stream, a.x, a.hist, a.sgn, a.maxval,
-                           a.hist_out, a.maxval_next, a.te_mem, a.N, a.L, a.T, a.d, a.NT, a.NE, eps_up, map, t, a.stamps, n_big, T2, a.eps_seen, a.eps_ahead);
+                           a.hist_out, a.maxval_next, a.te_mem, a.N, a.L, a.T, a.d, a.NT, a.NE, eps_up, map, t, a.stamps, n_big, T2, a.eps_seen, a.eps_ahead, gx, gy);
     } else {
         FirTaps<48> t;
         for (int j = 0; j < 48; ++j) t.te[j] = a.ctaps[j];
         if (a.eps_seen > 0.0f && a.NE - a.NC <= 98)
             hipLaunchKernelGGL((fir_sign_kernel<0, 48, 48, true>), grid, block, 0, stream, a.x, a.hist, a.sgn, a.maxval,
-                               a.hist_out, a.maxval_next, a.te_mem, a.N, a.L, a.T, a.d, a.NT, a.NE, eps_up, map, t, a.stamps, n_big, T2, a.eps_seen, a.eps_ahead);
+                               a.hist_out, a.maxval_next, a.te_mem, a.N, a.L, a.T, a.d, a.NT, a.NE, eps_up, map, t, a.stamps, n_big, T2, a.eps_seen, a.eps_ahead, gx, gy);
         else
         hipLaunchKernelGGL((fir_sign_kernel<0, 48, 48>), grid, block, 0, stream, a.x, a.hist, a.sgn, a.maxval,
-                           a.hist_out, a.maxval_next, a.te_mem, a.N, a.L, a.T, a.d, a.NT, a.NE, eps_up, map, t, a.stamps, n_big, T2, a.eps_seen, a.eps_ahead);
+                           a.hist_out, a.maxval_next, a.te_mem, a.N, a.L, a.T, a.d, a.NT, a.NE, eps_up, map, t, a.stamps, n_big, T2, a.eps_seen, a.eps_ahead, gx, gy);
     }
     return hipGetLastError();
 }

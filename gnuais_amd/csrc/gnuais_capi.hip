@@ -156,6 +156,7 @@ struct gnuais_batch {
     int fir_T = 512;
     int fir_map = 1;                            // K1s workgroup mapping (fir_slice.hip): XCD-contiguous channel groups
     int fir_T2 = 128;                           // K1s: segment length of the launch's tail (0: all segments alike)
+    int fir_persist = 0;                        // K1s (scalar forms): > 0 = that many workgroups per SIMD, each looping over the launch's items
     int fir_tail = 0;                           //   how much of the launch, in tenths of a full round of resident waves, takes the short segments
     int fir_cpl = 1;                            // K1s channels per lane: 1 (fir_slice.hip), 2 or 4 (fir_sign_wide.hip; even / 4-divisible N)
     unsigned long long *d_stamps = nullptr;     // experiment (fir_stamps): start / end clock of every K1s wave of the last call
@@ -476,6 +477,7 @@ int gnuais_batch_create(gnuais_batch **out, int device, int n_channels, const fl
     if (const char *v = getenv("GNUAIS_FIR_PK")) b->fir_pk = atoi(v) < 0 ? -1 : (atoi(v) != 0);
     if (const char *v = getenv("GNUAIS_FIR_CPL")) { const int c = atoi(v); if (c == 1 || c == 2 || c == 4) b->fir_cpl = c; }
     if (const char *v = getenv("GNUAIS_FIR_FORM")) b->fir_form = atoi(v);
+    if (const char *v = getenv("GNUAIS_FIR_PERSIST")) b->fir_persist = std::min(16, std::max(0, atoi(v)));
     if (const char *v = getenv("GNUAIS_FIR_T")) b->fir_T = std::max(64, atoi(v) / 32 * 32);
     *out = b;
     int rc = gnuais_batch_reset(b);
@@ -553,6 +555,9 @@ int gnuais_batch_set_option(gnuais_batch *b, const char *name, int value)
     } else if (!strcmp(name, "fir_T2")) {
         if (value < 0 || value % 32) return fail(GNUAIS_E_ARG, "fir_T2 must be a multiple of 32 (0: off)");
         b->fir_T2 = value;
+    } else if (!strcmp(name, "fir_persist")) {
+        if (value < 0 || value > 16) return fail(GNUAIS_E_ARG, "fir_persist: workgroups per SIMD, 0 (off) .. 16");
+        b->fir_persist = value;
     } else if (!strcmp(name, "fir_tail")) {
         b->fir_tail = value < 0 ? 0 : value;
     } else if (!strcmp(name, "fir_cpl")) {
@@ -679,6 +684,7 @@ static int run_fir(gnuais_batch *b, const int16_t *x, int len, float *dump, hipS
             f.n_big = std::max(0, nseg - tail_segs);
             if (f.T2 >= f.T) f.T2 = 0;
         }
+        f.persist = b->fir_persist * 4 * b->n_cu;
         if (cpl > 1) HIP_TRY(launch_fir_sign_wide(f, cpl, b->fir_form, s));
         else HIP_TRY(launch_fir_sign(f, s));
     } else if (b->NE != 32) {

@@ -29,6 +29,7 @@ struct FirLaunch {
     unsigned long long *stamps = nullptr;   // experiments: [waves][2] wall-clock start / end of every K1s wave
     int dbg = 0, lds_pad = 0;   // experiments (fir_sign_wide.hip): elimination switches, LDS claimed per wave to cap the occupancy
     int map;               // K1s workgroup -> (channel group, segment) mapping, see fir_sign_kernel
+    int persist = 0;       // K1s: > 0 = launch this many workgroups, each looping over the (group, segment) items
 };
 int launch_fir_sign_quantum(int NC);           // T must be a multiple of this
 hipError_t launch_fir_sign(const FirLaunch &a, hipStream_t stream);
