@@ -366,6 +366,45 @@ def test_node_example_program(tmp_path):
     assert p.stderr.decode().splitlines()[-1] == f"{len(lines)} frames drained, {len(lines)} received in all"
 
 
+def test_stream_example_program(tmp_path):
+    """examples/stream_vessels.c -- run_host_async + stream_nmea + the carried vessel table from plain C: its stdout is
+    the sentences a drain-type batch returns for the same chunks, its table the host fold over that batch's frames."""
+    import cases
+    from gnuais_amd import ReceiverBatch, vessels_from_frames
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = tmp_path / "stream_vessels"
+    subprocess.check_call(["gcc", "-O2", "-I" + os.path.join(root, "include"), os.path.join(root, "examples", "stream_vessels.c"),
+                           "-L" + os.path.join(root, "gnuais_amd"), "-lgnuais_hip",
+                           "-Wl,-rpath," + os.path.join(root, "gnuais_amd"), "-o", str(exe)])
+    n_ch, chunk, n_chunks = 64, 2560, 6
+    pool, _ = cases.vessel_frames(seed=41, n_channels=1, n=2000, n_mmsi=120)
+    bodies = [bytes(f["payload"][: int(f["nbits"]) // 8]) for f in pool if int(f["nbits"]) >= 8]
+
+    def payloads(rng, slot):
+        return bodies[int(rng.integers(0, len(bodies)))] if rng.random() < 0.8 else None
+
+    x = np.stack([synth.make_stream(chunk * n_chunks - 700, seed=43, channel=c, payloads=payloads)[0] for c in range(n_ch)], axis=1)
+    raw = tmp_path / "in.raw"
+    x.astype("<i2").tofile(raw)
+    p = subprocess.run([str(exe), str(n_ch), str(chunk), str(raw)], capture_output=True, timeout=300)
+    assert p.returncode == 0, p.stderr.decode()
+    b = ReceiverBatch(n_ch, max_len=chunk)
+    seq = np.zeros(n_ch, dtype=np.uint8)
+    want, table = b"", None
+    for i in range(0, len(x), chunk):
+        b.run(x[i:i + chunk])
+        want += b.drain_nmea(seq)[0]
+    assert p.stdout == want and want.count(b"\n") > 200
+    # the table: a second drain-type batch, frames folded on the host
+    b2 = ReceiverBatch(n_ch, max_len=chunk)
+    for i in range(0, len(x), chunk):
+        b2.run(x[i:i + chunk])
+        table = vessels_from_frames(b2.drain_frames(), table)
+    err = p.stderr.decode().splitlines()
+    assert err[-1].endswith(f"{len(table)} vessels") and len(table) > 50
+    assert [int(l.split()[1].rstrip(":")) for l in err[:-1]] == [int(m) for m in table["mmsi"]]
+
+
 def test_bench_two_workers_prints_n_gpus_2():
     """`bench.py --gpus 2` without torch.distributed.run: one worker process per device (both on
     device 0 when only one is visible), n_gpus 2 and a whole-job value in the line."""
