@@ -67,9 +67,23 @@ static struct rx_group *groups;
 static int n_groups, cap_groups;
 static pthread_mutex_t big_lock = PTHREAD_MUTEX_INITIALIZER;
 
+/* A fatal device error ends the program, as the reference's own fatal errors do (there is no CPU path to fall
+ * back to).  A host that wants to close its sinks first installs a handler: it is called with the message and,
+ * if it returns, abort() follows. */
+static void (*fatal_handler)(const char *message);
+
+void gnuais_receiver_on_fatal(void (*handler)(const char *message))
+{
+	fatal_handler = handler;
+}
+
 static void die(const char *what)
 {
-	fprintf(stderr, "gnuais-hip: %s: %s\n", what, gnuais_last_error());
+	char msg[600];
+	snprintf(msg, sizeof msg, "gnuais-hip: %s: %s", what, gnuais_last_error());
+	fprintf(stderr, "%s\n", msg);
+	if (fatal_handler)
+		fatal_handler(msg);
 	abort();
 }
 

@@ -65,6 +65,11 @@ extern struct receiver *init_receiver(char name, int num_ch, int ch_ofs,
 extern void free_receiver(struct receiver *rx);
 extern void receiver_run(struct receiver *rx, short *buf, int len);
 
+/* not in the reference: receiver_hip.c ends the program on a device error (no CPU path exists to fall back to, and
+ * receiver_run() returns nothing); a host may install a handler that is called with the message first, e.g. to close
+ * its sinks.  abort() follows if the handler returns. */
+extern void gnuais_receiver_on_fatal(void (*handler)(const char *message));
+
 /* src/protodec.h:73-76: stay in the reference's protodec.c (message layer) */
 void protodec_initialize(struct demod_state_t *d, struct serial_state_t *serial,
 			 struct ipc_state_t *ipc, char chanid);

@@ -116,3 +116,30 @@ def test_packed_fir_keeps_its_ring_out_of_the_compilers_registers():
         pytest.skip("no hipcc")
     r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "check_pk_registers.py")], capture_output=True, timeout=600)
     assert r.returncode == 0, r.stdout.decode() + r.stderr.decode()
+
+
+def test_dropin_fatal_handler_runs_before_abort(tmp_path):
+    """receiver_hip.c has no CPU path to fall back to: without a usable device init_receiver() ends the program
+    (receiver.c:104-105 does the same on its own fatal errors).  A host's handler (gnuais_receiver_on_fatal) is
+    called with the message first.  Runs with every device hidden, so it needs no GPU."""
+    import signal
+    code = r'''
+#include <stdio.h>
+#include "gnuais_receiver_abi.h"
+void protodec_initialize(struct demod_state_t *d, struct serial_state_t *s, struct ipc_state_t *i, char c) { (void) d; (void) s; (void) i; (void) c; }
+void protodec_getdata(int n, struct demod_state_t *d) { (void) n; (void) d; }
+static void handler(const char *m) { printf("handler: %s\n", m); fflush(stdout); }
+int main(void) { gnuais_receiver_on_fatal(handler); init_receiver('A', 2, 0, NULL, NULL); printf("not reached\n"); return 0; }
+'''
+    src = tmp_path / "f.c"
+    src.write_text(code)
+    exe = tmp_path / "f"
+    subprocess.check_call(["gcc", "-std=gnu11", "-I", os.path.join(ROOT, "include"), str(src),
+                           os.path.join(ROOT, "gnuais_amd", "csrc", "receiver_hip.c"),
+                           "-L" + os.path.join(ROOT, "gnuais_amd"), "-lgnuais_hip", "-lpthread",
+                           "-Wl,-rpath," + os.path.join(ROOT, "gnuais_amd"), "-o", str(exe)])
+    env = dict(os.environ, HIP_VISIBLE_DEVICES="-1", ROCR_VISIBLE_DEVICES="-1")
+    p = subprocess.run([str(exe)], capture_output=True, env=env, timeout=120)
+    assert p.returncode == -signal.SIGABRT, (p.returncode, p.stderr.decode())
+    out = p.stdout.decode()
+    assert out.startswith("handler: gnuais-hip: ") and "not reached" not in out
