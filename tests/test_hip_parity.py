@@ -447,7 +447,7 @@ def test_autotune_keeps_results_and_resets_state():
     big = np.ascontiguousarray(np.tile(x, (1, 64))[:, :128])      # enough channels to launch every stage
     b = batch(128, max_len=x.shape[0])
     ms = b.autotune(dev(big))
-    assert ms > 0
+    assert ms > 0 or os.environ.get("GNUAIS_PIPELINE") == "0"     # (one stream: nothing to assign, 0 is returned)
     assert int(b.counters()["receivedframes"].sum()) == 0          # reset
     b.run(dev(big))
     fr = b.drain_frames()
