@@ -201,3 +201,32 @@ def test_streamed_delivery_carries_the_table_on_the_device():
         b.stream_nmea()
     assert b.vessel_table().tobytes() == want.tobytes()
     assert total > 300 and len(want) > 100 and len(np.unique(want["set"])) >= 5
+
+
+@pytest.mark.gpu
+def test_carried_table_at_c3_size():
+    """BASELINE C3's shape through the streamed delivery with the table enabled: 16 384 channels x 48 000 samples,
+    three calls (the third on a shifted window, so its frames differ), ~3 x 10^5 frames per call over a few thousand
+    vessels, against the host fold over the frames a drain-type batch drained call by call."""
+    import torch
+    from gnuais_amd import ReceiverBatch, VESSEL_DTYPE, synth, tile_channels, vessels_from_frames
+    n_ch, total = 16384, 48000
+    base, _ = synth.make_base_streams(256, total)
+    x = tile_channels(torch.from_numpy(base).cuda(), n_ch)
+    a, b = ReceiverBatch(n_ch, max_len=total), ReceiverBatch(n_ch, max_len=total)
+    b.vessel_table_enable(1 << 16)
+    want = np.zeros(0, dtype=VESSEL_DTYPE)
+    n_frames = 0
+    for lo, hi in ((0, total), (0, total), (2000, 30000)):
+        a.run(x[lo:hi])
+        fr = a.drain_frames()
+        n_frames += len(fr)
+        want = vessels_from_frames(fr, want)
+        b.run(x[lo:hi], sync=False)
+        b.stream_nmea(copy=False)
+    got = b.vessel_table()
+    assert n_frames > 500000 and len(want) > 2000
+    assert len(got) == len(want)
+    for name in VESSEL_DTYPE.names:
+        assert np.array_equal(got[name], want[name]), name
+    assert got.tobytes() == want.tobytes()
