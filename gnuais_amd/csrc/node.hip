@@ -315,6 +315,29 @@ int gnuais_node_drain_frames(gnuais_node *nd, gnuais_frame *h_out, int max, int 
     return rc;              // GNUAIS_E_OVERFLOW of a device is reported with what was drained
 }
 
+// Streamed sentences of the whole node: gnuais_batch_stream_nmea() on every shard, each from its own thread.  Shard g's
+// channels all lie before shard g+1's and a sentence does not name its channel (protodec.c:857-859: always 'A'), so the
+// shards' texts written out in shard order are the node's sentences in the reference's order for that call.
+int gnuais_node_stream_nmea(gnuais_node *nd, const char **texts, size_t *lens, int *n_sentences, int *n_frames)
+{
+    if (!nd || !texts || !lens) return node_fail(GNUAIS_E_ARG, "node_stream_nmea: NULL argument");
+    std::vector<Shard *> &sh = nd->shards;
+    std::vector<int> ns(sh.size(), 0), nf(sh.size(), -1);
+    const int rc = run_all(nd, [&](Shard &s) {
+        const size_t i = (size_t) (std::find(sh.begin(), sh.end(), &s) - sh.begin());
+        return gnuais_batch_stream_nmea(s.b, &texts[i], &lens[i], &ns[i], &nf[i]);
+    });
+    int sent = 0, frames = 0;
+    bool filling = false;
+    for (size_t i = 0; i < sh.size(); ++i) {
+        sent += ns[i];
+        if (nf[i] < 0) filling = true; else frames += nf[i];
+    }
+    if (n_sentences) *n_sentences = sent;
+    if (n_frames) *n_frames = filling ? -1 : frames;        // every shard fills and drains in the same call
+    return rc;
+}
+
 int gnuais_node_discard_frames(gnuais_node *nd)
 {
     if (!nd) return node_fail(GNUAIS_E_ARG, "node_discard_frames: NULL");

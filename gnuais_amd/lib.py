@@ -93,6 +93,7 @@ SYMBOLS = {
     "gnuais_node_sync": (_I, [_P]),
     "gnuais_node_pending_frames": (_I, [_P, C.POINTER(_I)]),
     "gnuais_node_drain_frames": (_I, [_P, _P, _I, C.POINTER(_I)]),
+    "gnuais_node_stream_nmea": (_I, [_P, _P, _P, C.POINTER(_I), C.POINTER(_I)]),
     "gnuais_node_discard_frames": (_I, [_P]),
     "gnuais_node_counters": (_I, [_P, _P]),
     "gnuais_node_total_received": (_I, [_P, C.POINTER(C.c_longlong)]),

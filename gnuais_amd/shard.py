@@ -103,6 +103,17 @@ class ReceiverNode:
         self._raise(self._lib.gnuais_node_pending_frames(self._h, self._C.byref(n)))
         return n.value
 
+    def stream_nmea(self):
+        """gnuais_node_stream_nmea(): call after every run(); -> (sentences of every shard in shard order = the node's
+        text for the call `stream_depth` calls ago, sentences, frames); frames == -1 while the pipelines fill."""
+        C = self._C
+        n = len(self.shards)
+        texts, lens = (C.c_void_p * n)(), (C.c_size_t * n)()
+        ns, nf = C.c_int(0), C.c_int(0)
+        self._raise(self._lib.gnuais_node_stream_nmea(self._h, texts, lens, C.byref(ns), C.byref(nf)))
+        out = b"".join(C.string_at(texts[i], lens[i]) for i in range(n) if lens[i])
+        return out, ns.value, nf.value
+
     def discard_frames(self):
         self._raise(self._lib.gnuais_node_discard_frames(self._h))
 

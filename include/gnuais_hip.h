@@ -373,6 +373,11 @@ int  gnuais_node_sync(gnuais_node *nd);
 /* merged results: records of every device, channel = global index, reference order (channel, then time) */
 int  gnuais_node_pending_frames(gnuais_node *nd, int *n_out);
 int  gnuais_node_drain_frames(gnuais_node *nd, gnuais_frame *h_out, int max, int *n_out);
+/* gnuais_batch_stream_nmea() on every shard (each from its own thread): texts[g] / lens[g] = shard g's sentences of
+ * the call `stream_depth` calls ago (n_devices entries; valid until the next call).  Written out in shard order they
+ * are the node's sentences in the reference's order for that call: shard g's channels all lie before shard g+1's and
+ * a sentence does not name its channel.  *n_frames = -1 while the pipelines fill, else the total. */
+int  gnuais_node_stream_nmea(gnuais_node *nd, const char **texts, size_t *lens, int *n_sentences, int *n_frames);
 int  gnuais_node_discard_frames(gnuais_node *nd);
 int  gnuais_node_counters(gnuais_node *nd, gnuais_counters *h_out /* [n_channels] */);
 int  gnuais_node_total_received(gnuais_node *nd, long long *total);

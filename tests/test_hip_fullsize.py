@@ -345,6 +345,32 @@ def test_node_object_equals_one_unsharded_batch(tmp_path):
         node.run_host(np.zeros((total + 1, n_ch), dtype=np.int16))
 
 
+def test_node_streamed_sentences_equal_one_batch():
+    """gnuais_node_stream_nmea(): every shard streams its own sentences (formatted on its device, its own thread); in
+    shard order they are byte for byte what ONE batch over all channels streams for the same call, sequence digits
+    carried per channel, the fill and the final flush included."""
+    import torch
+    from gnuais_amd import ReceiverBatch, ReceiverNode
+    n_ch, call, n_calls = 384, 2 * 1280, 7
+    x = np.stack([synth.make_stream(call * n_calls, seed=91, channel=c % 53, occupancy=0.8)[0] for c in range(n_ch)], axis=1)
+    nd = torch.cuda.device_count()
+    node = ReceiverNode(n_ch, devices=[g % nd for g in range(3)], max_len=call)
+    one = ReceiverBatch(n_ch, max_len=call)
+    got, want = [], []
+    for i in range(n_calls):
+        seg = x[i * call:(i + 1) * call]
+        node.run([dev(seg[:, f:f + n], d) for d, f, n in node.shards])
+        got.append(node.stream_nmea())
+        one.run(dev(seg), sync=False)
+        want.append(one.stream_nmea())
+    for _ in range(one.stream_depth):
+        got.append(node.stream_nmea())
+        want.append(one.stream_nmea())
+    assert [g[2] for g in got] == [w[2] for w in want] and sum(w[2] for w in want if w[2] > 0) > 1000
+    for i, (g, w) in enumerate(zip(got, want)):
+        assert g[1] == w[1] and g[0] == bytes(w[0]), i
+
+
 def test_node_example_program(tmp_path):
     """examples/node_decode.c -- the 40-line C program of the node API -- builds against include/gnuais_hip.h and
     decodes a raw 64-channel file on whatever devices exist: as many frames as the oracle finds."""
