@@ -1794,6 +1794,24 @@ int gnuais_crc16_batch(int device, const uint8_t *h_data, int stride, const int3
     return GNUAIS_OK;
 }
 
+int gnuais_crc16_bits(int device, const uint8_t *h_bits, int n_bytes, uint16_t *h_crc, uint8_t *h_msb, int n_out)
+{
+    if (!h_bits || !h_crc || n_bytes <= 0 || n_bytes > 64 || n_out < 0 || n_out > 8 * n_bytes || (n_out > 0 && !h_msb))
+        return fail(GNUAIS_E_ARG, "crc16_bits: argument (1..64 bytes, n_out <= 8 * n_bytes)");
+    HIP_TRY(hipSetDevice(device));
+    // one allocation: [bits 512][msb 512][crc]
+    uint8_t *d = nullptr;
+    hipError_t e = hipMalloc((void **) &d, 512 + 512 + 16);
+    if (e == hipSuccess) e = hipMemcpy(d, h_bits, (size_t) n_bytes * 8, hipMemcpyHostToDevice);
+    if (e == hipSuccess)
+        e = launch_crc16_bits(d, n_bytes, reinterpret_cast<uint16_t *>(d + 1024), n_out ? d + 512 : nullptr, n_out, nullptr);
+    if (e == hipSuccess) e = hipMemcpy(h_crc, d + 1024, sizeof(uint16_t), hipMemcpyDeviceToHost);
+    if (e == hipSuccess && n_out) e = hipMemcpy(h_msb, d + 512, (size_t) n_out, hipMemcpyDeviceToHost);
+    (void) hipFree(d);
+    if (e != hipSuccess) return fail(GNUAIS_E_HIP, "crc16_bits", e);
+    return GNUAIS_OK;
+}
+
 int gnuais_tile_channels(const int16_t *d_base, int n_base, int len, int16_t *d_out,
                          int n_channels, void *stream)
 {

@@ -111,6 +111,9 @@ hipError_t launch_tile_channels(const int16_t *base, int n_base, int len, int16_
                                 int n_channels, hipStream_t stream);
 hipError_t launch_crc16(const uint8_t *data, int stride, const int32_t *len, int n,
                         uint16_t *crc, hipStream_t stream);
+// one frame's bits (a byte per bit) -> CRC + the bits byte-wise most-significant-first (util.hip)
+hipError_t launch_crc16_bits(const uint8_t *bits, int n_bytes, uint16_t *crc, uint8_t *msb, int n_out,
+                             hipStream_t stream);
 
 // K1s evaluates the NC = 12 central taps in direct form with symmetric pre-adds (fir_slice.hip); the
 // host's error bound for y_c follows the same order of operations (gnuais_capi.hip)

@@ -571,10 +571,14 @@ extern "C" int gnuais_vessels_from_frames(const gnuais_frame *frames, int n_fram
     return GNUAIS_OK;
 }
 
-// The MySQL sink's statements for a batch, reduced to the calls that leave something (include/gnuais_hip.h).  Every
-// argument is formed as the reference forms it at its call site (protodec.c:383-388, 430-433, 510-514, 612-617, 670-674,
-// 737-738, 768-771): float expressions in double, narrowed at the call.
-extern "C" int gnuais_sql_plan_from_frames(const gnuais_frame *frames, int n_frames, gnuais_sql_call *out, int cap, int *n_out)
+// The MySQL sink's calls for a batch (include/gnuais_hip.h).  Every argument is formed as the reference forms it at its
+// call site (protodec.c:383-388, 430-433, 510-514, 612-617, 670-674, 737-738, 768-771): float expressions in double,
+// narrowed at the call.  keepsmall != 0 (the reference's mysql_keepsmall, out_mysql.c:140: UPDATE ... WHERE mmsi, INSERT
+// only when no row was touched): per (vessel, kind) only the last call leaves anything, so only that one is kept.
+// keepsmall == 0 (the reference's default, cfg.c:74): every call INSERTs a row of its own, so every call is kept, in
+// arrival order.
+extern "C" int gnuais_sql_calls_from_frames(const gnuais_frame *frames, int n_frames, int keepsmall, gnuais_sql_call *out,
+                                            int cap, int *n_out)
 {
     if (n_frames < 0 || (n_frames > 0 && !frames) || !out || cap < 0 || !n_out) return GNUAIS_E_ARG;
     struct Rec { int mmsi, kind, order; gnuais_sql_call c; };
@@ -647,6 +651,12 @@ extern "C" int gnuais_sql_plan_from_frames(const gnuais_frame *frames, int n_fra
         default: break;
         }
     }
+    if (!keepsmall) {                               // every call is a row: nothing to reduce
+        *n_out = (int) recs.size();
+        if ((int) recs.size() > cap) return GNUAIS_E_OVERFLOW;
+        for (size_t i2 = 0; i2 < recs.size(); ++i2) out[i2] = recs[i2].c;
+        return GNUAIS_OK;
+    }
     // per (vessel, kind) the last call; survivors in arrival order
     std::stable_sort(recs.begin(), recs.end(), [](const Rec &a, const Rec &b_) {
         return a.mmsi != b_.mmsi ? a.mmsi < b_.mmsi : (a.kind != b_.kind ? a.kind < b_.kind : a.order < b_.order);
@@ -659,6 +669,12 @@ extern "C" int gnuais_sql_plan_from_frames(const gnuais_frame *frames, int n_fra
     if ((int) keep.size() > cap) return GNUAIS_E_OVERFLOW;
     for (size_t i2 = 0; i2 < keep.size(); ++i2) out[i2] = keep[i2].c;
     return GNUAIS_OK;
+}
+
+// the reduced plan under its round-3 name: what a database run with mysql_keepsmall on needs
+extern "C" int gnuais_sql_plan_from_frames(const gnuais_frame *frames, int n_frames, gnuais_sql_call *out, int cap, int *n_out)
+{
+    return gnuais_sql_calls_from_frames(frames, n_frames, 1, out, cap, n_out);
 }
 
 extern "C" int gnuais_nmea_from_frames(const gnuais_frame *frames, int n_frames, uint8_t *seqnr,

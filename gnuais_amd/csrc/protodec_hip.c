@@ -18,18 +18,28 @@
  * with the three names renamed (-Dprotodec_decode=ref_protodec_decode ...: nothing of its source changes) and leave
  * filter.c out; INTEGRATION.md has the link line, and the test suite builds and runs exactly that.
  *
- * protodec_decode() semantics.  The reference consumes `count` bits and returns with d current.  By default this
- * file does the same (every call is a device round trip: correct, slow -- receiver.c calls it once per bit).
- * gnuais_protodec_set_batching(n) lets up to n bits queue per decoder before they go to the device;
- * d's public fields (state, nstartsign, antallpreamble, antallenner, bitstuff, last, bufferpos, receivedframes,
- * lostframes, lostframes2) and the protodec_getdata() calls then happen at the flush -- the same calls in the same
- * order -- and gnuais_protodec_flush(d) forces one (NULL: every decoder).  d->buffer (the raw bits of a frame in
- * progress) is not mirrored.  Single caller thread, like the reference's main loop.  No CPU fallback: a HIP
- * failure aborts, as the reference does on its own fatal errors.
+ * protodec_decode() semantics.  The reference consumes `count` bits and returns with d current; its receiver.c
+ * calls it once per BIT (receiver.c:130), and a device round trip per bit is unusable at any rate.  So bits queue
+ * per decoder and go to the device in chunks: when GNUAIS_PROTODEC_CHUNK (2048) bits wait, and -- what keeps the
+ * observable order the reference's -- at the start of every filter_run_buf(), i.e. whenever receiver_run() begins
+ * its next buffer: every decoder with queued bits is flushed in creation order, so the protodec_getdata() calls of
+ * one buffer come out receiver by receiver, in time order inside a receiver, exactly as the per-bit path makes them
+ * (ais.c:237-247: A's frames of the buffer, then B's).  d's public fields (state, nstartsign, antallpreamble,
+ * antallenner, bitstuff, last, bufferpos, receivedframes, lostframes, lostframes2) are current as of the last flush:
+ * at most one buffer behind; gnuais_protodec_flush(d) (NULL: every decoder) brings them up to the last bit -- call
+ * it before reading the counters at shutdown (ais.c:296-310).  gnuais_protodec_set_batching(1) restores the strict
+ * per-call behaviour (every call returns with d current; slow).  d->buffer (the raw bits of a frame in progress)
+ * is not mirrored.
+ *
+ * Threads: the two tables are hashed by object address and guarded by one mutex, which is NOT held while the
+ * reference's protodec_getdata() runs (it writes to the serial port, takes the cache's lock and flushes stdout);
+ * one decoder / filter object must not be driven from two threads at once, as in the reference.  No CPU fallback:
+ * a HIP failure aborts, as the reference does on its own fatal errors.
  */
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <pthread.h>
 
 #ifdef GNUAIS_TREE
 #include "filter.h"
@@ -50,13 +60,16 @@ void protodec_getdata(int bufferlengde, struct demod_state_t *d);
 #endif
 #include "gnuais_hip.h"
 
+#define GNUAIS_PROTODEC_CHUNK 2048      /* bits that may wait per decoder before they go to the device */
+#define QUEUE_BITS 8192                 /* what one gnuais_batch_decode_bits() call of these batches takes */
+
 static void die(const char *what)
 {
 	fprintf(stderr, "gnuais-hip: %s: %s\n", what, gnuais_last_error());
 	abort();
 }
 
-/* ---------------------------------------------------------------- side tables (pointer -> device object) */
+/* ------------------------------------------------- object address -> device object (hashed, one lock) */
 
 struct f_ent {
 	struct filter *f;
@@ -67,27 +80,108 @@ struct f_ent {
 struct d_ent {
 	struct demod_state_t *d;
 	gnuais_batch *b;        /* one channel: only its deframer + CRC stages are used */
+	pthread_mutex_t lock;   /* the queue and d's mirror; held while this decoder's frames go to protodec_getdata() */
 	unsigned char *bits;
-	int n_bits, cap_bits;
+	int n_bits;
 	gnuais_frame *frames;
 	int cap_frames;
 };
-static struct f_ent *f_tab;
-static struct d_ent *d_tab;
-static int n_f, n_d, batching = 1;
 
-static struct f_ent *f_of(struct filter *f)
+/* open addressing, linear probing, backward-shift deletion; the entries themselves never move */
+struct ptab {
+	const void **key;
+	void **ent;
+	unsigned cap, used;
+};
+static struct ptab f_tab, d_tab;
+static struct d_ent **d_order;          /* decoders in creation order: the order flush-all serves them in */
+static int n_order, cap_order;
+static int batching = GNUAIS_PROTODEC_CHUNK;
+static pthread_mutex_t tab_lock = PTHREAD_MUTEX_INITIALIZER;
+
+static unsigned slot_of(const struct ptab *t, const void *key)
 {
-	int i;
-	for (i = 0; i < n_f; i++)
-		if (f_tab[i].f == f)
-			return &f_tab[i];
+	unsigned long long h = (unsigned long long) (size_t) key;
+	h ^= h >> 33;
+	h *= 0xff51afd7ed558ccdull;
+	h ^= h >> 29;
+	return (unsigned) h & (t->cap - 1);
+}
+
+static void *ptab_get(const struct ptab *t, const void *key)
+{
+	unsigned i;
+	if (!t->cap)
+		return NULL;
+	for (i = slot_of(t, key); t->key[i]; i = (i + 1) & (t->cap - 1))
+		if (t->key[i] == key)
+			return t->ent[i];
 	return NULL;
 }
 
+static void ptab_put(struct ptab *t, const void *key, void *ent)
+{
+	unsigned i;
+	if (4 * (t->used + 1) > 3 * t->cap) {           /* grow: rehash into twice the slots */
+		struct ptab n;
+		n.cap = t->cap ? 2 * t->cap : 16;
+		n.used = 0;
+		n.key = calloc(n.cap, sizeof(*n.key));
+		n.ent = calloc(n.cap, sizeof(*n.ent));
+		if (!n.key || !n.ent)
+			abort();
+		for (i = 0; i < t->cap; i++)
+			if (t->key[i])
+				ptab_put(&n, t->key[i], t->ent[i]);
+		free(t->key);
+		free(t->ent);
+		*t = n;
+	}
+	for (i = slot_of(t, key); t->key[i]; i = (i + 1) & (t->cap - 1))
+		;
+	t->key[i] = key;
+	t->ent[i] = ent;
+	t->used++;
+}
+
+static void ptab_del(struct ptab *t, const void *key)
+{
+	unsigned i, j, k;
+	if (!t->cap)
+		return;
+	for (i = slot_of(t, key); t->key[i] != key; i = (i + 1) & (t->cap - 1))
+		if (!t->key[i])
+			return;
+	for (j = i;;) {                                 /* close the gap so that every probe sequence stays unbroken */
+		j = (j + 1) & (t->cap - 1);
+		if (!t->key[j])
+			break;
+		k = slot_of(t, t->key[j]);
+		if ((i <= j) ? (i < k && k <= j) : (i < k || k <= j))
+			continue;
+		t->key[i] = t->key[j];
+		t->ent[i] = t->ent[j];
+		i = j;
+	}
+	t->key[i] = NULL;
+	t->ent[i] = NULL;
+	t->used--;
+}
+
+static struct f_ent *f_of(struct filter *f)
+{
+	struct f_ent *e;
+	pthread_mutex_lock(&tab_lock);
+	e = ptab_get(&f_tab, f);
+	pthread_mutex_unlock(&tab_lock);
+	return e;
+}
+
+static void flush_all(void);
+
 /* ---------------------------------------------------------------- src/filter.h:64-68 */
 
-/* src/filter.c:57-71 */
+/* src/filter.c:57-71: the object the caller sees, with its `length` taps; the sample window is on the device */
 struct filter *filter_init(int len, float *taps)
 {
 	struct filter *f;
@@ -97,18 +191,21 @@ struct filter *filter_init(int len, float *taps)
 		fprintf(stderr, "gnuais-hip: filter_init: %d taps (1..%d)\n", len, BufferLen - 1);
 		abort();
 	}
-	f = (struct filter *) hmalloc(sizeof(struct filter));
-	memset(f, 0, sizeof(struct filter));
-	f->taps = (float *) hmalloc(len * sizeof(float));
-	memcpy(f->taps, taps, len * sizeof(float));
+	f = hmalloc(sizeof *f);
+	memset(f, 0, sizeof *f);
 	f->length = len;
-	f->pointer = f->length;         /* kept for whoever looks; the window itself lives on the device */
-	f_tab = realloc(f_tab, sizeof(*f_tab) * (size_t) (n_f + 1));
-	e = &f_tab[n_f++];
-	memset(e, 0, sizeof(*e));
+	f->pointer = len;                       /* for whoever looks: the reference starts its ring here */
+	f->taps = hmalloc((size_t) len * sizeof(float));
+	memcpy(f->taps, taps, (size_t) len * sizeof(float));
+	e = calloc(1, sizeof *e);
+	if (!e)
+		abort();
 	e->f = f;
 	if (gnuais_batch_create(&e->b, 0, 1, taps, len, 0, 4096, 0) != GNUAIS_OK)
 		die("filter_init: gnuais_batch_create");
+	pthread_mutex_lock(&tab_lock);
+	ptab_put(&f_tab, f, e);
+	pthread_mutex_unlock(&tab_lock);
 	return f;
 }
 
@@ -118,11 +215,15 @@ void filter_free(struct filter *f)
 	struct f_ent *e;
 	if (!f)
 		return;
-	e = f_of(f);
+	pthread_mutex_lock(&tab_lock);
+	e = ptab_get(&f_tab, f);
+	if (e)
+		ptab_del(&f_tab, f);
+	pthread_mutex_unlock(&tab_lock);
 	if (e) {
 		gnuais_batch_destroy(e->b);
 		free(e->in);
-		*e = f_tab[--n_f];
+		free(e);
 	}
 	hfree(f->taps);
 	hfree(f);
@@ -139,6 +240,9 @@ short filter_run_buf(struct filter *f, short *in, float *out, int step, int len)
 		fprintf(stderr, "gnuais-hip: filter_run_buf: not a filter_init() object\n");
 		abort();
 	}
+	/* receiver_run() starts every buffer here (receiver.c:107): what the decoders still hold of the buffer
+	 * before goes to the device now, receiver by receiver */
+	flush_all();
 	while (done < len) {                    /* the batch takes 4096 samples a call; the peak is a running maximum */
 		const int n = len - done < 4096 ? len - done : 4096;
 		int16_t m = 0;
@@ -185,36 +289,34 @@ unsigned short protodec_sdlc_crc(const unsigned char *data, unsigned len)
 	return crc;
 }
 
+/* src/protodec.c:120-167, as ONE device call (gnuais_crc16_bits): the frame's cells d->buffer[0 .. 8 * (bytes + 2))
+ * are packed least-significant-bit first and run through the CRC there, and the payload comes back most-significant
+ * -bit first, which is what the message layer reads from d->rbuffer.  Verdict: the register equals 0x0f47.
+ * Two corners: a length that is not positive is refused (protodec.c:128-131); a payload that does not fit
+ * d->rbuffer fills it and is refused, as the reference's loop does when it reaches the end of the array.  The
+ * reference would read d->buffer past its DEMOD_BUFFER_LEN cells for frames that long (its deframer never produces
+ * them, protodec.c:1024); here those cells count as 0. */
 int protodec_calculate_crc(int length_bits, struct demod_state_t *d)
 {
-	int length_bytes, buflen, i, j, x;
-	unsigned char *buf;
-	unsigned short crc;
+	unsigned char cells[8 * 64];
+	uint16_t reg = 0;
+	const int payload = length_bits / 8, framed = payload + 2;
+	int have, shown;
 
-	if (length_bits <= 0)                           /* protodec.c:128-131 (the reference logs and returns 0) */
+	if (length_bits <= 0)
 		return 0;
-	length_bytes = length_bits / 8;
-	buflen = length_bytes + 2;
-	buf = (unsigned char *) hmalloc(sizeof(*buf) * buflen);
-	for (j = 0; j < buflen; j++) {                  /* protodec.c:138-143: bits LSB first */
-		unsigned char tmp = 0;
-		for (i = 0; i < 8; i++)
-			tmp |= (unsigned char) (d->buffer[i + 8 * j] << i);
-		buf[j] = tmp;
-	}
-	crc = protodec_sdlc_crc(buf, (unsigned) buflen);        /* on the device */
-	memset(d->rbuffer, 0, DEMOD_BUFFER_LEN);        /* protodec.c:150-162: payload bits MSB first */
-	for (j = 0; j < length_bytes; j++)
-		for (i = 0; i < 8; i++) {
-			x = j * 8 + i;
-			if (x >= DEMOD_BUFFER_LEN) {
-				hfree(buf);
-				return 0;
-			}
-			d->rbuffer[x] = (buf[j] >> (7 - i)) & 1;
-		}
-	hfree(buf);
-	return crc == 0x0f47;
+	memset(d->rbuffer, 0, DEMOD_BUFFER_LEN);
+	if (framed > 64)                                /* 496 payload bits: far beyond d->rbuffer, nothing to show */
+		return 0;
+	have = 8 * framed < DEMOD_BUFFER_LEN ? 8 * framed : DEMOD_BUFFER_LEN;
+	memset(cells, 0, sizeof cells);
+	memcpy(cells, d->buffer, (size_t) have);
+	shown = 8 * payload < DEMOD_BUFFER_LEN ? 8 * payload : DEMOD_BUFFER_LEN;
+	if (gnuais_crc16_bits(0, cells, framed, &reg, (uint8_t *) d->rbuffer, shown) != GNUAIS_OK)
+		die("protodec_calculate_crc");
+	if (8 * payload > DEMOD_BUFFER_LEN)
+		return 0;
+	return reg == 0x0f47;
 }
 
 /* ---------------------------------------------------------------- src/protodec.c:988-1122 */
@@ -222,24 +324,37 @@ int protodec_calculate_crc(int length_bits, struct demod_state_t *d)
 static struct d_ent *d_of(struct demod_state_t *d)
 {
 	struct d_ent *e;
-	int i;
-	for (i = 0; i < n_d; i++)
-		if (d_tab[i].d == d)
-			return &d_tab[i];
-	d_tab = realloc(d_tab, sizeof(*d_tab) * (size_t) (n_d + 1));
-	e = &d_tab[n_d++];
-	memset(e, 0, sizeof(*e));
-	e->d = d;
-	if (gnuais_batch_create(&e->b, 0, 1, NULL, 0, 0, 4096, 4096) != GNUAIS_OK)
-		die("protodec_decode: gnuais_batch_create");
-	e->cap_bits = 8192;
-	e->bits = malloc((size_t) e->cap_bits);
-	e->cap_frames = 256;
-	e->frames = malloc(sizeof(gnuais_frame) * (size_t) e->cap_frames);
+	pthread_mutex_lock(&tab_lock);
+	e = ptab_get(&d_tab, d);
+	if (!e) {
+		e = calloc(1, sizeof *e);
+		if (!e)
+			abort();
+		e->d = d;
+		pthread_mutex_init(&e->lock, NULL);
+		if (gnuais_batch_create(&e->b, 0, 1, NULL, 0, 0, 4096, 4096) != GNUAIS_OK)
+			die("protodec_decode: gnuais_batch_create");
+		e->bits = malloc(QUEUE_BITS);
+		e->cap_frames = 256;
+		e->frames = malloc(sizeof(gnuais_frame) * (size_t) e->cap_frames);
+		if (!e->bits || !e->frames)
+			abort();
+		ptab_put(&d_tab, d, e);
+		if (n_order == cap_order) {
+			cap_order = cap_order ? 2 * cap_order : 8;
+			d_order = realloc(d_order, sizeof(*d_order) * (size_t) cap_order);
+			if (!d_order)
+				abort();
+		}
+		d_order[n_order++] = e;
+	}
+	pthread_mutex_unlock(&tab_lock);
 	return e;
 }
 
-static void flush_one(struct d_ent *e)
+/* e->lock held: the queued bits through the device deframer, the frames it closed to protodec_getdata() in time
+ * order (protodec.c:1100-1104), then d's public fields from the device */
+static void flush_locked(struct d_ent *e)
 {
 	struct demod_state_t *d = e->d;
 	gnuais_counters c;
@@ -257,10 +372,12 @@ static void flush_one(struct d_ent *e)
 	if (pending > e->cap_frames) {
 		e->cap_frames = pending * 2;
 		e->frames = realloc(e->frames, sizeof(gnuais_frame) * (size_t) e->cap_frames);
+		if (!e->frames)
+			abort();
 	}
 	if (gnuais_batch_drain_frames(e->b, e->frames, e->cap_frames, &got) != GNUAIS_OK)
 		die("protodec_decode: gnuais_batch_drain_frames");
-	for (i = 0; i < got; i++) {                     /* time order; protodec.c:1100-1104 */
+	for (i = 0; i < got; i++) {
 		const gnuais_frame *f = &e->frames[i];
 		const int nbytes = f->nbits / 8;
 		memset(d->rbuffer, 0, DEMOD_BUFFER_LEN);
@@ -284,44 +401,86 @@ static void flush_one(struct d_ent *e)
 	d->bufferpos = st.bufferpos;
 }
 
+/* every decoder with queued bits, in creation order (the table lock is not held while one is served) */
+static void flush_all(void)
+{
+	int i;
+	for (i = 0;; i++) {
+		struct d_ent *e;
+		pthread_mutex_lock(&tab_lock);
+		e = i < n_order ? d_order[i] : NULL;
+		pthread_mutex_unlock(&tab_lock);
+		if (!e)
+			return;
+		pthread_mutex_lock(&e->lock);
+		flush_locked(e);
+		pthread_mutex_unlock(&e->lock);
+	}
+}
+
 void protodec_decode(char *in, int count, struct demod_state_t *d)
 {
 	struct d_ent *e = d_of(d);
 	int i;
+	pthread_mutex_lock(&e->lock);
 	for (i = 0; i < count; i++) {
-		if (e->n_bits == e->cap_bits)
-			flush_one(e);
+		if (e->n_bits == QUEUE_BITS)
+			flush_locked(e);
 		e->bits[e->n_bits++] = in[i] ? 1 : 0;
 	}
 	if (e->n_bits >= batching)
-		flush_one(e);
+		flush_locked(e);
+	pthread_mutex_unlock(&e->lock);
 }
 
-/* additive, not reference names: how many bits may wait per decoder (1: every call returns with d current) */
+/* additive, not reference names: how many bits may wait per decoder (1: every call returns with d current;
+ * default GNUAIS_PROTODEC_CHUNK) */
 void gnuais_protodec_set_batching(int bits)
 {
-	batching = bits < 1 ? 1 : (bits > 8192 ? 8192 : bits);
+	batching = bits < 1 ? 1 : (bits > QUEUE_BITS ? QUEUE_BITS : bits);
 }
 
 void gnuais_protodec_flush(struct demod_state_t *d)
 {
-	int i;
-	for (i = 0; i < n_d; i++)
-		if (!d || d_tab[i].d == d)
-			flush_one(&d_tab[i]);
+	struct d_ent *e;
+	if (!d) {
+		flush_all();
+		return;
+	}
+	pthread_mutex_lock(&tab_lock);
+	e = ptab_get(&d_tab, d);
+	pthread_mutex_unlock(&tab_lock);
+	if (e) {
+		pthread_mutex_lock(&e->lock);
+		flush_locked(e);
+		pthread_mutex_unlock(&e->lock);
+	}
 }
 
 /* releases the device objects of a decoder the caller is done with (the reference itself never frees one) */
 void gnuais_protodec_release(struct demod_state_t *d)
 {
+	struct d_ent *e;
 	int i;
-	for (i = 0; i < n_d; i++)
-		if (d_tab[i].d == d) {
-			flush_one(&d_tab[i]);
-			gnuais_batch_destroy(d_tab[i].b);
-			free(d_tab[i].bits);
-			free(d_tab[i].frames);
-			d_tab[i] = d_tab[--n_d];
-			return;
-		}
+	pthread_mutex_lock(&tab_lock);
+	e = ptab_get(&d_tab, d);
+	if (e) {
+		ptab_del(&d_tab, d);
+		for (i = 0; i < n_order && d_order[i] != e; i++)
+			;
+		if (i < n_order)
+			memmove(&d_order[i], &d_order[i + 1], sizeof(*d_order) * (size_t) (n_order - 1 - i));
+		n_order--;
+	}
+	pthread_mutex_unlock(&tab_lock);
+	if (!e)
+		return;
+	pthread_mutex_lock(&e->lock);
+	flush_locked(e);
+	pthread_mutex_unlock(&e->lock);
+	pthread_mutex_destroy(&e->lock);
+	gnuais_batch_destroy(e->b);
+	free(e->bits);
+	free(e->frames);
+	free(e);
 }

@@ -20,15 +20,24 @@
  * refreshes the public counters -- the reference's order (per buffer: receiver
  * A's frames, then receiver B's).
  *
- * The reference's main loop is one thread (ais.c:214-263); this file nevertheless takes one process-wide lock
- * around its table of groups and around every call, so receivers may be driven from several threads (they are
- * then served one call at a time).  The table grows as needed.
+ * The reference's main loop is one thread (ais.c:214-263).  This file takes one process-wide lock around its table
+ * of groups and around the device work of a call, so receivers may be driven from several threads -- under the one
+ * rule the shared batch imposes: the receivers of a group (same num_ch) are given the SAME buffer, round by round,
+ * as ais.c:237-247 does.  A round is started by the first call that brings a new buffer; a call that brings a
+ * different buffer while other members have not been served from the current one yet would advance every channel
+ * of the group with the wrong samples, so it is refused loudly (fatal) instead of decoding garbage.  The lock is NOT
+ * held while the reference's protodec_getdata() runs (it writes to the serial port, takes the position cache's lock
+ * and flushes stdout): a call copies its channel's frames out and delivers them unlocked.  It is recursive, so a
+ * fatal handler may call free_receiver().  The table grows as needed.
  *
  * Build inside the gnuais tree with -DGNUAIS_TREE (uses the tree's headers and
  * hlog); outside it, include/gnuais_receiver_abi.h carries the two public
  * structs.  There is no CPU fallback: if the HIP library cannot run, this
  * aborts like the reference does on its own fatal errors (receiver.c:104-105).
  */
+#ifndef _GNU_SOURCE
+#define _GNU_SOURCE                     /* PTHREAD_RECURSIVE_MUTEX_INITIALIZER_NP */
+#endif
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -65,7 +74,7 @@ struct rx_group {
 
 static struct rx_group *groups;
 static int n_groups, cap_groups;
-static pthread_mutex_t big_lock = PTHREAD_MUTEX_INITIALIZER;
+static pthread_mutex_t big_lock = PTHREAD_RECURSIVE_MUTEX_INITIALIZER_NP;  /* die() may run a handler that frees receivers */
 
 /* A fatal device error ends the program, as the reference's own fatal errors do (there is no CPU path to fall
  * back to).  A host that wants to close its sinks first installs a handler: it is called with the message and,
@@ -208,7 +217,10 @@ void receiver_run(struct receiver *rx, short *buf, int len)
 	struct rx_group *g;
 	struct demod_state_t *d = rx->decoder;
 	const int ch = rx->ch_ofs;
-	int i, j, k;
+	gnuais_frame local[16], *mine = local;  /* this call's frames of this channel, delivered after the lock is gone */
+	int n_mine = 0, cap_mine = 16, i, j, k;
+	gnuais_counters cnt;
+	int16_t peak;
 
 	if (len > MAX_LEN)                      /* receiver.c:104-105 */
 		abort();
@@ -218,17 +230,52 @@ void receiver_run(struct receiver *rx, short *buf, int len)
 	g = group_for(rx->num_ch);
 	/* a new round starts with a new buffer, or when this receiver has already
 	 * been served from the current one (ais.c reuses the same buffer address) */
-	if (g->round_buf != buf || g->round_len != len || g->ran[ch])
+	if (g->round_buf != buf || g->round_len != len || g->ran[ch]) {
+		if (g->round_buf && !g->ran[ch]) {
+			/* this member has not been served from the current round and brings something else:
+			 * a round started now would hand the members still waiting the wrong samples */
+			int served = 0;
+			for (k = 0; k < g->num_ch; k++)
+				served += g->members[k] && g->ran[k];
+			if (served) {
+				fprintf(stderr, "gnuais-hip: receiver_run: ch_ofs %d of a %d-channel group was given "
+					"another buffer (%p, %d) than the round in progress (%p, %d); the receivers of "
+					"one group share one buffer per round (ais.c:237-247)\n", ch, g->num_ch,
+					(void *) buf, len, (const void *) g->round_buf, g->round_len);
+				die("receiver_run: buffer mismatch inside a round");
+			}
+		}
 		start_round(g, buf, len);
+	}
 	g->ran[ch] = 1;
 
 	/* this channel's frames, already in time order (protodec.c:1100-1104) */
 	for (i = 0; i < g->n_frames; i++) {
-		const gnuais_frame *f = &g->frames[i];
-		int nbytes;
-		if ((int) f->channel != ch)
+		if ((int) g->frames[i].channel != ch)
 			continue;
-		nbytes = f->nbits / 8;
+		if (n_mine == cap_mine) {
+			gnuais_frame *grown = malloc(sizeof(*grown) * (size_t) cap_mine * 2);
+			if (!grown)
+				abort();
+			memcpy(grown, mine, sizeof(*grown) * (size_t) n_mine);
+			if (mine != local)
+				free(mine);
+			mine = grown;
+			cap_mine *= 2;
+		}
+		mine[n_mine++] = g->frames[i];
+	}
+	cnt = g->counters[ch];
+	/* public state the caller may read (receiver.h:38-44) */
+	rx->pll = g->pll[ch].pll;
+	rx->prev = g->pll[ch].prev;
+	rx->lastbit = g->pll[ch].lastbit;
+	peak = g->maxval[ch];
+	pthread_mutex_unlock(&big_lock);
+
+	for (i = 0; i < n_mine; i++) {
+		const gnuais_frame *f = &mine[i];
+		const int nbytes = f->nbits / 8;
 		memset(d->rbuffer, 0, DEMOD_BUFFER_LEN);        /* protodec.c:150 */
 		for (j = 0; j < nbytes; j++)
 			for (k = 0; k < 8; k++)                 /* protodec.c:151-162 */
@@ -236,17 +283,13 @@ void receiver_run(struct receiver *rx, short *buf, int len)
 		d->receivedframes++;                            /* protodec.c:1103 */
 		protodec_getdata(f->nbits, d);                  /* protodec.c:1104 */
 	}
-	/* public state the caller may read (ais.c:296-310, receiver.h:38-44) */
-	d->receivedframes = g->counters[ch].receivedframes;
-	d->lostframes = g->counters[ch].lostframes;
-	d->lostframes2 = g->counters[ch].lostframes2;
-	rx->pll = g->pll[ch].pll;
-	rx->prev = g->pll[ch].prev;
-	rx->lastbit = g->pll[ch].lastbit;
-	{
-		const int16_t peak = g->maxval[ch];
-		pthread_mutex_unlock(&big_lock);
-		(void) peak;
+	if (mine != local)
+		free(mine);
+	/* the counters the caller may read (ais.c:296-310) */
+	d->receivedframes = cnt.receivedframes;
+	d->lostframes = cnt.lostframes;
+	d->lostframes2 = cnt.lostframes2;
+	(void) peak;
 #ifdef GNUAIS_TREE
 	{       /* receiver.c:137-147 level log, from filter_run_buf()'s return value */
 		float level = (float) peak / (float) 32768 * (float) 100;
@@ -260,5 +303,4 @@ void receiver_run(struct receiver *rx, short *buf, int len)
 		}
 	}
 #endif
-	}
 }

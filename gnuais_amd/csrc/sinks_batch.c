@@ -193,6 +193,7 @@ extern int myout_ais_vesseldatab(struct mysql_state_t *my, time_t tid, int mmsi,
 extern int myout_ais_vesselname(struct mysql_state_t *my, time_t tid, int mmsi, const char *name,
 				const char *destination);
 extern int myout_nmea(struct mysql_state_t *my, time_t tid, char *nmea);
+extern int mysql_keepsmall;     /* src/cfg.h:80, set by the "mysql_keepsmall" directive (cfg.c:74); out_mysql.c:140 */
 
 int gnuais_sinks_deliver_mysql(gnuais_sinks *s, struct mysql_state_t *my, long t, const gnuais_frame *frames,
 			       int n_frames, const char *nmea, size_t nmea_len, long counts[2])
@@ -209,7 +210,9 @@ int gnuais_sinks_deliver_mysql(gnuais_sinks *s, struct mysql_state_t *my, long t
 		s->sql = q;
 		s->sql_cap = 2 * n_frames + 1;
 	}
-	rc = gnuais_sql_plan_from_frames(frames, n_frames, s->sql, s->sql_cap, &n);
+	/* keepsmall off (the default): every call INSERTs its own row and none may be dropped; on: UPDATE-else-INSERT,
+	 * only the last call of a kind per vessel leaves anything */
+	rc = gnuais_sql_calls_from_frames(frames, n_frames, mysql_keepsmall, s->sql, s->sql_cap, &n);
 	if (rc != GNUAIS_OK)
 		return rc;
 	for (i = 0; i < n; i++) {

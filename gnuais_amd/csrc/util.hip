@@ -55,6 +55,42 @@ __global__ void crc16_kernel(const uint8_t *__restrict__ data, int stride,
     out[i] = (uint16_t) (~crc & 0xffffu);
 }
 
+// protodec_calculate_crc's arithmetic (gnuais src/protodec.c:120-167) for ONE frame, one wave: lane j forms byte j
+// from the eight one-bit-per-byte cells bits[8j .. 8j+7], the first cell in the byte's LEAST significant position
+// (protodec.c:138-143; a cell is shifted as it is, like the reference's `buffer[..] << i` narrowed to a byte), lane 0
+// runs the CRC-16/X-25 register over the n_bytes bytes (protodec.c:106-118), and lane j writes cells 8j .. 8j+7 of
+// msb[] with the byte's MOST significant bit first (protodec.c:150-162), as far as n_out reaches.
+__global__ __launch_bounds__(64) void crc16_bits_kernel(const uint8_t *__restrict__ bits, int n_bytes,
+                                                        uint16_t *__restrict__ crc_out, uint8_t *__restrict__ msb,
+                                                        int n_out)
+{
+    __shared__ uint8_t bytes[64];
+    const int j = threadIdx.x;
+    uint32_t v = 0;
+    if (j < n_bytes)
+        for (int i = 0; i < 8; ++i) v |= ((uint32_t) bits[8 * j + i] << i) & 0xffu;
+    bytes[j] = (uint8_t) v;
+    __syncthreads();
+    if (j == 0) {
+        uint32_t crc = 0xffffu;
+        for (int k = 0; k < n_bytes; ++k) {
+            crc ^= bytes[k];
+            for (int b = 0; b < 8; ++b) crc = (crc >> 1) ^ (0x8408u & (0u - (crc & 1u)));
+        }
+        *crc_out = (uint16_t) (~crc & 0xffffu);
+    }
+    if (msb && j < n_bytes)
+        for (int i = 0; i < 8; ++i)
+            if (8 * j + i < n_out) msb[8 * j + i] = (uint8_t) ((v >> (7 - i)) & 1u);
+}
+
+hipError_t launch_crc16_bits(const uint8_t *bits, int n_bytes, uint16_t *crc, uint8_t *msb, int n_out,
+                             hipStream_t stream)
+{
+    hipLaunchKernelGGL(crc16_bits_kernel, dim3(1), dim3(64), 0, stream, bits, n_bytes, crc, msb, n_out);
+    return hipGetLastError();
+}
+
 hipError_t launch_tile_channels(const int16_t *base, int n_base, int len, int16_t *out,
                                 int n_channels, hipStream_t stream)
 {

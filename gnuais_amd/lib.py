@@ -58,6 +58,7 @@ SYMBOLS = {
     "gnuais_batch_n_taps": (_I, [_P]),
     "gnuais_default_taps": (_I, [_P]),
     "gnuais_crc16_batch": (_I, [_I, _P, _I, _P, _I, _P]),
+    "gnuais_crc16_bits": (_I, [_I, _P, _I, _P, _P, _I]),
     "gnuais_nmea_from_frames": (_I, [_P, _I, _P, _I, _P, C.c_size_t, C.POINTER(C.c_size_t), C.POINTER(_I)]),
     "gnuais_messages_from_frames": (_I, [_P, _I, _P, _P, _I, _P, C.c_size_t, C.POINTER(C.c_size_t), C.POINTER(_I),
                                          _P, C.c_size_t, C.POINTER(C.c_size_t), C.POINTER(_I)]),
@@ -75,6 +76,7 @@ SYMBOLS = {
     "gnuais_range_from_frames": (_I, [_P, _I, _I, C.c_float, C.c_float, _P]),
     "gnuais_vessels_from_frames": (_I, [_P, _I, _P, _I, C.POINTER(_I)]),
     "gnuais_sql_plan_from_frames": (_I, [_P, _I, _P, _I, C.POINTER(_I)]),
+    "gnuais_sql_calls_from_frames": (_I, [_P, _I, _I, _P, _I, C.POINTER(_I)]),
     "gnuais_tile_channels": (_I, [_P, _I, _I, _P, _I, _P]),
     "gnuais_batch_set_timing": (_I, [_P, _I]),
     "gnuais_batch_last_timing": (_I, [_P, _P]),

@@ -192,6 +192,14 @@ int  gnuais_default_taps(float *out36);
  * h_data = n_msgs rows of `stride` bytes, h_len[n_msgs]; h_crc[n_msgs] */
 int  gnuais_crc16_batch(int device, const uint8_t *h_data, int stride, const int32_t *h_len,
 			int n_msgs, uint16_t *h_crc);
+/* protodec_calculate_crc's arithmetic (src/protodec.c:120-167) for one frame in one device call:
+ * h_bits = 8 * n_bytes cells of one bit each, as the deframer leaves them in d->buffer (the first
+ * cell of a byte is its least significant bit, src/protodec.c:138-143); *h_crc = CRC-16/X-25 over the
+ * n_bytes bytes (a good frame + FCS gives 0x0f47, src/protodec.c:166); h_msb receives the first n_out
+ * cells byte by byte with the most significant bit first (d->rbuffer, src/protodec.c:150-162;
+ * n_out = 0: not wanted).  1 <= n_bytes <= 64, n_out <= 8 * n_bytes. */
+int  gnuais_crc16_bits(int device, const uint8_t *h_bits, int n_bytes, uint16_t *h_crc,
+		       uint8_t *h_msb, int n_out);
 /* Row f1, first part -- the NMEA 0183 sentences of CRC-valid frames, byte-identical to what the
  * reference passes to serial_write() (protodec_getdata src/protodec.c:896-926 +
  * protodec_generate_nmea src/protodec.c:780-894).  Host-side, like the reference's own
@@ -325,12 +333,15 @@ const char *gnuais_last_error(void);
 const char *gnuais_version(void);
 
 /* ---- the MySQL sink behind a batch (src/out_mysql.c:174-297, called from src/protodec.c:383,430,510,612,670,737,768,891) ----
- * Every myout_ais_*() call is "UPDATE <table> SET <this call's columns> WHERE mmsi, else INSERT": per table and vessel
- * only the LAST call of each kind leaves anything in the database.  gnuais_sql_plan_from_frames() walks a batch of frame
- * records in arrival order and returns those surviving calls -- kind, mmsi and the argument values the reference's
- * decoders would pass, bit for bit -- in their original relative order: the same final rows with <= 5 statements per
- * vessel and batch instead of one or two per message.  (The per-sentence myout_nmea() log rows are not reduced: one per
- * sentence of gnuais_nmea_from_frames().)  Host code. */
+ * What a myout_ais_*() call does depends on the reference's mysql_keepsmall (src/out_mysql.c:133-166, cfg.h:80):
+ *   keepsmall on : "UPDATE <table> SET <this call's columns> WHERE mmsi", INSERT only if no row was touched -- per
+ *                  table and vessel only the LAST call of each kind leaves anything in the database;
+ *   keepsmall off: (the reference's default, cfg.c:74) every call INSERTs a row of its own -- nothing may be dropped.
+ * gnuais_sql_calls_from_frames() walks a batch of frame records in arrival order and returns the calls to make -- kind,
+ * mmsi and the argument values the reference's decoders would pass, bit for bit: with keepsmall != 0 the surviving
+ * calls in their original relative order (the same final rows with <= 5 statements per vessel and batch instead of one
+ * or two per message), with keepsmall == 0 every call.  gnuais_sql_plan_from_frames() is the keepsmall != 0 form.
+ * (The per-sentence myout_nmea() log rows are never reduced: one per sentence of gnuais_nmea_from_frames().)  Host code. */
 #define GNUAIS_SQL_POSITION    1   /* myout_ais_position(my, t, mmsi, lat, lon, hdg, course, sog)            types 1-3, 18 */
 #define GNUAIS_SQL_BASESTATION 2   /* myout_ais_basestation(my, t, mmsi, lat, lon)                            type 4        */
 #define GNUAIS_SQL_VESSELDATA  3   /* myout_ais_vesseldata(my, t, mmsi, name, destination, draught, A, B, C, D) type 5      */
@@ -342,6 +353,8 @@ typedef struct gnuais_sql_call {
 	int32_t A, B, C, D;
 	char    name[24], destination[24];
 } gnuais_sql_call;
+int  gnuais_sql_calls_from_frames(const gnuais_frame *frames, int n_frames, int keepsmall, gnuais_sql_call *out,
+				  int cap, int *n_out);
 int  gnuais_sql_plan_from_frames(const gnuais_frame *frames, int n_frames, gnuais_sql_call *out, int cap, int *n_out);
 
 /* ---- the receivers of one NODE: N channels over several GPUs (src/ais.c:141-147, 237-247) ----------

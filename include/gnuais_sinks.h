@@ -12,9 +12,11 @@
  *   1 fwrite + 1 fflush                           for all stdout lines of the batch,
  *   <= 3 cache_*() calls per VESSEL seen in the batch (position, static data, persons)
  *                                                 instead of one per message.
- * The MySQL sink (src/out_mysql.c) gets a front of its own, gnuais_sinks_deliver_mysql(): its statements are
- * "UPDATE ... WHERE mmsi, else INSERT" per vessel and table, so only the last call of each kind per vessel and batch
- * is issued (gnuais_sql_plan_from_frames), plus the per-sentence myout_nmea() log rows.  The JSON uplink
+ * The MySQL sink (src/out_mysql.c) gets a front of its own, gnuais_sinks_deliver_mysql().  With the reference's
+ * mysql_keepsmall set (src/out_mysql.c:140) its statements are "UPDATE ... WHERE mmsi, else INSERT" per vessel and
+ * table, so only the last call of each kind per vessel and batch is issued; with it clear (the default, cfg.c:74)
+ * every message INSERTs its own row and every call is issued, in arrival order (gnuais_sql_calls_from_frames); in
+ * both cases plus the per-sentence myout_nmea() log rows.  The JSON uplink
  * (src/out_json.c) reads the position cache (cache_rotate) and is thereby served by the cache front above.
  *
  * Host C above libgnuais_hip.so (gnuais_amd/csrc/sinks_batch.c); links against the gnuais tree's
@@ -60,8 +62,9 @@ int  gnuais_sinks_deliver(gnuais_sinks *s, const gnuais_frame *frames, int n_fra
 int  gnuais_sinks_deliver_formatted(gnuais_sinks *s, int n_frames, int n_sentences, const char *nmea,
 				    size_t nmea_len, const char *text, size_t text_len,
 				    const gnuais_vessel *vessels, int n_vessels);
-/* The reference's own myout_ais_*() / myout_nmea() (src/out_mysql.h:37-45, unchanged) for one batch: the surviving
- * calls of gnuais_sql_plan_from_frames() in arrival order, then one myout_nmea() per sentence of `nmea` (the batch's
+/* The reference's own myout_ais_*() / myout_nmea() (src/out_mysql.h:37-45, unchanged) for one batch: the calls of
+ * gnuais_sql_calls_from_frames(..., mysql_keepsmall, ...) -- the reference's own switch (cfg.h:80), read at every
+ * call -- in arrival order, then one myout_nmea() per sentence of `nmea` (the batch's
  * "!AIVDM...\r\n" text; NULL: none).  t = received_t (src/protodec.c:905).  counts[0] += vessel-table calls,
  * counts[1] += myout_nmea calls.  Scratch comes from `s` (may be a zeroed struct). */
 struct mysql_state_t;           /* src/out_mysql.h:29-35 */

@@ -40,7 +40,7 @@ int main(int argc, char **argv)
 		return 2;
 	}
 #ifdef GNUAIS_SHIM
-	if (getenv("GNUAIS_PROTODEC_BATCH"))            /* default: every protodec_decode() call returns with d current */
+	if (getenv("GNUAIS_PROTODEC_BATCH"))            /* default: bits queue per decoder until the next buffer starts */
 		gnuais_protodec_set_batching(atoi(getenv("GNUAIS_PROTODEC_BATCH")));
 #endif
 	if (getenv("GNUAIS_LEVELLOG"))                  /* exercises receiver_run()'s level log (receiver.c:137-147) */

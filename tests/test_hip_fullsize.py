@@ -1,6 +1,7 @@
 """Parity at BASELINE.json's full sizes, on the slicer's certification threshold, and over more
 than one device: the HIP path (through the C ABI) against the CPU oracle, bit for bit."""
 import os
+import time
 import subprocess
 import threading
 
@@ -451,6 +452,18 @@ def test_bench_two_workers_prints_n_gpus_2():
 
 # ---------------------------------------------------------------- the drop-in with the reference's message layer
 
+def reference_main_lines(raw):
+    """What the reference's OWN receiver.c / filter.c / protodec.c print for this file behind the same ais.c-shaped
+    driver (oracle/_ref/ref_ais.bin, pure CPU): the lines in the reference's order ACROSS receivers (per buffer A's
+    frames, then B's, ais.c:237-247), and its counters line per receiver.  None where it was not built."""
+    exe = os.path.join(os.path.dirname(G), "..", "oracle", "_ref", "ref_ais.bin")
+    if not os.path.exists(exe):
+        return None, None
+    p = subprocess.run([exe, str(raw)], capture_output=True, timeout=300)
+    assert p.returncode == 0, p.stderr.decode()
+    return p.stdout.decode().splitlines(), p.stderr.decode().splitlines()[-2:]
+
+
 def test_dropin_with_the_reference_message_layer(tmp_path):
     """oracle/_ref/dropin_ais.bin = the reference's UNMODIFIED protodec.c message layer + support
     files, with gnuais_amd/csrc/receiver_hip.c in place of filter.c / receiver.c, behind an
@@ -472,28 +485,38 @@ def test_dropin_with_the_reference_message_layer(tmp_path):
     cnt = g["counters"]
     tail = p.stderr.decode().splitlines()[-2:]
     assert tail == [f"{'AB'[i]}: received {cnt[i][0]} lost {cnt[i][1]} lost2 {cnt[i][2]}" for i in range(2)]
+    ref_lines, ref_tail = reference_main_lines(raw)
+    if ref_lines is not None:                       # the same order across the two receivers, too
+        assert got == ref_lines and tail == ref_tail
 
 
-@pytest.mark.parametrize("batch_bits", [1, 512])
+@pytest.mark.parametrize("batch_bits", [0, 1, 512])
 def test_reference_receiver_over_the_named_shims(tmp_path, batch_bits):
     """oracle/_ref/shim_ais.bin = the reference's UNMODIFIED receiver.c (slicer / PLL / NRZI on the host) linked
     against gnuais_amd/csrc/protodec_hip.c: filter_init / filter_run_buf (exact FIR kernel, floats bit-identical),
     protodec_decode (device deframer + CRC, every valid frame handed to the reference's own protodec_getdata) --
     the reference's other public names of the hot path (filter.h:64-68, protodec.h:73-76).  Its stdout and counters
-    on the golden stereo recording are the reference's own, with every protodec_decode() call a device round trip
-    (1) and with 512 bits queued per decoder."""
+    on the golden stereo recording are the reference's own: at the shim's DEFAULT settings (0: bits queue per decoder
+    and go to the device when the next buffer starts -- there the whole output must also come out in the reference's
+    order, line for line, and fast), with every protodec_decode() call a device round trip (1) and with 512 bits
+    queued per decoder."""
     exe = os.path.join(os.path.dirname(G), "..", "oracle", "_ref", "shim_ais.bin")
     if not os.path.exists(exe):
         pytest.skip("oracle/_ref/shim_ais.bin was not built (no reference tree at build time)")
     g = np.load(os.path.join(G, "chain_48k.npz"))
-    x = g["x"] if batch_bits > 1 else g["x"][: 12 * 1280]          # a device round trip per bit: a shorter piece
+    x = g["x"] if batch_bits != 1 else g["x"][: 12 * 1280]         # a device round trip per bit: a shorter piece
     raw = tmp_path / "stereo.raw"
     x.astype("<i2").tofile(raw)
-    p = subprocess.run([exe, str(raw)], capture_output=True, timeout=900,
-                       env=dict(os.environ, GNUAIS_PROTODEC_BATCH=str(batch_bits)))
+    env = dict(os.environ)
+    env.pop("GNUAIS_PROTODEC_BATCH", None)
+    if batch_bits:
+        env["GNUAIS_PROTODEC_BATCH"] = str(batch_bits)
+    t0 = time.perf_counter()
+    p = subprocess.run([exe, str(raw)], capture_output=True, timeout=900, env=env)
+    took = time.perf_counter() - t0
     assert p.returncode == 0, p.stderr.decode()
     got = p.stdout.decode().splitlines()
-    if batch_bits > 1:
+    if batch_bits != 1:
         want = bytes(np.load(os.path.join(G, "nmea.npz"))["chain_48k_stdout"]).decode().splitlines()
         cnt = g["counters"]
     else:                                           # the piece's own answer: the oracle + the host message layer
@@ -507,6 +530,11 @@ def test_reference_receiver_over_the_named_shims(tmp_path, batch_bits):
     assert len(got) == len(want) > 0
     for ch in "AB":
         assert [l for l in got if l.startswith(f"ch {ch} ")] == [l for l in want if l.startswith(f"ch {ch} ")]
+    if batch_bits == 0:
+        ref_lines, ref_tail = reference_main_lines(raw)
+        if ref_lines is not None:                   # the reference's order across receivers as well
+            assert got == ref_lines
+        assert took < 60.0, took                    # process start + HIP init dominate; the per-bit path needs minutes
     tail = p.stderr.decode().splitlines()[-2:]
     assert tail == [f"{'AB'[i]}: received {cnt[i][0]} lost {cnt[i][1]} lost2 {cnt[i][2]}" for i in range(2)]
 

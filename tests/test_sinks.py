@@ -221,11 +221,21 @@ size_t stub_log_bytes(void) { return gn; }
 '''
 
 
-def sql_state(log: bytes):
-    """What the statements of a call log leave in the database: every myout_ais_*() call is UPDATE-else-INSERT of its own
-    columns WHERE mmsi (src/out_mysql.c:174-283); myout_nmea() appends a row (:286-297)."""
-    tables = {"ais_position": {}, "ais_basestation": {}, "ais_vesseldata": {}}
+def sql_state(log: bytes, keepsmall: bool = True):
+    """What the statements of a call log leave in the database (src/out_mysql.c:133-166, 174-283).  keepsmall: every
+    myout_ais_*() call is UPDATE of its own columns WHERE mmsi, INSERT only when no row was touched -- one row per vessel
+    and table.  Not keepsmall (the reference's default, cfg.c:74): every call INSERTs a row of its own, in call order.
+    myout_nmea() always appends a row (:286-297)."""
+    tables = {"ais_position": {}, "ais_basestation": {}, "ais_vesseldata": {}} if keepsmall else \
+             {"ais_position": [], "ais_basestation": [], "ais_vesseldata": []}
     nmea, calls = [], 0
+
+    def put(table, mmsi, **cols):
+        if keepsmall:
+            tables[table].setdefault(mmsi, {}).update(cols)
+        else:
+            tables[table].append(dict(cols, mmsi=mmsi))
+
     for line in log.decode("latin-1").splitlines():
         kind, _, rest = line.partition(" ")
         if kind == "nmea":
@@ -236,27 +246,30 @@ def sql_state(log: bytes):
         v = head.split()
         mmsi = int(v[0])
         if kind == "position":
-            tables["ais_position"].setdefault(mmsi, {}).update(dict(zip(("lat", "lon", "hdg", "course", "sog"), v[1:6])))
+            put("ais_position", mmsi, **dict(zip(("lat", "lon", "hdg", "course", "sog"), v[1:6])))
         elif kind == "basestation":
-            tables["ais_basestation"].setdefault(mmsi, {}).update(dict(zip(("lat", "lon"), v[1:3])))
+            put("ais_basestation", mmsi, **dict(zip(("lat", "lon"), v[1:3])))
         elif kind == "vesseldata":
-            tables["ais_vesseldata"].setdefault(mmsi, {}).update(dict(zip(("draught", "A", "B", "C", "D"), v[1:6]),
-                                                                    name=strs[0], destination=strs[1]))
+            put("ais_vesseldata", mmsi, **dict(zip(("draught", "A", "B", "C", "D"), v[1:6])), name=strs[0], destination=strs[1])
         elif kind == "vesseldatab":
-            tables["ais_vesseldata"].setdefault(mmsi, {}).update(dict(zip(("A", "B", "C", "D"), v[1:5])))
+            put("ais_vesseldata", mmsi, **dict(zip(("A", "B", "C", "D"), v[1:5])))
         elif kind == "vesselname":
-            tables["ais_vesseldata"].setdefault(mmsi, {}).update(name=strs[0], destination=strs[1])
+            put("ais_vesseldata", mmsi, name=strs[0], destination=strs[1])
         else:
             raise AssertionError(line)
     return tables, nmea, calls
 
 
-def test_mysql_front_leaves_the_rows_of_the_per_message_path(tmp_path):
-    """gnuais_sinks_deliver_mysql(): per batch only the last myout_ais_*() call of each kind per vessel (the statements are
-    UPDATE ... WHERE mmsi, else INSERT) and one myout_nmea() per sentence.  The reference's own protodec_getdata() is run
-    over the same frames with its MySQL sink switched on and its myout_*() calls written down (--wrap in oracle/_ref);
-    both call logs are applied to a model of the three tables: identical rows (argument values as printed with nine
-    significant digits, i.e. bit for bit), identical sentence log, and far fewer statements."""
+@pytest.mark.parametrize("keepsmall", [1, 0])
+def test_mysql_front_leaves_the_rows_of_the_per_message_path(tmp_path, keepsmall):
+    """gnuais_sinks_deliver_mysql() under both settings of the reference's mysql_keepsmall (out_mysql.c:140; the adapter
+    reads the reference's own global).  On: per batch only the last myout_ais_*() call of each kind per vessel (the
+    statements are UPDATE ... WHERE mmsi, else INSERT).  Off, the reference's default: every call INSERTs a row, so every
+    call must be issued, in order.  Either way one myout_nmea() per sentence.  The reference's own protodec_getdata() is
+    run over the same frames with its MySQL sink switched on and its myout_*() calls written down (--wrap in oracle/_ref);
+    both call logs are applied to a model of the three tables for that setting: identical rows (argument values as printed
+    with nine significant digits, i.e. bit for bit), identical sentence log, and -- with keepsmall on -- far fewer
+    statements."""
     from gnuais_amd import lib, nmea_from_frames
     ref = reference()
     fr, n_ch = mixed_traffic()
@@ -274,9 +287,12 @@ def test_mysql_front_leaves_the_rows_of_the_per_message_path(tmp_path):
     subprocess.check_call(["gcc", "-std=gnu11", "-w", "-shared", "-fPIC", "-Wl,-Bsymbolic-functions", "-I",
                            os.path.join(ROOT, "include"), os.path.join(ROOT, "gnuais_amd", "csrc", "sinks_batch.c"),
                            str(tmp_path / "stub.c"), "-o", so])
-    C.CDLL(REF_SO, mode=C.RTLD_GLOBAL)
+    refso = C.CDLL(REF_SO, mode=C.RTLD_GLOBAL)
     C.CDLL(lib.LIB_PATH, mode=C.RTLD_GLOBAL)
     L = C.CDLL(so)
+    flag = C.c_int.in_dll(refso, "mysql_keepsmall")    # cfg.h:80: the switch both sides read
+    old_flag = flag.value
+    flag.value = keepsmall
     L.gnuais_sinks_deliver_mysql.argtypes = [C.POINTER(Sinks2), C.c_void_p, C.c_long, C.c_void_p, C.c_int, C.c_char_p,
                                              C.c_size_t, C.POINTER(C.c_long)]
     L.stub_log.restype = C.c_void_p
@@ -289,12 +305,17 @@ def test_mysql_front_leaves_the_rows_of_the_per_message_path(tmp_path):
         part = np.ascontiguousarray(fr[lo:hi])
         text = nmea_from_frames(part, seq)
         assert L.gnuais_sinks_deliver_mysql(C.byref(s), C.c_void_p(16), 1234, part.ctypes.data, len(part), text, len(text), counts) == 0
+    flag.value = old_flag
     got_log = C.string_at(L.stub_log(), L.stub_log_bytes())
-    want_tables, want_nmea, want_calls = sql_state(want_log)
-    got_tables, got_nmea, got_calls = sql_state(got_log)
+    want_tables, want_nmea, want_calls = sql_state(want_log, bool(keepsmall))
+    got_tables, got_nmea, got_calls = sql_state(got_log, bool(keepsmall))
     assert got_tables == want_tables and sum(len(t) for t in want_tables.values()) > 100
     assert got_nmea == want_nmea and len(want_nmea) == counts[1] > 900
-    assert counts[0] == got_calls < want_calls              # fewer statements already with six small batches of 120 vessels
+    if keepsmall:
+        assert counts[0] == got_calls < want_calls          # fewer statements already with six small batches of 120 vessels
+    else:
+        assert counts[0] == got_calls == want_calls         # a row per call: none may go missing
+        assert sum(len(t) for t in want_tables.values()) == want_calls
     # one batch: exactly one call per (vessel, kind)
     from gnuais_amd.lib import load
     plan = np.zeros(2 * len(fr) + 1, dtype=np.dtype([("kind", "<i4"), ("mmsi", "<i4"), ("f", "<f4", (6,)), ("abcd", "<i4", (4,)), ("name", "S24"), ("destination", "S24")]))
