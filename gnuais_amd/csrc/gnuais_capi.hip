@@ -65,11 +65,17 @@ struct gnuais_batch {
     std::vector<float> taps;
     float te[128] = {0};
     // device state
-    int16_t *hist[2] = {nullptr, nullptr};
+    // The FIR's carry (the last NT input rows) and the per-call peak buffers rotate over HB buffers: call i reads
+    // hist[i % HB], writes hist[(i + 1) % HB], gathers its peaks in maxval[i % HB] and clears maxval[(i + 2) % HB].
+    // Two would do for FIR launches that run one after the other; four let launch i + 1 start while launch i is
+    // still running (fir_streams = 2): nothing launch i + 1 writes is read by launch i.
+    static constexpr int HB = 4;
+    int16_t *hist[HB] = {};
     int hist_cur = 0;
-    // every hand-off buffer exists NBUF times (index = call % NBUF), so K1 can run up
-    // to NBUF-1 calls ahead of the sequential stages
-    static constexpr int NBUF = 4;
+    // every hand-off buffer exists NBUF times; `nbuf` of them are in use (index = call % nbuf), so K1 can run up
+    // to nbuf-1 calls ahead of the sequential stages
+    static constexpr int NBUF = 8;
+    int nbuf = 4;
     uint32_t *sgn[NBUF] = {};                   // K1 -> K2
     uint32_t *pll = nullptr, *lastbit = nullptr, *prev = nullptr;   // receiver.h:38-44, carried by K2
     int n_cu = 256;
@@ -95,7 +101,7 @@ struct gnuais_batch {
     int cand_K = 64;
     int k2b_lag = 1;                // K2b of a call waits for K3 of the call this many calls before it
     int32_t *counters = nullptr;
-    int *maxval[2] = {nullptr, nullptr};   // ping-pong with the history buffers
+    int *maxval[HB] = {};                  // rotate with the history buffers
     int max_cur = 0, max_last = 0;
     gnuais_frame *frames = nullptr;
     float *d_taps = nullptr;
@@ -189,6 +195,18 @@ struct gnuais_batch {
     bool timed_last = false;
     hipStream_t last_stream = nullptr;
     int last_len = 0;
+    // FIR launches on two streams alternately (fir_streams = 2): launch i + 1 may begin while launch i's last
+    // workgroups are still running, so the FIR stage has no gap and no tail between calls.  What launch i + 1 needs of
+    // launch i -- the last NT input rows -- is copied by a small kernel queued IN FRONT of launch i.
+    int fir_streams = 1;
+    hipStream_t s_fir2 = nullptr;
+    hipEvent_t e_hist[2] = {nullptr, nullptr};  // the carry of the call on FIR stream q is written
+    hipEvent_t e_order = nullptr;               // the caller's stream has reached this call (its input is there)
+    // cold start: a call that finds the pipeline empty is followed by a FIR launch that would otherwise be dispatched
+    // before the first call's PLL stage and keep it waiting for a whole FIR launch; cold_hold_us >= 0 holds that
+    // second FIR launch back on the host until the first one has ended, plus this many microseconds
+    int cold_hold_us = -1;
+    unsigned long long cold_call = ~0ull;
 };
 
 static int set_device(const gnuais_batch *b)
@@ -226,8 +244,8 @@ void gnuais_batch_destroy(gnuais_batch *b)
         for (void *p : set)
             if (p) (void) hipFree(p);
     }
-    void *ptrs[] = {b->hist[0], b->hist[1], b->pll, b->lastbit, b->prev, b->ctl, b->cand,
-                    b->frame_count, b->counters, b->maxval[0], b->maxval[1], b->frames, b->d_taps,
+    void *ptrs[] = {b->hist[0], b->hist[1], b->hist[2], b->hist[3], b->pll, b->lastbit, b->prev, b->ctl, b->cand,
+                    b->frame_count, b->counters, b->maxval[0], b->maxval[1], b->maxval[2], b->maxval[3], b->frames, b->d_taps,
                     b->stage_x, b->d_seq[0], b->d_seq[1], b->d_text, b->nmea_scratch, b->d_msg, b->d_word, b->d_stamps, b->stage_f, b->vt, b->vt_fslot};
     for (void *p : ptrs)
         if (p) (void) hipFree(p);
@@ -239,6 +257,9 @@ void gnuais_batch_destroy(gnuais_batch *b)
             if (e) (void) hipEventDestroy(e);
     for (auto &st : b->pool)
         if (st) (void) hipStreamDestroy(st);
+    if (b->s_fir2) (void) hipStreamDestroy(b->s_fir2);
+    for (hipEvent_t e : {b->e_hist[0], b->e_hist[1], b->e_order})
+        if (e) (void) hipEventDestroy(e);
     for (int q = 0; q < gnuais_batch::NRING; ++q) {
         if (q > 0 && b->ring[q]) (void) hipFree(b->ring[q]);          // ring 0 is frames / frame_count
         if (q > 0 && b->ring_count[q]) (void) hipFree(b->ring_count[q]);
@@ -384,8 +405,7 @@ int gnuais_batch_create(gnuais_batch **out, int device, int n_channels, const fl
         if (e == hipSuccess) e = hipMalloc(p, bytes);
         if (e == hipSuccess) e = hipMemset(*p, 0, bytes);
     };
-    alloc((void **) &b->hist[0], sizeof(int16_t) * N * b->NT);
-    alloc((void **) &b->hist[1], sizeof(int16_t) * N * b->NT);
+    for (int q = 0; q < gnuais_batch::HB; ++q) alloc((void **) &b->hist[q], sizeof(int16_t) * N * b->NT);
     b->n_seg = (b->sgn_words + SEG_WORDS - 1) / SEG_WORDS;
     b->seg_words = (int) (((uint64_t) SEG_WORDS * 32 * step / 65536 + 2 + 31) / 32) + 1;
     if (b->seg_words > 16) {       // K2b keeps one segment pack (<= 16 words) in registers
@@ -417,8 +437,7 @@ int gnuais_batch_create(gnuais_batch **out, int device, int n_channels, const fl
     alloc((void **) &b->cand, sizeof(uint32_t) * N * (size_t) (b->k2b_lag * b->cand_K) * CAND_WORDS);
     alloc((void **) &b->frame_count, sizeof(uint32_t) * 4);
     alloc((void **) &b->counters, sizeof(int32_t) * N * 3);
-    alloc((void **) &b->maxval[0], sizeof(int) * N);
-    alloc((void **) &b->maxval[1], sizeof(int) * N);
+    for (int q = 0; q < gnuais_batch::HB; ++q) alloc((void **) &b->maxval[q], sizeof(int) * N);
     alloc((void **) &b->frames, sizeof(gnuais_frame) * (size_t) b->frame_cap);
     alloc((void **) &b->d_taps, sizeof(float) * b->NT);
     if (e == hipSuccess)
@@ -429,6 +448,9 @@ int gnuais_batch_create(gnuais_batch **out, int device, int n_channels, const fl
     for (auto &pair : b->e_done)
         for (auto &ev : pair)
             if (e == hipSuccess) e = hipEventCreateWithFlags(&ev, hipEventDisableTiming);
+    for (auto &ev : b->e_hist)
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&ev, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&b->e_order, hipEventDisableTiming);
     {
         // the sequential stages are short on parallelism, long on latency: give them
         // dispatch priority over the FIR's tens of thousands of workgroups
@@ -466,6 +488,9 @@ int gnuais_batch_create(gnuais_batch **out, int device, int n_channels, const fl
         for (; made < gnuais_batch::POOL; ++made)
             if (e == hipSuccess) e = hipStreamCreateWithPriority(&b->pool[made], hipStreamNonBlocking, made < 8 ? hi : 0);
     }
+    if (const char *v = getenv("GNUAIS_NBUF")) b->nbuf = std::min((int) gnuais_batch::NBUF, std::max(2, atoi(v)));
+    if (const char *v = getenv("GNUAIS_COLD_HOLD_US")) b->cold_hold_us = atoi(v);
+    if (const char *v = getenv("GNUAIS_FIR_STREAMS")) b->fir_streams = atoi(v) == 2 ? 2 : 1;
     if (const char *v = getenv("GNUAIS_PIPELINE")) b->pipeline = atoi(v) != 0;
     if (const char *v = getenv("GNUAIS_HDLC_VARIANT")) b->hdlc_variant = atoi(v) != 0;
     if (const char *v = getenv("GNUAIS_HDLC_LPW")) b->hdlc_lpw = std::min(64, std::max(1, atoi(v)));
@@ -494,8 +519,8 @@ int gnuais_batch_reset(gnuais_batch *b)
     if (int rc = set_device(b)) return rc;
     const size_t N = (size_t) b->N;
     HIP_TRY(hipDeviceSynchronize());
-    HIP_TRY(hipMemset(b->hist[0], 0, sizeof(int16_t) * N * b->NT));   // filter.c:62
-    HIP_TRY(hipMemset(b->hist[1], 0, sizeof(int16_t) * N * b->NT));
+    for (int q = 0; q < gnuais_batch::HB; ++q)
+        HIP_TRY(hipMemset(b->hist[q], 0, sizeof(int16_t) * N * b->NT));   // filter.c:62
     b->hist_cur = 0;
     HIP_TRY(hipMemset(b->pll, 0, sizeof(uint32_t) * N));              // receiver.c:66-71
     HIP_TRY(hipMemset(b->lastbit, 0, sizeof(uint32_t) * N));
@@ -505,9 +530,10 @@ int gnuais_batch_reset(gnuais_batch *b)
     b->calls = 0;
     b->hdlc_calls = 0;
     HIP_TRY(hipMemset(b->counters, 0, sizeof(int32_t) * N * 3));      // protodec.c:62-64
-    HIP_TRY(hipMemset(b->maxval[0], 0, sizeof(int) * N));
-    HIP_TRY(hipMemset(b->maxval[1], 0, sizeof(int) * N));
+    for (int q = 0; q < gnuais_batch::HB; ++q) HIP_TRY(hipMemset(b->maxval[q], 0, sizeof(int) * N));
     b->max_cur = 0;
+    b->max_last = 0;
+    b->cold_call = ~0ull;
     HIP_TRY(hipMemset(b->frame_count, 0, sizeof(uint32_t) * 4));
     for (int q = 1; q < gnuais_batch::NRING; ++q)
         if (b->ring_count[q]) HIP_TRY(hipMemset(b->ring_count[q], 0, sizeof(uint32_t) * 4));
@@ -534,6 +560,17 @@ int gnuais_batch_set_option(gnuais_batch *b, const char *name, int value)
         b->fir_T = value;
     } else if (!strcmp(name, "fir_map")) {
         b->fir_map = value;
+    } else if (!strcmp(name, "nbuf")) {             // hand-off sets in use: the calls that may be in flight
+        if (value < 2 || value > gnuais_batch::NBUF) return fail(GNUAIS_E_ARG, "nbuf must be 2..8");
+        if (int rc = gnuais_batch_sync(b)) return rc;
+        HIP_TRY(hipDeviceSynchronize());
+        b->nbuf = value;
+    } else if (!strcmp(name, "fir_streams")) {
+        if (value != 1 && value != 2) return fail(GNUAIS_E_ARG, "fir_streams must be 1 or 2");
+        if (int rc = gnuais_batch_sync(b)) return rc;
+        b->fir_streams = value;
+    } else if (!strcmp(name, "cold_hold_us")) {
+        b->cold_hold_us = value < 0 ? -1 : value;
     } else if (!strcmp(name, "streaming")) {
         // 0: leave the streamed delivery (gnuais_batch_stream_nmea / autotune_delivery switch it on): everything in
         // flight is flushed and DROPPED, K3 goes back to ring 0, the drain-type calls work again.  The rings, texts
@@ -611,8 +648,8 @@ static void fill_fir(const gnuais_batch *b, FirLaunch &f, const int16_t *x, int 
     f.sgn = b->sgn[k];
     f.dump = dump;
     f.maxval = b->maxval[b->max_cur];
-    f.hist_out = b->hist[b->hist_cur ^ 1];
-    f.maxval_next = b->maxval[b->max_cur ^ 1];
+    f.hist_out = b->hist[(b->hist_cur + 1) % gnuais_batch::HB];
+    f.maxval_next = b->maxval[(b->max_cur + 2) % gnuais_batch::HB];
     f.d_taps = b->d_taps;
     memcpy(f.te, b->te, sizeof f.te);
     f.N = b->N;
@@ -667,9 +704,9 @@ static int run_fir(gnuais_batch *b, const int16_t *x, int len, float *dump, hipS
             // waves: 16384 x 192000 is 32000 segments of 1536) halve its share
             f.T = ((f.NC == 48 && b->fir_T <= 768 ? 1536 : b->fir_T) + qp - 1) / qp * qp;
             HIP_TRY(launch_fir_sign_pk(f, s));
-            b->hist_cur ^= 1;
+            b->hist_cur = (b->hist_cur + 1) % gnuais_batch::HB;
             b->max_last = b->max_cur;
-            b->max_cur ^= 1;
+            b->max_cur = (b->max_cur + 1) % gnuais_batch::HB;
             return GNUAIS_OK;
         }
         const int cpl = (f.NC == 12 && f.NE == 32 && b->fir_cpl > 1 && b->N % b->fir_cpl == 0 &&
@@ -688,9 +725,9 @@ static int run_fir(gnuais_batch *b, const int16_t *x, int len, float *dump, hipS
         if (cpl > 1) HIP_TRY(launch_fir_sign_wide(f, cpl, b->fir_form, s));
         else HIP_TRY(launch_fir_sign(f, s));
     } else if (b->NE != 32) {
-        HIP_TRY(hipMemsetAsync(b->maxval[b->max_cur ^ 1], 0, sizeof(int) * (size_t) b->N, s));
+        HIP_TRY(hipMemsetAsync(b->maxval[(b->max_cur + 2) % gnuais_batch::HB], 0, sizeof(int) * (size_t) b->N, s));
         HIP_TRY(launch_fir_generic(f, s));
-        HIP_TRY(launch_fir_history(x, b->hist[b->hist_cur], b->hist[b->hist_cur ^ 1], b->N, len,
+        HIP_TRY(launch_fir_history(x, b->hist[b->hist_cur], b->hist[(b->hist_cur + 1) % gnuais_batch::HB], b->N, len,
                                    b->NT, s));
     } else if (b->fir_variant == 1) {
         HIP_TRY(packed::launch_fir_slice(f, s));
@@ -699,9 +736,9 @@ static int run_fir(gnuais_batch *b, const int16_t *x, int len, float *dump, hipS
     } else {
         HIP_TRY(scalar::launch_fir_slice(f, s));
     }
-    b->hist_cur ^= 1;
+    b->hist_cur = (b->hist_cur + 1) % gnuais_batch::HB;
     b->max_last = b->max_cur;
-    b->max_cur ^= 1;
+    b->max_cur = (b->max_cur + 1) % gnuais_batch::HB;
     return GNUAIS_OK;
 }
 
@@ -729,7 +766,7 @@ static int run_tail(gnuais_batch *b, int k, int len, bool tm, hipEvent_t *ev,
     // reused after cand_K frame starts, which one call cannot exceed but two could
     if (pl && after) HIP_TRY(hipStreamWaitEvent(sC, after, 0));
     if (pl && b->calls >= (unsigned) b->k2b_lag)
-        HIP_TRY(hipStreamWaitEvent(sC, b->e_done[4][(k + gnuais_batch::NBUF - b->k2b_lag) % gnuais_batch::NBUF], 0));
+        HIP_TRY(hipStreamWaitEvent(sC, b->e_done[4][(k + b->nbuf - b->k2b_lag) % b->nbuf], 0));
     if (tm) HIP_TRY(hipEventRecord(ev[5], sC));
     if (b->stage_mask & 8) HIP_TRY(b->hdlc_variant ? launch_hdlc_events(h, sC) : launch_hdlc_deframe(h, sC));
     if (tm) HIP_TRY(hipEventRecord(ev[7], sC));
@@ -752,31 +789,66 @@ int gnuais_batch_run(gnuais_batch *b, const int16_t *d_samples, int len, void *s
     if (int rc = set_device(b)) return rc;
     hipStream_t s0 = (hipStream_t) stream;
     const bool pl = b->pipeline;
-    const int k = (int) (b->calls % gnuais_batch::NBUF);      // hand-off buffer set of this call
-    const bool reuse = pl && b->calls >= (unsigned) gnuais_batch::NBUF;   // set k last used by call i-NBUF
+    const int k = (int) (b->calls % (unsigned) b->nbuf);      // hand-off buffer set of this call
+    const bool reuse = pl && b->calls >= (unsigned) b->nbuf;  // set k last used by call i-nbuf
     const bool tm = b->timing && (b->calls % (unsigned) b->timing_stride) == 0;
     hipEvent_t *ev = b->evr[b->timed_calls % gnuais_batch::TIMING_RING];
 
     {
         hipStream_t sA = pl ? b->s_k[0] : s0;
-        // Hand-off set k was last used by call i-NBUF.  Its last user is that call's K3; wait for
+        // Cold start.  A call that finds the pipeline empty has its PLL stage ready when its FIR launch ends, but the
+        // next call's FIR launch is queued right behind and its 24 000 workgroups are dispatched first: the PLL stage
+        // then starts a whole FIR launch late (profiles/r03_region_timeline_20steps.txt: ready at 438 us, started at
+        // 848), and everything behind it with it.  So the launch that follows a cold call is held back on the host until
+        // the cold call's FIR has ended (+ cold_hold_us); it would have started ~50 us after that anyway.
+        if (pl && b->cold_hold_us >= 0 && b->calls > 0 && b->calls == b->cold_call + 1) {
+            HIP_TRY(hipEventSynchronize(b->e_done[0][b->last_k]));
+            if (b->cold_hold_us > 0) {
+                const double until = now_ms() + b->cold_hold_us * 1e-3;
+                while (now_ms() < until) {}
+            }
+        }
+        if (pl && b->cold_hold_us >= 0 &&
+            (b->calls == 0 || hipEventQuery(b->e_done[4][b->last_k]) == hipSuccess))
+            b->cold_call = b->calls;            // nothing of an earlier call is left on the device
+        // Hand-off set k was last used by call i-nbuf.  Its last user is that call's K3; wait for
         // it on the HOST (normally long done): five stream-wait packets per call, each ~20 us of
         // queue time on the stream it sits in, for a condition that is practically always true.
-        // A caller that runs more than NBUF-1 calls ahead of the device blocks here.
+        // A caller that runs more than nbuf-1 calls ahead of the device blocks here.
         if (reuse) HIP_TRY(hipEventSynchronize(b->e_done[4][k]));
         // K1 carries the FIR history and the peak buffers from call to call in stream order: a caller
         // that changes streams between calls gets the old stream drained first
         if (b->calls > 0 && s0 != b->last_stream) HIP_TRY(hipStreamSynchronize(b->last_stream));
-        if (tm) HIP_TRY(hipEventRecord(ev[0], s0));
+        // fir_streams = 2: the FIR launches alternate between the caller's stream and an internal one.  The launch on
+        // the internal stream starts once the caller's stream has reached this call (its input is there); the caller's
+        // stream waits for it to end (the caller may reuse the input after the call, in stream order).  Launch i needs
+        // of launch i-1 only the carry, which a small kernel in front of launch i-1 has written (e_hist).
+        const bool two = pl && b->fir_streams == 2 && b->fir_variant == 3 && b->sign_ok && (b->stage_mask & 1);
+        const int q = two ? (int) (b->calls & 1) : 0;
+        hipStream_t sF = s0;
+        if (two) {
+            if (!b->s_fir2) HIP_TRY(hipStreamCreateWithFlags(&b->s_fir2, hipStreamNonBlocking));
+            if (q) {
+                sF = b->s_fir2;
+                HIP_TRY(hipEventRecord(b->e_order, s0));
+                HIP_TRY(hipStreamWaitEvent(sF, b->e_order, 0));
+            }
+            if (b->calls > 0) HIP_TRY(hipStreamWaitEvent(sF, b->e_hist[q ^ 1], 0));
+            HIP_TRY(launch_fir_history(d_samples, b->hist[b->hist_cur], b->hist[(b->hist_cur + 1) % gnuais_batch::HB],
+                                       b->N, len, b->NT, sF));
+            HIP_TRY(hipEventRecord(b->e_hist[q], sF));
+        }
+        if (tm) HIP_TRY(hipEventRecord(ev[0], sF));
         if (b->stage_mask & 1)
-            if (int rc = run_fir(b, d_samples, len, nullptr, s0, k)) return rc;
-        if (tm) HIP_TRY(hipEventRecord(ev[1], s0));
+            if (int rc = run_fir(b, d_samples, len, nullptr, sF, k)) return rc;
+        if (tm) HIP_TRY(hipEventRecord(ev[1], sF));
         if (b->e_in_hook) {                     // run_host_async: its staging pair is free once K1 has read it --
-            HIP_TRY(hipEventRecord(b->e_in_hook, s0));      // also when the whole chain runs on this one stream
+            HIP_TRY(hipEventRecord(b->e_in_hook, sF));      // also when the whole chain runs on this one stream
             b->e_in_hook = nullptr;
         }
-        if (pl) HIP_TRY(hipEventRecord(b->e_done[0][k], s0));
-        // K2: this call's sign words -> bit packs segbits[k] (read by K2b of call i-NBUF); in order
+        if (pl) HIP_TRY(hipEventRecord(b->e_done[0][k], sF));
+        if (two && q) HIP_TRY(hipStreamWaitEvent(s0, b->e_done[0][k], 0));
+        // K2: this call's sign words -> bit packs segbits[k] (read by K2b of call i-nbuf); in order
         // across calls (it carries the receivers' pll / prev / lastbit)
         PllLaunch p;
         fill_pll(b, p, k, len);
@@ -891,6 +963,7 @@ int gnuais_batch_sync(gnuais_batch *b)
     if (!b) return fail(GNUAIS_E_ARG, "sync: NULL batch");
     if (int rc = set_device(b)) return rc;
     HIP_TRY(hipStreamSynchronize(b->last_stream));
+    if (b->s_fir2) HIP_TRY(hipStreamSynchronize(b->s_fir2));
     for (auto &st : b->s_k) HIP_TRY(hipStreamSynchronize(st));
     return GNUAIS_OK;
 }
@@ -1037,7 +1110,7 @@ int gnuais_batch_filter(gnuais_batch *b, const int16_t *d_samples, int len, floa
     if (int rc = set_device(b)) return rc;
     hipStream_t s = (hipStream_t) stream;
     if (int rc = gnuais_batch_sync(b)) return rc;       // the sign-word scratch is shared
-    if (int rc = run_fir(b, d_samples, len, d_out, s, (int) (b->calls % gnuais_batch::NBUF))) return rc;
+    if (int rc = run_fir(b, d_samples, len, d_out, s, (int) (b->calls % (unsigned) b->nbuf))) return rc;
     b->last_stream = s;
     b->timed_last = false;
     return GNUAIS_OK;

@@ -489,7 +489,8 @@ static int frame_cmp(const void *a, const void *b)
  * (ais.c:237-247 calls receiver_run per channel) */
 void ais_oracle_sort_frames(ais_oracle *o)
 {
-	qsort(o->frames, o->n_frames, sizeof(ais_frame), frame_cmp);
+	if (o->n_frames > 1)
+		qsort(o->frames, o->n_frames, sizeof(ais_frame), frame_cmp);
 }
 
 void ais_oracle_get_pll(const ais_oracle *o, int ch, uint32_t *pll, int *prev, int *lastbit)
