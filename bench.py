@@ -36,7 +36,9 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.3 TB/s measured)
-TIMING_STRIDE = 4              # per-kernel events on every 4th call of the timed region
+TIMING_STRIDE = 4              # per-kernel events on every 4th call of the timed region (the records cost stream time)
+KERNEL_LEG_CALLS = 120         # the leg behind the timed region that `kernel_ms` comes from: events on every 2nd of
+KERNEL_LEG_STRIDE = 2          # these calls = 60 samples per kernel (the library's event ring holds 64 calls)
 
 CONFIGS = {
     # stage_mask: bit 0 FIR/slicer, bit 1 PLL + NRZI, bit 3 HDLC deframer, bit 4 CRC + delivery
@@ -91,7 +93,7 @@ def cpu_baseline(x_host, n_sample_ch, total, x_wide=None):
         dt = time.perf_counter() - t
         got = int(o.counters()[:, 0].sum())
         kind = "port"
-    res = {"value": n_sample_ch * total / dt / 1e6, "unit": "Msamples/s", "cores": 1,
+    res = {"value": n_sample_ch * total / dt / 1e6, "unit": "Msamples/s", "cores": 1, "cpu": cpu_model(),
            "kind": kind, "sample": sample, "seconds": round(dt, 2), "msgs": int(got)}
     # context: the same work on every host core (the reference itself is single-threaded by
     # design; this is the C restatement with channels partitioned over pthreads)
@@ -163,7 +165,8 @@ class DistSync:
         return (t, m, s, ranks) if self.rank == 0 else None
 
 
-def measure(cfg, args, local, rank, sync, steps, warmup, isolated=True, post=False, keep_input=False):
+def measure(cfg, args, local, rank, sync, steps, warmup, isolated=True, post=False, keep_input=False, kernel_leg=True,
+            options=None):
     """One workload on this rank's GPU.  Returns a dict of raw measurements."""
     import torch
     from gnuais_amd import ReceiverBatch, params, synth, tile_channels
@@ -187,6 +190,8 @@ def measure(cfg, args, local, rank, sync, steps, warmup, isolated=True, post=Fal
     # part of the pipeline's speed; the library measures it on this input.
     b.autotune(x, stream)
     b.set_option("stage_mask", cfg["stage_mask"])
+    for k_, v_ in (options or {}).items():
+        b.set_option(k_, v_)
     for _ in range(warmup):
         step()
     torch.cuda.synchronize()
@@ -222,8 +227,32 @@ def measure(cfg, args, local, rank, sync, steps, warmup, isolated=True, post=Fal
     b.set_timing(False)
     b.set_option("timing_stride", 1)
     out = {"n_ch": n_ch, "len": total, "dt": dt, "dt_own": dt_own, "steps": steps, "msgs": float(rx1 - rx0),
-           "kernel_ms": {k: float(live[k]) for k in b.KERNELS}, "kernel_ms_isolated": iso,
-           "kernel_ms_calls": int(live["calls"])}
+           "kernel_ms_timed_region": {k: float(live[k]) for k in b.KERNELS}, "kernel_ms_isolated": iso,
+           "kernel_ms_timed_region_calls": int(live["calls"])}
+    # `kernel_ms`: the same loop again, long enough for a stable mean -- a 20-step region sampled on every 4th call gives
+    # five samples per kernel, and which of two stages of nearly equal length "dominates" then flips from run to run
+    leg = max(KERNEL_LEG_CALLS, 0) if kernel_leg else 0
+    if leg:
+        b.set_timing(True)
+        b.set_option("timing_stride", KERNEL_LEG_STRIDE)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(leg):
+            step()
+        torch.cuda.synchronize()
+        t_leg = time.perf_counter() - t0
+        live2 = b.mean_timing()
+        b.set_timing(False)
+        b.set_option("timing_stride", 1)
+        out["kernel_ms"] = {k: float(live2[k]) for k in b.KERNELS}
+        out["kernel_ms_calls"] = int(live2["calls"])
+        out["kernel_ms_leg"] = {"calls": leg, "events_on_every": KERNEL_LEG_STRIDE, "ms_per_step": t_leg / leg * 1e3,
+                                "what": "the timed loop continued for %d calls with the library's per-kernel HIP events on "
+                                        "every %d-th call (each kernel on the stream it is launched on); kernel_ms is the mean "
+                                        "over the sampled calls" % (leg, KERNEL_LEG_STRIDE)}
+    else:
+        out["kernel_ms"] = out["kernel_ms_timed_region"]
+        out["kernel_ms_calls"] = out["kernel_ms_timed_region_calls"]
     if post and steps < 100:
         # beside a short timed region (the driver's 20 steps carry one fill and one drain of the stage pipeline:
         # a call is about 1.5 ms from its first kernel to its last): the same loop over 200 steps
@@ -325,19 +354,25 @@ def measure(cfg, args, local, rank, sync, steps, warmup, isolated=True, post=Fal
 MEASURED_HBM_GBS = 6290.0      # MI355X_MICROARCH.md: float4 copy, 79 % of the 8 TB/s spec
 
 
-def roofline_of(m, ms_per_step=None, traffic=None):
+def roofline_of(m, ms_per_step=None, traffic=None, n_taps=36):
     """`roofline` of the bench line.  The unit of work is one input sample = 2 algorithmic bytes, a call
     is N x L of them, and every kernel of the chain works on the same call; `achieved` divides the call's
-    algorithmic bytes by the mean duration of the kernel that takes LONGEST inside the timed region (HIP events on
+    algorithmic bytes by the mean duration of the kernel that takes LONGEST inside the pipelined loop (HIP events on
     that kernel's own stream) -- the stage that sets the pipeline's period.  `chain` is the same bytes over the
-    driver-visible ms_per_step, `fir` the kernel that actually moves 98 % of them."""
+    driver-visible ms_per_step, `fir` the kernel that actually moves 98 % of them.  `bound` says what binds that
+    kernel: north_star asks for the HBM fraction (achieved / peak / frac are always that), but SURVEY 8d / BASELINE.md 3
+    also ask which bound binds -- "valu" when the kernel's VALU issue floor (PMC) exceeds the time HBM needs for its
+    bytes and fills most of the launch, "hbm" when that time does, "latency" when neither comes near the launch's
+    duration (the per-channel recurrences: one wave per 16-64 channels, serial through the call)."""
     alg = m["n_ch"] * m["len"] * 2.0
     km = {k: v for k, v in m["kernel_ms"].items() if v and v > 0}
     dom = max(km, key=km.get)
     ach = alg / (km[dom] * 1e-3) / 1e9
     r = {"bound": "hbm", "kernel": dom, "kernel_ms": km[dom], "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
          "frac": ach / HBM_PEAK_GBS, "traffic": None, "algorithmic_bytes_per_launch": alg,
-         "why_this_kernel": "largest mean duration of the chain's kernels in the timed region (all of them process "
+         "algorithmic_flops_per_launch": m["n_ch"] * m["len"] * 2.0 * n_taps,
+         "kernel_ms_samples": m.get("kernel_ms_calls"),
+         "why_this_kernel": "largest mean duration of the chain's kernels in the pipelined loop (all of them process "
                             "the same N x L samples per launch)"}
     if "fir_slice" in km:
         f = alg / (km["fir_slice"] * 1e-3) / 1e9
@@ -350,16 +385,67 @@ def roofline_of(m, ms_per_step=None, traffic=None):
         r["chain"] = {"achieved": c, "frac": c / HBM_PEAK_GBS, "frac_of_measured_peak": c / MEASURED_HBM_GBS,
                       "measured_peak": MEASURED_HBM_GBS, "ms_per_step": ms_per_step,
                       "what": "N*L*2 bytes / ms_per_step of this line (whole chain, as the driver clocks it)"}
-    if traffic:
+    if traffic and not traffic.get("error"):
         r["traffic"] = traffic.get("chain_bytes_per_call")
+        r["traffic_detail"] = {k: v for k, v in traffic.items() if k != "valu"}
+        valu = traffic.get("valu") or {}
+        wave_samples = m["n_ch"] * m["len"] / 64.0
+        per = {}
+        for k, v in valu.items():
+            hbm_ms = (traffic["bytes_per_launch"].get(k, 0.0)) / (HBM_PEAK_GBS * 1e9) * 1e3
+            in_pipe = km.get(k)
+            if v["issue_floor_ms"] >= hbm_ms and in_pipe and v["issue_floor_ms"] >= 0.5 * v["launch_ms_in_this_pass"]:
+                bound = "valu"
+            elif in_pipe and hbm_ms >= 0.5 * v["launch_ms_in_this_pass"]:
+                bound = "hbm"
+            else:
+                bound = "latency"
+            per[k] = dict(v, insts_per_sample=(v["insts_per_launch"] / wave_samples) if v.get("insts_per_launch") else None,
+                          hbm_ms_for_its_traffic=hbm_ms, bound=bound)
+        if per:
+            r["valu"] = dict(per.get(dom, {}), kernel=dom) if dom in per else None
+            r["valu_by_kernel"] = per
+            chain_floor = sum(v["issue_floor_ms"] for v in per.values())
+            r["valu_chain"] = {"issue_floor_ms": chain_floor, "hbm_ms_for_algorithmic_bytes": alg / (HBM_PEAK_GBS * 1e9) * 1e3,
+                               "what": "sum of the chain's kernels' VALU issue floors (they share the chip's 1024 SIMDs in "
+                                       "the pipelined loop) against the time 8 TB/s needs for the call's algorithmic bytes"}
+            r["bound"] = per[dom]["bound"] if dom in per else r["bound"]
+            if r["bound"] == "latency":
+                r["latency_note"] = ("a per-channel recurrence: one wave per 16-64 channels walks the call serially "
+                                     "(receiver.c:113-134 / protodec.c:988-1122); the PLL's row costs ~46 clock ticks per "
+                                     "transition on its wave (profiles/r03_ubench_pll_step6.txt), ~14 000 steps per call "
+                                     "for the noisiest lane of a wave")
+            r["bound_why"] = ("%s: VALU issue floor %.3f ms, HBM time for its own traffic %.3f ms, launch alone %.3f ms, "
+                              "in the pipeline %.3f ms; the chain as a whole: VALU floor %.3f ms against %.3f ms of HBM time"
+                              % (dom, per[dom]["issue_floor_ms"], per[dom]["hbm_ms_for_its_traffic"],
+                                 per[dom]["launch_ms_in_this_pass"], km[dom], chain_floor,
+                                 alg / (HBM_PEAK_GBS * 1e9) * 1e3)) if dom in per else None
+    elif traffic:
         r["traffic_detail"] = traffic
     return r
 
 
+N_SIMD = 1024                  # 256 CUs x 4 SIMDs (MI355X_MICROARCH.md)
+SPEC_CLOCK_HZ = 2.4e9          # max engine clock; the PMC pass reports the clock it saw when GRBM_GUI_ACTIVE is readable
+
+
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except Exception:
+        pass
+    return "unknown"
+
+
 def pmc_traffic(args, config):
-    """HBM bytes per launch from the PMC counters, as MI355X_MICROARCH.md's HBM section prescribes: two separate
-    rocprofv3 passes (--pmc FETCH_SIZE, --pmc WRITE_SIZE, with --kernel-trace only) over a 6-step child run of this
-    same script; both counters are in KiB, FETCH_SIZE is doubled (gfx950 tallies 128-byte requests at 64 bytes)."""
+    """PMC counters per launch, collected as MI355X_MICROARCH.md's HBM / rocprofv3 section prescribes: separate
+    rocprofv3 passes with --kernel-trace only, each over a 6-step child run of this same script.
+      * HBM bytes: --pmc FETCH_SIZE and --pmc WRITE_SIZE (KiB; FETCH_SIZE doubled: gfx950 tallies 128-byte requests at 64);
+      * VALU issue: --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_WAVES (+ GRBM_GUI_ACTIVE for the clock):
+        wave-instructions per launch, the quad-cycles the VALU was issuing, and from them the kernel's issue floor
+        = SQ_ACTIVE_INST_VALU x 4 cycles / (1024 SIMDs x clock) and the share of the launch it fills."""
     import csv
     import shutil
     import subprocess
@@ -368,7 +454,7 @@ def pmc_traffic(args, config):
     if not os.path.exists(exe):
         return {"error": "rocprofv3 not found"}
     child = [sys.executable, os.path.join(ROOT, "bench.py"), "--config", config, "--no-cpu", "--no-others", "--no-e2e",
-             "--no-traffic", "--steps", "6", "--warmup", "1", "--base", str(args.base)]
+             "--no-traffic", "--no-kernel-leg", "--steps", "6", "--warmup", "1", "--base", str(args.base)]
     short = (("fir_sign", "fir_slice"), ("fir_slice_generic", "fir_slice"), ("fir_slice", "fir_slice"), ("pll3_kernel", "pll"), ("pll_kernel", "pll"),
              ("hdlc_events", "hdlc_deframe"), ("hdlc_deframe", "hdlc_deframe"), ("hdlc_crc", "hdlc_crc"))
     env = dict(os.environ, TMPDIR="/tmp")
@@ -376,36 +462,70 @@ def pmc_traffic(args, config):
         env.pop(k, None)
     res, raw = {}, {}
     tmp = tempfile.mkdtemp(prefix="gnuais_pmc_", dir="/tmp")
+
+    def one_pass(tag, counters):
+        """-> ({kernel: {counter: mean per launch}}, {kernel: mean duration of a launch in this pass, ms}) or None"""
+        d = os.path.join(tmp, tag)
+        cmd = [exe, "--kernel-trace", "--pmc"] + counters + ["--output-format", "csv", "-d", d, "-o", "pmc", "--"] + child
+        try:
+            subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL,
+                           timeout=420, check=False)
+        except subprocess.TimeoutExpired:
+            return None
+        acc, dur = {}, {}
+        for dp, _, fs in os.walk(d):
+            for f in fs:
+                if not f.endswith("counter_collection.csv"):
+                    continue
+                with open(os.path.join(dp, f)) as fh:
+                    for row in csv.DictReader(fh):
+                        name = next((s_ for pat, s_ in short if pat in row["Kernel_Name"]), None)
+                        if not name:
+                            continue
+                        acc.setdefault(name, {}).setdefault(row["Counter_Name"], []).append(float(row["Counter_Value"]))
+                        try:
+                            dur.setdefault(name, {})[row["Dispatch_Id"]] = (int(row["End_Timestamp"]) - int(row["Start_Timestamp"])) / 1e6
+                        except (KeyError, ValueError):
+                            pass
+        if not acc:
+            return None
+        return ({k: {c: sum(v) / len(v) for c, v in cs.items()} for k, cs in acc.items()},
+                {k: sum(v.values()) / len(v) for k, v in dur.items() if v})
+
     try:
         for counter in ("FETCH_SIZE", "WRITE_SIZE"):
-            d = os.path.join(tmp, counter)
-            cmd = [exe, "--kernel-trace", "--pmc", counter, "--output-format", "csv", "-d", d, "-o", "pmc", "--"] + child
-            try:
-                subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL,
-                               timeout=240, check=False)
-            except subprocess.TimeoutExpired:
-                return {"error": f"rocprofv3 --pmc {counter} timed out"}
-            acc = {}
-            for dp, _, fs in os.walk(d):
-                for f in fs:
-                    if not f.endswith("counter_collection.csv"):
-                        continue
-                    with open(os.path.join(dp, f)) as fh:
-                        for row in csv.DictReader(fh):
-                            name = next((s_ for pat, s_ in short if pat in row["Kernel_Name"]), None)
-                            if name and row["Counter_Name"] == counter:
-                                acc.setdefault(name, []).append(float(row["Counter_Value"]))
-            if not acc:
+            got = one_pass(counter, [counter])
+            if not got:
                 return {"error": f"no {counter} rows in the rocprofv3 output"}
-            raw[counter] = {k: sum(v) / len(v) for k, v in acc.items()}
+            raw[counter] = {k: v.get(counter, 0.0) for k, v in got[0].items()}
         for k in raw["FETCH_SIZE"]:
             res[k] = (2.0 * raw["FETCH_SIZE"][k] + raw["WRITE_SIZE"].get(k, 0.0)) * 1024.0
+        valu = None
+        sq = ["SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "SQ_WAVE_CYCLES", "SQ_WAVES"]
+        got = one_pass("SQ", sq + ["GRBM_GUI_ACTIVE"]) or one_pass("SQ2", sq)
+        if got:
+            valu = {}
+            for k, c in got[0].items():
+                ms = got[1].get(k)
+                if not ms or "SQ_ACTIVE_INST_VALU" not in c:
+                    continue
+                clock = SPEC_CLOCK_HZ
+                if c.get("GRBM_GUI_ACTIVE"):
+                    clock = c["GRBM_GUI_ACTIVE"] / 8.0 / (ms * 1e-3)         # the counter sums the 8 XCDs
+                floor_ms = c["SQ_ACTIVE_INST_VALU"] * 4.0 / (N_SIMD * clock) * 1e3
+                valu[k] = {"insts_per_launch": c.get("SQ_INSTS_VALU"), "active_quad_cycles": c["SQ_ACTIVE_INST_VALU"],
+                           "waves": c.get("SQ_WAVES"), "launch_ms_in_this_pass": ms, "clock_ghz": clock / 1e9,
+                           "clock_from": "GRBM_GUI_ACTIVE / 8 XCDs / duration" if c.get("GRBM_GUI_ACTIVE") else "spec",
+                           "issue_floor_ms": floor_ms, "busy_frac": floor_ms / ms,
+                           "valu_share_of_wave_cycles": (c["SQ_ACTIVE_INST_VALU"] / c["SQ_WAVE_CYCLES"]) if c.get("SQ_WAVE_CYCLES") else None}
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
-    return {"bytes_per_launch": res, "chain_bytes_per_call": sum(res.values()), "raw_kib_per_launch": raw,
-            "how": "rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE (separate passes) -- python bench.py --config "
-                   + config + " --no-cpu --no-others --no-e2e --no-traffic --steps 6 --warmup 1, launched by this run; "
-                   "KiB; FETCH_SIZE x 2 (gfx950 correction of MI355X_MICROARCH.md)"}
+    return {"bytes_per_launch": res, "chain_bytes_per_call": sum(res.values()), "raw_kib_per_launch": raw, "valu": valu,
+            "how": "rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE | SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES "
+                   "SQ_WAVES GRBM_GUI_ACTIVE (three separate passes) -- python bench.py --config " + config +
+                   " --no-cpu --no-others --no-e2e --no-traffic --no-kernel-leg --steps 6 --warmup 1, launched by this run; "
+                   "sizes in KiB, FETCH_SIZE x 2 (gfx950 correction of MI355X_MICROARCH.md); issue_floor_ms = "
+                   "SQ_ACTIVE_INST_VALU x 4 cycles / (1024 SIMDs x clock); launches run one at a time under the profiler"}
 
 
 def float_path(args, local, shapes=(("C2", 256, 48000), ("C3", 16384, 48000))):
@@ -454,7 +574,8 @@ def rank_main(rank, local, world, args, sync):
     if args.len:
         cfg = dict(cfg, len=args.len)
     want_cpu = rank == 0 and world == 1 and args.cpu and args.config == "C3"
-    m = measure(cfg, args, local, rank, sync, args.steps, args.warmup, post=(rank == 0), keep_input=want_cpu)
+    m = measure(cfg, args, local, rank, sync, args.steps, args.warmup, post=(rank == 0), keep_input=want_cpu,
+                kernel_leg=args.kernel_leg)
     x_cpu, x_wide = m.pop("x_cpu", None), m.pop("x_wide", None)
     per_rank = {"rank": rank, "device": local, "ms_per_step": m["dt_own"] / m["steps"] * 1e3}
     red = sync.reduce(m["dt"], m["msgs"], float(m["n_ch"]) * m["len"] * m["steps"], per_rank)
@@ -474,21 +595,37 @@ def rank_main(rank, local, world, args, sync):
         "valid_crc_msgs_per_s": msgs / dt,
         "x_realtime_channels": value / (cfg["rate"] / 1e6),
         "kernel_ms": m["kernel_ms"], "kernel_ms_isolated": m["kernel_ms_isolated"],
-        "kernel_ms_calls": m["kernel_ms_calls"],
+        "kernel_ms_calls": m["kernel_ms_calls"], "kernel_ms_leg": m.get("kernel_ms_leg"),
+        "kernel_ms_timed_region": m.get("kernel_ms_timed_region"),
         "per_gpu": ranks,
         "end_to_end": m.get("end_to_end"),
         "message_lines": m.get("message_lines"),
         "roofline": roofline_of(m, dt / args.steps * 1e3,
-                                pmc_traffic(args, args.config) if (world == 1 and args.traffic) else None),
+                                pmc_traffic(args, args.config) if (world == 1 and args.traffic) else None,
+                                n_taps=144 if cfg["wide"] else 36),
         "float_path": float_path(args, local) if (world == 1 and args.e2e and args.config == "C3") else None,
         "steady_state": m.get("steady_state"),
         "note": "the receive path slices the sign of the filter output and never stores the pre-slicer "
                 "floats; gnuais_batch_filter() produces them (bit-exact, tests/test_hip_parity.py)",
     }
     if world == 1 and args.others and args.config == "C3" and not args.channels and not args.len:
+        # the same chain with the EXACT FIR in it (fir_slice_kernel: the reference's ordered 36-tap fp32 sum formed for
+        # every sample, then `out > 0`) instead of the sign-certified slicer the receive path runs by default: same
+        # bits, frames and counters (checked here on the message count), the floats' cost made visible
+        e = measure(cfg, args, local, rank, sync, args.steps, args.warmup, isolated=False, kernel_leg=False,
+                    options={"fir_variant": 0})
+        ems = e["dt"] / e["steps"] * 1e3
+        out["exact_chain"] = {
+            "what": "full chain with fir_variant = 0: K1 forms the reference's exact ordered fp32 sum for every sample "
+                    "(fir_slice_kernel) instead of certifying its sign (K1s); everything downstream unchanged",
+            "steps": e["steps"], "ms_per_step": ems, "Msamples_per_s": e["n_ch"] * e["len"] * e["steps"] / e["dt"] / 1e6,
+            "frac_of_hbm_peak": e["n_ch"] * e["len"] * 2.0 / (ems * 1e-3) / 1e9 / HBM_PEAK_GBS,
+            "kernel_ms_timed_region": e["kernel_ms_timed_region"],
+            "valid_crc_msgs": e["msgs"], "same_msgs_as_the_default_chain": e["msgs"] == m["msgs"]}
         others = {}
         for name in ("C2", "C5"):
-            o = measure(CONFIGS[name], args, local, rank, sync, *((60, 10) if name == "C2" else (20, 4)))
+            o = measure(CONFIGS[name], args, local, rank, sync, *((60, 10) if name == "C2" else (20, 4)),
+                        kernel_leg=args.kernel_leg)
             v = o["n_ch"] * o["len"] * o["steps"] / o["dt"] / 1e6
             others[name] = {"workload": CONFIGS[name]["what"], "value": v, "unit": "Msamples/s",
                             "ms_per_step": o["dt"] / o["steps"] * 1e3, "steps": o["steps"],
@@ -496,7 +633,9 @@ def rank_main(rank, local, world, args, sync):
                             "x_realtime_channels": v / (CONFIGS[name]["rate"] / 1e6),
                             "kernel_ms": o["kernel_ms"], "kernel_ms_isolated": o["kernel_ms_isolated"],
                             "dominant_kernel": max(o["kernel_ms"], key=o["kernel_ms"].get),
-                            "roofline": roofline_of(o, o["dt"] / o["steps"] * 1e3)}
+                            "roofline": roofline_of(o, o["dt"] / o["steps"] * 1e3,
+                                                    pmc_traffic(args, name) if args.traffic else None,
+                                                    n_taps=144 if CONFIGS[name]["wide"] else 36)}
         out["other_configs"] = others
     if x_cpu is not None:
         out["cpu_baseline"] = cpu_baseline(x_cpu, args.cpu_channels, m["len"], x_wide)
@@ -538,6 +677,7 @@ def node_main(world, args):
     rx0 = node.total_received()
     for d in set(devs):
         torch.cuda.synchronize(d)
+    node.mark()                     # per-shard bookkeeping inside the library: a slow device must show by itself
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
@@ -545,6 +685,7 @@ def node_main(world, args):
     for d in set(devs):
         torch.cuda.synchronize(d)
     dt = time.perf_counter() - t0
+    stats = node.shard_stats()
     msgs = node.total_received() - rx0
     samples = float(per) * world * total * args.steps
     value = samples / dt / 1e6
@@ -558,12 +699,24 @@ def node_main(world, args):
                       "parallelism": f"channels in {world} contiguous blocks over device(s) {devs}, one process, one host "
                                      "thread + batch per device (gnuais_node_*), no collectives"},
            "valid_crc_msgs_per_s": msgs / dt, "x_realtime_channels": value / (cfg["rate"] / 1e6),
-           "per_gpu": [{"shard": g, "device": d, "first_channel": f, "channels": n} for g, (d, f, n) in enumerate(node.shards)],
+           "per_gpu": [{"shard": g, "device": st["device"], "pci": st["pci"], "numa_node": st["numa_node"],
+                        "host_thread_pinned_to_cpus": st["pinned_cpus"], "first_channel": st["first_channel"],
+                        "channels": st["n_channels"], "calls": st["calls"],
+                        "ms_per_step": st["busy_ms"] / max(1, st["calls"]),
+                        "host_submit_ms_per_step": st["submit_ms"] / max(1, st["calls"])}
+                       for g, st in enumerate(stats)],
+           "per_gpu_what": "per shard, measured inside the library (gnuais_node_mark / gnuais_node_shard_stats): "
+                           "ms_per_step = from the shard's first submission of the timed region to the end of its own sync, "
+                           "over its calls; host_submit = time its host thread spent inside the run calls",
            "roofline": {"bound": "hbm", "kernel": "chain (all devices)", "achieved": c, "peak": HBM_PEAK_GBS * len(set(devs)),
                         "unit": "GB/s", "frac": c / (HBM_PEAK_GBS * len(set(devs))), "traffic": None,
                         "algorithmic_bytes_per_launch": alg,
                         "what": "N*L*2 bytes of all shards / ms_per_step against 8 TB/s per distinct device; per-kernel "
                                 "figures come from the single-GPU line"}}
+    if args.cpu:
+        # the reference's own code on this host beside it (a bounded sample of shard 0's input; one core)
+        x0 = slabs[0][:, : min(args.cpu_channels, slabs[0].shape[1])].cpu().numpy()
+        out["cpu_baseline"] = cpu_baseline(x0, x0.shape[1], total)
     node.close()
     print(json.dumps(out), flush=True)
 
@@ -589,6 +742,8 @@ def main():
     ap.add_argument("--procs", action="store_true",
                     help="--gpus N as N worker processes (one per device) instead of the in-process node object")
     ap.add_argument("--no-cpu", dest="cpu", action="store_false")
+    ap.add_argument("--no-kernel-leg", dest="kernel_leg", action="store_false",
+                    help="skip the 120-call leg behind the timed region that kernel_ms is averaged over")
     ap.add_argument("--no-traffic", dest="traffic", action="store_false",
                     help="skip the rocprofv3 --pmc child runs that fill roofline.traffic")
     ap.add_argument("--no-e2e", dest="e2e", action="store_false",

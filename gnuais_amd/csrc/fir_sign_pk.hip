@@ -150,9 +150,9 @@ __device__ __forceinline__ void fir_sign_pk_body(
     // The accumulator ring (and, for 48 taps, the odd tap pairs) sits in fixed registers above PK_VGPR_BASE, outside
     // the compiler's budget; everything that touches it is one of the generated instruction streams.
     (void) NP;
-    if constexpr (NC == 12) asm volatile(PK12_ZERO ::: PK12_CLOBBERS);
+    if constexpr (NC == 12) asm volatile(PK12_ZERO);
     else {
-        asm volatile(PK48_ZERO ::: PK48_CLOBBERS);
+        asm volatile(PK48_ZERO);
         pk48_load_o(tp);
     }
     // warm-up: samples i = 0 .. NC-2 (ring phase i + 1); nothing they complete is an output of this segment.  The loads

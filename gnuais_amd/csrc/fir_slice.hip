@@ -1002,25 +1002,27 @@ hipError_t launch_fir_sign(const FirLaunch &a, hipStream_t stream)
     const int map = (a.map == 1 && grid.x % 8 == 0) ? 1 : 0;
     const int gx = (int) grid.x, gy = (int) grid.y;
     if (a.persist > 0 && (long) gx * gy > a.persist) grid = dim3((a.persist + 7) & ~7);   // a multiple of 8: a workgroup's items stay on its XCD
+    // the stamp buffer (a debugging option) is written by workgroup id: a grid it has no room for gets none
+    unsigned long long *const stamps_ok = ((size_t) grid.x * grid.y <= a.stamps_waves) ? a.stamps : nullptr;
     if (a.NC == 12 && a.NE == 32) {
         FirTaps<32> t;
         for (int j = 0; j < 32; ++j) t.te[j] = a.te[j];
         hipLaunchKernelGGL((fir_sign_kernel<32, 12, 32>), grid, block, a.lds_pad, stream, a.x, a.hist, a.sgn, a.maxval,
-                           a.hist_out, a.maxval_next, a.te_mem, a.N, a.L, a.T, a.d, a.NT, a.NE, eps_up, map, t, a.stamps, n_big, T2, a.eps_seen, a.eps_ahead, gx, gy);
+                           a.hist_out, a.maxval_next, a.te_mem, a.N, a.L, a.T, a.d, a.NT, a.NE, eps_up, map, t, stamps_ok, n_big, T2, a.eps_seen, a.eps_ahead, gx, gy);
     } else if (a.NC == 12) {
         FirTaps<12> t;
         for (int j = 0; j < 12; ++j) t.te[j] = a.ctaps[j];
         hipLaunchKernelGGL((fir_sign_kernel<0, 12, 12>), grid, block, 0, stream, a.x, a.hist, a.sgn, a.maxval,
-                           a.hist_out, a.maxval_next, a.te_mem, a.N, a.L, a.T, a.d, a.NT, a.NE, eps_up, map, t, a.stamps, n_big, T2, a.eps_seen, a.eps_ahead, gx, gy);
+                           a.hist_out, a.maxval_next, a.te_mem, a.N, a.L, a.T, a.d, a.NT, a.NE, eps_up, map, t, stamps_ok, n_big, T2, a.eps_seen, a.eps_ahead, gx, gy);
     } else {
         FirTaps<48> t;
         for (int j = 0; j < 48; ++j) t.te[j] = a.ctaps[j];
         if (a.eps_seen > 0.0f && a.NE - a.NC <= 98)
             hipLaunchKernelGGL((fir_sign_kernel<0, 48, 48, true>), grid, block, 0, stream, a.x, a.hist, a.sgn, a.maxval,
-                               a.hist_out, a.maxval_next, a.te_mem, a.N, a.L, a.T, a.d, a.NT, a.NE, eps_up, map, t, a.stamps, n_big, T2, a.eps_seen, a.eps_ahead, gx, gy);
+                               a.hist_out, a.maxval_next, a.te_mem, a.N, a.L, a.T, a.d, a.NT, a.NE, eps_up, map, t, stamps_ok, n_big, T2, a.eps_seen, a.eps_ahead, gx, gy);
         else
         hipLaunchKernelGGL((fir_sign_kernel<0, 48, 48>), grid, block, 0, stream, a.x, a.hist, a.sgn, a.maxval,
-                           a.hist_out, a.maxval_next, a.te_mem, a.N, a.L, a.T, a.d, a.NT, a.NE, eps_up, map, t, a.stamps, n_big, T2, a.eps_seen, a.eps_ahead, gx, gy);
+                           a.hist_out, a.maxval_next, a.te_mem, a.N, a.L, a.T, a.d, a.NT, a.NE, eps_up, map, t, stamps_ok, n_big, T2, a.eps_seen, a.eps_ahead, gx, gy);
     }
     return hipGetLastError();
 }

@@ -612,7 +612,9 @@ int gnuais_batch_set_option(gnuais_batch *b, const char *name, int value)
         b->fir_lds = value;
     } else if (!strcmp(name, "fir_stamps")) {
         if (value && !b->d_stamps) {
-            b->stamps_waves = (size_t) (b->N / 64 + 1) * (size_t) (b->max_len / 128 + 2);
+            // one pair of stamps per workgroup of the largest grid the launcher can make: the shortest segment it
+            // accepts is 64 outputs (fir_T >= 64; the short tail segments fir_T2 are multiples of the same quantum)
+            b->stamps_waves = (size_t) (b->N / 64 + 1) * (size_t) (b->max_len / 64 + 2);
             HIP_TRY(hipMalloc((void **) &b->d_stamps, b->stamps_waves * 16));
             HIP_TRY(hipMemset(b->d_stamps, 0, b->stamps_waves * 16));
         }
@@ -669,6 +671,7 @@ static void fill_fir(const gnuais_batch *b, FirLaunch &f, const int16_t *x, int 
     f.map = b->fir_map;
     f.dbg = b->fir_dbg;
     f.stamps = b->d_stamps;
+    f.stamps_waves = b->stamps_waves;
     f.lds_pad = b->fir_lds;
 }
 

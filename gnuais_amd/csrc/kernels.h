@@ -27,6 +27,7 @@ struct FirLaunch {
     float ctaps[48];       //   te[(NE-NC)/2 .. +NC)
     const float *te_mem;   //   the NE effective taps in device memory (exact re-evaluation)
     unsigned long long *stamps = nullptr;   // experiments: [waves][2] wall-clock start / end of every K1s wave
+    size_t stamps_waves = 0;                //   how many waves the buffer has room for (a larger grid gets no stamps)
     int dbg = 0, lds_pad = 0;   // experiments (fir_sign_wide.hip): elimination switches, LDS claimed per wave to cap the occupancy
     int map;               // K1s workgroup -> (channel group, segment) mapping, see fir_sign_kernel
     int persist = 0;       // K1s: > 0 = launch this many workgroups, each looping over the (group, segment) items

@@ -9,11 +9,18 @@
 //
 // Built on the public batch ABI only (include/gnuais_hip.h); the HIP runtime is used for the host-buffer split
 // (a strided 2-D copy per device) and nothing else.
+#ifndef _GNU_SOURCE
+#define _GNU_SOURCE
+#endif
 #include <hip/hip_runtime.h>
+#include <sched.h>
 #include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
+#include <chrono>
 #include <condition_variable>
 #include <functional>
 #include <mutex>
@@ -24,6 +31,19 @@
 #include "../../include/gnuais_hip.h"
 
 namespace {
+
+thread_local std::string g_node_err;
+
+int node_fail(int code, const std::string &what)
+{
+    g_node_err = what;
+    return code;
+}
+
+double wall_ms()
+{
+    return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
 
 struct Worker {
     std::thread th;
@@ -45,8 +65,11 @@ struct Worker {
                 j = std::move(job);
                 has_job = false;
             }
+            g_node_err.clear();
             const int r = j();
-            std::string e = r != GNUAIS_OK ? std::string(gnuais_last_error()) : std::string();   // thread-local text
+            // the job's own message (node_fail: hipSetDevice, staging, copies) if it left one, else the batch layer's
+            // (both are thread-local and this is the thread the job ran on)
+            std::string e = r == GNUAIS_OK ? std::string() : (!g_node_err.empty() ? g_node_err : std::string(gnuais_last_error()));
             {
                 std::lock_guard<std::mutex> l(m);
                 rc = r;
@@ -81,15 +104,62 @@ struct Shard {
     hipStream_t s_in = nullptr;
     hipEvent_t e_free[2] = {nullptr, nullptr};  // the FIR that read d_in[q] is done (recorded behind the run on s_in)
     unsigned long long host_calls = 0;
+    // where the shard's host thread runs: the NUMA node of its device (sysfs, via the device's PCI address) and how many
+    // CPUs of that node the thread was pinned to (0: not pinned -- no sysfs entry, one node only, or GNUAIS_NODE_PIN=0)
+    int numa_node = -1, pinned_cpus = 0;
+    char pci[32] = {0};
+    // since the last gnuais_node_mark(): calls, the host time spent inside the run calls (submission), and the wall clock
+    // of the first submission and of the end of the shard's last sync -- so that one slow device shows by itself
+    unsigned long long m_calls = 0;
+    double m_submit_ms = 0.0, m_first = 0.0, m_last_sync = 0.0;
     Worker w;
 };
 
-thread_local std::string g_node_err;
-
-int node_fail(int code, const std::string &what)
+// "0-15,32-47" -> CPUs set in `set`; returns how many
+int parse_cpulist(const char *text, cpu_set_t *set)
 {
-    g_node_err = what;
-    return code;
+    int n = 0;
+    CPU_ZERO(set);
+    for (const char *p = text; *p;) {
+        char *e;
+        long a = strtol(p, &e, 10), b = a;
+        if (e == p) break;
+        if (*e == '-') b = strtol(e + 1, &e, 10);
+        for (long c = a; c <= b && c < CPU_SETSIZE; ++c) { CPU_SET((int) c, set); ++n; }
+        p = (*e == ',') ? e + 1 : e;
+        if (*e != ',' ) break;
+    }
+    return n;
+}
+
+// Runs ON the shard's thread, before anything else: pin it to the CPUs of the NUMA node its device hangs off, so that
+// what the thread allocates and touches from here on (the batch's pinned staging buffers, the launch path's queues)
+// is local to that device's root complex.  Every step may fail quietly: the thread then stays where the OS put it.
+void pin_to_device_node(Shard &s)
+{
+    if (hipDeviceGetPCIBusId(s.pci, (int) sizeof s.pci, s.device) != hipSuccess) { s.pci[0] = 0; return; }
+    for (char *c = s.pci; *c; ++c) if (*c >= 'A' && *c <= 'F') *c = (char) (*c - 'A' + 'a');   // sysfs spells it lower case
+    char path[160], buf[4096];
+    snprintf(path, sizeof path, "/sys/bus/pci/devices/%s/numa_node", s.pci);
+    FILE *f = fopen(path, "r");
+    if (!f) return;
+    int node = -1;
+    if (fscanf(f, "%d", &node) != 1) node = -1;
+    fclose(f);
+    s.numa_node = node;
+    const char *off = getenv("GNUAIS_NODE_PIN");
+    if (node < 0 || (off && atoi(off) == 0)) return;
+    snprintf(path, sizeof path, "/sys/devices/system/node/node%d/cpulist", node);
+    f = fopen(path, "r");
+    if (!f) return;
+    const bool ok = fgets(buf, sizeof buf, f) != nullptr;
+    fclose(f);
+    if (!ok) return;
+    cpu_set_t want, have, both;
+    if (parse_cpulist(buf, &want) == 0 || sched_getaffinity(0, sizeof have, &have) != 0) return;
+    CPU_AND(&both, &want, &have);               // only CPUs this process may use at all (cgroup / taskset)
+    const int n = CPU_COUNT(&both);
+    if (n > 0 && sched_setaffinity(0, sizeof both, &both) == 0) s.pinned_cpus = n;
 }
 
 } // namespace
@@ -171,7 +241,7 @@ int gnuais_node_create(gnuais_node **out, const int *devices, int n_devices, int
         s->device = devs[g];
         s->first = lo;
         s->n = hi - lo;
-        s->w.th = std::thread([s] { s->w.loop(); });
+        s->w.th = std::thread([s] { pin_to_device_node(*s); s->w.loop(); });
         nd->shards.push_back(s);
     }
     const int rc = run_all(nd, [&](Shard &s) {
@@ -214,7 +284,11 @@ int gnuais_node_run(gnuais_node *nd, const int16_t *const *d_samples, int len, v
     std::vector<Shard *> &sh = nd->shards;
     return run_all(nd, [&](Shard &s) {
         const size_t i = (size_t) (std::find(sh.begin(), sh.end(), &s) - sh.begin());
-        return gnuais_batch_run(s.b, d_samples[i], len, streams ? streams[i] : nullptr);
+        const double t0 = wall_ms();
+        const int rc = gnuais_batch_run(s.b, d_samples[i], len, streams ? streams[i] : nullptr);
+        if (s.m_calls++ == 0) s.m_first = t0;
+        s.m_submit_ms += wall_ms() - t0;
+        return rc;
     });
 }
 
@@ -224,6 +298,9 @@ int gnuais_node_run_host(gnuais_node *nd, const int16_t *h_samples, int len)
     if (len <= 0 || len > nd->max_len) return node_fail(GNUAIS_E_ARG, "node_run_host: len out of range");
     const int N = nd->N, max_len = nd->max_len;
     return run_all(nd, [=](Shard &s) -> int {
+        const double t0 = wall_ms();
+        if (s.m_calls++ == 0) s.m_first = t0;
+        struct Stop { Shard &s; double t0; ~Stop() { s.m_submit_ms += wall_ms() - t0; } } stop{s, t0};
         if (hipSetDevice(s.device) != hipSuccess) return node_fail(GNUAIS_E_HIP, "node_run_host: hipSetDevice");
         if (!s.s_in) {
             if (hipStreamCreateWithFlags(&s.s_in, hipStreamNonBlocking) != hipSuccess)
@@ -255,7 +332,40 @@ int gnuais_node_run_host(gnuais_node *nd, const int16_t *h_samples, int len)
 int gnuais_node_sync(gnuais_node *nd)
 {
     if (!nd) return node_fail(GNUAIS_E_ARG, "node_sync: NULL");
-    return run_all(nd, [](Shard &s) { return gnuais_batch_sync(s.b); });
+    return run_all(nd, [](Shard &s) {
+        const int rc = gnuais_batch_sync(s.b);
+        s.m_last_sync = wall_ms();
+        return rc;
+    });
+}
+
+// Per-shard bookkeeping for whoever times a node (bench.py --gpus N): gnuais_node_mark() starts a measurement,
+// gnuais_node_shard_stats() reads one shard's after a gnuais_node_sync().
+int gnuais_node_mark(gnuais_node *nd)
+{
+    if (!nd) return node_fail(GNUAIS_E_ARG, "node_mark: NULL");
+    return run_all(nd, [](Shard &s) {
+        s.m_calls = 0;
+        s.m_submit_ms = s.m_first = s.m_last_sync = 0.0;
+        return GNUAIS_OK;
+    });
+}
+
+int gnuais_node_shard_stats(const gnuais_node *nd, int i, gnuais_node_shard_stat *out)
+{
+    if (!nd || !out || i < 0 || i >= (int) nd->shards.size()) return node_fail(GNUAIS_E_ARG, "node_shard_stats: argument");
+    const Shard *s = nd->shards[i];
+    memset(out, 0, sizeof *out);
+    out->device = s->device;
+    out->first_channel = s->first;
+    out->n_channels = s->n;
+    out->numa_node = s->numa_node;
+    out->pinned_cpus = s->pinned_cpus;
+    out->calls = (long long) s->m_calls;
+    out->submit_ms = s->m_submit_ms;
+    out->busy_ms = (s->m_calls && s->m_last_sync > s->m_first) ? s->m_last_sync - s->m_first : 0.0;
+    snprintf(out->pci, sizeof out->pci, "%s", s->pci);
+    return GNUAIS_OK;
 }
 
 int gnuais_node_pending_frames(gnuais_node *nd, int *n_out)
@@ -323,6 +433,7 @@ int gnuais_node_stream_nmea(gnuais_node *nd, const char **texts, size_t *lens, i
     if (!nd || !texts || !lens) return node_fail(GNUAIS_E_ARG, "node_stream_nmea: NULL argument");
     std::vector<Shard *> &sh = nd->shards;
     std::vector<int> ns(sh.size(), 0), nf(sh.size(), -1);
+    for (size_t i = 0; i < sh.size(); ++i) { texts[i] = nullptr; lens[i] = 0; }    // a shard that fails leaves nothing stale
     const int rc = run_all(nd, [&](Shard &s) {
         const size_t i = (size_t) (std::find(sh.begin(), sh.end(), &s) - sh.begin());
         return gnuais_batch_stream_nmea(s.b, &texts[i], &lens[i], &ns[i], &nf[i]);

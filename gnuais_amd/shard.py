@@ -105,14 +105,41 @@ class ReceiverNode:
 
     def stream_nmea(self):
         """gnuais_node_stream_nmea(): call after every run(); -> (sentences of every shard in shard order = the node's
-        text for the call `stream_depth` calls ago, sentences, frames); frames == -1 while the pipelines fill."""
+        text for the call `stream_depth` calls ago, sentences, frames); frames == -1 while the pipelines fill.
+        If a shard fails, the GnuaisError raised carries what the others delivered as `.partial` (bytes)."""
         C = self._C
         n = len(self.shards)
         texts, lens = (C.c_void_p * n)(), (C.c_size_t * n)()
         ns, nf = C.c_int(0), C.c_int(0)
-        self._raise(self._lib.gnuais_node_stream_nmea(self._h, texts, lens, C.byref(ns), C.byref(nf)))
-        out = b"".join(C.string_at(texts[i], lens[i]) for i in range(n) if lens[i])
+        rc = self._lib.gnuais_node_stream_nmea(self._h, texts, lens, C.byref(ns), C.byref(nf))
+        out = b"".join(C.string_at(texts[i], lens[i]) for i in range(n) if texts[i] and lens[i])
+        try:
+            self._raise(rc)
+        except Exception as e:
+            e.partial = out
+            raise
         return out, ns.value, nf.value
+
+    def mark(self):
+        """start a per-shard measurement (gnuais_node_mark)"""
+        self._raise(self._lib.gnuais_node_mark(self._h))
+
+    def shard_stats(self):
+        """after sync(): per shard, where its host thread runs and how long it was busy since mark()"""
+        C = self._C
+
+        class Stat(C.Structure):
+            _fields_ = [("device", C.c_int32), ("first_channel", C.c_int32), ("n_channels", C.c_int32),
+                        ("numa_node", C.c_int32), ("pinned_cpus", C.c_int32), ("calls", C.c_longlong),
+                        ("submit_ms", C.c_double), ("busy_ms", C.c_double), ("pci", C.c_char * 32)]
+        out = []
+        for i in range(len(self.shards)):
+            st = Stat()
+            self._raise(self._lib.gnuais_node_shard_stats(self._h, i, C.byref(st)))
+            out.append(dict(device=st.device, first_channel=st.first_channel, n_channels=st.n_channels,
+                            pci=st.pci.decode(), numa_node=st.numa_node, pinned_cpus=st.pinned_cpus, calls=st.calls,
+                            submit_ms=st.submit_ms, busy_ms=st.busy_ms))
+        return out
 
     def discard_frames(self):
         self._raise(self._lib.gnuais_node_discard_frames(self._h))

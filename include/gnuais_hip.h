@@ -401,6 +401,23 @@ int  gnuais_node_set_option(gnuais_node *nd, const char *name, int value);      
 int  gnuais_node_autotune(gnuais_node *nd, const int16_t *const *d_samples, int len, void *const *streams,
 			  float *best_ms_max);
 const char *gnuais_node_last_error(void);   /* of the calling thread: which device failed and why */
+/* Where a shard runs and how it fared, for whoever times a node (a slow device must show by itself): every shard's
+ * host thread is pinned, when it starts, to the CPUs of the NUMA node its device hangs off (the device's PCI address
+ * -> /sys/bus/pci/devices/<addr>/numa_node -> /sys/devices/system/node/node<n>/cpulist, intersected with what the
+ * process may use; GNUAIS_NODE_PIN=0 leaves the threads alone), so that what it allocates from then on -- the batch's
+ * pinned staging buffers among it -- is local to that device.  gnuais_node_mark() starts a measurement;
+ * after a gnuais_node_sync(), shard i reports: calls since the mark, submit_ms = host time inside its run calls,
+ * busy_ms = from its first submission to the end of its own sync. */
+typedef struct gnuais_node_shard_stat {
+	int32_t device, first_channel, n_channels;
+	int32_t numa_node;      /* -1: unknown */
+	int32_t pinned_cpus;    /* 0: not pinned */
+	long long calls;
+	double  submit_ms, busy_ms;
+	char    pci[32];
+} gnuais_node_shard_stat;
+int  gnuais_node_mark(gnuais_node *nd);
+int  gnuais_node_shard_stats(const gnuais_node *nd, int i, gnuais_node_shard_stat *out);
 
 #ifdef __cplusplus
 }

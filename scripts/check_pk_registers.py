@@ -1,30 +1,46 @@
-"""fir_sign_pk.hip keeps its accumulator ring in fixed VGPRs above the compiler's budget.  The budget attribute is
-not a hard limit, so this compiles the file to ISA and checks that no compiler-generated instruction (anything outside
-the ASMSTART/ASMEND blocks) names a register of the ring or above.  Exit status 0 = clean."""
+"""fir_sign_pk.hip keeps its accumulator ring (and, for 48 taps, its tap pairs) in fixed VGPRs above the compiler's
+budget.  The budget attribute is not a hard limit and a clobber list cannot protect state between asm statements, so the
+ISA is scanned: no compiler-generated instruction (anything outside the ASMSTART/ASMEND blocks) of the two kernels may
+name a register of the ring or above.  A violation shows as rare wrong sign bits, not as a crash -- so the Makefile runs
+this on the ISA of the very object it builds (same flags) and fails the build on a finding.
+
+usage: check_pk_registers.py [file.s]     without an argument the file is compiled here with the Makefile's flags
+Exit status 0 = clean."""
 import os, re, subprocess, sys, tempfile
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = os.path.join(root, "gnuais_amd", "csrc", "fir_sign_pk.hip")
 inc = open(os.path.join(root, "gnuais_amd", "csrc", "fir_sign_pk_asm.inc")).read()
 base = {nc: int(re.search(rf"#define PK{nc}_VGPR_BASE (\d+)", inc).group(1)) for nc in (12, 48)}
-with tempfile.TemporaryDirectory() as d:
-    out = os.path.join(d, "pk.s")
-    subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC",
-                           "-mllvm", "-pragma-unroll-threshold=200000", "-fno-slp-vectorize", "-S", "--cuda-device-only",
-                           "-w", src, "-o", out])
-    text = open(out).read().splitlines()
+if len(sys.argv) > 1:
+    text = open(sys.argv[1]).read().splitlines()
+else:
+    with tempfile.TemporaryDirectory() as d:
+        out = os.path.join(d, "pk.s")
+        subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC",
+                               "-mllvm", "-pragma-unroll-threshold=200000", "-fno-slp-vectorize", "-S", "--cuda-device-only",
+                               "-w", src, "-o", out])
+        text = open(out).read().splitlines()
 bad = 0
 for nc in (12, 48):
-    inside = in_asm = False
+    inside = in_asm = found = False
     top = -1
-    for line in text:
-        if re.match(rf"^_ZN.*fir_sign_pk{nc}_kernel.*:", line): inside = True
+    where = None
+    for no, line in enumerate(text, 1):
+        if re.match(rf"^_ZN.*fir_sign_pk{nc}_kernel.*:", line): inside = found = True
         if not inside: continue
         if "ASMSTART" in line: in_asm = True
         elif "ASMEND" in line: in_asm = False
         elif not in_asm and not line.lstrip().startswith((";", ".")):
             for m in re.finditer(r"\bv(\d+)\b|\bv\[(\d+):(\d+)\]", line):
-                top = max(top, int(m.group(1) or m.group(3)))
+                r = int(m.group(1) or m.group(3))
+                if r > top: top, where = r, (no, line.strip())
         if "s_endpgm" in line: break
-    print(f"fir_sign_pk{nc}_kernel: compiler code uses v0..v{top}, the ring starts at v{base[nc]}")
-    bad += top >= base[nc]
+    if not found:
+        print(f"fir_sign_pk{nc}_kernel: not found in the ISA")
+        bad += 1
+        continue
+    ok = top < base[nc]
+    print(f"fir_sign_pk{nc}_kernel: compiler code uses v0..v{top}, the ring starts at v{base[nc]}" +
+          ("" if ok else f"  <-- VIOLATION at line {where[0]}: {where[1]}"))
+    bad += not ok
 sys.exit(1 if bad else 0)
