@@ -36,9 +36,9 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.3 TB/s measured)
-TIMING_STRIDE = 4              # per-kernel events on every 4th call of the timed region (the records cost stream time)
 KERNEL_LEG_CALLS = 120         # the leg behind the timed region that `kernel_ms` comes from: events on every 2nd of
-KERNEL_LEG_STRIDE = 2          # these calls = 60 samples per kernel (the library's event ring holds 64 calls)
+KERNEL_LEG_STRIDE = 2          # these calls = 60 samples per kernel (the library's event ring holds 64 calls);
+                               # --no-kernel-leg shortens it to 12 calls (the profiler's child runs)
 
 CONFIGS = {
     # stage_mask: bit 0 FIR/slicer, bit 1 PLL + NRZI, bit 3 HDLC deframer, bit 4 CRC + delivery
@@ -209,10 +209,10 @@ def measure(cfg, args, local, rank, sync, steps, warmup, isolated=True, post=Fal
         iso = {k: float(np.mean(v)) for k, v in acc.items()}
     rx0 = b.total_received()
 
-    # timed region: K steps, asynchronous; the library records HIP events around every
-    # kernel on the stream it is launched on (event ring), read back after the region
-    b.set_timing(True)
-    b.set_option("timing_stride", TIMING_STRIDE)    # the event records themselves cost stream time
+    # timed region: exactly K steps, asynchronous, nothing else on the streams -- the per-kernel HIP events the library
+    # can record cost stream time themselves (ten records a call: the 20-step figure was 4 % higher with them on every
+    # 4th call), so they are NOT taken here but in the leg that continues this loop right behind the region (below)
+    b.set_timing(False)
     sync.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -223,15 +223,11 @@ def measure(cfg, args, local, rank, sync, steps, warmup, isolated=True, post=Fal
     sync.barrier()
     dt = time.perf_counter() - t0
     rx1 = b.total_received()
-    live = b.mean_timing()
-    b.set_timing(False)
-    b.set_option("timing_stride", 1)
     out = {"n_ch": n_ch, "len": total, "dt": dt, "dt_own": dt_own, "steps": steps, "msgs": float(rx1 - rx0),
-           "kernel_ms_timed_region": {k: float(live[k]) for k in b.KERNELS}, "kernel_ms_isolated": iso,
-           "kernel_ms_timed_region_calls": int(live["calls"])}
+           "kernel_ms_isolated": iso}
     # `kernel_ms`: the same loop again, long enough for a stable mean -- a 20-step region sampled on every 4th call gives
     # five samples per kernel, and which of two stages of nearly equal length "dominates" then flips from run to run
-    leg = max(KERNEL_LEG_CALLS, 0) if kernel_leg else 0
+    leg = KERNEL_LEG_CALLS if kernel_leg else 12
     if leg:
         b.set_timing(True)
         b.set_option("timing_stride", KERNEL_LEG_STRIDE)
@@ -250,9 +246,7 @@ def measure(cfg, args, local, rank, sync, steps, warmup, isolated=True, post=Fal
                                 "what": "the timed loop continued for %d calls with the library's per-kernel HIP events on "
                                         "every %d-th call (each kernel on the stream it is launched on); kernel_ms is the mean "
                                         "over the sampled calls" % (leg, KERNEL_LEG_STRIDE)}
-    else:
-        out["kernel_ms"] = out["kernel_ms_timed_region"]
-        out["kernel_ms_calls"] = out["kernel_ms_timed_region_calls"]
+
     if post and steps < 100:
         # beside a short timed region (the driver's 20 steps carry one fill and one drain of the stage pipeline:
         # a call is about 1.5 ms from its first kernel to its last): the same loop over 200 steps
@@ -596,7 +590,6 @@ def rank_main(rank, local, world, args, sync):
         "x_realtime_channels": value / (cfg["rate"] / 1e6),
         "kernel_ms": m["kernel_ms"], "kernel_ms_isolated": m["kernel_ms_isolated"],
         "kernel_ms_calls": m["kernel_ms_calls"], "kernel_ms_leg": m.get("kernel_ms_leg"),
-        "kernel_ms_timed_region": m.get("kernel_ms_timed_region"),
         "per_gpu": ranks,
         "end_to_end": m.get("end_to_end"),
         "message_lines": m.get("message_lines"),
@@ -620,7 +613,7 @@ def rank_main(rank, local, world, args, sync):
                     "(fir_slice_kernel) instead of certifying its sign (K1s); everything downstream unchanged",
             "steps": e["steps"], "ms_per_step": ems, "Msamples_per_s": e["n_ch"] * e["len"] * e["steps"] / e["dt"] / 1e6,
             "frac_of_hbm_peak": e["n_ch"] * e["len"] * 2.0 / (ems * 1e-3) / 1e9 / HBM_PEAK_GBS,
-            "kernel_ms_timed_region": e["kernel_ms_timed_region"],
+            "kernel_ms": e["kernel_ms"],
             "valid_crc_msgs": e["msgs"], "same_msgs_as_the_default_chain": e["msgs"] == m["msgs"]}
         others = {}
         for name in ("C2", "C5"):

@@ -150,9 +150,9 @@ __device__ __forceinline__ void fir_sign_pk_body(
     // The accumulator ring (and, for 48 taps, the odd tap pairs) sits in fixed registers above PK_VGPR_BASE, outside
     // the compiler's budget; everything that touches it is one of the generated instruction streams.
     (void) NP;
-    if constexpr (NC == 12) asm volatile(PK12_ZERO);
+    if constexpr (NC == 12) asm volatile(PK12_ZERO ::: PK12_CLOBBERS);
     else {
-        asm volatile(PK48_ZERO);
+        asm volatile(PK48_ZERO ::: PK48_CLOBBERS);
         pk48_load_o(tp);
     }
     // warm-up: samples i = 0 .. NC-2 (ring phase i + 1); nothing they complete is an output of this segment.  The loads
@@ -366,9 +366,16 @@ __device__ __forceinline__ void fir_sign_pk_body(
     }
 }
 
-// the attribute wants a literal: one kernel per instantiation; the compiler's VGPR budget ends GAP registers below the ring
+// One kernel per instantiation.  NO amdgpu_num_vgpr attribute: with it the compiler treats every register above the budget
+// as "reserved", IGNORES them in the asm statements' clobber lists (with a warning per statement) -- and, had the lists
+// not been there at all, would allocate the wave only its own 44 / 64 registers while the streams write up to v155.
+// Without it the clobber lists are honoured: the compiler knows every generated stream destroys the ring's registers, so
+// no value of its own can sit there across one, and the kernel's register count covers them.  What a clobber cannot say
+// is "these registers hold MY state between two asm statements": that the compiler's own code (a few dozen registers,
+// allocated from v0 up) stays below the ring is checked on the ISA of every build, together with the allocated count
+// (scripts/check_pk_registers.py, run by the Makefile; a violation fails the build).
 #define PK_KERNEL(NAME, NCV, INL, BASE)                                                                              \
-    __global__ __launch_bounds__(64) __attribute__((amdgpu_num_vgpr(BASE))) void NAME(                                \
+    __global__ __launch_bounds__(64) void NAME(                                                                       \
         const int16_t *__restrict__ x, const int16_t *__restrict__ hist, uint32_t *__restrict__ sgn,                 \
         int *__restrict__ maxval, int16_t *__restrict__ hist_out, int *__restrict__ maxval_next,                     \
         const float *__restrict__ te_mem, int N, int L, int T, int d, int NTaps, int NE_rt, float eps_up,            \

@@ -207,6 +207,7 @@ struct gnuais_batch {
     // second FIR launch back on the host until the first one has ended, plus this many microseconds
     int cold_hold_us = -1;
     unsigned long long cold_call = ~0ull;
+    uint32_t *h_started = nullptr;              // pinned: the PLL launch of a cold call writes its stamp here when it has its place
 };
 
 static int set_device(const gnuais_batch *b)
@@ -258,6 +259,7 @@ void gnuais_batch_destroy(gnuais_batch *b)
     for (auto &st : b->pool)
         if (st) (void) hipStreamDestroy(st);
     if (b->s_fir2) (void) hipStreamDestroy(b->s_fir2);
+    if (b->h_started) (void) hipHostFree(b->h_started);
     for (hipEvent_t e : {b->e_hist[0], b->e_hist[1], b->e_order})
         if (e) (void) hipEventDestroy(e);
     for (int q = 0; q < gnuais_batch::NRING; ++q) {
@@ -804,11 +806,14 @@ int gnuais_batch_run(gnuais_batch *b, const int16_t *d_samples, int len, void *s
         // then starts a whole FIR launch late (profiles/r03_region_timeline_20steps.txt: ready at 438 us, started at
         // 848), and everything behind it with it.  So the launch that follows a cold call is held back on the host until
         // the cold call's FIR has ended (+ cold_hold_us); it would have started ~50 us after that anyway.
-        if (pl && b->cold_hold_us >= 0 && b->calls > 0 && b->calls == b->cold_call + 1) {
-            HIP_TRY(hipEventSynchronize(b->e_done[0][b->last_k]));
+        if (pl && b->cold_hold_us >= 0 && b->calls > 0 && b->calls == b->cold_call + 1 && b->h_started) {
+            // ... until the cold call's PLL launch has placed its last workgroup (it says so itself), at most 3 ms
+            const uint32_t want = (uint32_t) b->cold_call + 1u;
+            const double until = now_ms() + 3.0;
+            while (__atomic_load_n(b->h_started, __ATOMIC_RELAXED) != want && now_ms() < until) {}
             if (b->cold_hold_us > 0) {
-                const double until = now_ms() + b->cold_hold_us * 1e-3;
-                while (now_ms() < until) {}
+                const double more = now_ms() + b->cold_hold_us * 1e-3;
+                while (now_ms() < more) {}
             }
         }
         if (pl && b->cold_hold_us >= 0 &&
@@ -855,6 +860,14 @@ int gnuais_batch_run(gnuais_batch *b, const int16_t *d_samples, int len, void *s
         // across calls (it carries the receivers' pll / prev / lastbit)
         PllLaunch p;
         fill_pll(b, p, k, len);
+        if (pl && b->cold_hold_us >= 0 && b->cold_call == b->calls) {
+            if (!b->h_started) {
+                HIP_TRY(hipHostMalloc((void **) &b->h_started, 64, hipHostMallocDefault));
+                *b->h_started = 0;
+            }
+            p.started = b->h_started;
+            p.stamp = (uint32_t) b->calls + 1u;
+        }
         if (pl) HIP_TRY(hipStreamWaitEvent(sA, b->e_done[0][k], 0));
         if (tm) HIP_TRY(hipEventRecord(ev[2], sA));
         if (b->stage_mask & 2) HIP_TRY(launch_pll(p, sA));

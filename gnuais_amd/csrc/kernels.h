@@ -71,6 +71,8 @@ struct PllLaunch {
     uint32_t pllinc;
     int n_cu;              // compute units of the batch's device
     int variant = 0;       // 0: by channel count; 3 / 6: the three- / six-wave form
+    uint32_t *started = nullptr;   // host-visible word (or NULL): the launch's last workgroup writes `stamp` when it starts
+    uint32_t stamp = 0;
 };
 int pll_need_lds();                                                      // bytes of LDS a PLL workgroup cannot do without
 hipError_t pll_prepare_device();                                         // once per device, after hipSetDevice

@@ -226,7 +226,8 @@ template <int NSC, int NTG>
 __global__ __launch_bounds__(64 * (2 + NSC + NTG)) __attribute__((amdgpu_waves_per_eu(7, 8))) void pll_kernel(
     const uint4 *__restrict__ sgn4, uint32_t *__restrict__ pllst, uint32_t *__restrict__ prevst,
     uint32_t *__restrict__ lastbit, uint32_t *__restrict__ segbits, uint32_t *__restrict__ segcnt,
-    uint32_t *__restrict__ watchdog, int N, int L, int n_seg_alloc, uint32_t pllinc)
+    uint32_t *__restrict__ watchdog, int N, int L, int n_seg_alloc, uint32_t pllinc,
+    uint32_t *__restrict__ started, uint32_t stamp)
 {
     extern __shared__ uint8_t lds[];
     uint64_t *lut = reinterpret_cast<uint64_t *>(lds);
@@ -247,6 +248,10 @@ __global__ __launch_bounds__(64 * (2 + NSC + NTG)) __attribute__((amdgpu_waves_p
     // published, [3] packs written, [4] scanners done, [5] / [6] the next block the even / odd toggler takes,
     // [7] / [8] blocks scanned by the even / odd scanner (last block + 1)
     if (threadIdx.x < 16) flag[threadIdx.x] = (NTG == 2 && threadIdx.x == 6) ? 1u : 0u;
+    // the launch's LAST workgroup is running (workgroups are placed in order): tell the host, which holds the next FIR
+    // launch back after a cold start until this stage has its place (gnuais_capi.hip: cold start)
+    if (started && blockIdx.x == gridDim.x - 1 && threadIdx.x == 0)
+        __hip_atomic_store(started, stamp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     if (role == 0) sign0[lane] = prevst[c] & 1u;               // receiver.h:44 prev, before the scanner rewrites it
     for (int v = threadIdx.x; v < 256; v += 64 * (2 + NSC + NTG)) {
         uint64_t e = 0;
@@ -536,7 +541,7 @@ hipError_t launch_pll(const PllLaunch &a, hipStream_t stream)
 #define PLL_FORM(NSC, NTG)                                                                                     \
     hipLaunchKernelGGL((pll_kernel<NSC, NTG>), dim3(groups), dim3(64 * (2 + NSC + NTG)), lds, stream,             \
                        (const uint4 *) a.sgn, a.pll, a.prev, a.lastbit, a.segbits, a.segcnt, a.watchdog, a.N, a.L, \
-                       a.n_seg, a.pllinc)
+                       a.n_seg, a.pllinc, a.started, a.stamp)
     if (variant == 4) PLL_FORM(1, 1);
     else if (variant == 51) PLL_FORM(2, 1);          // measurement forms: which of the two is short of a wave
     else if (variant == 52) PLL_FORM(1, 2);

@@ -182,7 +182,8 @@ template <int NSC>
 __global__ __launch_bounds__(64 * (2 + NSC)) __attribute__((amdgpu_waves_per_eu(7, 8))) void pll3_kernel(
     const uint4 *__restrict__ sgn4, uint32_t *__restrict__ pllst, uint32_t *__restrict__ prevst,
     uint32_t *__restrict__ lastbit, uint32_t *__restrict__ segbits, uint32_t *__restrict__ segcnt,
-    uint32_t *__restrict__ watchdog, int N, int L, int n_seg_alloc, uint32_t pllinc)
+    uint32_t *__restrict__ watchdog, int N, int L, int n_seg_alloc, uint32_t pllinc,
+    uint32_t *__restrict__ started, uint32_t stamp)
 {
     extern __shared__ uint8_t lds[];
     uint64_t *lut = reinterpret_cast<uint64_t *>(lds);
@@ -200,6 +201,10 @@ __global__ __launch_bounds__(64 * (2 + NSC)) __attribute__((amdgpu_waves_per_eu(
     // flag[1] blocks consumed, [2] segments finished, [3] packs written, [4] scanners done, [5] / [6] blocks scanned by
     // the first / second scanner (last block + 1)
     if (threadIdx.x < 16) flag[threadIdx.x] = 0;
+    // the launch's LAST workgroup is running (workgroups are placed in order): tell the host, which holds the next FIR
+    // launch back after a cold start until this stage has its place (gnuais_capi.hip: cold start)
+    if (started && blockIdx.x == gridDim.x - 1 && threadIdx.x == 0)
+        __hip_atomic_store(started, stamp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     if (role == 0) sign0[lane] = prevst[c] & 1u;               // receiver.h:44 prev, before the scanner rewrites it
     for (int v = threadIdx.x; v < 256; v += 64 * (2 + NSC)) {
         uint64_t e = 0;
@@ -516,10 +521,10 @@ hipError_t launch_pll3(const PllLaunch &a, hipStream_t stream)
     if (lds > 160 * 1024) return hipErrorInvalidValue;
     if (nsc == 2)
         hipLaunchKernelGGL(pll3_kernel<2>, dim3(groups), dim3(64 * 4), lds, stream, (const uint4 *) a.sgn, a.pll,
-                           a.prev, a.lastbit, a.segbits, a.segcnt, a.watchdog, a.N, a.L, a.n_seg, a.pllinc);
+                           a.prev, a.lastbit, a.segbits, a.segcnt, a.watchdog, a.N, a.L, a.n_seg, a.pllinc, a.started, a.stamp);
     else
         hipLaunchKernelGGL(pll3_kernel<1>, dim3(groups), dim3(64 * 3), lds, stream, (const uint4 *) a.sgn, a.pll,
-                           a.prev, a.lastbit, a.segbits, a.segcnt, a.watchdog, a.N, a.L, a.n_seg, a.pllinc);
+                           a.prev, a.lastbit, a.segbits, a.segcnt, a.watchdog, a.N, a.L, a.n_seg, a.pllinc, a.started, a.stamp);
     return hipGetLastError();
 }
 

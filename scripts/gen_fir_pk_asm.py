@@ -15,8 +15,9 @@ no packed instruction sits next to an instruction that depends on it (the assemb
 """
 import os
 BASE = {12: 72, 48: int(os.environ.get("PK48_BASE", "56"))}      # first register of the ring per instantiation
-GAP = 8     # amdgpu_num_vgpr(BASE - GAP): the attribute is not a hard limit (the compiler was seen four registers above
-            # it); tests/test_abi_exports.py scans the generated ISA for compiler code that touches the ring
+GAP = 8     # what the compiler's own code may use ends at least GAP registers below the ring (PK*_VGPR_BUDGET, for the
+            # record: nothing enforces it in the language -- scripts/check_pk_registers.py, run by the Makefile on every
+            # build, scans the generated ISA for compiler code that touches the ring and checks the wave's allocation)
 
 E48_SGPR = os.environ.get("PK48_E", "vgpr") == "sgpr"
 
@@ -77,10 +78,12 @@ def gen(nc, warm):
             out[name] = lines
     return out
 
-# No clobber lists: the ring and the tap registers lie above the kernel's register budget (amdgpu_num_vgpr), which the
-# compiler reports as "reserved" and IGNORES in a clobber list -- and a clobber could not protect them anyway: it says an
-# asm destroys a register, not that the register holds state BETWEEN two asm statements.  What keeps the compiler's own
-# code out of them is checked on the ISA of every build (scripts/check_pk_registers.py, run by the Makefile).
+def clobbers(nc):
+    B = BASE[nc]
+    regs = list(range(B, B + nc + 2))
+    if nc == 48:
+        regs += list(range(B + nc + 2, B + nc + 2 + 26 + 24))
+    return ", ".join(f'"v{r}"' for r in regs)
 
 path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gnuais_amd", "csrc", "fir_sign_pk_asm.inc")
 with open(path, "w") as f:
@@ -89,6 +92,7 @@ with open(path, "w") as f:
         B = BASE[nc]
         f.write(f"#define PK{nc}_VGPR_BASE {B}\n")
         f.write(f"#define PK{nc}_VGPR_BUDGET {B - GAP}\n")
+        f.write(f"#define PK{nc}_CLOBBERS {clobbers(nc)}\n")
         zero = "\\n\\t".join(f"v_mov_b32 v{B + s}, 0" for s in range(nc + 1))
         f.write(f'#define PK{nc}_ZERO "{zero}"\n')
         for warm in (True, False):
@@ -111,13 +115,13 @@ with open(path, "w") as f:
         tapsc = (", " + taps) if taps else ""
         f.write(f"template <int P> __device__ __forceinline__ void pk{nc}_step(uint32_t &neg, uint32_t &amb, pk_f2 x, float eps, const PkTaps<{nc}> &tp)\n{{\n")
         for i, P in enumerate(range(0, nc, 2)):
-            f.write(f"    {'if' if i == 0 else 'else if'} constexpr (P == {P}) asm volatile(PK{nc}_STEP_{P} : \"+v\"(neg), \"+v\"(amb) : \"v\"(x), \"v\"(eps){tapsc});\n")
+            f.write(f"    {'if' if i == 0 else 'else if'} constexpr (P == {P}) asm volatile(PK{nc}_STEP_{P} : \"+v\"(neg), \"+v\"(amb) : \"v\"(x), \"v\"(eps){tapsc} : PK{nc}_CLOBBERS);\n")
         f.write("}\n")
         f.write(f"template <int P, bool HALF> __device__ __forceinline__ void pk{nc}_warm(pk_f2 x, const PkTaps<{nc}> &tp)\n{{\n")
-        f.write(f"    if constexpr (HALF) asm volatile(PK{nc}_WARM_0_HALF :: \"v\"(x){tapsc});\n")
+        f.write(f"    if constexpr (HALF) asm volatile(PK{nc}_WARM_0_HALF :: \"v\"(x){tapsc} : PK{nc}_CLOBBERS);\n")
         for P in range(0, nc, 2):
-            f.write(f"    else if constexpr (P == {P}) asm volatile(PK{nc}_WARM_{P} :: \"v\"(x){tapsc});\n")
+            f.write(f"    else if constexpr (P == {P}) asm volatile(PK{nc}_WARM_{P} :: \"v\"(x){tapsc} : PK{nc}_CLOBBERS);\n")
         f.write("}\n")
     f.write("__device__ __forceinline__ void pk48_load_o(const PkTaps<48> &tp)\n{\n    asm volatile(PK48_LOAD_O :: " +
-            ", ".join([f'\"s\"(tp.O[{j}])' for j in range(13)] + [f'\"s\"(tp.E[{j}])' for j in range(12)]) + ");\n}\n")
+            ", ".join([f'\"s\"(tp.O[{j}])' for j in range(13)] + [f'\"s\"(tp.E[{j}])' for j in range(12)]) + " : PK48_CLOBBERS);\n}\n")
 print("wrote", path)
