@@ -401,6 +401,8 @@ def roofline_of(m, ms_per_step=None, traffic=None, n_taps=36):
             r["valu_by_kernel"] = per
             chain_floor = sum(v["issue_floor_ms"] for v in per.values())
             r["valu_chain"] = {"issue_floor_ms": chain_floor, "hbm_ms_for_algorithmic_bytes": alg / (HBM_PEAK_GBS * 1e9) * 1e3,
+                               "bound": ("valu" if ms_per_step and chain_floor >= 0.8 * ms_per_step else
+                                         ("hbm" if ms_per_step and alg / (HBM_PEAK_GBS * 1e9) * 1e3 >= 0.8 * ms_per_step else "latency")),
                                "what": "sum of the chain's kernels' VALU issue floors (they share the chip's 1024 SIMDs in "
                                        "the pipelined loop) against the time 8 TB/s needs for the call's algorithmic bytes"}
             r["bound"] = per[dom]["bound"] if dom in per else r["bound"]
@@ -605,7 +607,8 @@ def rank_main(rank, local, world, args, sync):
         # the same chain with the EXACT FIR in it (fir_slice_kernel: the reference's ordered 36-tap fp32 sum formed for
         # every sample, then `out > 0`) instead of the sign-certified slicer the receive path runs by default: same
         # bits, frames and counters (checked here on the message count), the floats' cost made visible
-        e = measure(cfg, args, local, rank, sync, args.steps, args.warmup, isolated=False, kernel_leg=False,
+        # (the same sequence of calls as the headline measurement, so that the message counts can be compared)
+        e = measure(cfg, args, local, rank, sync, args.steps, args.warmup, isolated=True, kernel_leg=False,
                     options={"fir_variant": 0})
         ems = e["dt"] / e["steps"] * 1e3
         out["exact_chain"] = {

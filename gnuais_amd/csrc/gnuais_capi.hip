@@ -490,6 +490,7 @@ int gnuais_batch_create(gnuais_batch **out, int device, int n_channels, const fl
         for (; made < gnuais_batch::POOL; ++made)
             if (e == hipSuccess) e = hipStreamCreateWithPriority(&b->pool[made], hipStreamNonBlocking, made < 8 ? hi : 0);
     }
+    if (const char *v = getenv("GNUAIS_PLL_VARIANT")) b->pll_variant = atoi(v);
     if (const char *v = getenv("GNUAIS_NBUF")) b->nbuf = std::min((int) gnuais_batch::NBUF, std::max(2, atoi(v)));
     if (const char *v = getenv("GNUAIS_COLD_HOLD_US")) b->cold_hold_us = atoi(v);
     if (const char *v = getenv("GNUAIS_FIR_STREAMS")) b->fir_streams = atoi(v) == 2 ? 2 : 1;
@@ -630,7 +631,8 @@ int gnuais_batch_set_option(gnuais_batch *b, const char *name, int value)
         b->pipeline = value != 0;
 
     } else if (!strcmp(name, "pll_variant")) {
-        if (value != 0 && value != 3 && value != 4 && value != 6 && value != 32 && value != 51 && value != 52) return fail(GNUAIS_E_ARG, "pll_variant must be 0, 3, 4 or 6");
+        if (value != 0 && value != 3 && value != 4 && value != 6 && value != 7 && value != 32 && value != 51 && value != 52)
+            return fail(GNUAIS_E_ARG, "pll_variant must be 0 (by channel count), 3, 4, 6 (lane-per-channel forms) or 7 (time-parallel)");
         b->pll_variant = value;
     } else if (!strcmp(name, "hdlc_variant")) {
         b->hdlc_variant = value != 0;
@@ -1811,6 +1813,16 @@ int gnuais_debug_fir_stamps(gnuais_batch *b, unsigned long long *h_out, size_t m
     if (int rc = set_device(b)) return rc;
     HIP_TRY(hipDeviceSynchronize());
     HIP_TRY(hipMemcpy(h_out, b->d_stamps, std::min(max_waves, b->stamps_waves) * 16, hipMemcpyDeviceToHost));
+    return GNUAIS_OK;
+}
+
+// experiments only (not in the header): wall-clock (100 MHz) stamps of the time-parallel PLL's phases, workgroup 0, last launch
+int gnuais_debug_pll_tp_stamps(gnuais_batch *b, unsigned long long *h8)
+{
+    if (!b || !h8) return fail(GNUAIS_E_ARG, "debug_pll_tp_stamps: argument");
+    if (int rc = set_device(b)) return rc;
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(pll_tp_read_stamps(h8));
     return GNUAIS_OK;
 }
 

@@ -70,13 +70,18 @@ struct PllLaunch {
     int N, L, n_seg, seg_words;
     uint32_t pllinc;
     int n_cu;              // compute units of the batch's device
-    int variant = 0;       // 0: by channel count; 3 / 6: the three- / six-wave form
+    int variant = 0;       // 0: by channel count; 3 / 6: the three- / six-wave form; 7: the time-parallel form (pll_tp.hip)
     uint32_t *started = nullptr;   // host-visible word (or NULL): the launch's last workgroup writes `stamp` when it starts
     uint32_t stamp = 0;
 };
 int pll_need_lds();                                                      // bytes of LDS a PLL workgroup cannot do without
 hipError_t pll_prepare_device();                                         // once per device, after hipSetDevice
 hipError_t launch_pll(const PllLaunch &a, hipStream_t stream);           // K2
+// K2 in its time-parallel form (pll_tp.hip): a workgroup per channel, lanes = candidate phases; small batches
+bool pll_tp_applicable(const PllLaunch &a);
+hipError_t launch_pll_tp(const PllLaunch &a, hipStream_t stream);
+hipError_t pll_tp_read_stamps(unsigned long long *h8);                   // experiments: phase stamps of workgroup 0
+constexpr int PLL_TP_MAX_CHANNELS = 512;  // launch_pll() takes the time-parallel form by itself up to this many channels
 
 // ---- K2b: HDLC deframer, K3: CRC-16 + frame delivery (hdlc_crc.hip) ---------
 constexpr int HDLC_CTL_WORDS = 6;

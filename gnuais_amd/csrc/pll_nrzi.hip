@@ -528,6 +528,8 @@ hipError_t pll_prepare_device()
 // pipelined call takes 0.535 ms with three waves, 0.56-0.59 with six).
 hipError_t launch_pll(const PllLaunch &a, hipStream_t stream)
 {
+    // small batches: the time-parallel form (pll_tp.hip), where this implementation of it applies
+    if ((a.variant == 7 || (a.variant == 0 && a.N <= PLL_TP_MAX_CHANNELS)) && pll_tp_applicable(a)) return launch_pll_tp(a, stream);
     const int n_cu = a.n_cu > 0 ? a.n_cu : 256;
     const int groups = (a.N + 63) / 64;
     const int variant = a.variant == 3 || a.variant == 4 || a.variant == 6 || a.variant == 32 || a.variant == 51 || a.variant == 52

@@ -176,7 +176,7 @@ def run_both(x, chunks, n_ch, taps=None, pllinc=0, fir_T=None, pll_variant=0):
     return o, b
 
 
-@pytest.mark.parametrize("pll_variant", [3, 32, 4, 51, 52, 6])
+@pytest.mark.parametrize("pll_variant", [3, 32, 4, 51, 52, 6, 7])      # 7: the time-parallel form (pll_tp.hip)
 def test_chain_vs_oracle_ragged_chunks(pll_variant):
     n_ch, total = 70, 30 * 1280
     x = np.stack([synth.make_stream(total, seed=31, channel=c,
@@ -188,7 +188,7 @@ def test_chain_vs_oracle_ragged_chunks(pll_variant):
     assert o.counters()[:, 0].sum() > 300
 
 
-@pytest.mark.parametrize("pll_variant", [3, 32, 4, 51, 52, 6])
+@pytest.mark.parametrize("pll_variant", [3, 32, 4, 51, 52, 6, 7])
 def test_chain_vs_oracle_noise_only_and_extremes(pll_variant):
     rng = np.random.default_rng(33)
     total = 40000
@@ -200,6 +200,21 @@ def test_chain_vs_oracle_noise_only_and_extremes(pll_variant):
     x = np.clip(np.rint(np.stack(cols, axis=1)), -32768, 32767).astype(np.int16)
     run_both(x, [total], x.shape[1], pll_variant=pll_variant)
     run_both(x, [2049, 255, 257, total - 2561], x.shape[1], pll_variant=pll_variant)   # block / segment edges
+
+
+def test_time_parallel_pll_walks_out_of_its_window():
+    """pll_tp.hip: a block's map is tabulated on a window of +-64 nudges around the chunk's first value; a channel whose
+    phase diffuses further inside a chunk (long stretches of loud noise: one nudge per transition, either way) makes the
+    walker run blocks itself from the true value.  48 000 samples of noise at several levels, with and without
+    messages, one call and ragged calls, the 192 kHz parameter set too: bits, frames, counters, PLL carry == oracle."""
+    rng = np.random.default_rng(77)
+    total = 48000
+    cols = [rng.normal(0, s, total) for s in (200, 1000, 5000, 20000)]
+    cols += [synth.make_stream(total, seed=91, channel=c, sigma=(1000.0, 9000.0)[c % 2])[0].astype(np.float64) for c in range(4)]
+    x = np.clip(np.rint(np.stack(cols, axis=1)), -32768, 32767).astype(np.int16)
+    run_both(x, [total], x.shape[1], pll_variant=7)
+    run_both(x, [16384, 300, 256, 257, total - 17197], x.shape[1], pll_variant=7)
+    run_both(x[:40000], [40000], x.shape[1], taps=params.taps_192k(), pllinc=params.PLLINC_192K, pll_variant=7)
 
 
 def test_chain_vs_oracle_digital_silence_patterns():
