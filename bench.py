@@ -404,7 +404,11 @@ def roofline_of(m, ms_per_step=None, traffic=None, n_taps=36):
                                "bound": ("valu" if ms_per_step and chain_floor >= 0.8 * ms_per_step else
                                          ("hbm" if ms_per_step and alg / (HBM_PEAK_GBS * 1e9) * 1e3 >= 0.8 * ms_per_step else "latency")),
                                "what": "sum of the chain's kernels' VALU issue floors (they share the chip's 1024 SIMDs in "
-                                       "the pipelined loop) against the time 8 TB/s needs for the call's algorithmic bytes"}
+                                       "the pipelined loop) against the time 8 TB/s needs for the call's algorithmic bytes. "
+                                       "The floor prices every wave-instruction at the 4 cycles SQ_ACTIVE_INST_VALU counts it "
+                                       "as; micro-benchmarked issue costs on this chip are 2.4 (add, mul) to 4.7 (fma with a "
+                                       "scalar operand, packed) cycles, so read it as an upper estimate of how full the VALU "
+                                       "is: between ~0.65 x and 1 x this figure"}
             r["bound"] = per[dom]["bound"] if dom in per else r["bound"]
             if r["bound"] == "latency":
                 r["latency_note"] = ("a per-channel recurrence: one wave per 16-64 channels walks the call serially "

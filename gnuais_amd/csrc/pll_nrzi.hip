@@ -1,125 +1,36 @@
-// pll_nrzi.hip -- K2, six-wave form: bit-clock recovery PLL, slice and NRZI decode for gfx950 (and the
-// choice between this form and the three-wave one of pll_nrzi3.hip, launch_pll() at the end).
+// pll_nrzi.hip -- K2, the forms with togglers of their own (four to six waves per 64 channels): bit-clock recovery PLL,
+// slice and NRZI decode for gfx950 (gnuais src/receiver.c:109-135) -- and launch_pll(), which picks a form.
 //
-// Stands in for the per-sample loop of receiver_run(), gnuais src/receiver.c:109-135, for a whole
-// batch of channels.
-//
-// The reference touches the phase on every sample, but only a sign change of the filter output
-// (a "transition", receiver.c:113) makes it do anything that is not linear:
-//
-//     transition at sample t :  pll += (pll < 0x8000) ? +pllinc/16 : -pllinc/16     receiver.c:114-117
-//     every sample           :  pll += pllinc;  overflow -> slice, pll &= 0xffff    receiver.c:122-133
-//
-// Write the phase without the `& 0xffff`: U(t) = pll0 + t * pllinc + K(t), K = the nudges so far.
-// U only grows (pllinc > pllinc/16), a nudge never crosses a multiple of 2^16 (pll < 0x8000 -> +q
-// stays below 0x10000, pll >= 0x8000 -> -q stays above 0), and pllinc + q < 2^16, so the slices are
-// exactly the times U crosses a multiple of 2^16: slice number m happens at the first sample whose
-// increment takes U to (m + 1) * 2^16 or beyond, and floor(U / 2^16) slices have happened before
-// sample t.  The nudge at a transition needs U mod 2^16 there, nothing else.
-//
-// The bit the reference emits at a slice is 1 if the level (sign of the filter output) is the same
-// as at the previous slice, 0 if it differs (receiver.c:126-132), i.e. NOT the parity of the
-// transitions since the previous slice.  A transition at sample t (the level seen by a slice AT t is
-// already the new one) therefore toggles exactly one bit of the output: number floor(U(t) / 2^16).
-// So:
-//     bits = ~( XOR over the transitions of  1 << floor(U(t_j) / 2^16) )
-//
-// That turns 48 000 dependent steps per channel and call into ~10 000 (one per transition; the max
-// over the 64 channels of a wave, re-synchronised every 256 samples).  One kernel, one workgroup
-// per 64 channels, five waves that hand work to each other through LDS (pll_kernel below): a
-// scanner turns sign words into lists of transition positions, the recurrence walks them and leaves
-// the number of the bit each transition toggles, two togglers apply those, a writer takes the
-// finished bit packs to HBM.
-//
-// Output: one pack of <= PACK_STRIDE words + a bit count per (channel, 2048-sample segment); bit k
-// of a pack is at word k/32, bit k%32.
+// What is computed, and why a transition toggles exactly one output bit (bits = ~XOR_j 1 << floor(U(t_j) / 2^16)), is
+// derived in pll_nrzi3.hip, the form in which the recurrence wave toggles the bits itself.  Here the recurrence only
+// advances the phase and leaves, per transition, the NUMBER of the slice it toggles; togglers apply those: fewer
+// instructions on the critical wave, a third more in total -- for batches that leave the chip half empty.  What the forms
+// share (block geometry, LDS hand-over, the scanners, the way a pack leaves) is in pll_common.h; the time-parallel form
+// for small batches is pll_tp.hip.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
 #include <algorithm>
 #include "kernels.h"
+#include "pll_common.h"      // geometry, LDS hand-over primitives, the scanner and the writer's pack handling: shared with pll_nrzi3.hip
 
 namespace gnuais {
 
-__device__ __forceinline__ uint32_t wave_max(uint32_t v)
-{
-#pragma unroll
-    for (int o = 32; o; o >>= 1) {
-        const uint32_t u = (uint32_t) __shfl_xor((int) v, o);
-        v = u > v ? u : v;
-    }
-    return v;
-}
-
-// Unit of hand-over: a "block" = 256 samples = two of the four-word pieces K1 stores side by side.
-//   scanner    (wave 1) loads a block's 32 bytes of sign bits per lane (PLL_AHEAD blocks in flight),
-//              forms the transition bits D = S ^ (S >> 1) (receiver.c:113) and expands them BYTE BY
-//              BYTE through a 256-entry table in LDS -- the positions of a byte's set bits, eight to
-//              an 8-byte entry -- appending each entry with one unaligned ds_write_b64 to the lane's
-//              strip of the block's slot and advancing the cursor by the byte's popcount.  Seven
-//              instructions per 8 samples whatever the data; a loop over the set bits costs twelve
-//              per transition and runs max-over-lanes times.
-//   recurrence (wave 0) takes a slot when it is complete: rows = the longest lane's transitions,
-//              four to a ds_read_b32, lanes masked off step by step where their list has ended
-//              (v_cmpx).  Six instructions per transition: it only advances the phase and writes
-//              the number of the slice the transition toggles -- relative to the block's first
-//              sample, so that it fits a byte -- over the position it has just read (one
-//              ds_write_b32 per row).  It touches only LDS: beside a FIR that keeps the CU's vector
-//              memory pipeline full, every global access of this wave costs it microseconds.
-//   togglers   (waves 3, 4: even / odd blocks) XOR 1 << bit into the segment's pack in LDS for every
-//              entry of a block the recurrence has finished (six instructions + a ds_xor_b32 each):
-//              this was two thirds of the recurrence's work when it did it itself.
-//   writer     (wave 2) takes a finished segment's pack out of LDS: complement, trim to the bit
-//              count, carry the toggles that fall on a later segment's first slice, 64 bytes per
-//              lane to HBM; clears the buffer for the segment after next.
-// Monotonic LDS counters hand things over: blocks scanned / consumed, segments finished / written.
-// The launch asks for more than half a CU's 160 KB of LDS, so the dispatcher places at most ONE of
-// these workgroups per CU and two chains never share a SIMD.
-constexpr int BLK_QUADS = 2;         // 16-byte pieces (four sign words) per block
-constexpr int BLK_LEN = 128 * BLK_QUADS;   // samples per block: positions fit a byte
-constexpr int SEG_BLKS = SEG_LEN / BLK_LEN;
-constexpr int PLL_STRIP = BLK_LEN + 12;    // bytes per lane and slot: the positions + an 8-byte store's overhang +
-                                     // the recurrence's read-ahead; 67 dwords (odd): lanes hit different banks
+// Waves of a workgroup (pll_nrzi3.hip describes the scanner, the recurrence's rows and the writer):
+//   recurrence (wave 0) six instructions per transition: it only advances the phase and writes the number of the slice
+//              the transition toggles -- relative to the block's first sample, so that it fits a byte -- over the
+//              position it has just read (one ds_write_b32 per row).  It touches only LDS.
+//   scanners   (wave 1, and 5 with NSC = 2: even / odd blocks), writer (wave 2): pll_common.h
+//   togglers   (wave 3, and 4 with NTG = 2: even / odd blocks) XOR 1 << bit into the segment's pack in LDS for every
+//              entry of a block the recurrence has finished (six instructions + a ds_xor_b32 each): this was two thirds
+//              of the recurrence's work when it did it itself.
 #ifndef PLL_SLOTS_N
 #define PLL_SLOTS_N 6
 #endif
 constexpr int PLL_SLOTS = PLL_SLOTS_N;   // block slots between scanner, recurrence and togglers
-#ifndef SCAN_EXP
-#define SCAN_EXP 0
-#endif
-#ifndef PLL_SCAN_PRIO
-#define PLL_SCAN_PRIO 3     // the scanner beside five FIR waves on its SIMD: in-pipeline PLL 0.52 -> 0.50 ms (C3), period -1 %
-#endif
-#ifndef PLL_AHEAD_N
-#define PLL_AHEAD_N 2
-#endif
-constexpr int PLL_AHEAD = PLL_AHEAD_N;         // blocks of sign words the scanner has in flight
 constexpr int PLL_SLOT_BYTES = 64 * PLL_STRIP + 64 * 4 + 64 + 64 * 4;     // strips, counts, rows, slices before the block
-constexpr int PLL_PACKW = PACK_STRIDE + 1;   // words per lane and pack buffer: the pack + its bit count
-constexpr int PLL_LUT_BYTES = 2048;
 constexpr int PLL_FLAG_WORDS = 16 + 2 * 64 + 4 * 64;  // counters, the sign before / after the call per lane, bit counts of four segments
 constexpr int PLL_NEED_LDS = PLL_LUT_BYTES + PLL_SLOTS * PLL_SLOT_BYTES + 2 * PLL_PACKW * 64 * 4 + PLL_FLAG_WORDS * 4;
-static_assert(SEG_LEN % BLK_LEN == 0, "segments are whole blocks");
-static_assert(BLK_LEN <= 256 && (PLL_STRIP / 4) % 2 == 1 && PLL_STRIP % 4 == 0, "byte positions, odd dword stride");
-
-// The hand-over counters live in LDS and guard LDS data only.  The LDS unit executes a wave's DS
-// instructions in order, so "data, then counter" on the producer side and "counter, then data" on
-// the consumer side is all the ordering needed; a C++ release / acquire here would also wait for
-// every global load and store the wave has in flight (s_waitcnt vmcnt(0)) -- which is exactly what
-// the scanner's load queue must not do.
-__device__ __forceinline__ void lds_flag_store(uint32_t *f, uint32_t v)
-{
-    asm volatile("" ::: "memory");
-    __hip_atomic_store(f, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    asm volatile("" ::: "memory");
-}
-__device__ __forceinline__ uint32_t lds_flag_load(uint32_t *f)
-{
-    asm volatile("" ::: "memory");
-    const uint32_t v = __hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    asm volatile("" ::: "memory");
-    return v;
-}
 
 // One transition at position p (byte k of the list word E) of the current block.
 // X = (pll0 + K + p0 * pllinc) * 2^7 + spare with p0 = the block's first sample and the slices before
@@ -210,11 +121,6 @@ __device__ __forceinline__ void pll_toggle_rows(uint32_t cnt, uint32_t ad, uint3
         : "vcc", "scc", "memory");
 }
 
-__host__ __device__ inline int n_seg_cap(int L)
-{
-    return (((L + 31) >> 5) + SEG_WORDS - 1) / SEG_WORDS;
-}
-
 // LDS map (dynamic, from address 0: this kernel has no static LDS and the asm above relies on it):
 //   [0, 2048)                       lut: positions of the set bits of a byte, MSB (oldest sample) first
 //   PLL_SLOTS x PLL_SLOT_BYTES      block slots: 64 strips of PLL_STRIP bytes, cnt[64], rows
@@ -253,13 +159,7 @@ __global__ __launch_bounds__(64 * (2 + NSC + NTG)) __attribute__((amdgpu_waves_p
     if (started && blockIdx.x == gridDim.x - 1 && threadIdx.x == 0)
         __hip_atomic_store(started, stamp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     if (role == 0) sign0[lane] = prevst[c] & 1u;               // receiver.h:44 prev, before the scanner rewrites it
-    for (int v = threadIdx.x; v < 256; v += 64 * (2 + NSC + NTG)) {
-        uint64_t e = 0;
-        int n = 0;
-        for (int b = 7; b >= 0; --b)
-            if (v & (1 << b)) e |= (uint64_t) (7 - b) << (8 * n++);
-        lut[v] = e;
-    }
+    pll_fill_lut(lut, (int) threadIdx.x, 64 * (2 + NSC + NTG));
     for (int q = threadIdx.x; q < 2 * PLL_PACKW * 64; q += 64 * (2 + NSC + NTG)) pack[q] = 0;
     __syncthreads();
     const unsigned long long t_start = wall_clock64();
@@ -277,96 +177,16 @@ __global__ __launch_bounds__(64 * (2 + NSC + NTG)) __attribute__((amdgpu_waves_p
         __builtin_amdgcn_s_setprio(PLL_SCAN_PRIO);
 #endif
         const int w = role == 1 ? 0 : 1;                           // (role 5 exists with NSC == 2 only)
-        const uint4 *__restrict__ src = sgn4 + c;                  // piece i of this lane: src[i * N]
-        // a block's lists depend on the sign before its first sample only: the newest bit of the block before
-        auto last_word = [&](int b) -> uint32_t {                  // word 8 b - 1 (any valid word when there is none)
-            if (NSC == 1) return 0;                                // a lone scanner carries the bit itself
-            const int quad = (b >= 1 && b < n_blk) ? b * BLK_QUADS - 1 : 0;
-            return reinterpret_cast<const uint32_t *>(src + (size_t) quad * (size_t) N)[3];
-        };
-        const int n_own = (n_blk - w + NSC - 1) / NSC;             // blocks w, w + NSC, ...
-        uint4 q[PLL_AHEAD][BLK_QUADS];
-        uint32_t pw[PLL_AHEAD];
-#pragma unroll
-        for (int j = 0; j < PLL_AHEAD; ++j) {
-            const int b = j < n_own ? w + NSC * j : w;
-#pragma unroll
-            for (int h = 0; h < BLK_QUADS; ++h) q[j][h] = src[(size_t) ((b < n_blk ? b : 0) * BLK_QUADS + h) * (size_t) N];
-            pw[j] = last_word(b);
-        }
-        int seen = 0;
-        bool dead = false;
-        uint32_t prev = sign0[lane];
-        for (int i0 = 0; i0 < n_own && !dead; i0 += PLL_AHEAD) {
-#pragma unroll
-            for (int j = 0; j < PLL_AHEAD; ++j) {
-                const int i = i0 + j, b = w + NSC * i;
-                uint32_t S[4 * BLK_QUADS];
-#pragma unroll
-                for (int h = 0; h < BLK_QUADS; ++h) {
-                    S[4 * h] = q[j][h].x; S[4 * h + 1] = q[j][h].y; S[4 * h + 2] = q[j][h].z; S[4 * h + 3] = q[j][h].w;
-                }
-                const uint32_t pword = pw[j];
-                {   // loads are unconditional (past the end: an early block again), so that the compiler
-                    // counts them and waits for exactly the oldest
-                    const int nb = b + NSC * PLL_AHEAD;
-                    const int lb = nb < n_blk ? nb : (w < n_blk ? w : 0);
-#pragma unroll
-                    for (int h = 0; h < BLK_QUADS; ++h) q[j][h] = src[(size_t) (lb * BLK_QUADS + h) * (size_t) N];
-                    pw[j] = last_word(lb);
-                }
-                if (i < n_own && !dead) {
-                    while (b - seen >= PLL_SLOTS && !dead) {       // slot b % PLL_SLOTS still in use?
-                        const int t0 = __builtin_amdgcn_readfirstlane((int) lds_flag_load(flag + 5));
-                        const int t1 = NTG == 2 ? __builtin_amdgcn_readfirstlane((int) lds_flag_load(flag + 6)) : t0;
-                        seen = t0 < t1 ? t0 : t1;              // every block before this one has been toggled
-                        if (b - seen >= PLL_SLOTS) {
-                            if (expired()) dead = true;
-                            __builtin_amdgcn_s_sleep(2);
-                        }
-                    }
-                    if (!dead) {
-                        if (NSC == 2) prev = b == 0 ? sign0[lane] : (pword & 1u);
-                        uint8_t *slot = slots + (b % PLL_SLOTS) * PLL_SLOT_BYTES;
-                        uint32_t cur = (uint32_t) (slot - lds) + (uint32_t) (lane * PLL_STRIP);   // LDS address
-                        const uint32_t cur0 = cur;
-                        const int nv = L - b * BLK_LEN;            // valid samples of this block (>= 1)
-#pragma unroll
-                        for (int w8 = 0; w8 < 4 * BLK_QUADS; ++w8) {
-                            const int k = nv - 32 * w8;            // valid samples of this word
-                            uint32_t d = S[w8] ^ ((S[w8] >> 1) | (prev << 31));      // receiver.c:113
-                            if (k <= 0) {
-                                d = 0;
-                            } else if (k < 32) {
-                                d &= ~0u << (32 - k);
-                                prev = (S[w8] >> (32 - k)) & 1u;
-                            } else {
-                                prev = S[w8] & 1u;
-                            }
-                            uint64_t ent[4];
-#pragma unroll
-                            for (int y = 0; y < 4; ++y) ent[y] = lut[(d >> (24 - 8 * y)) & 0xffu];
-#pragma unroll
-                            for (int y = 0; y < 4; ++y) {
-                                const uint32_t base = 0x01010101u * (uint32_t) (32 * w8 + 8 * y);
-                                const uint64_t e = ent[y] + (((uint64_t) base << 32) | base);
-#if SCAN_EXP            // timing experiment only (wrong lists): what the unaligned stores cost
-                                asm volatile("ds_write_b64 %0, %1" :: "v"(cur & ~7u), "v"(e) : "memory");
-#else
-                                asm volatile("ds_write_b64 %0, %1" :: "v"(cur), "v"(e) : "memory");   // any byte address
-#endif
-                                cur += (uint32_t) __popc((d >> (24 - 8 * y)) & 0xffu);
-                            }
-                        }
-                        const uint32_t cnt = cur - cur0;
-                        reinterpret_cast<uint32_t *>(slot + 64 * PLL_STRIP)[lane] = cnt;
-                        const uint32_t ng = wave_max((cnt + 3u) >> 2);
-                        if (lane == 0) reinterpret_cast<uint32_t *>(slot + 64 * PLL_STRIP + 256)[0] = ng;
-                        lds_flag_store(flag + 7 + w, (uint32_t) (b + 1));
-                    }
-                }
-            }
-        }
+        uint32_t prev;
+        const bool ok = pll_scan_blocks<NSC, PLL_SLOTS, PLL_SLOT_BYTES>(
+            w, sgn4, c, N, L, n_blk, lds, slots, lut, flag + 7 + w, sign0, prev, lane,
+            [&]() {                                                // every block before this one has been toggled
+                const int t0 = __builtin_amdgcn_readfirstlane((int) lds_flag_load(flag + 5));
+                const int t1 = NTG == 2 ? __builtin_amdgcn_readfirstlane((int) lds_flag_load(flag + 6)) : t0;
+                return t0 < t1 ? t0 : t1;
+            },
+            expired);
+        const bool dead = !ok;
         if (((n_blk - 1) % NSC) == w) {                              // this scanner had the call's last block
             sign1[lane] = prev;
             lds_flag_store(flag + 4, 1u);
@@ -394,29 +214,10 @@ __global__ __launch_bounds__(64 * (2 + NSC + NTG)) __attribute__((amdgpu_waves_p
             }
             uint32_t *pk = pack + (s & 1) * PLL_PACKW * 64 + lane;
             const uint32_t nb = nbuf[(s & 3) * 64 + lane];        // slices of the segment = bits of the pack
-            uint32_t out[PACK_STRIDE], pd = 0;
-#pragma unroll
-            for (int w = 0; w < PACK_STRIDE; ++w) {
-                const uint32_t tg = pk[w * 64];
-                pk[w * 64] = 0;
-                const int k = (int) nb - 32 * w;                  // valid bits of this word
-                out[w] = ~tg & (k >= 32 ? ~0u : k > 0 ? (1u << k) - 1u : 0u);
-                if (k >= 0 && k < 32) pd = (tg >> k) & 1u;        // toggles that fall on the NEXT slice
-            }
+            uint32_t out[PACK_STRIDE], pd;
+            pll_pack_out(pk, nb, out, pd);
             lds_flag_store(flag + 3, (uint32_t) (s + 1));
-            if (nb) {
-                out[0] ^= par;
-                par = pd;
-            } else {
-                par ^= pd;
-            }
-            if (live) {
-                uint4 *__restrict__ dst = reinterpret_cast<uint4 *>(segbits + ((size_t) cg * n_seg_alloc + s) * PACK_STRIDE);
-#pragma unroll
-                for (int k = 0; k < PACK_STRIDE / 4; ++k)
-                    dst[k] = make_uint4(out[4 * k], out[4 * k + 1], out[4 * k + 2], out[4 * k + 3]);
-                segcnt[(size_t) cg * n_seg_alloc + s] = nb;
-            }
+            pll_pack_store(out, nb, pd, par, live, segbits, segcnt, (size_t) cg, n_seg_alloc, s);
         }
         while (lds_flag_load(flag + 4) == 0)
             if (expired()) return;

@@ -41,18 +41,9 @@
 
 #include <algorithm>
 #include "kernels.h"
+#include "pll_common.h"      // geometry, LDS hand-over primitives, the scanner and the writer's pack handling: shared with pll_nrzi.hip
 
 namespace gnuais {
-
-__device__ __forceinline__ uint32_t wave_max(uint32_t v)
-{
-#pragma unroll
-    for (int o = 32; o; o >>= 1) {
-        const uint32_t u = (uint32_t) __shfl_xor((int) v, o);
-        v = u > v ? u : v;
-    }
-    return v;
-}
 
 // Unit of hand-over: a "block" = 256 samples = two of the four-word pieces K1 stores side by side.
 //   scanner    (wave 1) loads a block's 32 bytes of sign bits per lane (PLL_AHEAD blocks in flight),
@@ -72,48 +63,13 @@ __device__ __forceinline__ uint32_t wave_max(uint32_t v)
 // Monotonic LDS counters hand things over: blocks scanned / consumed, segments finished / written.
 // The launch asks for more than half a CU's 160 KB of LDS, so the dispatcher places at most ONE of
 // these workgroups per CU and two chains never share a SIMD.
-constexpr int BLK_QUADS = 2;         // 16-byte pieces (four sign words) per block
-constexpr int BLK_LEN = 128 * BLK_QUADS;   // samples per block: positions fit a byte
-constexpr int SEG_BLKS = SEG_LEN / BLK_LEN;
-constexpr int PLL_STRIP = BLK_LEN + 12;    // bytes per lane and slot: the positions + an 8-byte store's overhang +
-                                     // the recurrence's read-ahead; 67 dwords (odd): lanes hit different banks
 constexpr int PLL_SLOTS = 4;         // block slots between scanner and recurrence
 #ifndef PLL3_LONE_SCANNER
 #define PLL3_LONE_SCANNER 1
 #endif
-#ifndef PLL_SCAN_PRIO
-#define PLL_SCAN_PRIO 3     // the scanner beside five FIR waves on its SIMD: in-pipeline PLL 0.52 -> 0.50 ms (C3), period -1 %
-#endif
-#ifndef PLL_AHEAD_N
-#define PLL_AHEAD_N 2
-#endif
-constexpr int PLL_AHEAD = PLL_AHEAD_N;         // blocks of sign words the scanner has in flight
 constexpr int PLL_SLOT_BYTES = 64 * PLL_STRIP + 64 * 4 + 64;     // strips, counts, rows
-constexpr int PLL_PACKW = PACK_STRIDE + 1;   // words per lane and pack buffer: the pack + its bit count
-constexpr int PLL_LUT_BYTES = 2048;
 constexpr int PLL_FLAG_WORDS = 16 + 2 * 64;  // counters, then the sign before / after the call per lane
 constexpr int PLL_NEED_LDS = PLL_LUT_BYTES + PLL_SLOTS * PLL_SLOT_BYTES + 2 * PLL_PACKW * 64 * 4 + PLL_FLAG_WORDS * 4;
-static_assert(SEG_LEN % BLK_LEN == 0, "segments are whole blocks");
-static_assert(BLK_LEN <= 256 && (PLL_STRIP / 4) % 2 == 1 && PLL_STRIP % 4 == 0, "byte positions, odd dword stride");
-
-// The hand-over counters live in LDS and guard LDS data only.  The LDS unit executes a wave's DS
-// instructions in order, so "data, then counter" on the producer side and "counter, then data" on
-// the consumer side is all the ordering needed; a C++ release / acquire here would also wait for
-// every global load and store the wave has in flight (s_waitcnt vmcnt(0)) -- which is exactly what
-// the scanner's load queue must not do.
-__device__ __forceinline__ void lds_flag_store(uint32_t *f, uint32_t v)
-{
-    asm volatile("" ::: "memory");
-    __hip_atomic_store(f, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    asm volatile("" ::: "memory");
-}
-__device__ __forceinline__ uint32_t lds_flag_load(uint32_t *f)
-{
-    asm volatile("" ::: "memory");
-    const uint32_t v = __hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    asm volatile("" ::: "memory");
-    return v;
-}
 
 // One transition at position p (byte k of the list word E) of the current block.
 // X = (pll0 + K + block start * pllinc) * 2^7 + spare, T = p * pllinc * 2^7, so U = X + T is the
@@ -167,11 +123,6 @@ __device__ __forceinline__ void pll3_rows(uint32_t &X, uint32_t cnt, uint32_t ad
         : "vcc", "scc", "memory");
 }
 
-__host__ __device__ inline int n_seg_cap(int L)
-{
-    return (((L + 31) >> 5) + SEG_WORDS - 1) / SEG_WORDS;
-}
-
 // LDS map (dynamic, from address 0: this kernel has no static LDS and the asm above relies on it):
 //   [0, 2048)                       lut: positions of the set bits of a byte, MSB (oldest sample) first
 //   PLL_SLOTS x PLL_SLOT_BYTES      block slots: 64 strips of PLL_STRIP bytes, cnt[64], rows
@@ -206,13 +157,7 @@ __global__ __launch_bounds__(64 * (2 + NSC)) __attribute__((amdgpu_waves_per_eu(
     if (started && blockIdx.x == gridDim.x - 1 && threadIdx.x == 0)
         __hip_atomic_store(started, stamp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     if (role == 0) sign0[lane] = prevst[c] & 1u;               // receiver.h:44 prev, before the scanner rewrites it
-    for (int v = threadIdx.x; v < 256; v += 64 * (2 + NSC)) {
-        uint64_t e = 0;
-        int n = 0;
-        for (int b = 7; b >= 0; --b)
-            if (v & (1 << b)) e |= (uint64_t) (7 - b) << (8 * n++);
-        lut[v] = e;
-    }
+    pll_fill_lut(lut, (int) threadIdx.x, 64 * (2 + NSC));
     for (int q = threadIdx.x; q < 2 * PLL_PACKW * 64; q += 64 * (2 + NSC)) pack[q] = 0;
     __syncthreads();
     const unsigned long long t_start = wall_clock64();
@@ -264,37 +209,7 @@ __global__ __launch_bounds__(64 * (2 + NSC)) __attribute__((amdgpu_waves_per_eu(
                         }
                     }
                     if (!dead) {
-                        uint8_t *slot = slots + (b % SLOTS) * PLL_SLOT_BYTES;
-                        uint32_t cur = (uint32_t) (slot - lds) + (uint32_t) (lane * PLL_STRIP);   // LDS address
-                        const uint32_t cur0 = cur;
-                        const int nv = L - b * BLK_LEN;            // valid samples of this block (>= 1)
-#pragma unroll
-                        for (int w = 0; w < 4 * BLK_QUADS; ++w) {
-                            const int k = nv - 32 * w;             // valid samples of this word
-                            uint32_t d = S[w] ^ ((S[w] >> 1) | (prev << 31));      // receiver.c:113
-                            if (k <= 0) {
-                                d = 0;
-                            } else if (k < 32) {
-                                d &= ~0u << (32 - k);
-                                prev = (S[w] >> (32 - k)) & 1u;
-                            } else {
-                                prev = S[w] & 1u;
-                            }
-                            uint64_t ent[4];
-#pragma unroll
-                            for (int y = 0; y < 4; ++y) ent[y] = lut[(d >> (24 - 8 * y)) & 0xffu];
-#pragma unroll
-                            for (int y = 0; y < 4; ++y) {
-                                const uint32_t base = 0x01010101u * (uint32_t) (32 * w + 8 * y);
-                                const uint64_t e = ent[y] + (((uint64_t) base << 32) | base);
-                                asm volatile("ds_write_b64 %0, %1" :: "v"(cur), "v"(e) : "memory");   // any byte address
-                                cur += (uint32_t) __popc((d >> (24 - 8 * y)) & 0xffu);
-                            }
-                        }
-                        const uint32_t cnt = cur - cur0;
-                        reinterpret_cast<uint32_t *>(slot + 64 * PLL_STRIP)[lane] = cnt;
-                        const uint32_t ng = wave_max((cnt + 3u) >> 2);
-                        if (lane == 0) reinterpret_cast<uint32_t *>(slot + 64 * PLL_STRIP + 256)[0] = ng;
+                        pll_expand_block(S, prev, L - b * BLK_LEN, lds, slots + (b % SLOTS) * PLL_SLOT_BYTES, lut, lane);
                         lds_flag_store(flag + 5, (uint32_t) (b + 1));
                     }
                 }
@@ -311,91 +226,12 @@ __global__ __launch_bounds__(64 * (2 + NSC)) __attribute__((amdgpu_waves_per_eu(
         __builtin_amdgcn_s_setprio(PLL_SCAN_PRIO);
 #endif
         const int w = role == 1 ? 0 : 1;                           // (role 3 exists with NSC == 2 only)
-        const uint4 *__restrict__ src = sgn4 + c;                  // piece i of this lane: src[i * N]
-        // a block's lists depend on the sign before its first sample only: the newest bit of the block before
-        auto last_word = [&](int b) -> uint32_t {                  // word 8 b - 1 (any valid word when there is none)
-            if (NSC == 1) return 0;                                // a lone scanner carries the bit itself
-            const int quad = (b >= 1 && b < n_blk) ? b * BLK_QUADS - 1 : 0;
-            return reinterpret_cast<const uint32_t *>(src + (size_t) quad * (size_t) N)[3];
-        };
-        const int n_own = (n_blk - w + NSC - 1) / NSC;             // blocks w, w + NSC, ...
-        uint4 q[PLL_AHEAD][BLK_QUADS];
-        uint32_t pw[PLL_AHEAD];
-#pragma unroll
-        for (int j = 0; j < PLL_AHEAD; ++j) {
-            const int b = j < n_own ? w + NSC * j : w;
-#pragma unroll
-            for (int h = 0; h < BLK_QUADS; ++h) q[j][h] = src[(size_t) ((b < n_blk ? b : 0) * BLK_QUADS + h) * (size_t) N];
-            pw[j] = last_word(b);
-        }
-        int seen = 0;
-        bool dead = false;
-        uint32_t prev = sign0[lane];
-        for (int i0 = 0; i0 < n_own && !dead; i0 += PLL_AHEAD) {
-#pragma unroll
-            for (int j = 0; j < PLL_AHEAD; ++j) {
-                const int i = i0 + j, b = w + NSC * i;
-                uint32_t S[4 * BLK_QUADS];
-#pragma unroll
-                for (int h = 0; h < BLK_QUADS; ++h) {
-                    S[4 * h] = q[j][h].x; S[4 * h + 1] = q[j][h].y; S[4 * h + 2] = q[j][h].z; S[4 * h + 3] = q[j][h].w;
-                }
-                const uint32_t pword = pw[j];
-                {   // loads are unconditional (past the end: an early block again), so that the compiler
-                    // counts them and waits for exactly the oldest
-                    const int nb = b + NSC * PLL_AHEAD;
-                    const int lb = nb < n_blk ? nb : (w < n_blk ? w : 0);
-#pragma unroll
-                    for (int h = 0; h < BLK_QUADS; ++h) q[j][h] = src[(size_t) (lb * BLK_QUADS + h) * (size_t) N];
-                    pw[j] = last_word(lb);
-                }
-                if (i < n_own && !dead) {
-                    while (b - seen >= SLOTS && !dead) {       // slot b % SLOTS still in use?
-                        seen = __builtin_amdgcn_readfirstlane((int) lds_flag_load(flag + 1));   // blocks consumed
-                        if (b - seen >= SLOTS) {
-                            if (expired()) dead = true;
-                            __builtin_amdgcn_s_sleep(2);
-                        }
-                    }
-                    if (!dead) {
-                        if (NSC == 2) prev = b == 0 ? sign0[lane] : (pword & 1u);
-                        uint8_t *slot = slots + (b % SLOTS) * PLL_SLOT_BYTES;
-                        uint32_t cur = (uint32_t) (slot - lds) + (uint32_t) (lane * PLL_STRIP);   // LDS address
-                        const uint32_t cur0 = cur;
-                        const int nv = L - b * BLK_LEN;            // valid samples of this block (>= 1)
-#pragma unroll
-                        for (int w8 = 0; w8 < 4 * BLK_QUADS; ++w8) {
-                            const int k = nv - 32 * w8;            // valid samples of this word
-                            uint32_t d = S[w8] ^ ((S[w8] >> 1) | (prev << 31));      // receiver.c:113
-                            if (k <= 0) {
-                                d = 0;
-                            } else if (k < 32) {
-                                d &= ~0u << (32 - k);
-                                prev = (S[w8] >> (32 - k)) & 1u;
-                            } else {
-                                prev = S[w8] & 1u;
-                            }
-                            uint64_t ent[4];
-#pragma unroll
-                            for (int y = 0; y < 4; ++y)
-                                ent[y] = lut[(d >> (24 - 8 * y)) & 0xffu];
-#pragma unroll
-                            for (int y = 0; y < 4; ++y) {
-                                const uint32_t base = 0x01010101u * (uint32_t) (32 * w8 + 8 * y);
-                                const uint64_t e = ent[y] + (((uint64_t) base << 32) | base);
-                                asm volatile("ds_write_b64 %0, %1" :: "v"(cur), "v"(e) : "memory");   // any byte address
-                                cur += (uint32_t) __popc((d >> (24 - 8 * y)) & 0xffu);
-                            }
-                        }
-                        const uint32_t cnt = cur - cur0;
-                        reinterpret_cast<uint32_t *>(slot + 64 * PLL_STRIP)[lane] = cnt;
-                        const uint32_t ng = wave_max((cnt + 3u) >> 2);
-                        if (lane == 0) reinterpret_cast<uint32_t *>(slot + 64 * PLL_STRIP + 256)[0] = ng;
-                        lds_flag_store(flag + 5 + w, (uint32_t) (b + 1));
-                    }
-                }
-            }
-        }
+        uint32_t prev;
+        const bool ok = pll_scan_blocks<NSC, SLOTS, PLL_SLOT_BYTES>(
+            w, sgn4, c, N, L, n_blk, lds, slots, lut, flag + 5 + w, sign0, prev, lane,
+            [&]() { return __builtin_amdgcn_readfirstlane((int) lds_flag_load(flag + 1)); },      // blocks consumed
+            expired);
+        const bool dead = !ok;
         if (((n_blk - 1) % NSC) == w) {                              // this scanner had the call's last block
             sign1[lane] = prev;
             lds_flag_store(flag + 4, 1u);
@@ -421,29 +257,10 @@ __global__ __launch_bounds__(64 * (2 + NSC)) __attribute__((amdgpu_waves_per_eu(
             }
             uint32_t *pk = pack + (s & 1) * PLL_PACKW * 64 + lane;
             const uint32_t nb = pk[PACK_STRIDE * 64];             // slices of the segment = bits of the pack
-            uint32_t out[PACK_STRIDE], pd = 0;
-#pragma unroll
-            for (int w = 0; w < PACK_STRIDE; ++w) {
-                const uint32_t tg = pk[w * 64];
-                pk[w * 64] = 0;
-                const int k = (int) nb - 32 * w;                  // valid bits of this word
-                out[w] = ~tg & (k >= 32 ? ~0u : k > 0 ? (1u << k) - 1u : 0u);
-                if (k >= 0 && k < 32) pd = (tg >> k) & 1u;        // toggles that fall on the NEXT slice
-            }
+            uint32_t out[PACK_STRIDE], pd;
+            pll_pack_out(pk, nb, out, pd);
             lds_flag_store(flag + 3, (uint32_t) (s + 1));
-            if (nb) {
-                out[0] ^= par;
-                par = pd;
-            } else {
-                par ^= pd;
-            }
-            if (live) {
-                uint4 *__restrict__ dst = reinterpret_cast<uint4 *>(segbits + ((size_t) cg * n_seg_alloc + s) * PACK_STRIDE);
-#pragma unroll
-                for (int k = 0; k < PACK_STRIDE / 4; ++k)
-                    dst[k] = make_uint4(out[4 * k], out[4 * k + 1], out[4 * k + 2], out[4 * k + 3]);
-                segcnt[(size_t) cg * n_seg_alloc + s] = nb;
-            }
+            pll_pack_store(out, nb, pd, par, live, segbits, segcnt, (size_t) cg, n_seg_alloc, s);
         }
         while (lds_flag_load(flag + 4) == 0)
             if (expired()) return;
