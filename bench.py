@@ -188,8 +188,8 @@ def measure(cfg, args, local, rank, sync, steps, warmup, isolated=True, post=Fal
     # one-time calibration (untimed, before the warm-up): which internal stream serves which stage.
     # The hardware queue a stream gets depends on what the process created before and decides a good
     # part of the pipeline's speed; the library measures it on this input.
+    b.set_option("stage_mask", cfg["stage_mask"])    # before the calibration: its calls run this workload's stages only
     b.autotune(x, stream)
-    b.set_option("stage_mask", cfg["stage_mask"])
     for k_, v_ in (options or {}).items():
         b.set_option(k_, v_)
     for _ in range(warmup):
@@ -455,7 +455,7 @@ def pmc_traffic(args, config):
         return {"error": "rocprofv3 not found"}
     child = [sys.executable, os.path.join(ROOT, "bench.py"), "--config", config, "--no-cpu", "--no-others", "--no-e2e",
              "--no-traffic", "--no-kernel-leg", "--steps", "6", "--warmup", "1", "--base", str(args.base)]
-    short = (("fir_sign", "fir_slice"), ("fir_slice_generic", "fir_slice"), ("fir_slice", "fir_slice"), ("pll3_kernel", "pll"), ("pll_kernel", "pll"),
+    short = (("fir_sign", "fir_slice"), ("fir_slice_generic", "fir_slice"), ("fir_slice", "fir_slice"), ("pll3_kernel", "pll"), ("pll_kernel", "pll"), ("pll_tp_kernel", "pll"),
              ("hdlc_events", "hdlc_deframe"), ("hdlc_deframe", "hdlc_deframe"), ("hdlc_crc", "hdlc_crc"))
     env = dict(os.environ, TMPDIR="/tmp")
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
@@ -665,8 +665,8 @@ def node_main(world, args):
             slabs.append(tile_channels(torch.from_numpy(base).to(f"cuda:{d}"), n))
     for d in set(devs):
         torch.cuda.synchronize(d)
-    node.autotune(slabs)
     node.set_option("stage_mask", cfg["stage_mask"])
+    node.autotune(slabs)
 
     def step():
         node.run(slabs)
