@@ -338,6 +338,16 @@ def test_node_object_equals_one_unsharded_batch(tmp_path):
         assert node.total_received() == one.total_received() > 1000
         one.reset()
         node.reset()
+    # per-shard bookkeeping (gnuais_node_mark / gnuais_node_shard_stats): what bench.py --gpus N prints per shard
+    node.mark()
+    for _ in range(3):
+        node.run_host(x[:4000].copy())
+    node.sync()
+    st = node.shard_stats()
+    assert [s_["first_channel"] for s_ in st] == [0, 250, 500, 750] and all(s_["calls"] == 3 for s_ in st)
+    assert all(s_["busy_ms"] > 0 and 0 < s_["submit_ms"] <= s_["busy_ms"] * 1.001 for s_ in st)
+    assert all(s_["pci"] and s_["pinned_cpus"] >= 0 and s_["numa_node"] >= -1 for s_ in st)
+    node.reset()
     # argument errors name the call; a device index that does not exist is refused
     from gnuais_amd.lib import GnuaisError
     with pytest.raises(GnuaisError):

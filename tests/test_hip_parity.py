@@ -426,6 +426,79 @@ def test_crc16_device_known_answers():
     assert int(crc16_batch([b"123456789"])[0]) == 0x906E
 
 
+def test_crc16_bits_is_protodec_calculate_crc_in_one_call():
+    """gnuais_crc16_bits(): the cells of d->buffer (one bit each, the first cell of a byte its LEAST significant bit,
+    protodec.c:138-143) -> the CRC-16/X-25 register over the packed bytes (0x0f47 for a good frame + FCS, :166) and the
+    cells back byte by byte MOST significant bit first (d->rbuffer, :150-162).  Against the oracle's CRC and numpy's bit
+    packing for every golden message with its FCS appended, lengths 1 .. 64 bytes, and cells that are not 0 / 1 (the
+    reference shifts whatever the cell holds)."""
+    import ctypes as C
+    from gnuais_amd import lib as _lib
+    from oracle_lib import crc16_x25
+    L = _lib.load()
+    g = load("crc16")
+    data, pos, msgs = g["data"].tobytes(), 0, []
+    for n in g["lens"]:
+        msgs.append(data[pos:pos + n])
+        pos += n
+    rng = np.random.default_rng(9)
+    msgs += [bytes(rng.integers(0, 256, n, dtype=np.uint8)) for n in (1, 2, 7, 55, 62)]
+    for m in msgs:
+        if len(m) > 62 or len(m) == 0:
+            continue
+        fcs = crc16_x25(m)
+        framed = m + bytes([fcs & 0xFF, fcs >> 8])
+        cells = np.unpackbits(np.frombuffer(framed, dtype=np.uint8), bitorder="little").astype(np.uint8)
+        out = np.full(8 * len(m), 7, dtype=np.uint8)
+        crc = C.c_uint16(0)
+        assert L.gnuais_crc16_bits(0, cells.ctypes.data, len(framed), C.byref(crc), out.ctypes.data, len(out)) == 0
+        assert crc.value == 0x0F47
+        assert np.array_equal(out, np.unpackbits(np.frombuffer(m, dtype=np.uint8), bitorder="big"))
+        crc2 = C.c_uint16(0)
+        assert L.gnuais_crc16_bits(0, cells.ctypes.data, len(m), C.byref(crc2), None, 0) == 0
+        assert crc2.value == fcs
+    odd = np.array([3, 0, 0, 0, 0, 0, 0, 2] * 2, dtype=np.uint8)      # cell << i, narrowed to a byte: 0x03 | 0x00 (2 << 7 falls out)
+    crc = C.c_uint16(0)
+    out = np.zeros(16, dtype=np.uint8)
+    assert L.gnuais_crc16_bits(0, odd.ctypes.data, 2, C.byref(crc), out.ctypes.data, 16) == 0
+    assert crc.value == crc16_x25(bytes([3, 3])) and out.tolist() == [0, 0, 0, 0, 0, 0, 1, 1] * 2
+    assert L.gnuais_crc16_bits(0, odd.ctypes.data, 65, C.byref(crc), None, 0) != 0         # more than 64 bytes: refused
+
+
+@pytest.mark.parametrize("opts", [dict(nbuf=2), dict(nbuf=7, fir_streams=2), dict(fir_streams=2, cold_hold_us=0),
+                                  dict(nbuf=5, cold_hold_us=25)])
+def test_scheduling_options_leave_every_result_alone(opts):
+    """Round 4's host-side knobs -- hand-off depth, FIR launches alternating between two streams (the carry and peak
+    buffers rotate over four), the cold-start hold -- only move launches around: bits, frames, counters, PLL carry and
+    peaks equal the oracle's over ragged calls, queued without a sync in between."""
+    import torch
+    n_ch, total = 130, 24 * 1280
+    x = np.stack([synth.make_stream(total, seed=57, channel=c, sigma=(800.0, 2500.0)[c % 2])[0] for c in range(n_ch)], axis=1)
+    chunks = [4096, 1020, 33, 7000, 5000, 1, 300]
+    chunks.append(total - sum(chunks))
+    o = Oracle(n_ch)
+    b = batch(n_ch, max_len=max(chunks))
+    for k, v in opts.items():
+        b.set_option(k, v)
+    stream = torch.cuda.current_stream().cuda_stream
+    pos = 0
+    xs = []
+    for n in chunks:
+        seg = x[pos:pos + n]
+        pos += n
+        o.run(seg)
+        xs.append(dev(seg))
+        b.run(xs[-1], stream=stream, sync=False)               # no sync: the calls pile up in the stage pipeline
+    b.sync()
+    assert b.drain_frames().tobytes() == o.frames().tobytes()
+    cnt = b.counters()
+    assert np.array_equal(np.stack([cnt["receivedframes"], cnt["lostframes"], cnt["lostframes2"]], axis=1), o.counters())
+    p = b.pll_state()
+    assert [(int(a), int(bb), int(cc)) for a, bb, cc in zip(p["pll"], p["prev"], p["lastbit"])] == [o.pll(c) for c in range(n_ch)]
+    assert np.array_equal(b.maxval(), np.where(x[-chunks[-1]:].max(axis=0) > 0, x[-chunks[-1]:].max(axis=0), 0).astype(np.int16))
+    assert np.array_equal(b.history(), x[-36:].T)
+
+
 # ---------------------------------------------------------------- full size (BASELINE C3)
 
 # (BASELINE's full sizes, every channel: tests/test_hip_fullsize.py)
