@@ -708,8 +708,9 @@ static int run_fir(gnuais_batch *b, const int16_t *x, int len, float *dump, hipS
             ((f.NC == 12 && f.NE == 32) || (f.NC == 48 && f.NE - f.NC <= 98 && f.eps_seen > 0.0f))) {
             const int qp = launch_fir_sign_pk_quantum();
             // 48 taps: a segment's warm-up is 47 pair steps' worth of samples; longer segments (there are plenty of
-            // waves: 16384 x 192000 is 32000 segments of 1536) halve its share
-            f.T = ((f.NC == 48 && b->fir_T <= 768 ? 1536 : b->fir_T) + qp - 1) / qp * qp;
+            // waves: 16384 x 192000 is 16000 segments of 3072) cut its share (round 4: 3072 against 1536, 4.29 against
+            // 4.39 ms per C5 call in steady state, profiles/r04_c5_ring_and_segments.txt)
+            f.T = ((f.NC == 48 && b->fir_T <= 768 ? 3072 : b->fir_T) + qp - 1) / qp * qp;
             HIP_TRY(launch_fir_sign_pk(f, s));
             b->hist_cur = (b->hist_cur + 1) % gnuais_batch::HB;
             b->max_last = b->max_cur;
