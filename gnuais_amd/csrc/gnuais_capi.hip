@@ -75,7 +75,12 @@ struct gnuais_batch {
     // every hand-off buffer exists NBUF times; `nbuf` of them are in use (index = call % nbuf), so K1 can run up
     // to nbuf-1 calls ahead of the sequential stages
     static constexpr int NBUF = 8;
-    int nbuf = 4;
+    // Depth in use.  The host waits for K3 of call i-nbuf before it launches the FIR of call i, so the pipeline is a
+    // closed loop: period >= latency of a call / nbuf.  Round 4, C3, same box (profiles/r04_nbuf_3_vs_4.txt): depth 3
+    // and 4 give the same steady state (0.518 ms: at 3 the loop's bound and the PLL stage's duration meet), 5-8 no
+    // better (0.53-0.55), 2 starves (0.70); a short timed region ends sooner with fewer calls in flight to drain
+    // (20 steps: 0.574 against 0.583), so 3.
+    int nbuf = 3;
     uint32_t *sgn[NBUF] = {};                   // K1 -> K2
     uint32_t *pll = nullptr, *lastbit = nullptr, *prev = nullptr;   // receiver.h:38-44, carried by K2
     int n_cu = 256;
