@@ -210,6 +210,13 @@ struct gnuais_batch {
     // cold start: a call that finds the pipeline empty is followed by a FIR launch that would otherwise be dispatched
     // before the first call's PLL stage and keep it waiting for a whole FIR launch; cold_hold_us >= 0 holds that
     // second FIR launch back on the host until the first one has ended, plus this many microseconds
+    // K2b started beside the PLL launch of its own call and fed segment by segment (kernels.h: PllLaunch::progress): a
+    // call's latency loses one stage.  Bit-exact (GPU suite + fuzz with it on), and measured a LOSS except at depth 2
+    // (profiles/r04_k2b_dataflow.txt: 20 steps 0.606 against 0.556 at depth 3, 0.636 against 0.729 at depth 2): the
+    // deframer's waves are then resident for the whole PLL launch, throttled at its front, and what a stage costs the
+    // others is the time its waves hold their registers.  Off; kept as an option for that measurement.
+    int k2b_dataflow = 0;
+    uint32_t *progress = nullptr;               // [groups of 64 channels] segments of the running call in HBM, + call * n_seg
     int cold_hold_us = -1;
     unsigned long long cold_call = ~0ull;
     uint32_t *h_started = nullptr;              // pinned: the PLL launch of a cold call writes its stamp here when it has its place
@@ -265,6 +272,7 @@ void gnuais_batch_destroy(gnuais_batch *b)
         if (st) (void) hipStreamDestroy(st);
     if (b->s_fir2) (void) hipStreamDestroy(b->s_fir2);
     if (b->h_started) (void) hipHostFree(b->h_started);
+    if (b->progress) (void) hipFree(b->progress);
     for (hipEvent_t e : {b->e_hist[0], b->e_hist[1], b->e_order})
         if (e) (void) hipEventDestroy(e);
     for (int q = 0; q < gnuais_batch::NRING; ++q) {
@@ -432,6 +440,7 @@ int gnuais_batch_create(gnuais_batch **out, int device, int n_channels, const fl
     alloc((void **) &b->lastbit, sizeof(uint32_t) * N);
     alloc((void **) &b->prev, sizeof(uint32_t) * N);
     alloc((void **) &b->ctl, sizeof(uint32_t) * N * HDLC_CTL_WORDS);
+    alloc((void **) &b->progress, sizeof(uint32_t) * ((N + 63) / 64 + 1));
     // candidate ring, per channel and call.  The deframer cannot open frames faster than one per
     // 30 bits (16 alternating bits to leave ST_SKURR, protodec.c:1030-1043, six ones each for the
     // opening and the closing flag, a bit in ST_STOPSIGN), so this many slots hold whatever a call
@@ -496,6 +505,7 @@ int gnuais_batch_create(gnuais_batch **out, int device, int n_channels, const fl
             if (e == hipSuccess) e = hipStreamCreateWithPriority(&b->pool[made], hipStreamNonBlocking, made < 8 ? hi : 0);
     }
     if (const char *v = getenv("GNUAIS_PLL_VARIANT")) b->pll_variant = atoi(v);
+    if (const char *v = getenv("GNUAIS_K2B_DATAFLOW")) b->k2b_dataflow = atoi(v) != 0;
     if (const char *v = getenv("GNUAIS_NBUF")) b->nbuf = std::min((int) gnuais_batch::NBUF, std::max(2, atoi(v)));
     if (const char *v = getenv("GNUAIS_COLD_HOLD_US")) b->cold_hold_us = atoi(v);
     if (const char *v = getenv("GNUAIS_FIR_STREAMS")) b->fir_streams = atoi(v) == 2 ? 2 : 1;
@@ -537,6 +547,7 @@ int gnuais_batch_reset(gnuais_batch *b)
         HIP_TRY(hipMemset(b->segcnt[k], 0, sizeof(uint32_t) * N * (size_t) b->n_seg));
     b->calls = 0;
     b->hdlc_calls = 0;
+    HIP_TRY(hipMemset(b->progress, 0, sizeof(uint32_t) * ((N + 63) / 64 + 1)));
     HIP_TRY(hipMemset(b->counters, 0, sizeof(int32_t) * N * 3));      // protodec.c:62-64
     for (int q = 0; q < gnuais_batch::HB; ++q) HIP_TRY(hipMemset(b->maxval[q], 0, sizeof(int) * N));
     b->max_cur = 0;
@@ -577,6 +588,9 @@ int gnuais_batch_set_option(gnuais_batch *b, const char *name, int value)
         if (value != 1 && value != 2) return fail(GNUAIS_E_ARG, "fir_streams must be 1 or 2");
         if (int rc = gnuais_batch_sync(b)) return rc;
         b->fir_streams = value;
+    } else if (!strcmp(name, "k2b_dataflow")) {
+        if (int rc = gnuais_batch_sync(b)) return rc;
+        b->k2b_dataflow = value != 0;
     } else if (!strcmp(name, "cold_hold_us")) {
         b->cold_hold_us = value < 0 ? -1 : value;
     } else if (!strcmp(name, "streaming")) {
@@ -768,12 +782,14 @@ static void fill_pll(const gnuais_batch *b, PllLaunch &p, int k, int len)
 // K2b, K3 of one call, each on its own stream (pipeline) or all on s0, after `after`
 // (the event that says this call's PLL stage is done; null = stream order on s0).
 static int run_tail(gnuais_batch *b, int k, int len, bool tm, hipEvent_t *ev,
-                    hipStream_t s0, hipEvent_t after)
+                    hipStream_t s0, hipEvent_t after, const uint32_t *progress = nullptr, uint32_t progress_base = 0)
 {
     const bool pl = b->pipeline;
     hipStream_t sC = pl ? b->s_k[2] : s0, sD = pl ? b->s_k[3] : s0;
     HdlcLaunch h;
     fill_hdlc(b, h, k);
+    h.progress = progress;                      // K2b beside the PLL launch (`after` is then the FIR's event, not the PLL's)
+    h.progress_base = progress_base;
     // K2b: needs segbits[k]; fills cand_first/count[k] (read by K3 of call - NBUF).  It also writes
     // the per-channel candidate ring that K3 of the PREVIOUS call may still be reading: slots are
     // reused after cand_K frame starts, which one call cannot exceed but two could
@@ -877,11 +893,19 @@ int gnuais_batch_run(gnuais_batch *b, const int16_t *d_samples, int len, void *s
             p.stamp = (uint32_t) b->calls + 1u;
         }
         if (pl) HIP_TRY(hipStreamWaitEvent(sA, b->e_done[0][k], 0));
+        // K2b of this call starts with the PLL launch (behind the same FIR event) and takes the packs segment by segment
+        // as the PLL stage's writer publishes them, where the PLL form that runs has the hand-over (the three-wave one)
+        const bool flow = pl && b->k2b_dataflow && !b->streaming && b->hdlc_variant == 1 && (b->stage_mask & 0x0a) == 0x0a && pll_form_of(p) == 3;
+        if (flow) {
+            p.progress = b->progress;
+            p.progress_base = (uint32_t) (b->calls * (unsigned long long) b->n_seg);
+        }
         if (tm) HIP_TRY(hipEventRecord(ev[2], sA));
         if (b->stage_mask & 2) HIP_TRY(launch_pll(p, sA));
         if (tm) HIP_TRY(hipEventRecord(ev[6], sA));
         if (pl) HIP_TRY(hipEventRecord(b->e_done[1][k], sA));
-        if (int rc = run_tail(b, k, len, tm, ev, s0, pl ? b->e_done[1][k] : nullptr)) return rc;
+        if (int rc = run_tail(b, k, len, tm, ev, s0, pl ? (flow ? b->e_done[0][k] : b->e_done[1][k]) : nullptr,
+                              flow ? b->progress : nullptr, p.progress_base)) return rc;
     }
 
     b->timed_last = tm;

@@ -73,7 +73,12 @@ struct PllLaunch {
     int variant = 0;       // 0: by channel count; 3 / 6: the three- / six-wave form; 7: the time-parallel form (pll_tp.hip)
     uint32_t *started = nullptr;   // host-visible word (or NULL): the launch's last workgroup writes `stamp` when it starts
     uint32_t stamp = 0;
+    // segment-level hand-over to K2b (the three-wave form only): progress[group of 64 channels] is raised to
+    // progress_base + s + 1 (agent-scope release) once segment s of the call is in HBM, to progress_base + n_seg at the end
+    uint32_t *progress = nullptr;
+    uint32_t progress_base = 0;
 };
+int pll_form_of(const PllLaunch &a);                                     // the form launch_pll() will take: 3, 32, 4, 51, 52, 6, 7
 int pll_need_lds();                                                      // bytes of LDS a PLL workgroup cannot do without
 hipError_t pll_prepare_device();                                         // once per device, after hipSetDevice
 hipError_t launch_pll(const PllLaunch &a, hipStream_t stream);           // K2
@@ -102,6 +107,10 @@ struct HdlcLaunch {
     int N, n_seg, seg_words, K;   // K: slots of a channel's candidate ring
     int K_call = 0;        // most frame starts one call can have (<= K; 0: K); sizes the chunk table
     int lanes_per_wave;    // channels per wave in K2b (blockDim)
+    // K2b started TOGETHER with the PLL launch that writes its packs: segment s of 64-channel group g may be read once
+    // progress[g] - progress_base > s (agent-scope acquire); NULL: the packs are complete when K2b starts
+    const uint32_t *progress = nullptr;
+    uint32_t progress_base = 0;
     uint2 *chunks = nullptr;   // optional [blocks of K3][k3_passes(K)]: where each pass of each K3 block put its
                            // frames in the ring (start, count).  (block, pass, position) is the reference's
                            // print order -- channel, then time -- so a ring that holds ONE call needs no sort

@@ -195,9 +195,13 @@ __device__ __forceinline__ void pll_pack_out(uint32_t *pk, uint32_t nb, uint32_t
         if (k >= 0 && k < 32) pd = (tg >> k) & 1u;        // toggles that fall on the NEXT slice
     }
 }
+// through == true: the pack is read by ANOTHER launch while this one still runs (K2b fed segment by segment): the words
+// leave as agent-scope stores (written through to where every XCD sees them), so that no cache has to be flushed to
+// publish them -- an agent-scope release fence writes back the XCD's whole L2, and the deframer's matching acquire
+// invalidates one, once per segment and workgroup: measured, that alone took the pipeline from 0.57 to 0.85 ms per call.
 __device__ __forceinline__ void pll_pack_store(uint32_t (&out)[PACK_STRIDE], uint32_t nb, uint32_t pd, uint32_t &par,
                                                bool live, uint32_t *__restrict__ segbits, uint32_t *__restrict__ segcnt,
-                                               size_t cg, int n_seg_alloc, int s)
+                                               size_t cg, int n_seg_alloc, int s, bool through = false)
 {
     if (nb) {
         out[0] ^= par;
@@ -205,7 +209,12 @@ __device__ __forceinline__ void pll_pack_store(uint32_t (&out)[PACK_STRIDE], uin
     } else {
         par ^= pd;
     }
-    if (live) {
+    if (live && through) {
+        uint32_t *dst = segbits + (cg * n_seg_alloc + s) * PACK_STRIDE;
+#pragma unroll
+        for (int k = 0; k < PACK_STRIDE; ++k) __hip_atomic_store(dst + k, out[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(segcnt + cg * n_seg_alloc + s, nb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else if (live) {
         uint4 *__restrict__ dst = reinterpret_cast<uint4 *>(segbits + (cg * n_seg_alloc + s) * PACK_STRIDE);
 #pragma unroll
         for (int k = 0; k < PACK_STRIDE / 4; ++k)

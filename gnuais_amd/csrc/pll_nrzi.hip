@@ -327,14 +327,22 @@ hipError_t pll_prepare_device()
 // groups than half the CUs -- the PLL stage's latency is what a call takes (BASELINE C2: 256 channels, 4 groups);
 // where every CU holds a PLL workgroup beside five FIR waves per SIMD, the instructions are what it costs (C3: the
 // pipelined call takes 0.535 ms with three waves, 0.56-0.59 with six).
-hipError_t launch_pll(const PllLaunch &a, hipStream_t stream)
+int pll_form_of(const PllLaunch &a)
 {
     // small batches: the time-parallel form (pll_tp.hip), where this implementation of it applies
-    if ((a.variant == 7 || (a.variant == 0 && a.N <= PLL_TP_MAX_CHANNELS)) && pll_tp_applicable(a)) return launch_pll_tp(a, stream);
+    if ((a.variant == 7 || (a.variant == 0 && a.N <= PLL_TP_MAX_CHANNELS)) && pll_tp_applicable(a)) return 7;
     const int n_cu = a.n_cu > 0 ? a.n_cu : 256;
     const int groups = (a.N + 63) / 64;
-    const int variant = a.variant == 3 || a.variant == 4 || a.variant == 6 || a.variant == 32 || a.variant == 51 || a.variant == 52
-                            ? a.variant : (2 * groups <= n_cu ? 6 : 3);
+    return a.variant == 3 || a.variant == 4 || a.variant == 6 || a.variant == 32 || a.variant == 51 || a.variant == 52
+               ? a.variant : (2 * groups <= n_cu ? 6 : 3);
+}
+
+hipError_t launch_pll(const PllLaunch &a, hipStream_t stream)
+{
+    const int variant = pll_form_of(a);
+    if (variant == 7) return launch_pll_tp(a, stream);
+    const int n_cu = a.n_cu > 0 ? a.n_cu : 256;
+    const int groups = (a.N + 63) / 64;
     if (variant == 3 || variant == 32) return launch_pll3(a, stream);
     // one workgroup per CU while the channel groups fit one round; beyond that share the CUs evenly
     const int per_cu = (groups + n_cu - 1) / n_cu;

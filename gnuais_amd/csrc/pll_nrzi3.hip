@@ -134,7 +134,7 @@ __global__ __launch_bounds__(64 * (2 + NSC)) __attribute__((amdgpu_waves_per_eu(
     const uint4 *__restrict__ sgn4, uint32_t *__restrict__ pllst, uint32_t *__restrict__ prevst,
     uint32_t *__restrict__ lastbit, uint32_t *__restrict__ segbits, uint32_t *__restrict__ segcnt,
     uint32_t *__restrict__ watchdog, int N, int L, int n_seg_alloc, uint32_t pllinc,
-    uint32_t *__restrict__ started, uint32_t stamp)
+    uint32_t *__restrict__ started, uint32_t stamp, uint32_t *__restrict__ progress, uint32_t progress_base)
 {
     extern __shared__ uint8_t lds[];
     uint64_t *lut = reinterpret_cast<uint64_t *>(lds);
@@ -260,13 +260,30 @@ __global__ __launch_bounds__(64 * (2 + NSC)) __attribute__((amdgpu_waves_per_eu(
             uint32_t out[PACK_STRIDE], pd;
             pll_pack_out(pk, nb, out, pd);
             lds_flag_store(flag + 3, (uint32_t) (s + 1));
-            pll_pack_store(out, nb, pd, par, live, segbits, segcnt, (size_t) cg, n_seg_alloc, s);
+            pll_pack_store(out, nb, pd, par, live, segbits, segcnt, (size_t) cg, n_seg_alloc, s, progress != nullptr);
+            if (progress) {
+                // the segment is K2b's from here on (it runs beside this launch): every lane's write-through stores
+                // acknowledged, then the group's counter
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                if (lane == 0)
+                    __hip_atomic_store(progress + blockIdx.x, progress_base + (uint32_t) s + 1u, __ATOMIC_RELAXED,
+                                       __HIP_MEMORY_SCOPE_AGENT);
+            }
         }
         while (lds_flag_load(flag + 4) == 0)
             if (expired()) return;
         if (live) {
-            for (int s = n_seg; s < n_seg_alloc; ++s) segcnt[(size_t) cg * n_seg_alloc + s] = 0;
+            for (int s = n_seg; s < n_seg_alloc; ++s) {
+                if (progress) __hip_atomic_store(segcnt + (size_t) cg * n_seg_alloc + s, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                else segcnt[(size_t) cg * n_seg_alloc + s] = 0;
+            }
             lastbit[cg] = (sign1[lane] ^ par) & 1u;
+        }
+        if (progress) {                                        // the empty segments behind a short call
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (lane == 0)
+                __hip_atomic_store(progress + blockIdx.x, progress_base + (uint32_t) n_seg_alloc, __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_AGENT);
         }
         return;
     }
@@ -338,10 +355,10 @@ hipError_t launch_pll3(const PllLaunch &a, hipStream_t stream)
     if (lds > 160 * 1024) return hipErrorInvalidValue;
     if (nsc == 2)
         hipLaunchKernelGGL(pll3_kernel<2>, dim3(groups), dim3(64 * 4), lds, stream, (const uint4 *) a.sgn, a.pll,
-                           a.prev, a.lastbit, a.segbits, a.segcnt, a.watchdog, a.N, a.L, a.n_seg, a.pllinc, a.started, a.stamp);
+                           a.prev, a.lastbit, a.segbits, a.segcnt, a.watchdog, a.N, a.L, a.n_seg, a.pllinc, a.started, a.stamp, a.progress, a.progress_base);
     else
         hipLaunchKernelGGL(pll3_kernel<1>, dim3(groups), dim3(64 * 3), lds, stream, (const uint4 *) a.sgn, a.pll,
-                           a.prev, a.lastbit, a.segbits, a.segcnt, a.watchdog, a.N, a.L, a.n_seg, a.pllinc, a.started, a.stamp);
+                           a.prev, a.lastbit, a.segbits, a.segcnt, a.watchdog, a.N, a.L, a.n_seg, a.pllinc, a.started, a.stamp, a.progress, a.progress_base);
     return hipGetLastError();
 }
 
