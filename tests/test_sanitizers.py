@@ -128,3 +128,22 @@ def test_buffer_mismatch_inside_a_round_is_refused_and_the_handler_may_free(run)
     err = p.stderr.decode()
     assert p.returncode == 7, err
     assert "another buffer" in err and "buffer mismatch inside a round" in err and "handler: receivers freed" in err
+
+
+def test_host_code_under_thread_sanitizer(run):
+    """The same program under -fsanitize=thread (`make -C tests/c tsan`): its two-thread section drives two receiver
+    groups at once through receiver_hip.c (process-wide recursive lock around the device work, frames delivered
+    unlocked) -- no data race reported, and the two threads' outputs are what the single-threaded run printed."""
+    d, g, _ = run
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "tests", "c"), "tsan"])
+    exe = os.path.join(ROOT, "tests", "c", "tsan_host.bin")
+    p = subprocess.run([exe, str(d)], capture_output=True, timeout=900,
+                       env=dict(os.environ, TSAN_OPTIONS="halt_on_error=1:second_deadlock_stack=1"))
+    err = p.stderr.decode()
+    if p.returncode != 0 and "FATAL: ThreadSanitizer" in err and "WARNING" not in err:
+        pytest.skip("ThreadSanitizer cannot run in this container: " + err.splitlines()[0])
+    assert p.returncode == 0 and "WARNING: ThreadSanitizer" not in err, err[-4000:]
+    fr = np.frombuffer(np.ascontiguousarray(g["frames"]).tobytes(), dtype=FRAME_DTYPE)
+    mt = open(d / "out_dropin_mt.txt").read().splitlines()
+    for ch, name in enumerate("AB"):
+        assert [l for l in mt if l.startswith(f"ch {name} ")] == [frame_line(name, f) for f in fr if int(f["channel"]) == ch]
