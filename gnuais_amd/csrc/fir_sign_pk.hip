@@ -62,6 +62,13 @@ struct PkTaps {
     pk_f2 E[NC / 4];            // E[j] = { tc[2j], tc[2j+1] },   j < NC/4
     pk_f2 O[NC / 4 + 1];        // O[j] = { tc[2j], tc[2j-1] },   j <= NC/4, tc[-1] = tc[NC-1]
 };
+#ifndef PK_DEFER
+#define PK_DEFER 1          // 0: every open sign is settled where it is found (rounds 3-4; kept for the A/B)
+#endif
+#ifndef PK_EXACT_BATCH
+#define PK_EXACT_BATCH 6          // loads in flight in the ordered sum (8 cost the 48-tap kernel a 145th register: 152 per wave instead of 144)
+#endif
+#define PK_PEND 8           // noted outputs per lane (1 KB of LDS per wave); more than that are settled on the spot
 template <int NES> struct PkExact { float te[NES > 0 ? NES : 1]; };
 
 // the next group's rows are requested before this group's steps run
@@ -116,15 +123,15 @@ __device__ __forceinline__ void fir_sign_pk_body(
             }
             return sum > 0.0f;
         }
-        for (int j0 = 0; j0 < NE; j0 += 8) {        // eight loads in flight: this rare path must not set the kernel's register count
-            int xs[8];
+        for (int j0 = 0; j0 < NE; j0 += PK_EXACT_BATCH) {      // a few loads in flight: this rare path must not set the kernel's register count
+            int xs[PK_EXACT_BATCH];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
+            for (int j = 0; j < PK_EXACT_BATCH; ++j) {
                 const int jj = j0 + j < NE ? j0 + j : NE - 1;
                 xs[j] = pk_load_sample(x, hist, n - d + jj, N, NTaps, c);
             }
 #pragma unroll
-            for (int j = 0; j < 8; ++j)
+            for (int j = 0; j < PK_EXACT_BATCH; ++j)
                 if (j0 + j < NE) sum = sum + te_mem[j0 + j] * (float) xs[j];
         }
         return sum > 0.0f;
@@ -190,7 +197,8 @@ __device__ __forceinline__ void fir_sign_pk_body(
     uint32_t neg = 0, amb = 0, zor = 0;
     bool zprev_known = false, zprev = false;
     float eps_w = eps_up;
-    constexpr int NHIST = 6;                    // see fir_sign_kernel: 96 rows behind a group cover NC - 1 + J0 for J0 <= 49
+    constexpr int NHIST = 3;                    // maxima of |x|: [0] this turn of three groups so far, [1] the turn before, [2] the one before
+    static_assert(NG == 3, "two whole turns of three 16-row groups = the 96 rows behind a group cover NC - 1 + J0 for J0 <= 49");
     float hmax[NHIST];
     if constexpr (INLOOP) {
         float Pm = 0.0f;
@@ -211,6 +219,8 @@ __device__ __forceinline__ void fir_sign_pk_body(
     }
 
     uint32_t wq[4] = {0u, 0u, 0u, 0u};
+    __shared__ uint16_t pend[PK_PEND * 64];     // per lane: outputs (relative to t0; < 65536, the launcher caps T) whose sign the central sum left open
+    int n_pend = 0;
     auto flush = [&](int obase) __attribute__((always_inline)) {               // one finished sign word: outputs obase .. obase+31
         const int mb = m0 + NC - 1 + obase;
         uint32_t w = ~neg;
@@ -231,15 +241,52 @@ __device__ __forceinline__ void fir_sign_pk_body(
         }
         zprev_known = zc_known;
         zprev = zc;
-        while (amb) {
-            const int pos = __clz((int) amb);
-            const uint32_t bit = 0x80000000u >> pos;
-            amb &= ~bit;
-            if (exact_positive(t0 + obase + pos)) w |= bit; else w &= ~bit;
-        }
+        // What is left needs the reference's ordered sum.  One lane doing that while 63 wait was 2 of the 48-tap
+        // kernel's 36 instructions per sample (a quarter of a wave's words hold one such sample somewhere); instead the
+        // lane notes the output, leaves the bit 0, and all lanes work their lists off TOGETHER -- the k-th noted output of
+        // every lane at the same time -- after the segment's last word, or at once when a lane has more than its list
+        // holds.  (The rows differ per lane, the channel does not: as many cache lines per load as lanes at work, the
+        // same lines the one-at-a-time form fetched.)  A word that has left for memory gets its bit by an atomic OR (this
+        // lane stored it: one location, one thread, program order); the up to four words still in registers are patched
+        // there.  Same scheme as fir_sign_kernel's.
+        w &= ~amb;
         const int slot = (obase >> 5) & 3;
-        if (slot == 0) wq[0] = w; else if (slot == 1) wq[1] = w; else if (slot == 2) wq[2] = w; else wq[3] = w;
         const bool last = t0 + obase + 32 >= t1;
+        if (PK_DEFER) {
+            while (amb && n_pend < PK_PEND) {
+                const int pos = __clz((int) amb);
+                amb &= ~(0x80000000u >> pos);
+                pend[n_pend * 64 + lane] = (uint16_t) (obase + pos);
+                ++n_pend;
+            }
+        }
+        if (slot == 0) wq[0] = w; else if (slot == 1) wq[1] = w; else if (slot == 2) wq[2] = w; else wq[3] = w;
+        if (__any(amb != 0) || (PK_DEFER && last && __any(n_pend != 0))) {
+            const int held = (obase >> 5) - slot;                   // first word that is still in wq[]
+            for (int k = 0;; ++k) {
+                int o = -1;
+                if (k < n_pend) {
+                    o = (int) pend[k * 64 + lane];
+                } else if (amb) {
+                    const int pos = __clz((int) amb);
+                    amb &= ~(0x80000000u >> pos);
+                    o = obase + pos;
+                }
+                if (!__any(o >= 0)) break;
+                if (o < 0 || !exact_positive(t0 + o)) continue;
+                const uint32_t bit = 0x80000000u >> (o & 31);
+                const int wi = (o >> 5) - held;
+                if (wi < 0) {
+                    if (live) atomicOr(sgn + sgn_index((t0 + o) >> 5, N, cg), bit);
+                } else {
+                    wq[0] |= wi == 0 ? bit : 0u;
+                    wq[1] |= wi == 1 ? bit : 0u;
+                    wq[2] |= wi == 2 ? bit : 0u;
+                    wq[3] |= wi == 3 ? bit : 0u;
+                }
+            }
+            n_pend = 0;
+        }
         if (live && (slot == 3 || last)) {
             uint32_t *dst = sgn + sgn_index(((t0 + obase) >> 5) - slot, N, cg);
             if (slot == 3) {
@@ -317,12 +364,17 @@ __device__ __forceinline__ void fir_sign_pk_body(
                 float gm = 0.0f;
 #pragma unroll
                 for (int p = 0; p < GROUP; ++p) gm = __builtin_fmaxf(gm, __builtin_fabsf(xp[p / 2][p % 2]));
-                float M = gm;
-#pragma unroll
-                for (int k = 0; k < NHIST; ++k) M = __builtin_fmaxf(M, hmax[k]);
-#pragma unroll
-                for (int k = 0; k + 1 < NHIST; ++k) hmax[k] = hmax[k + 1];
-                hmax[NHIST - 1] = gm;
+                // the window behind a group (NC - 1 + J0 <= 96 rows = six groups) as three maxima: this loop turn's groups
+                // so far, the turn before, the turn before that -- six to eight groups, never fewer (a larger M only
+                // widens the band); one v_max3 per group instead of a six-deep history that is shifted every time
+                if constexpr (g == 0) {
+                    hmax[2] = hmax[1];
+                    hmax[1] = hmax[0];
+                    hmax[0] = gm;
+                } else {
+                    hmax[0] = __builtin_fmaxf(hmax[0], gm);
+                }
+                const float M = __builtin_fmaxf(__builtin_fmaxf(hmax[0], hmax[1]), hmax[2]);
                 gmax_group = gm;
                 eps_w = __builtin_fmaf(eps_seen, M * (1.0f / 32768.0f), eps_ahead);
             }

@@ -340,8 +340,12 @@ __global__ __launch_bounds__(64) void fir_slice_kernel(
 //
 // Same mapping as K1 (lane = channel, wave = 64 channels x one time segment), but
 // 12 accumulators rotate, so 96 phases (three sign words) are unrolled.
+#ifndef FIR_SIGN_DEFER
+#define FIR_SIGN_DEFER 1        // 0: every open sign is settled where it is found (rounds 1-4; kept for the A/B)
+#endif
+#define FIR_SIGN_PEND 8         // noted outputs per lane (1 KB of LDS per wave); more than that are settled on the spot
 #ifndef FIR_SIGN_CLAIM
-#define FIR_SIGN_CLAIM "v87"        // the highest VGPR the 12-tap kernel pretends to use (see fir_sign_kernel)
+#define FIR_SIGN_CLAIM "v103"       // the highest VGPR the 12-tap kernel pretends to use (see fir_sign_kernel; profiles/r04_fir_claim.txt)
 #endif
 #ifndef FIR_SIGN_FENCE
 #define FIR_SIGN_FENCE 4
@@ -410,14 +414,15 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NC == 48 ? 4
     const int J0 = (NE - NC) / 2;               // first central tap (10 of 32 for the reference table)
     auto ctap = [&](int q) -> float { return NES > 0 ? taps.te[(NES - NC) / 2 + q] : taps.te[q]; };
 #if FIR_SIGN_FENCE > 0
-    if constexpr (NC == 12)
-    // Claim 88 VGPRs although the fenced code needs 68: five waves per SIMD then leave 72
-    // registers for a wave of each of the stages that run beside us (the PLL stage needs 64).  At seven
+    if constexpr (NC <= 12)
+    // Claim 104 VGPRs although the fenced code needs 68: four waves per SIMD then leave 96
+    // registers for waves of the stages that run beside us (the PLL stage needs 64).  At seven
     // waves per SIMD this kernel would fill the register file and they would wait for FIR
-    // waves to retire before they could even be placed.
+    // waves to retire before they could even be placed.  88 (five waves, 72 left: rounds 1-3) gives the same 20-call
+    // figure and a steady state 5-7 % slower; 96, 112 and 128 are worse than both (profiles/r04_fir_claim.txt).
     asm volatile("" ::: FIR_SIGN_CLAIM);
 #endif
-    static_assert(96 % NC == 0 && NC % 2 == 0, "96 unrolled phases must hold whole turns of the accumulator ring");
+    static_assert((K1S_DIRECT(NC) || 96 % NC == 0) && NC % 2 == 0, "96 unrolled phases must hold whole turns of the accumulator ring");
     const int lane = threadIdx.x;
     // Workgroup -> (channel group, time segment).  The dispatcher deals consecutive workgroup ids
     // round-robin over the 8 XCDs.  map 0: id = segment * groups + group, so an XCD works on every
@@ -535,6 +540,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NC == 48 ? 4
         const int nblk = (t1 - t0 + UW * 32 - 1) / (UW * 32);
         constexpr bool WIDE = K1S_DIRECT(NC) && (UW == 4 || UW == 2 || UW == 1);   // T % 128 == 0: t0's word index is 0 mod 4
         uint32_t wq[4] = {0u, 0u, 0u, 0u};                      // the sign words of 128 outputs, stored as one
+        __shared__ uint16_t pend[FIR_SIGN_PEND * 64];           // per lane: outputs (relative to t0; the launcher caps T
+        int n_pend = 0;                                         // below 65536) whose sign the central sum left open
         for (int b = 0; b < nblk; ++b) {
     #pragma unroll
             for (int w3 = 0; w3 < UW; ++w3) {
@@ -676,18 +683,58 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NC == 48 ? 4
                 }
                 zprev_known = zc_known;
                 zprev = zc;
-                // the samples whose sign y_c cannot certify: exact ordered sum
-                while (amb) {
-                    const int pos = __clz((int) amb);
-                    const uint32_t bit = 0x80000000u >> pos;
-                    amb &= ~bit;
-                    if (exact_positive(t0 + obase + pos)) w |= bit; else w &= ~bit;
+                // The samples whose sign y_c cannot certify need the reference's ordered sum.  One lane doing that while
+                // 63 wait is what this used to cost (a sixth of a wave's words hold such a sample somewhere); instead the
+                // lane notes the output, leaves its bit 0, and the lanes work their lists off TOGETHER -- the k-th noted
+                // output of every lane at the same time -- after the segment's last word, or at once when a lane has more
+                // than its list holds (a silent or clipped stretch).  The rows differ per lane, the channel does not: as
+                // many cache lines per load as lanes at work, the lines the one-at-a-time form fetched.  A word that has
+                // left for memory gets its bit by an atomic OR (this lane stored it: one location, one thread, program
+                // order); the up to four words still in registers are patched there.
+                w &= ~amb;
+                const int wi = b * UW + w3;                     // word of the segment (wave-uniform; static mod 4 for UW = 4)
+                const int slot = WIDE ? (wi & 3) : 0;
+                const bool last = t0 + obase + 32 >= t1;        // the segment's last word
+                if constexpr (WIDE && FIR_SIGN_DEFER) {
+                    while (amb && n_pend < FIR_SIGN_PEND) {
+                        const int pos = __clz((int) amb);
+                        amb &= ~(0x80000000u >> pos);
+                        pend[n_pend * 64 + lane] = (uint16_t) (obase + pos);
+                        ++n_pend;
+                    }
                 }
                 if constexpr (WIDE) {
-                    const int wi = b * UW + w3;                 // word of the segment (wave-uniform; static mod 4 for UW = 4)
-                    const int slot = wi & 3;
                     if (slot == 0) wq[0] = w; else if (slot == 1) wq[1] = w; else if (slot == 2) wq[2] = w; else wq[3] = w;
-                    const bool last = t0 + obase + 32 >= t1;    // the segment's last word
+                }
+                if (__any(amb != 0) || (WIDE && FIR_SIGN_DEFER && last && __any(n_pend != 0))) {
+                    const int held = wi - slot;                 // first word that is still in registers
+                    for (int k = 0;; ++k) {
+                        int o = -1;
+                        if (k < n_pend) {
+                            o = (int) pend[k * 64 + lane];
+                        } else if (amb) {
+                            const int pos = __clz((int) amb);
+                            amb &= ~(0x80000000u >> pos);
+                            o = obase + pos;
+                        }
+                        if (!__any(o >= 0)) break;
+                        if (o < 0 || !exact_positive(t0 + o)) continue;
+                        const uint32_t bit = 0x80000000u >> (o & 31);
+                        const int rel = (o >> 5) - held;
+                        if (rel < 0) {
+                            if (live) atomicOr(sgn + sgn_index((t0 + o) >> 5, N, cg), bit);
+                        } else if constexpr (WIDE) {
+                            wq[0] |= rel == 0 ? bit : 0u;
+                            wq[1] |= rel == 1 ? bit : 0u;
+                            wq[2] |= rel == 2 ? bit : 0u;
+                            wq[3] |= rel == 3 ? bit : 0u;
+                        } else {
+                            w |= bit;
+                        }
+                    }
+                    n_pend = 0;
+                }
+                if constexpr (WIDE) {
                     if (live && (slot == 3 || last)) {
                         uint32_t *dst = sgn + sgn_index(((t0 + obase) >> 5) - slot, N, cg);
                         if (slot == 3) {
@@ -984,13 +1031,14 @@ int launch_fir_sign_quantum(int NC)
 {
     // the 12-tap kernel stores four sign words at once: segments start on a multiple of 128 outputs
     // (the 48-tap one too, and its unrolled body is three words: 384)
-    return NC == 12 ? ((FIR_DIRECT_UNROLL == 4 || FIR_DIRECT_UNROLL == 2 || FIR_DIRECT_UNROLL == 1) ? 128 : 32 * FIR_DIRECT_UNROLL) : 384;
+    return NC <= 12 ? ((FIR_DIRECT_UNROLL == 4 || FIR_DIRECT_UNROLL == 2 || FIR_DIRECT_UNROLL == 1) ? 128 : 32 * FIR_DIRECT_UNROLL) : 384;
 }
 
 hipError_t launch_fir_sign(const FirLaunch &a, hipStream_t stream)
 {
-    if (a.dump || a.T % launch_fir_sign_quantum(a.NC) || !a.te_mem || (a.NC != 12 && a.NC != 48) || a.NE < a.NC || (a.NE - a.NC) % 2)
+    if (a.dump || a.T % launch_fir_sign_quantum(a.NC) || !a.te_mem || (a.NC != 10 && a.NC != 12 && a.NC != 48) || a.NE < a.NC || (a.NE - a.NC) % 2)
         return hipErrorInvalidValue;
+    if (a.T > 65280) return hipErrorInvalidValue;       // the kernel notes open outputs as 16-bit offsets into the segment
     dim3 grid((a.N + 63) / 64, (a.L + a.T - 1) / a.T), block(64);
     int n_big = 1 << 30, T2 = a.T;
     if (a.T2 > 0 && a.T2 < a.T && a.T2 % launch_fir_sign_quantum(a.NC) == 0 && a.n_big < (int) grid.y) {
@@ -1004,7 +1052,15 @@ hipError_t launch_fir_sign(const FirLaunch &a, hipStream_t stream)
     if (a.persist > 0 && (long) gx * gy > a.persist) grid = dim3((a.persist + 7) & ~7);   // a multiple of 8: a workgroup's items stay on its XCD
     // the stamp buffer (a debugging option) is written by workgroup id: a grid it has no room for gets none
     unsigned long long *const stamps_ok = ((size_t) grid.x * grid.y <= a.stamps_waves) ? a.stamps : nullptr;
-    if (a.NC == 12 && a.NE == 32) {
+    if (a.NC == 10 && a.NE == 32) {
+        // ten central taps: one symmetric pair less per output than twelve, an ambiguity band three times as wide
+        FirTaps<32> t;
+        for (int j = 0; j < 32; ++j) t.te[j] = a.te[j];
+        hipLaunchKernelGGL((fir_sign_kernel<32, 10, 32>), grid, block, a.lds_pad, stream, a.x, a.hist, a.sgn, a.maxval,
+                           a.hist_out, a.maxval_next, a.te_mem, a.N, a.L, a.T, a.d, a.NT, a.NE, eps_up, map, t, stamps_ok, n_big, T2, a.eps_seen, a.eps_ahead, gx, gy);
+    } else if (a.NC == 10) {
+        return hipErrorInvalidValue;
+    } else if (a.NC == 12 && a.NE == 32) {
         FirTaps<32> t;
         for (int j = 0; j < 32; ++j) t.te[j] = a.te[j];
         hipLaunchKernelGGL((fir_sign_kernel<32, 12, 32>), grid, block, a.lds_pad, stream, a.x, a.hist, a.sgn, a.maxval,

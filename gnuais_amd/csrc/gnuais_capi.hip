@@ -185,6 +185,9 @@ struct gnuais_batch {
     float sign_eps_seen = 0.0f, sign_eps_ahead = 0.0f;   // sign_eps split: what scales with the samples seen / what cannot
     int fir_inloop = 1;             // 48-tap K1s: running window maximum in the loop (0: the per-segment pre-pass)
     int sign_NC = 12;               // central taps K1s evaluates
+    int sign_NC_lo = 0;             // ... and the shorter sum the one-channel-per-lane 12-tap kernel may take instead (0: none)
+    float sign_eps_lo = 0.0f;       //     with its bound
+    int fir_nc = 0;                 // 0: the shorter sum where there is one; 12: never
     int k0 = 0;                     // first effective tap
     int pll_variant = 0;            // 0: by channel count; 3 / 6 (kernels.h: PllLaunch::variant)
     int hdlc_lpw = 0;               // channels per wave in K2b; 0 = the variant's own default (16 event-driven, 64 bit-serial)
@@ -406,6 +409,23 @@ int gnuais_batch_create(gnuais_batch **out, int device, int n_channels, const fl
                     ahead += std::fabs((double) b->te[i - 1]) * (1.0 + (std::pow(1 + u, NE - i + 2) - 1));
                 b->sign_eps_ahead = (float) (X * ahead * 1.1 + 1e-30);
                 b->sign_eps_seen = (float) ((bound - X * ahead) * 1.1);
+                // Since the open signs are settled lane-parallel (fir_sign_kernel, round 4) an open sign costs a
+                // fraction of what it did, and the outermost pair of the twelve weighs 3.7e-6: ten central taps leave
+                // a band three times as wide (0.41 against 0.136: 2.5e-4 of a noisy channel's outputs open instead of
+                // 0.9e-4) and take two instructions off every output.  Same derivation, NC - 2.
+                if (NC == 12 && NE == 32 && K1S_DIRECT(10)) {
+                    const int NL = 10, JL = (NE - NL) / 2;
+                    double out_lo = 0, cen = 0;
+                    for (int j = 0; j < NE; ++j)
+                        if (j < JL || j >= JL + NL) out_lo += std::fabs((double) b->te[j]);
+                    for (int i = 1; i <= NL / 2; ++i)
+                        cen += 2.0 * std::fabs((double) b->te[JL + i - 1]) * (std::pow(1 + u, i == 1 ? NL / 2 : NL / 2 - i + 2) - 1);
+                    const double bound_lo = X * (ordered(0, NE) + cen + out_lo) + 1e-30;
+                    if (std::isfinite(bound_lo) && bound_lo < 2.0) {
+                        b->sign_NC_lo = NL;
+                        b->sign_eps_lo = (float) (bound_lo * 1.1);
+                    }
+                }
             }
         }
     }
@@ -517,6 +537,7 @@ int gnuais_batch_create(gnuais_batch **out, int device, int n_channels, const fl
         return fail(GNUAIS_E_HIP, "create: device allocation", e);
     }
     if (const char *v = getenv("GNUAIS_FIR_VARIANT")) b->fir_variant = atoi(v);
+    if (const char *v = getenv("GNUAIS_FIR_NC")) b->fir_nc = atoi(v) == 12 ? 12 : 0;
     if (const char *v = getenv("GNUAIS_FIR_PK")) b->fir_pk = atoi(v) < 0 ? -1 : (atoi(v) != 0);
     if (const char *v = getenv("GNUAIS_FIR_CPL")) { const int c = atoi(v); if (c == 1 || c == 2 || c == 4) b->fir_cpl = c; }
     if (const char *v = getenv("GNUAIS_FIR_FORM")) b->fir_form = atoi(v);
@@ -624,6 +645,9 @@ int gnuais_batch_set_option(gnuais_batch *b, const char *name, int value)
         b->fir_cpl = value;
     } else if (!strcmp(name, "fir_form")) {
         b->fir_form = value;
+    } else if (!strcmp(name, "fir_nc")) {
+        if (value != 0 && value != 12) return fail(GNUAIS_E_ARG, "fir_nc: 0 (the shortest certified central sum) or 12");
+        b->fir_nc = value;
     } else if (!strcmp(name, "fir_pk")) {
         b->fir_pk = value < 0 ? -1 : (value != 0);
     } else if (!strcmp(name, "fir_inloop")) {
@@ -712,6 +736,13 @@ static void fill_hdlc(const gnuais_batch *b, HdlcLaunch &h, int k)
     h.chunks = (b->streaming && b->ring_runs[b->ring_cur] == 0) ? b->ring_chunks[b->ring_cur] : nullptr;
 }
 
+// does the receive path run the shorter central sum?  (only the one-channel-per-lane scalar kernel is built for it)
+static bool sign_lo(const gnuais_batch *b)
+{
+    return b->sign_ok && b->sign_NC == 12 && b->sign_NC_lo > 0 && b->fir_nc != 12 && b->fir_variant == 3 &&
+           b->fir_pk != 1 && b->fir_cpl <= 1;
+}
+
 // K1 + carry.  The specialised kernel updates the history and clears the next peak
 // buffer itself; the generic fallback needs the two helper launches.
 static int run_fir(gnuais_batch *b, const int16_t *x, int len, float *dump, hipStream_t s, int k)
@@ -720,7 +751,7 @@ static int run_fir(gnuais_batch *b, const int16_t *x, int len, float *dump, hipS
     fill_fir(b, f, x, len, dump, k);
     if (b->fir_variant == 3 && b->sign_ok && !dump) {
         const int q = launch_fir_sign_quantum(f.NC);        // whole loop turns of the kernel's unrolled body
-        f.T = (f.T + q - 1) / q * q;
+        f.T = std::min((f.T + q - 1) / q * q, 65280 / q * q);       // K1s notes open outputs as 16-bit offsets into the segment
         // several adjacent channels per lane (wide typed loads) where the table, the channel count and the
         // buffer's alignment allow; one channel per lane otherwise
         if ((b->fir_pk == 1 || (b->fir_pk < 0 && f.NC == 48)) &&
@@ -730,6 +761,7 @@ static int run_fir(gnuais_batch *b, const int16_t *x, int len, float *dump, hipS
             // waves: 16384 x 192000 is 16000 segments of 3072) cut its share (round 4: 3072 against 1536, 4.29 against
             // 4.39 ms per C5 call in steady state, profiles/r04_c5_ring_and_segments.txt)
             f.T = ((f.NC == 48 && b->fir_T <= 768 ? 3072 : b->fir_T) + qp - 1) / qp * qp;
+            f.T = std::min(f.T, 65280 / qp * qp);           // the kernel notes open outputs as 16-bit offsets into the segment
             HIP_TRY(launch_fir_sign_pk(f, s));
             b->hist_cur = (b->hist_cur + 1) % gnuais_batch::HB;
             b->max_last = b->max_cur;
@@ -749,8 +781,16 @@ static int run_fir(gnuais_batch *b, const int16_t *x, int len, float *dump, hipS
             if (f.T2 >= f.T) f.T2 = 0;
         }
         f.persist = b->fir_persist * 4 * b->n_cu;
-        if (cpl > 1) HIP_TRY(launch_fir_sign_wide(f, cpl, b->fir_form, s));
-        else HIP_TRY(launch_fir_sign(f, s));
+        if (cpl > 1) {
+            HIP_TRY(launch_fir_sign_wide(f, cpl, b->fir_form, s));
+        } else {
+            if (sign_lo(b)) {                   // the one-channel-per-lane kernel: ten central taps where the table allows
+                f.NC = b->sign_NC_lo;
+                f.eps = b->sign_eps_lo;
+                for (int j = 0; j < f.NC; ++j) f.ctaps[j] = b->te[(b->NE - f.NC) / 2 + j];
+            }
+            HIP_TRY(launch_fir_sign(f, s));
+        }
     } else if (b->NE != 32) {
         HIP_TRY(hipMemsetAsync(b->maxval[(b->max_cur + 2) % gnuais_batch::HB], 0, sizeof(int) * (size_t) b->N, s));
         HIP_TRY(launch_fir_generic(f, s));
@@ -1819,10 +1859,10 @@ int gnuais_batch_info(const gnuais_batch *b, const char *name, double *value)
 {
     if (!b || !name || !value) return fail(GNUAIS_E_ARG, "info: argument");
     if (!strcmp(name, "sign_exact")) *value = b->sign_ok && b->fir_variant == 3;
-    else if (!strcmp(name, "sign_eps")) *value = b->sign_eps;
+    else if (!strcmp(name, "sign_eps")) *value = sign_lo(b) ? b->sign_eps_lo : b->sign_eps;     // of the kernel the options select
     else if (!strcmp(name, "sign_eps_seen")) *value = b->sign_eps_seen;
     else if (!strcmp(name, "sign_eps_ahead")) *value = b->sign_eps_ahead;
-    else if (!strcmp(name, "sign_central_taps")) *value = b->sign_NC;
+    else if (!strcmp(name, "sign_central_taps")) *value = sign_lo(b) ? b->sign_NC_lo : b->sign_NC;
     else if (!strcmp(name, "first_effective_tap")) *value = b->k0;
     else if (!strcmp(name, "n_effective_taps")) *value = b->NE;
     else if (!strcmp(name, "compute_units")) *value = b->n_cu;

@@ -137,7 +137,7 @@ hipError_t launch_crc16_bits(const uint8_t *bits, int n_bytes, uint16_t *crc, ui
 #ifndef K1S_DIRECT_12
 #define K1S_DIRECT_12 1
 #endif
-#define K1S_DIRECT(nc) (K1S_DIRECT_12 && (nc) == 12)
+#define K1S_DIRECT(nc) (K1S_DIRECT_12 && (nc) <= 12)
 
 // ---- f1 on the device (nmea_device.hip) ---------------------------------------
 size_t nmea_scratch_bytes(int n_frames, int n_chunks = 0);

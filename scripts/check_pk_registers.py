@@ -2,7 +2,8 @@
 uses.  The asm statements list them as clobbers (so the compiler keeps nothing of its own there ACROSS a statement and
 counts them into the wave's allocation), but a clobber list cannot protect state BETWEEN two statements, so the ISA is
 scanned: (1) no compiler-generated instruction (anything outside the ASMSTART/ASMEND blocks) of the two kernels may name
-a register of the ring or above; (2) the kernel descriptor must allocate the wave every register the streams name.  A
+a register the streams own (base .. the highest clobbered one; a register ABOVE them is the compiler's to use -- it
+parks spilled SGPRs there when v0..base-1 are taken); (2) the kernel descriptor must allocate the wave every register the streams name.  A
 violation of (1) shows as rare wrong sign bits, of (2) as corrupted neighbours, neither as a crash -- so the Makefile
 runs this on the ISA of the very object it builds (same flags) and fails the build on a finding.
 
@@ -28,7 +29,8 @@ else:
 bad = 0
 for nc in (12, 48):
     inside = in_asm = found = False
-    top = -1
+    top = -1                     # highest register of the compiler's own code below the streams' block
+    above = -1                   # ... and above it
     where = None
     for no, line in enumerate(text, 1):
         if re.match(rf"^_ZN.*fir_sign_pk{nc}_kernel.*:", line): inside = found = True
@@ -37,15 +39,18 @@ for nc in (12, 48):
         elif "ASMEND" in line: in_asm = False
         elif not in_asm and not line.lstrip().startswith((";", ".")):
             for m in re.finditer(r"\bv(\d+)\b|\bv\[(\d+):(\d+)\]", line):
+                lo = int(m.group(1) or m.group(2))
                 r = int(m.group(1) or m.group(3))
-                if r > top: top, where = r, (no, line.strip())
+                if lo > ring_top[nc]: above = max(above, r)
+                elif r > top: top, where = r, (no, line.strip())
         if "s_endpgm" in line: break
     if not found:
         print(f"fir_sign_pk{nc}_kernel: not found in the ISA")
         bad += 1
         continue
     ok = top < base[nc]
-    print(f"fir_sign_pk{nc}_kernel: compiler code uses v0..v{top}, the ring starts at v{base[nc]}" +
+    print(f"fir_sign_pk{nc}_kernel: compiler code uses v0..v{top}" + (f" and v{ring_top[nc] + 1}..v{above}" if above >= 0 else "") +
+          f", the streams own v{base[nc]}..v{ring_top[nc]}" +
           ("" if ok else f"  <-- VIOLATION at line {where[0]}: {where[1]}"))
     bad += not ok
     # the kernel descriptor: registers the hardware gives a wave.  The streams' registers count only because the asm

@@ -194,15 +194,18 @@ def test_c5_full_size():
 
 # ---------------------------------------------------------------- the slicer's threshold
 
-def test_sign_exact_slicer_on_its_threshold():
-    """K1s certifies the sign of the reference's ordered 32-term sum from the 12 central taps when
-    |y_c| > eps and re-evaluates exactly otherwise.  Inputs built so that |y_c| lands within a few
-    percent of eps on BOTH sides (and of both signs), each alone in silence: the decisions must be
+@pytest.mark.parametrize("fir_nc", [0, 12])
+def test_sign_exact_slicer_on_its_threshold(fir_nc):
+    """K1s certifies the sign of the reference's ordered 32-term sum from the 10 (default) or 12 (`fir_nc` = 12) central
+    taps when |y_c| > eps and re-evaluates exactly otherwise.  Inputs built so that |y_c| lands within a few
+    percent of the running kernel's eps on BOTH sides (and of both signs), each alone in silence: the decisions must be
     those of the exact filter, sample for sample."""
     taps = params.taps_48k().astype(np.float64)
     b0 = batch(64, max_len=4096)
-    assert b0.info("sign_exact") == 1 and b0.info("sign_central_taps") == 12
+    b0.set_option("fir_nc", fir_nc)
+    assert b0.info("sign_exact") == 1 and b0.info("sign_central_taps") == (12 if fir_nc else 10)
     eps = b0.info("sign_eps")
+    assert (eps < 0.2) == (fir_nc == 12)
     k0 = int(b0.info("first_effective_tap"))
     j0 = k0 + (int(b0.info("n_effective_taps")) - 12) // 2           # first central tap in the 36-tap table
     assert 0.05 < eps < 0.5
@@ -248,6 +251,7 @@ def test_sign_exact_slicer_on_its_threshold():
     xd = dev(x)
     for chunk in (total, 33, 1):                                     # and under awkward call boundaries
         b = batch(n_ch, max_len=total)
+        b.set_option("fir_nc", fir_nc)
         signs = []
         for lo in range(0, total, chunk):
             hi = min(total, lo + chunk)

@@ -242,6 +242,46 @@ def test_chain_vs_oracle_digital_silence_patterns():
     run_both(x, [4096, 4096, 4096, 777], x.shape[1], fir_T=512)
     run_both(x, [total], x.shape[1])
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("kernel", ["scalar10", "scalar12", "packed12", "packed48"])
+def test_open_signs_settled_in_bulk(kernel):
+    """K1s notes the outputs whose sign its central sum cannot certify and settles them lane-parallel after the segment
+    (eight per lane; more are settled on the spot, all lanes together).  Sparse +-1 / +-2 dither makes most outputs of a
+    word open without the word being silent, at densities from one per segment to nearly all: lists that stay short, lists
+    that overflow in every word, bits patched in registers and bits patched in memory, channel counts that leave lanes
+    of the last wave without a channel, segment and call boundaries.  Decisions == (reference float > 0), sample for
+    sample, and the chain behind them == oracle."""
+    rng = np.random.default_rng(77)
+    n_ch, total = 70, 9000
+    taps = params.taps_192k() if kernel == "packed48" else None
+    pllinc = params.PLLINC_192K if kernel == "packed48" else 0
+    cols = []
+    for c in range(n_ch):
+        p = (0.0005, 0.003, 0.02, 0.1, 0.4, 0.9)[c % 6]
+        v = np.where(rng.random(total) < p, rng.integers(1, 3, total) * rng.choice([-1, 1], total), 0)
+        if c % 7 == 3:
+            v[2000:2600] = rng.normal(0, 4000, 600)          # a live stretch between the quiet ones
+        cols.append(v)
+    x = np.stack(cols, axis=1).astype(np.int16)
+    o = Oracle(n_ch, taps=taps, pllinc=pllinc)
+    want = (o.run(x, want_filtered=True)["filtered"] > 0).T.astype(np.uint8)
+    xd = dev(x)
+    for chunks in ([total], [4096, 3000, 1, 1903], [511] * 17 + [313]):
+        b = batch(n_ch, taps=taps, pllinc=pllinc, max_len=max(chunks))
+        if kernel == "packed12":
+            b.set_option("fir_pk", 1)
+        if kernel == "scalar12":
+            b.set_option("fir_nc", 12)
+        assert b.info("sign_exact") == 1 and b.info("sign_central_taps") == int(kernel[-2:])
+        got, pos = [], 0
+        for n in chunks:
+            b.run(xd[pos:pos + n])
+            got.append(b.last_signs(n))
+            pos += n
+        got = np.concatenate(got, axis=1)
+        assert np.array_equal(got, want), (chunks[0], np.argwhere(got != want)[:5])
+    run_both(x, [4096, 4904], n_ch, taps=taps, pllinc=pllinc)
+
 
 def test_more_channel_groups_than_cus():
     """N/64 > 256: the PLL stage then shares CUs between workgroups (its LDS reservation is
