@@ -113,8 +113,47 @@ __device__ __forceinline__ void fir_sign_pk_body(
     const int dc = d - J0;                      // y_c[n] = sum_q tc[q] * x[n - dc + q]
     const int m0 = t0 - dc;                     // local sample i <-> row m0 + i; output o completes with sample o + NC - 1
 
+    // A segment whose every reference window lies inside this call's input reads the window through a typed buffer
+    // descriptor based at its first row (fir_slice.hip: fir_sign_kernel has the reasoning): two VALU instructions
+    // per tap instead of twenty.
+    const uint32_t e_rowbytes = (uint32_t) N * 2u;
+    const int e_row = t0 - d;
+    const bool e_inner = e_row >= 0 && t1 - 1 - d + NE - 1 <= L - 1 &&
+                         (unsigned long long) (t1 - t0 + NE) * e_rowbytes < 0x7fffffffull;
+    const unsigned long long e_span = e_inner ? (unsigned long long) (L - e_row) * e_rowbytes : 0ull;
+    const unsigned long long e_base = (unsigned long long) (x + (size_t) (e_inner ? e_row : 0) * (size_t) N);
+    const pk_v4i rsrc_e = {(int) (e_base & 0xffffffffull), (int) ((e_base >> 32) & 0xffffull),
+                           (int) (e_span > 0xffffffffull ? 0xffffffffull : e_span), 0x13004};    // R | SSCALED | 16
     auto exact_positive = [&](int n) __attribute__((always_inline)) -> bool {  // filter.h:40-49 order
         float sum = 0.0f;
+        if (e_inner) {
+            const int voff = (n - t0) * (int) e_rowbytes + c * 2;
+            if constexpr (NES > 0) {
+#pragma unroll
+                for (int j0 = 0; j0 < NES; j0 += 8) {
+                    float xs[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j)
+                        xs[j] = pk_load_format_f32(rsrc_e, voff, (int) ((uint32_t) (j0 + j < NES ? j0 + j : NES - 1) * e_rowbytes), 0);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j)
+                        if (j0 + j < NES) sum = sum + ex.te[j0 + j] * xs[j];
+                }
+                return sum > 0.0f;
+            }
+            for (int j0 = 0; j0 < NE; j0 += PK_EXACT_BATCH) {
+                float xs[PK_EXACT_BATCH];
+#pragma unroll
+                for (int j = 0; j < PK_EXACT_BATCH; ++j) {
+                    const int jj = j0 + j < NE ? j0 + j : NE - 1;
+                    xs[j] = pk_load_format_f32(rsrc_e, voff, (int) ((uint32_t) jj * e_rowbytes), 0);
+                }
+#pragma unroll
+                for (int j = 0; j < PK_EXACT_BATCH; ++j)
+                    if (j0 + j < NE) sum = sum + te_mem[j0 + j] * xs[j];
+            }
+            return sum > 0.0f;
+        }
         if constexpr (NES > 0) {
 #pragma unroll
             for (int j = 0; j < NES; ++j) {

@@ -391,15 +391,21 @@ __device__ __forceinline__ void touch12(float *a)
 // NES > 0: the table has exactly NES effective taps and travels whole in SGPRs (`taps`, NT = NES);
 // NES == 0: only the NC central taps do, the exact re-evaluation reads the NE taps from memory.
 // INLOOP (48-tap instantiation): eps follows a running maximum of |x| kept in the loop instead of a pre-pass over the segment
-template <int NES, int NC, int NT, bool INLOOP = false>
+// FL2 (direct form): the central taps arrive scaled by `fscale`, a power of two (exact), chosen by the host so that the
+// certified distance becomes |y'| >= 2.0 -- bit 30 of the float, the top bit of its exponent.  ONE v_alignbit_b32 by 30
+// then collects the sign AND that bit of every output (even and odd outputs in two words, pulled apart by four bit
+// operations per 32 outputs) where the plain form needs |y| - eps and two alignbits: one instruction per output for the
+// flags instead of three.  The band is the next power of two above eps (0.5 for 0.38 with the reference table).
+template <int NES, int NC, int NT, bool INLOOP = false, bool FL2 = false>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NC == 48 ? 4 : 1))) void fir_sign_kernel(
     const int16_t *__restrict__ x, const int16_t *__restrict__ hist,
     uint32_t *__restrict__ sgn, int *__restrict__ maxval,
     int16_t *__restrict__ hist_out, int *__restrict__ maxval_next,
     const float *__restrict__ te_mem, int N, int L, int T, int d, int NTaps, int NE_rt, float eps_up,
     int map, FirTaps<NT> taps, unsigned long long *stamps, int n_big, int T2, float eps_seen, float eps_ahead,
-    int gx, int gy)
+    int gx, int gy, float fscale)
 {
+    static_assert(!FL2 || K1S_DIRECT(NC), "the two-bit flag gather belongs to the direct form");
     const int NE = NES > 0 ? NES : NE_rt;
     const int wave_id = (int) (blockIdx.y * gridDim.x + blockIdx.x);
     if (stamps && threadIdx.x == 0) stamps[2 * wave_id] = wall_clock64();
@@ -455,8 +461,45 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NC == 48 ? 4
 
     // exact value of output n: filter.h:40-49 order, samples re-read from memory 32 at a time
     // (all loads of a chunk in flight together), taps from memory (uniform: scalar loads)
+    // A segment whose every reference window lies inside this call's input (all but the call's first and last ones:
+    // rows t0 - d .. t1 - 1 - d + NE - 1 within [0, L)) reads the window through a typed buffer descriptor based at its
+    // first row: the lane's byte offset is ONE multiply, the tap's row goes into the scalar offset, and the memory
+    // pipeline delivers the sample as a float -- two VALU instructions per tap (the product and the sum, rounded
+    // separately as filter.h:40-49 rounds them) instead of twenty of address arithmetic, selects and conversion
+    // around every load (650 per evaluation of the 32-tap table, a tenth of this kernel's instructions at C3).
+    const uint32_t e_rowbytes = (uint32_t) N * 2u;
+    const int e_row = t0 - d;
+    const bool e_inner = e_row >= 0 && t1 - 1 - d + NE - 1 <= L - 1 &&
+                         (unsigned long long) (t1 - t0 + NE) * e_rowbytes < 0x7fffffffull;
+    const unsigned long long e_span = e_inner ? (unsigned long long) (L - e_row) * e_rowbytes : 0ull;
+    const unsigned long long e_base = (unsigned long long) (x + (size_t) (e_inner ? e_row : 0) * (size_t) N);
+    const fir_v4i rsrc_e = {(int) (e_base & 0xffffffffull), (int) ((e_base >> 32) & 0xffffull),
+                            (int) (e_span > 0xffffffffull ? 0xffffffffull : e_span), 0x13004};   // R | SSCALED | 16
     auto exact_positive = [&](int n) -> bool {
         float sum = 0.0f;
+        if (e_inner) {
+            const int voff = (n - t0) * (int) e_rowbytes + c * 2;
+            if constexpr (NES > 0) {
+                float xs[NES];
+#pragma unroll
+                for (int j = 0; j < NES; ++j) xs[j] = fir_load_format_f32(rsrc_e, voff, (int) ((uint32_t) j * e_rowbytes), 0);
+#pragma unroll
+                for (int j = 0; j < NES; ++j) sum = sum + taps.te[j] * xs[j];
+                return sum > 0.0f;
+            }
+            for (int j0 = 0; j0 < NE; j0 += 32) {
+                float xs[32];
+#pragma unroll
+                for (int j = 0; j < 32; ++j) {
+                    const int jj = j0 + j < NE ? j0 + j : NE - 1;
+                    xs[j] = fir_load_format_f32(rsrc_e, voff, (int) ((uint32_t) jj * e_rowbytes), 0);
+                }
+#pragma unroll
+                for (int j = 0; j < 32; ++j)
+                    if (j0 + j < NE) sum = sum + te_mem[j0 + j] * xs[j];
+            }
+            return sum > 0.0f;
+        }
         if constexpr (NES > 0) {
 #pragma unroll
             for (int j = 0; j < NES; ++j) {
@@ -601,11 +644,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NC == 48 ? 4
                 //   amb  collects the sign bit of |y_c| - eps_up, eps_up = nextafter(eps): set
                 //        exactly when |y_c| <= eps (a - b is negative or -0 iff a < b).
                 uint32_t neg = 0, amb = 0;
+                uint32_t fe = 0, fo = 0;                        // FL2: (sign, exponent bit 7) of the even / the odd outputs
                 // FIR_VTAPS_12: the direct form's taps in vector registers (see FIR_VTAPS_48 below for the rates)
                 float dtap[NC / 2];
     #pragma unroll
                 for (int q = 0; q < NC / 2; ++q) {
-                    dtap[q] = ctap(q);
+                    dtap[q] = FL2 ? ctap(q) * fscale : ctap(q);
 #if FIR_VTAPS_12
                     asm volatile("" : "+v"(dtap[q]));
 #endif
@@ -648,8 +692,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NC == 48 ? 4
     #pragma unroll
                     for (int pd = 0; pd < FIR_PAD; ++pd) asm volatile("v_mov_b32 %0, %0" : "+v"(peakbits));
 #endif
+                    if constexpr (FL2) {
+                        if (p & 1) fo = __builtin_amdgcn_alignbit(fo, __float_as_uint(y), 30);
+                        else fe = __builtin_amdgcn_alignbit(fe, __float_as_uint(y), 30);
+                    } else {
                     neg = __builtin_amdgcn_alignbit(neg, __float_as_uint(y), 31);
                     amb = __builtin_amdgcn_alignbit(amb, __float_as_uint(__builtin_fabsf(y) - eps_up), 31);
+                    }
     #if FIR_SIGN_FENCE > 0
                     if (p % FIR_SIGN_FENCE == FIR_SIGN_FENCE - 1 && !K1S_DIRECT(NC)) {
     #pragma unroll
@@ -660,6 +709,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NC == 48 ? 4
                 if constexpr (K1S_DIRECT(NC)) {
     #pragma unroll
                     for (int k = 0; k < NC - 1; ++k) tail[k] = xf[32 - (NC - 1) + k];
+                }
+                if constexpr (FL2) {
+                    // output 2k sits in bits 31-2k (sign), 30-2k (|y'| >= 2) of fe, output 2k+1 in the same bits of fo
+                    neg = (fe & 0xaaaaaaaau) | ((fo >> 1) & 0x55555555u);
+                    amb = ~(((fe << 1) & 0xaaaaaaaau) | (fo & 0x55555555u));
                 }
                 uint32_t w = ~neg;
                 const int valid = t1 - (t0 + obase);
@@ -1056,29 +1110,41 @@ hipError_t launch_fir_sign(const FirLaunch &a, hipStream_t stream)
         // ten central taps: one symmetric pair less per output than twelve, an ambiguity band three times as wide
         FirTaps<32> t;
         for (int j = 0; j < 32; ++j) t.te[j] = a.te[j];
+        if (a.fscale > 0.0f)
+            hipLaunchKernelGGL((fir_sign_kernel<32, 10, 32, false, true>), grid, block, a.lds_pad, stream, a.x, a.hist, a.sgn, a.maxval,
+                               a.hist_out, a.maxval_next, a.te_mem, a.N, a.L, a.T, a.d, a.NT, a.NE, eps_up, map, t, stamps_ok, n_big, T2, a.eps_seen, a.eps_ahead, gx, gy, a.fscale);
+        else
         hipLaunchKernelGGL((fir_sign_kernel<32, 10, 32>), grid, block, a.lds_pad, stream, a.x, a.hist, a.sgn, a.maxval,
-                           a.hist_out, a.maxval_next, a.te_mem, a.N, a.L, a.T, a.d, a.NT, a.NE, eps_up, map, t, stamps_ok, n_big, T2, a.eps_seen, a.eps_ahead, gx, gy);
+                           a.hist_out, a.maxval_next, a.te_mem, a.N, a.L, a.T, a.d, a.NT, a.NE, eps_up, map, t, stamps_ok, n_big, T2, a.eps_seen, a.eps_ahead, gx, gy, a.fscale);
     } else if (a.NC == 10) {
         return hipErrorInvalidValue;
     } else if (a.NC == 12 && a.NE == 32) {
         FirTaps<32> t;
         for (int j = 0; j < 32; ++j) t.te[j] = a.te[j];
+        if (a.fscale > 0.0f)
+            hipLaunchKernelGGL((fir_sign_kernel<32, 12, 32, false, true>), grid, block, a.lds_pad, stream, a.x, a.hist, a.sgn, a.maxval,
+                               a.hist_out, a.maxval_next, a.te_mem, a.N, a.L, a.T, a.d, a.NT, a.NE, eps_up, map, t, stamps_ok, n_big, T2, a.eps_seen, a.eps_ahead, gx, gy, a.fscale);
+        else
         hipLaunchKernelGGL((fir_sign_kernel<32, 12, 32>), grid, block, a.lds_pad, stream, a.x, a.hist, a.sgn, a.maxval,
-                           a.hist_out, a.maxval_next, a.te_mem, a.N, a.L, a.T, a.d, a.NT, a.NE, eps_up, map, t, stamps_ok, n_big, T2, a.eps_seen, a.eps_ahead, gx, gy);
+                           a.hist_out, a.maxval_next, a.te_mem, a.N, a.L, a.T, a.d, a.NT, a.NE, eps_up, map, t, stamps_ok, n_big, T2, a.eps_seen, a.eps_ahead, gx, gy, a.fscale);
     } else if (a.NC == 12) {
         FirTaps<12> t;
         for (int j = 0; j < 12; ++j) t.te[j] = a.ctaps[j];
+        if (a.fscale > 0.0f)
+            hipLaunchKernelGGL((fir_sign_kernel<0, 12, 12, false, true>), grid, block, 0, stream, a.x, a.hist, a.sgn, a.maxval,
+                               a.hist_out, a.maxval_next, a.te_mem, a.N, a.L, a.T, a.d, a.NT, a.NE, eps_up, map, t, stamps_ok, n_big, T2, a.eps_seen, a.eps_ahead, gx, gy, a.fscale);
+        else
         hipLaunchKernelGGL((fir_sign_kernel<0, 12, 12>), grid, block, 0, stream, a.x, a.hist, a.sgn, a.maxval,
-                           a.hist_out, a.maxval_next, a.te_mem, a.N, a.L, a.T, a.d, a.NT, a.NE, eps_up, map, t, stamps_ok, n_big, T2, a.eps_seen, a.eps_ahead, gx, gy);
+                           a.hist_out, a.maxval_next, a.te_mem, a.N, a.L, a.T, a.d, a.NT, a.NE, eps_up, map, t, stamps_ok, n_big, T2, a.eps_seen, a.eps_ahead, gx, gy, a.fscale);
     } else {
         FirTaps<48> t;
         for (int j = 0; j < 48; ++j) t.te[j] = a.ctaps[j];
         if (a.eps_seen > 0.0f && a.NE - a.NC <= 98)
             hipLaunchKernelGGL((fir_sign_kernel<0, 48, 48, true>), grid, block, 0, stream, a.x, a.hist, a.sgn, a.maxval,
-                               a.hist_out, a.maxval_next, a.te_mem, a.N, a.L, a.T, a.d, a.NT, a.NE, eps_up, map, t, stamps_ok, n_big, T2, a.eps_seen, a.eps_ahead, gx, gy);
+                               a.hist_out, a.maxval_next, a.te_mem, a.N, a.L, a.T, a.d, a.NT, a.NE, eps_up, map, t, stamps_ok, n_big, T2, a.eps_seen, a.eps_ahead, gx, gy, a.fscale);
         else
         hipLaunchKernelGGL((fir_sign_kernel<0, 48, 48>), grid, block, 0, stream, a.x, a.hist, a.sgn, a.maxval,
-                           a.hist_out, a.maxval_next, a.te_mem, a.N, a.L, a.T, a.d, a.NT, a.NE, eps_up, map, t, stamps_ok, n_big, T2, a.eps_seen, a.eps_ahead, gx, gy);
+                           a.hist_out, a.maxval_next, a.te_mem, a.N, a.L, a.T, a.d, a.NT, a.NE, eps_up, map, t, stamps_ok, n_big, T2, a.eps_seen, a.eps_ahead, gx, gy, a.fscale);
     }
     return hipGetLastError();
 }

@@ -188,6 +188,9 @@ struct gnuais_batch {
     int sign_NC_lo = 0;             // ... and the shorter sum the one-channel-per-lane 12-tap kernel may take instead (0: none)
     float sign_eps_lo = 0.0f;       //     with its bound
     int fir_nc = 0;                 // 0: the shorter sum where there is one; 12: never
+    int fir_flag2 = 1;              // the direct-form K1s gathers sign and threshold bit with one instruction per output (FL2)
+    float sign_fscale = 0.0f;       //   the power of two its central taps are scaled by (0: the table does not allow it)
+    float sign_fscale_lo = 0.0f;    //   ... for the shorter sum
     int k0 = 0;                     // first effective tap
     int pll_variant = 0;            // 0: by channel count; 3 / 6 (kernels.h: PllLaunch::variant)
     int hdlc_lpw = 0;               // channels per wave in K2b; 0 = the variant's own default (16 event-driven, 64 bit-serial)
@@ -208,6 +211,11 @@ struct gnuais_batch {
     // launch i -- the last NT input rows -- is copied by a small kernel queued IN FRONT of launch i.
     int fir_streams = 1;
     hipStream_t s_fir2 = nullptr;
+    // CU split (experiment, GNUAIS_CU_SPLIT = R): the deframer and K3 on streams whose kernels only run on R reserved
+    // CUs, the FIR on an internal stream that runs on the others (hipExtStreamCreateWithCUMask); the PLL stage needs a
+    // workgroup on every CU and keeps the whole chip
+    hipStream_t s_firm = nullptr, s_small[2] = {nullptr, nullptr};
+    int cu_split = 0;
     hipEvent_t e_hist[2] = {nullptr, nullptr};  // the carry of the call on FIR stream q is written
     hipEvent_t e_order = nullptr;               // the caller's stream has reached this call (its input is there)
     // cold start: a call that finds the pipeline empty is followed by a FIR launch that would otherwise be dispatched
@@ -274,6 +282,8 @@ void gnuais_batch_destroy(gnuais_batch *b)
     for (auto &st : b->pool)
         if (st) (void) hipStreamDestroy(st);
     if (b->s_fir2) (void) hipStreamDestroy(b->s_fir2);
+    for (hipStream_t st : {b->s_firm, b->s_small[0], b->s_small[1]})
+        if (st) (void) hipStreamDestroy(st);
     if (b->h_started) (void) hipHostFree(b->h_started);
     if (b->progress) (void) hipFree(b->progress);
     for (hipEvent_t e : {b->e_hist[0], b->e_hist[1], b->e_order})
@@ -426,6 +436,29 @@ int gnuais_batch_create(gnuais_batch **out, int device, int n_channels, const fl
                         b->sign_eps_lo = (float) (bound_lo * 1.1);
                     }
                 }
+                // FL2 (fir_sign_kernel): the direct form's central taps times k = 2 / P, P = the power of two at or above
+                // eps.  k is a power of two >= 1, so every product, pre-add and partial sum of the scaled evaluation is
+                // exactly k times the unscaled one (nothing overflows: |y'| <= 2 X sum|t| / eps < 1e9; an underflow the
+                // unscaled sum has, the scaled one has at most as badly) and |y_c| < P  <=>  |y'| < 2  <=>  exponent
+                // bit 7 of y' clear.  P >= eps: the band only widens.  Not taken when a central tap is subnormal or k
+                // would leave [1, 2^60].
+                auto flag_scale = [&](float eps, int nc) -> float {
+                    if (!(eps > 0.0f) || !(eps <= 2.0f) || !K1S_DIRECT(nc)) return 0.0f;
+                    int e = 0;
+                    const float m = std::frexp(eps, &e);            // eps = m 2^e, m in [0.5, 1)
+                    const float P = std::ldexp(1.0f, m == 0.5f ? e - 1 : e);
+                    const float k = 2.0f / P;
+                    if (!(k >= 1.0f) || !(k <= 1.152921504606846976e18f)) return 0.0f;
+                    for (int j = 0; j < nc; ++j) {
+                        const float t = b->te[(NE - nc) / 2 + j];
+                        if (t != 0.0f && (!std::isnormal(t) || !std::isnormal(t * k))) return 0.0f;
+                    }
+                    return k;
+                };
+                if (NC == 12) {
+                    b->sign_fscale = flag_scale(b->sign_eps, 12);
+                    if (b->sign_NC_lo) b->sign_fscale_lo = flag_scale(b->sign_eps_lo, b->sign_NC_lo);
+                }
             }
         }
     }
@@ -524,6 +557,28 @@ int gnuais_batch_create(gnuais_batch **out, int device, int n_channels, const fl
         for (; made < gnuais_batch::POOL; ++made)
             if (e == hipSuccess) e = hipStreamCreateWithPriority(&b->pool[made], hipStreamNonBlocking, made < 8 ? hi : 0);
     }
+    if (const char *v = getenv("GNUAIS_CU_SPLIT")) {
+        const int R = atoi(v), n = b->n_cu;
+        const char *lay = getenv("GNUAIS_CU_LAYOUT");
+        const int layout = lay ? atoi(lay) : 0;
+        if (e == hipSuccess && R > 0 && R < n && n % 32 == 0 && n <= 1024) {
+            uint32_t small[32] = {}, big[32] = {};
+            const int per_xcd = n / 8;
+            for (int i = 0; i < n; ++i) {
+                // layout 0: mask bit i is CU i / 8 of XCD i % 8 (bits dealt round-robin over the XCDs); 1: XCD i / per_xcd
+                const bool res = layout == 0 ? i < R : (i % per_xcd) < R / 8;
+                (res ? small : big)[i >> 5] |= 1u << (i & 31);
+            }
+            e = hipExtStreamCreateWithCUMask(&b->s_firm, (uint32_t) (n / 32), big);
+            for (auto &st : b->s_small)
+                if (e == hipSuccess) e = hipExtStreamCreateWithCUMask(&st, (uint32_t) (n / 32), small);
+            if (e == hipSuccess) {
+                b->cu_split = R;
+                b->s_k[2] = b->s_small[0];
+                b->s_k[3] = b->s_small[1];
+            }
+        }
+    }
     if (const char *v = getenv("GNUAIS_PLL_VARIANT")) b->pll_variant = atoi(v);
     if (const char *v = getenv("GNUAIS_K2B_DATAFLOW")) b->k2b_dataflow = atoi(v) != 0;
     if (const char *v = getenv("GNUAIS_NBUF")) b->nbuf = std::min((int) gnuais_batch::NBUF, std::max(2, atoi(v)));
@@ -538,6 +593,7 @@ int gnuais_batch_create(gnuais_batch **out, int device, int n_channels, const fl
     }
     if (const char *v = getenv("GNUAIS_FIR_VARIANT")) b->fir_variant = atoi(v);
     if (const char *v = getenv("GNUAIS_FIR_NC")) b->fir_nc = atoi(v) == 12 ? 12 : 0;
+    if (const char *v = getenv("GNUAIS_FIR_FLAG2")) b->fir_flag2 = atoi(v) != 0;
     if (const char *v = getenv("GNUAIS_FIR_PK")) b->fir_pk = atoi(v) < 0 ? -1 : (atoi(v) != 0);
     if (const char *v = getenv("GNUAIS_FIR_CPL")) { const int c = atoi(v); if (c == 1 || c == 2 || c == 4) b->fir_cpl = c; }
     if (const char *v = getenv("GNUAIS_FIR_FORM")) b->fir_form = atoi(v);
@@ -645,6 +701,9 @@ int gnuais_batch_set_option(gnuais_batch *b, const char *name, int value)
         b->fir_cpl = value;
     } else if (!strcmp(name, "fir_form")) {
         b->fir_form = value;
+    } else if (!strcmp(name, "fir_flag2")) {         // 0: |y| - eps and two alignbits per output (rounds 1-4)
+        if (value != 0 && value != 1) return fail(GNUAIS_E_ARG, "fir_flag2: 0 or 1");
+        b->fir_flag2 = value;
     } else if (!strcmp(name, "fir_nc")) {
         if (value != 0 && value != 12) return fail(GNUAIS_E_ARG, "fir_nc: 0 (the shortest certified central sum) or 12");
         b->fir_nc = value;
@@ -784,9 +843,11 @@ static int run_fir(gnuais_batch *b, const int16_t *x, int len, float *dump, hipS
         if (cpl > 1) {
             HIP_TRY(launch_fir_sign_wide(f, cpl, b->fir_form, s));
         } else {
+            if (f.NC == 12 && b->fir_flag2) f.fscale = b->sign_fscale;
             if (sign_lo(b)) {                   // the one-channel-per-lane kernel: ten central taps where the table allows
                 f.NC = b->sign_NC_lo;
                 f.eps = b->sign_eps_lo;
+                f.fscale = b->fir_flag2 ? b->sign_fscale_lo : 0.0f;
                 for (int j = 0; j < f.NC; ++j) f.ctaps[j] = b->te[(b->NE - f.NC) / 2 + j];
             }
             HIP_TRY(launch_fir_sign(f, s));
@@ -910,6 +971,12 @@ int gnuais_batch_run(gnuais_batch *b, const int16_t *d_samples, int len, void *s
                                        b->N, len, b->NT, sF));
             HIP_TRY(hipEventRecord(b->e_hist[q], sF));
         }
+        const bool masked = pl && !two && b->cu_split && (b->stage_mask & 1);
+        if (masked) {                           // the FIR on the internal stream that owns the unreserved CUs
+            sF = b->s_firm;
+            HIP_TRY(hipEventRecord(b->e_order, s0));
+            HIP_TRY(hipStreamWaitEvent(sF, b->e_order, 0));
+        }
         if (tm) HIP_TRY(hipEventRecord(ev[0], sF));
         if (b->stage_mask & 1)
             if (int rc = run_fir(b, d_samples, len, nullptr, sF, k)) return rc;
@@ -919,7 +986,7 @@ int gnuais_batch_run(gnuais_batch *b, const int16_t *d_samples, int len, void *s
             b->e_in_hook = nullptr;
         }
         if (pl) HIP_TRY(hipEventRecord(b->e_done[0][k], sF));
-        if (two && q) HIP_TRY(hipStreamWaitEvent(s0, b->e_done[0][k], 0));
+        if ((two && q) || masked) HIP_TRY(hipStreamWaitEvent(s0, b->e_done[0][k], 0));
         // K2: this call's sign words -> bit packs segbits[k] (read by K2b of call i-nbuf); in order
         // across calls (it carries the receivers' pll / prev / lastbit)
         PllLaunch p;
@@ -967,7 +1034,7 @@ int gnuais_batch_discard_frames(gnuais_batch *b, void *stream);
 int gnuais_batch_autotune(gnuais_batch *b, const int16_t *d_samples, int len, void *stream, float *ms_per_call)
 {
     if (!b || !d_samples) return fail(GNUAIS_E_ARG, "autotune: NULL argument");
-    if (!b->pipeline) {                         // one stream, nothing to assign
+    if (!b->pipeline || b->cu_split) {          // one stream, nothing to assign (CU split: the assignment is the experiment)
         if (ms_per_call) *ms_per_call = 0.0f;
         return GNUAIS_OK;
     }
@@ -1052,6 +1119,7 @@ int gnuais_batch_sync(gnuais_batch *b)
     if (int rc = set_device(b)) return rc;
     HIP_TRY(hipStreamSynchronize(b->last_stream));
     if (b->s_fir2) HIP_TRY(hipStreamSynchronize(b->s_fir2));
+    if (b->s_firm) HIP_TRY(hipStreamSynchronize(b->s_firm));
     for (auto &st : b->s_k) HIP_TRY(hipStreamSynchronize(st));
     return GNUAIS_OK;
 }
@@ -1859,7 +1927,11 @@ int gnuais_batch_info(const gnuais_batch *b, const char *name, double *value)
 {
     if (!b || !name || !value) return fail(GNUAIS_E_ARG, "info: argument");
     if (!strcmp(name, "sign_exact")) *value = b->sign_ok && b->fir_variant == 3;
-    else if (!strcmp(name, "sign_eps")) *value = sign_lo(b) ? b->sign_eps_lo : b->sign_eps;     // of the kernel the options select
+    else if (!strcmp(name, "sign_eps")) {            // of the kernel the options select; FL2: the power of two it works with
+        const float fs = !b->fir_flag2 || b->fir_cpl > 1 || b->fir_pk == 1 ? 0.0f : sign_lo(b) ? b->sign_fscale_lo : b->sign_NC == 12 ? b->sign_fscale : 0.0f;
+        *value = fs > 0.0f ? 2.0f / fs : sign_lo(b) ? b->sign_eps_lo : b->sign_eps;
+    }
+    else if (!strcmp(name, "sign_flag_scale")) *value = !b->fir_flag2 ? 0.0f : sign_lo(b) ? b->sign_fscale_lo : b->sign_NC == 12 ? b->sign_fscale : 0.0f;
     else if (!strcmp(name, "sign_eps_seen")) *value = b->sign_eps_seen;
     else if (!strcmp(name, "sign_eps_ahead")) *value = b->sign_eps_ahead;
     else if (!strcmp(name, "sign_central_taps")) *value = sign_lo(b) ? b->sign_NC_lo : b->sign_NC;

@@ -21,6 +21,8 @@ struct FirLaunch {
     int n_big = 1 << 30, T2 = 0;   // K1s: segments 0 .. n_big-1 are T outputs long, the rest T2 (the launch's tail, see run_fir)
     int NT, NE, d;         // out[n] = sum_j te[j] * x[n - d + j], j < NE
     float eps;             // sign-exact slicer: |central sum| > eps certifies the sign
+    float fscale = 0;      // K1s direct form: > 0 = a power of two the central taps are scaled by so that the certified distance
+                           //   is |y'| >= 2.0 and one v_alignbit_b32 gathers sign and exponent bit (fir_sign_kernel FL2); eps is then unused
     float eps_pk = 0;      // fir_sign_pk.hip, 12 taps: the bound for the transposed fused sum (the direct form's is eps)
     float eps_seen = 0, eps_ahead = 0;     // 48-tap K1s with the running maximum (eps_seen > 0): eps = eps_seen * M / 32768 + eps_ahead
     int NC;                //   central taps used (12 or 48)

@@ -194,21 +194,26 @@ def test_c5_full_size():
 
 # ---------------------------------------------------------------- the slicer's threshold
 
+@pytest.mark.parametrize("flag2", [1, 0])
 @pytest.mark.parametrize("fir_nc", [0, 12])
-def test_sign_exact_slicer_on_its_threshold(fir_nc):
+def test_sign_exact_slicer_on_its_threshold(fir_nc, flag2):
     """K1s certifies the sign of the reference's ordered 32-term sum from the 10 (default) or 12 (`fir_nc` = 12) central
     taps when |y_c| > eps and re-evaluates exactly otherwise.  Inputs built so that |y_c| lands within a few
     percent of the running kernel's eps on BOTH sides (and of both signs), each alone in silence: the decisions must be
-    those of the exact filter, sample for sample."""
+    those of the exact filter, sample for sample.  `flag2` = 1 (default): the kernel works with the power of two at or
+    above eps and reads the decision off the exponent of the scaled sum (0.5 and 0.125 for the reference table)."""
     taps = params.taps_48k().astype(np.float64)
     b0 = batch(64, max_len=4096)
     b0.set_option("fir_nc", fir_nc)
+    b0.set_option("fir_flag2", flag2)
     assert b0.info("sign_exact") == 1 and b0.info("sign_central_taps") == (12 if fir_nc else 10)
     eps = b0.info("sign_eps")
     assert (eps < 0.2) == (fir_nc == 12)
+    if flag2:
+        assert eps == (0.125 if fir_nc else 0.5) and b0.info("sign_flag_scale") == 2.0 / eps
     k0 = int(b0.info("first_effective_tap"))
     j0 = k0 + (int(b0.info("n_effective_taps")) - 12) // 2           # first central tap in the 36-tap table
-    assert 0.05 < eps < 0.5
+    assert 0.05 < eps <= 0.5
     # y(n) = sum_k taps[k] x[n - 36 + k]: three small integers under taps j0+3, j0+2, j0+1
     # (0.0696, 0.0059, 0.00022) reach any value near eps in steps of 2e-4
     t3, t2, t1 = taps[j0 + 3], taps[j0 + 2], taps[j0 + 1]
@@ -252,6 +257,7 @@ def test_sign_exact_slicer_on_its_threshold(fir_nc):
     for chunk in (total, 33, 1):                                     # and under awkward call boundaries
         b = batch(n_ch, max_len=total)
         b.set_option("fir_nc", fir_nc)
+        b.set_option("fir_flag2", flag2)
         signs = []
         for lo in range(0, total, chunk):
             hi = min(total, lo + chunk)
