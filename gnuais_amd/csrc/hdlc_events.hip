@@ -60,6 +60,9 @@ __device__ __forceinline__ int wave_max_i(int v, int lanes, int lane)
 // NA[EW], CB[EW], E6[EW], SF[EW], PS[EW + 1] (stuffed 0s before word q)
 constexpr int EV_ROWS = (EW + 2) + 4 * EW + (EW + 1);
 
+#ifndef EV_BITMAPS32
+#define EV_BITMAPS32 1              // 0: the pack's bitmaps through 64-bit shifts of {word, word before} (rounds 2-4; kept for the A/B)
+#endif
 #ifndef EV_WAVES_PER_EU
 #define EV_WAVES_PER_EU 0           // 0: whatever the kernel wants (116 VGPRs); 7 (72 VGPRs) spilt and lost
 #endif
@@ -68,6 +71,9 @@ constexpr int EV_ROWS = (EW + 2) + 4 * EW + (EW + 1);
 #else
 #define EV_OCC
 #endif
+// TPB: lanes per workgroup when the launcher knows them (8 / 16 / 32 / 64: every LDS row offset is then an immediate of
+// its ds instruction); 0: taken from blockDim
+template <int TPB>
 __global__ __launch_bounds__(64) EV_OCC void hdlc_events_kernel(
     const uint32_t *__restrict__ segbits, const uint32_t *__restrict__ segcnt,
     uint32_t *__restrict__ ctl, uint32_t *__restrict__ cand, uint32_t *__restrict__ cand_first,
@@ -77,7 +83,7 @@ __global__ __launch_bounds__(64) EV_OCC void hdlc_events_kernel(
 {
     __builtin_amdgcn_s_setprio(3);      // latency-bound chain: take every issue slot it can use
     extern __shared__ uint32_t lds[];
-    const int tpb = (int) blockDim.x, tx = (int) threadIdx.x;
+    const int tpb = TPB > 0 ? TPB : (int) blockDim.x, tx = (int) threadIdx.x;
     const int cg = blockIdx.x * blockDim.x + threadIdx.x;
     const bool live = cg < N;
     const size_t c = (size_t) (live ? cg : N - 1), n_ = (size_t) N;
@@ -268,6 +274,49 @@ __global__ __launch_bounds__(64) EV_OCC void hdlc_events_kernel(
             }
         }
         const int nwq = __builtin_amdgcn_readfirstlane((int) wave_max_i((tile_end + 31) >> 5, tpb, tx));
+#if EV_BITMAPS32
+        // Every "bit i of (v << d) is bit i-d of v" below takes the bits that come in from the word before out of THAT
+        // word's value of the same quantity (one v_alignbit_b32 each), instead of carrying the chain through 64-bit
+        // shifts and ANDs of {this word, the word before}: the same bits -- no term reaches further back than the word
+        // before, and the word before the pack has nothing but zeros below it in either form -- for 45 instead of
+        // 118 VALU instructions per word, three quarters of what this kernel issues.
+        auto shl_in = [](uint32_t v, uint32_t below, int n) -> uint32_t {    // (v << n) | (below >> (32 - n)), 0 < n < 32
+            return __builtin_amdgcn_alignbit(v, below, 32 - n);
+        };
+        uint32_t pA = 0, pa2 = 0, pa4 = 0, pa8 = 0;                          // nothing alternates before the pack (hunt0 has that)
+        uint32_t pu2 = prevw & (prevw << 1);
+        uint32_t pt = (pu2 & (pu2 << 2)) & (prevw << 4);
+#pragma unroll
+        for (int q = 0; q < EW; ++q) {
+            if (q >= nwq) {                 // beyond every lane's bits: empty
+                XW(q) = 0; NAa[q * tpb] = 0; CBa[q * tpb] = 0; E6a[q * tpb] = 0; SFa[q * tpb] = 0; PSa[q * tpb] = ps;
+                continue;
+            }
+            const uint32_t vm = lowmask(tile_end - 32 * q);
+            const uint32_t xw = XW(q) & vm;
+            const uint32_t A = (xw ^ shl_in(xw, prevw, 1)) & vm;                // x[k] != x[k-1]
+            const uint32_t a2 = A & shl_in(A, pA, 1), a4 = a2 & shl_in(a2, pa2, 2), a8 = a4 & shl_in(a4, pa4, 4);
+            const uint32_t a15 = a8 & shl_in(a8, pa8, 7);                       // alternations at k-14 .. k
+            const uint32_t u2 = xw & shl_in(xw, prevw, 1), u4 = u2 & shl_in(u2, pu2, 2);     // 1s at k-1..k, k-3..k
+            const uint32_t t5 = u4 & shl_in(xw, prevw, 4);                      // 1s at k-4..k
+            const uint32_t na = ~A & vm, cb = a15 & ~xw & vm;
+            const uint32_t e6 = u4 & shl_in(u2, pu2, 4) & vm;                   // 1s at k-5..k
+            const uint32_t sf = shl_in(t5, pt, 1) & ~xw & vm;                   // 1s at k-5..k-1, 0 at k
+            XW(q) = xw;
+            NAa[q * tpb] = na;
+            CBa[q * tpb] = cb;
+            E6a[q * tpb] = e6;
+            SFa[q * tpb] = sf;
+            PSa[q * tpb] = ps;
+            ps += (uint32_t) __popc(sf);
+            nzNA |= (na < 1u ? na : 1u) << q;
+            nzCB |= (cb < 1u ? cb : 1u) << q;
+            nzE6 |= (e6 < 1u ? e6 : 1u) << q;
+            pA = A; pa2 = a2; pa4 = a4; pa8 = a8; pu2 = u2; pt = t5;
+            prevw = xw;
+        }
+        (void) prevA;
+#else
 #pragma unroll 1
         for (int q = 0; q < EW; ++q) {
             if (q >= nwq) {                 // beyond every lane's bits: empty
@@ -298,6 +347,7 @@ __global__ __launch_bounds__(64) EV_OCC void hdlc_events_kernel(
             prevA = A;
             prevw = xw;
         }
+#endif
         XW(EW) = 0;
         PSa[EW * tpb] = ps;
 
@@ -543,9 +593,19 @@ hipError_t launch_hdlc_events(const HdlcLaunch &a, hipStream_t stream)
 {
     if (a.seg_words > PACK_STRIDE) return hipErrorInvalidValue;
     const int lpw = a.lanes_per_wave >= 1 && a.lanes_per_wave <= 64 ? a.lanes_per_wave : 64;
-    hipLaunchKernelGGL(hdlc_events_kernel, dim3((a.N + lpw - 1) / lpw), dim3(lpw), EV_ROWS * lpw * sizeof(uint32_t), stream,
-                       a.segbits, a.segcnt, a.ctl, a.cand, a.cand_first, a.cand_count, a.counters,
-                       a.frame_count, a.N, a.n_seg, a.seg_words, a.K, a.progress, a.progress_base);
+    const dim3 grid((a.N + lpw - 1) / lpw), block(lpw);
+    const size_t lds = EV_ROWS * lpw * sizeof(uint32_t);
+#define EV_LAUNCH(T)                                                                                                  \
+    hipLaunchKernelGGL(hdlc_events_kernel<T>, grid, block, lds, stream, a.segbits, a.segcnt, a.ctl, a.cand, a.cand_first, \
+                       a.cand_count, a.counters, a.frame_count, a.N, a.n_seg, a.seg_words, a.K, a.progress, a.progress_base)
+    switch (lpw) {
+    case 8: EV_LAUNCH(8); break;
+    case 16: EV_LAUNCH(16); break;
+    case 32: EV_LAUNCH(32); break;
+    case 64: EV_LAUNCH(64); break;
+    default: EV_LAUNCH(0); break;
+    }
+#undef EV_LAUNCH
     return hipGetLastError();
 }
 
