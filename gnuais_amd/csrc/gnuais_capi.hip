@@ -187,7 +187,12 @@ struct gnuais_batch {
     int sign_NC = 12;               // central taps K1s evaluates
     int sign_NC_lo = 0;             // ... and the shorter sum the one-channel-per-lane 12-tap kernel may take instead (0: none)
     float sign_eps_lo = 0.0f;       //     with its bound
-    int fir_nc = 0;                 // 0: the shorter sum where there is one; 12: never
+    // 12: the twelve central taps; 0: the shorter sum (ten) where the table allows one.  Ten taps take two instructions
+    // off every output and leave a band four times as wide (0.5 against 0.125 with FL2): four times the open signs,
+    // each of which re-reads its 32 rows -- FIR traffic 2.18 against 1.84 GB per C3 call, the launch 0.37 against 0.325 ms
+    // alone, the chain 1-1.5 % slower (profiles/r04_fir_twelve_taps_again.txt).  Since the flags cost one instruction
+    // per output the launch is bound by its memory accesses, not its instructions: twelve is the default again.
+    int fir_nc = 12;
     int fir_flag2 = 1;              // the direct-form K1s gathers sign and threshold bit with one instruction per output (FL2)
     float sign_fscale = 0.0f;       //   the power of two its central taps are scaled by (0: the table does not allow it)
     float sign_fscale_lo = 0.0f;    //   ... for the shorter sum

@@ -18,6 +18,7 @@ def measure(nbuf, hold, firs, lag, pll=0, lpw=0):
     b.set_option("nbuf", nbuf); b.set_option("cold_hold_us", hold); b.set_option("fir_streams", firs)
     if pll: b.set_option("pll_variant", pll)
     if lpw: b.set_option("hdlc_lpw", lpw)
+    if os.environ.get("FIR_LDS"): b.set_option("fir_lds", int(os.environ["FIR_LDS"]))    # LDS claimed per FIR wave (caps its occupancy)
     b.autotune(x, stream)
     def step():
         b.run(x, stream=stream, sync=False); b.discard_frames(stream)

@@ -144,11 +144,13 @@ def test_full_chain_golden(name):
     assert np.array_equal(b.maxval(), g["maxval"])
 
 
-def run_both(x, chunks, n_ch, taps=None, pllinc=0, fir_T=None, pll_variant=0):
+def run_both(x, chunks, n_ch, taps=None, pllinc=0, fir_T=None, pll_variant=0, options=None):
     o = Oracle(n_ch, taps=taps, pllinc=pllinc)
     b = batch(n_ch, taps=taps, pllinc=pllinc, max_len=max(chunks))
     if fir_T:
         b.set_option("fir_T", fir_T)
+    for k, v in (options or {}).items():
+        b.set_option(k, v)
     b.set_option("pll_variant", pll_variant)      # 0: by channel count (six waves for these sizes)
     pos = 0
     gbits = [[] for _ in range(n_ch)]
@@ -186,6 +188,22 @@ def test_chain_vs_oracle_ragged_chunks(pll_variant):
     chunks.append(total - sum(chunks))
     o, b = run_both(x, chunks, n_ch, fir_T=512, pll_variant=pll_variant)
     assert o.counters()[:, 0].sum() > 300
+
+
+@pytest.mark.parametrize("lpw", [8, 16, 24, 32, 64])
+@pytest.mark.parametrize("flag2", [0, 1])
+def test_chain_vs_oracle_deframer_widths_and_flag_forms(lpw, flag2):
+    """The deframer is built for 8 / 16 / 32 / 64 channels per workgroup (LDS offsets as immediates) and for any other
+    width with the offsets computed; K1s gathers its flags with one alignbit per output (fir_flag2 = 1) or with the
+    subtract + two alignbits of rounds 1-4.  Ragged calls over channels at five noise levels, everything == oracle."""
+    n_ch, total = 70, 24 * 1280
+    x = np.stack([synth.make_stream(total, seed=37, channel=c,
+                                    sigma=(500.0, 1000.0, 3000.0, 6000.0, 20000.0)[c % 5])[0]
+                  for c in range(n_ch)], axis=1)
+    chunks = [1020] * 6 + [1, 33, 4096, 2047, 10000]
+    chunks.append(total - sum(chunks))
+    o, b = run_both(x, chunks, n_ch, fir_T=512, options={"hdlc_lpw": lpw, "fir_flag2": flag2})
+    assert o.counters()[:, 0].sum() > 200
 
 
 @pytest.mark.parametrize("pll_variant", [3, 32, 4, 51, 52, 6, 7])
@@ -270,8 +288,7 @@ def test_open_signs_settled_in_bulk(kernel):
         b = batch(n_ch, taps=taps, pllinc=pllinc, max_len=max(chunks))
         if kernel == "packed12":
             b.set_option("fir_pk", 1)
-        if kernel == "scalar12":
-            b.set_option("fir_nc", 12)
+        b.set_option("fir_nc", 0 if kernel == "scalar10" else 12)
         assert b.info("sign_exact") == 1 and b.info("sign_central_taps") == int(kernel[-2:])
         got, pos = [], 0
         for n in chunks:
