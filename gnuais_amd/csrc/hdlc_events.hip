@@ -515,12 +515,16 @@ __global__ __launch_bounds__(64) EV_OCC void hdlc_events_kernel(
                         rs = t; hunt0 = false;
                         pos = t + 1;
                     } else {
+#ifdef EV_NO_RAW_COPY      /* timing experiment only (wrong records): what would a deframer cost that leaves the raw bits where they are? */
+                        rawpos += e - pos;
+#else
                         for (int p = pos; p < e;) {
                             const int sh = p & 31;
                             const int take = (32 - sh < e - p) ? 32 - sh : e - p;
                             RAW_APPEND((XW(p >> 5) >> sh) & lowmask(take), take);
                             p += take;
                         }
+#endif
                         bufferpos += stored;
                         if (e6 < tile_end) {                    // the sixth 1
                             state = ST_STOPSIGN;
