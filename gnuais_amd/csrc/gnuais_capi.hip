@@ -221,6 +221,10 @@ struct gnuais_batch {
     // workgroup on every CU and keeps the whole chip
     hipStream_t s_firm = nullptr, s_small[2] = {nullptr, nullptr};
     int cu_split = 0;
+    // K3 on the deframer's stream: at ring lag 1 the two never overlap (deframer(i) -> K3(i) -> deframer(i+1)), so the two
+    // cross-stream event waits per call in the loop that sets the period become stream order: 20-step 0.550 -> 0.544,
+    // steady 0.527 -> 0.522 (three A/B pairs, profiles/r04_k3_on_the_deframers_stream.txt).  0 = a stream of its own.
+    int k3_same = 1;
     hipEvent_t e_hist[2] = {nullptr, nullptr};  // the carry of the call on FIR stream q is written
     hipEvent_t e_order = nullptr;               // the caller's stream has reached this call (its input is there)
     // cold start: a call that finds the pipeline empty is followed by a FIR launch that would otherwise be dispatched
@@ -584,6 +588,7 @@ int gnuais_batch_create(gnuais_batch **out, int device, int n_channels, const fl
             }
         }
     }
+    if (const char *v = getenv("GNUAIS_K3_SAME")) b->k3_same = atoi(v) != 0;
     if (const char *v = getenv("GNUAIS_PLL_VARIANT")) b->pll_variant = atoi(v);
     if (const char *v = getenv("GNUAIS_K2B_DATAFLOW")) b->k2b_dataflow = atoi(v) != 0;
     if (const char *v = getenv("GNUAIS_NBUF")) b->nbuf = std::min((int) gnuais_batch::NBUF, std::max(2, atoi(v)));
@@ -706,6 +711,10 @@ int gnuais_batch_set_option(gnuais_batch *b, const char *name, int value)
         b->fir_cpl = value;
     } else if (!strcmp(name, "fir_form")) {
         b->fir_form = value;
+    } else if (!strcmp(name, "k3_same")) {           // K3 on the deframer's stream (1, default) or on its own
+        if (value != 0 && value != 1) return fail(GNUAIS_E_ARG, "k3_same: 0 or 1");
+        if (int rc = gnuais_batch_sync(b)) return rc;
+        b->k3_same = value;
     } else if (!strcmp(name, "fir_flag2")) {         // 0: |y| - eps and two alignbits per output (rounds 1-4)
         if (value != 0 && value != 1) return fail(GNUAIS_E_ARG, "fir_flag2: 0 or 1");
         b->fir_flag2 = value;
@@ -801,6 +810,12 @@ static void fill_hdlc(const gnuais_batch *b, HdlcLaunch &h, int k)
 }
 
 // does the receive path run the shorter central sum?  (only the one-channel-per-lane scalar kernel is built for it)
+// the stream K3 runs on (and everything that has to come behind the last K3)
+static hipStream_t k3_stream(const gnuais_batch *b)
+{
+    return (b->k3_same && b->k2b_lag == 1) ? b->s_k[2] : b->s_k[3];
+}
+
 static bool sign_lo(const gnuais_batch *b)
 {
     return b->sign_ok && b->sign_NC == 12 && b->sign_NC_lo > 0 && b->fir_nc != 12 && b->fir_variant == 3 &&
@@ -891,7 +906,7 @@ static int run_tail(gnuais_batch *b, int k, int len, bool tm, hipEvent_t *ev,
                     hipStream_t s0, hipEvent_t after, const uint32_t *progress = nullptr, uint32_t progress_base = 0)
 {
     const bool pl = b->pipeline;
-    hipStream_t sC = pl ? b->s_k[2] : s0, sD = pl ? b->s_k[3] : s0;
+    hipStream_t sC = pl ? b->s_k[2] : s0, sD = pl ? k3_stream(b) : s0;
     HdlcLaunch h;
     fill_hdlc(b, h, k);
     h.progress = progress;                      // K2b beside the PLL launch (`after` is then the FIR's event, not the PLL's)
@@ -900,14 +915,14 @@ static int run_tail(gnuais_batch *b, int k, int len, bool tm, hipEvent_t *ev,
     // the per-channel candidate ring that K3 of the PREVIOUS call may still be reading: slots are
     // reused after cand_K frame starts, which one call cannot exceed but two could
     if (pl && after) HIP_TRY(hipStreamWaitEvent(sC, after, 0));
-    if (pl && b->calls >= (unsigned) b->k2b_lag)
+    if (pl && b->calls >= (unsigned) b->k2b_lag && sD != sC)
         HIP_TRY(hipStreamWaitEvent(sC, b->e_done[4][(k + b->nbuf - b->k2b_lag) % b->nbuf], 0));
     if (tm) HIP_TRY(hipEventRecord(ev[5], sC));
     if (b->stage_mask & 8) HIP_TRY(b->hdlc_variant ? launch_hdlc_events(h, sC) : launch_hdlc_deframe(h, sC));
     if (tm) HIP_TRY(hipEventRecord(ev[7], sC));
     if (pl) HIP_TRY(hipEventRecord(b->e_done[3][k], sC));
     // K3
-    if (pl) HIP_TRY(hipStreamWaitEvent(sD, b->e_done[3][k], 0));
+    if (pl && sD != sC) HIP_TRY(hipStreamWaitEvent(sD, b->e_done[3][k], 0));
     if (tm) HIP_TRY(hipEventRecord(ev[9], sD));
     if (b->stage_mask & 16) HIP_TRY(launch_hdlc_crc(h, sD));
     if (b->streaming) b->ring_runs[b->ring_cur]++;
@@ -952,7 +967,9 @@ int gnuais_batch_run(gnuais_batch *b, const int16_t *d_samples, int len, void *s
         // Hand-off set k was last used by call i-nbuf.  Its last user is that call's K3; wait for
         // it on the HOST (normally long done): five stream-wait packets per call, each ~20 us of
         // queue time on the stream it sits in, for a condition that is practically always true.
-        // A caller that runs more than nbuf-1 calls ahead of the device blocks here.
+        // A caller that runs more than nbuf-1 calls ahead of the device blocks here.  (Round 4, measured once more at
+        // depth 3, where this wait IS the loop: ONE wait packet on the caller's stream instead, the host held back only
+        // by that call's FIR launch -- 0.583 against 0.542 ms per step, profiles/r04_k3_on_the_deframers_stream.txt.)
         if (reuse) HIP_TRY(hipEventSynchronize(b->e_done[4][k]));
         // K1 carries the FIR history and the peak buffers from call to call in stream order: a caller
         // that changes streams between calls gets the old stream drained first
@@ -1583,7 +1600,7 @@ int gnuais_batch_vessel_table_update(gnuais_batch *b)
     if (!b || !b->vt) return fail(GNUAIS_E_STATE, "vessel_table_update: no table (gnuais_batch_vessel_table_enable)");
     if (b->streaming) return fail(GNUAIS_E_STATE, "vessel_table_update: a streaming batch updates its table by itself");
     if (int rc = gnuais_batch_sync(b)) return rc;             // a drain-type call: waits for the chain like the drains do
-    hipStream_t s = b->pipeline ? b->s_k[3] : b->last_stream;
+    hipStream_t s = b->pipeline ? k3_stream(b) : b->last_stream;
     HIP_TRY(vessel_table_update_enqueue(b->frames, b->frame_count, b->frame_cap, b->vt, b->vt_slots, b->vt_fslot, s));
     return GNUAIS_OK;
 }
@@ -1594,7 +1611,7 @@ int gnuais_batch_vessel_table(gnuais_batch *b, gnuais_vessel *vessels, int cap, 
     *n_vessels = 0;
     if (!b->vt) return fail(GNUAIS_E_STATE, "vessel_table: no table (gnuais_batch_vessel_table_enable)");
     if (int rc = set_device(b)) return rc;
-    hipStream_t s = b->streaming ? b->s_post : (b->pipeline ? b->s_k[3] : b->last_stream);
+    hipStream_t s = b->streaming ? b->s_post : (b->pipeline ? k3_stream(b) : b->last_stream);
     uint32_t info[4] = {0, 0, 0, 0};
     int n = 0;
     HIP_TRY(vessel_table_fetch(b->vt, b->vt_slots, vessels, cap, &n, info, s));
@@ -1721,7 +1738,7 @@ int gnuais_batch_stream_nmea(gnuais_batch *b, const char **text, size_t *len, in
         HIP_TRY(hipDeviceSynchronize());
         b->streaming = true;
     }
-    hipStream_t sD = b->pipeline ? b->s_k[3] : b->last_stream;
+    hipStream_t sD = b->pipeline ? k3_stream(b) : b->last_stream;
     const int c = b->ring_cur;
     // (1) ring c: everything K3 has been asked to append so far
     HIP_TRY(hipEventRecord(b->e_fill[c], sD));
@@ -1825,7 +1842,7 @@ int gnuais_batch_discard_frames(gnuais_batch *b, void *stream)
     if (!b) return fail(GNUAIS_E_ARG, "discard_frames: NULL batch");
     if (b->streaming) return fail(GNUAIS_E_STATE, "discard_frames: the batch is streaming (gnuais_batch_stream_nmea)");
     if (int rc = set_device(b)) return rc;
-    hipStream_t s = b->pipeline ? b->s_k[3] : (hipStream_t) stream;   // behind the last K3
+    hipStream_t s = b->pipeline ? k3_stream(b) : (hipStream_t) stream;   // behind the last K3
     HIP_TRY(hipMemsetAsync(b->frame_count, 0, sizeof(uint32_t) * 3, s));
     b->hdlc_calls = 0;
     return GNUAIS_OK;

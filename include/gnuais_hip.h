@@ -316,7 +316,11 @@ int  gnuais_batch_mean_timing(gnuais_batch *b, float *ms5, int *n_calls);
  * "hdlc_lpw" (channels per wave in the bit-serial deframer, 1..64), "timing_stride" (with
  * set_timing on, time every n-th call only: the event records of a timed call cost ~0.05 ms
  * of stream time), "stage_mask" (experiments: bit 0 = FIR/slicer, bit 1 = PLL/NRZI, bit 3 =
- * deframer, bit 4 = unstuff/CRC; results are wrong unless 0x1f) */
+ * deframer, bit 4 = unstuff/CRC; results are wrong unless 0x1f), "nbuf" (hand-off sets in use = calls that
+ * may be in flight, 2..8, default 3), "fir_flag2" (1 = the sign-exact slicer reads sign and threshold of an output
+ * off one scaled sum with one instruction, the default; 0 = subtract + two gathers), "fir_nc" (12 = twelve
+ * central taps certify the sign, the default; 0 = the shortest certified sum, ten for the reference table),
+ * "pll_variant" 7 (time-parallel PLL: automatic up to 512 channels).  Every setting is bit-exact. */
 int  gnuais_batch_set_option(gnuais_batch *b, const char *name, int value);
 /* Optional, once, before real work: time the stage -> stream assignments on `d_samples` (about 1.3 s
  * of pipelined calls: two greedy searches and a longer head-to-head with the default) and keep the fastest; RESETS the batch.  Which hardware queue a stream gets
