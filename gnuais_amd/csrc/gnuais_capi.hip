@@ -216,11 +216,6 @@ struct gnuais_batch {
     // launch i -- the last NT input rows -- is copied by a small kernel queued IN FRONT of launch i.
     int fir_streams = 1;
     hipStream_t s_fir2 = nullptr;
-    // CU split (experiment, GNUAIS_CU_SPLIT = R): the deframer and K3 on streams whose kernels only run on R reserved
-    // CUs, the FIR on an internal stream that runs on the others (hipExtStreamCreateWithCUMask); the PLL stage needs a
-    // workgroup on every CU and keeps the whole chip
-    hipStream_t s_firm = nullptr, s_small[2] = {nullptr, nullptr};
-    int cu_split = 0;
     // K3 on the deframer's stream: at ring lag 1 the two never overlap (deframer(i) -> K3(i) -> deframer(i+1)), so the two
     // cross-stream event waits per call in the loop that sets the period become stream order: 20-step 0.550 -> 0.544,
     // steady 0.527 -> 0.522 (three A/B pairs, profiles/r04_k3_on_the_deframers_stream.txt).  0 = a stream of its own.
@@ -291,8 +286,6 @@ void gnuais_batch_destroy(gnuais_batch *b)
     for (auto &st : b->pool)
         if (st) (void) hipStreamDestroy(st);
     if (b->s_fir2) (void) hipStreamDestroy(b->s_fir2);
-    for (hipStream_t st : {b->s_firm, b->s_small[0], b->s_small[1]})
-        if (st) (void) hipStreamDestroy(st);
     if (b->h_started) (void) hipHostFree(b->h_started);
     if (b->progress) (void) hipFree(b->progress);
     for (hipEvent_t e : {b->e_hist[0], b->e_hist[1], b->e_order})
@@ -565,28 +558,6 @@ int gnuais_batch_create(gnuais_batch **out, int device, int n_channels, const fl
         // stream got -- so the assignment can be measured instead
         for (; made < gnuais_batch::POOL; ++made)
             if (e == hipSuccess) e = hipStreamCreateWithPriority(&b->pool[made], hipStreamNonBlocking, made < 8 ? hi : 0);
-    }
-    if (const char *v = getenv("GNUAIS_CU_SPLIT")) {
-        const int R = atoi(v), n = b->n_cu;
-        const char *lay = getenv("GNUAIS_CU_LAYOUT");
-        const int layout = lay ? atoi(lay) : 0;
-        if (e == hipSuccess && R > 0 && R < n && n % 32 == 0 && n <= 1024) {
-            uint32_t small[32] = {}, big[32] = {};
-            const int per_xcd = n / 8;
-            for (int i = 0; i < n; ++i) {
-                // layout 0: mask bit i is CU i / 8 of XCD i % 8 (bits dealt round-robin over the XCDs); 1: XCD i / per_xcd
-                const bool res = layout == 0 ? i < R : (i % per_xcd) < R / 8;
-                (res ? small : big)[i >> 5] |= 1u << (i & 31);
-            }
-            e = hipExtStreamCreateWithCUMask(&b->s_firm, (uint32_t) (n / 32), big);
-            for (auto &st : b->s_small)
-                if (e == hipSuccess) e = hipExtStreamCreateWithCUMask(&st, (uint32_t) (n / 32), small);
-            if (e == hipSuccess) {
-                b->cu_split = R;
-                b->s_k[2] = b->s_small[0];
-                b->s_k[3] = b->s_small[1];
-            }
-        }
     }
     if (const char *v = getenv("GNUAIS_K3_SAME")) b->k3_same = atoi(v) != 0;
     if (const char *v = getenv("GNUAIS_PLL_VARIANT")) b->pll_variant = atoi(v);
@@ -993,12 +964,6 @@ int gnuais_batch_run(gnuais_batch *b, const int16_t *d_samples, int len, void *s
                                        b->N, len, b->NT, sF));
             HIP_TRY(hipEventRecord(b->e_hist[q], sF));
         }
-        const bool masked = pl && !two && b->cu_split && (b->stage_mask & 1);
-        if (masked) {                           // the FIR on the internal stream that owns the unreserved CUs
-            sF = b->s_firm;
-            HIP_TRY(hipEventRecord(b->e_order, s0));
-            HIP_TRY(hipStreamWaitEvent(sF, b->e_order, 0));
-        }
         if (tm) HIP_TRY(hipEventRecord(ev[0], sF));
         if (b->stage_mask & 1)
             if (int rc = run_fir(b, d_samples, len, nullptr, sF, k)) return rc;
@@ -1008,7 +973,7 @@ int gnuais_batch_run(gnuais_batch *b, const int16_t *d_samples, int len, void *s
             b->e_in_hook = nullptr;
         }
         if (pl) HIP_TRY(hipEventRecord(b->e_done[0][k], sF));
-        if ((two && q) || masked) HIP_TRY(hipStreamWaitEvent(s0, b->e_done[0][k], 0));
+        if (two && q) HIP_TRY(hipStreamWaitEvent(s0, b->e_done[0][k], 0));
         // K2: this call's sign words -> bit packs segbits[k] (read by K2b of call i-nbuf); in order
         // across calls (it carries the receivers' pll / prev / lastbit)
         PllLaunch p;
@@ -1056,7 +1021,7 @@ int gnuais_batch_discard_frames(gnuais_batch *b, void *stream);
 int gnuais_batch_autotune(gnuais_batch *b, const int16_t *d_samples, int len, void *stream, float *ms_per_call)
 {
     if (!b || !d_samples) return fail(GNUAIS_E_ARG, "autotune: NULL argument");
-    if (!b->pipeline || b->cu_split) {          // one stream, nothing to assign (CU split: the assignment is the experiment)
+    if (!b->pipeline) {                         // one stream, nothing to assign
         if (ms_per_call) *ms_per_call = 0.0f;
         return GNUAIS_OK;
     }
@@ -1141,7 +1106,6 @@ int gnuais_batch_sync(gnuais_batch *b)
     if (int rc = set_device(b)) return rc;
     HIP_TRY(hipStreamSynchronize(b->last_stream));
     if (b->s_fir2) HIP_TRY(hipStreamSynchronize(b->s_fir2));
-    if (b->s_firm) HIP_TRY(hipStreamSynchronize(b->s_firm));
     for (auto &st : b->s_k) HIP_TRY(hipStreamSynchronize(st));
     return GNUAIS_OK;
 }
