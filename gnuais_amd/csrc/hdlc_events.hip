@@ -63,6 +63,9 @@ constexpr int EV_ROWS = (EW + 2) + 4 * EW + (EW + 1);
 #ifndef EV_BITMAPS32
 #define EV_BITMAPS32 1              // 0: the pack's bitmaps through 64-bit shifts of {word, word before} (rounds 2-4; kept for the A/B)
 #endif
+#ifndef EV_HUNT_TWICE
+#define EV_HUNT_TWICE 1             // the hunting section also at the bottom of an event turn (see there); 0 for the A/B
+#endif
 #ifndef EV_WAVES_PER_EU
 #define EV_WAVES_PER_EU 0           // 0: whatever the kernel wants (116 VGPRs); 7 (72 VGPRs) spilt and lost
 #endif
@@ -149,6 +152,9 @@ __global__ __launch_bounds__(64) EV_OCC void hdlc_events_kernel(
 
     // the reference, one bit (protodec.c:993-1120); x = in[i], at = its position in the pack
     auto slow_bit = [&](uint32_t x, int at) {
+        int ns_v = nstartsign, bp_v = bufferpos;
+        {
+        int nstartsign = ns_v, bufferpos = bp_v;
         switch (state) {
         case ST_DATA:
             if (bitstuff) {
@@ -202,6 +208,9 @@ __global__ __launch_bounds__(64) EV_OCC void hdlc_events_kernel(
             HDLC_RESET();
             break;
         }
+        ns_v = nstartsign; bp_v = bufferpos;
+        }
+        nstartsign = ns_v; bufferpos = bp_v;
         last = x;
     };
 
@@ -383,53 +392,58 @@ __global__ __launch_bounds__(64) EV_OCC void hdlc_events_kernel(
         bool hunt0 = true;              // a hunt that began before the pack: antallpreamble counts from there
         bool slow = false;              // this lane goes bit by bit until its state changes
 
+        // ---- hunting: protodec.c:1030-1043 ---------------------------------------------------------
+        // (a lane in ST_SKURR at `pos`; runs at the top of a turn and again at its bottom: a lane whose frame has just
+        // closed -- or whose flag count has just been reset -- goes on hunting in the SAME turn instead of holding the
+        // whole wave for one more: a pack with f frames on its busiest lane takes f turns, not f + 1)
+        auto hunt = [&]() {
+            int trig = NONE;
+            if (rs < 0 && hunt0) {
+                // the count carried into the pack keeps running while the bits alternate from the
+                // pack's first bit on: alternations at 0 .. t0-1; bit k brings it to ap0 + k + 1
+                const int t0 = first_set(NAa, nzNA, 0);
+                int k0 = 14 - antallpreamble;
+                if (k0 < 0) k0 = 0;
+                const int lim = t0 < tile_end ? t0 : tile_end;
+                if (k0 < lim && bit_at(k0)) ++k0;           // the bits alternate: the next one is a 0
+                if (k0 < lim) trig = k0;
+                const int cb = first_set(CBa, nzCB, 0);
+                if (cb < trig) trig = cb;
+            } else {
+                // a count that started after the reset at rs: 15 alternations at rs+1 ..
+                const int from = rs + 15 > pos ? rs + 15 : pos;
+                trig = first_set(CBa, nzCB, from);
+            }
+            if (trig < tile_end) {
+                state = ST_PREAMBLE;
+                antallpreamble = 0;
+                last = 0;
+                pos = trig + 1;
+            } else {
+                // to the pack's end: the alternations that end there, counted from the reset / the
+                // carried count
+                int lastna = -1;                                   // last position with x[k] == x[k-1]
+                for (uint32_t nz = nzNA; nz;) {
+                    const int q = 31 - clz32(nz);
+                    const uint32_t m = NAa[q * tpb];
+                    lastna = 32 * q + 31 - clz32(m);
+                    break;
+                }
+                int ap;
+                if (rs < 0 && hunt0) ap = lastna < 0 ? antallpreamble + tile_end : tile_end - 1 - lastna;
+                else {
+                    const int since = tile_end - 1 - rs, run = tile_end - 1 - lastna;
+                    ap = since < run ? since : run;
+                }
+                antallpreamble = ap > 15 ? 15 : ap;
+                last = bit_at(tile_end - 1);
+                pos = tile_end;
+            }
+        };
+
         while (__any(pos < tile_end)) {
             if (pos < tile_end) {
-                // ---- hunting: protodec.c:1030-1043 -------------------------------------------------
-                if (state == ST_SKURR && !slow) {
-                    int trig = NONE;
-                    if (rs < 0 && hunt0) {
-                        // the count carried into the pack keeps running while the bits alternate from the
-                        // pack's first bit on: alternations at 0 .. t0-1; bit k brings it to ap0 + k + 1
-                        const int t0 = first_set(NAa, nzNA, 0);
-                        int k0 = 14 - antallpreamble;
-                        if (k0 < 0) k0 = 0;
-                        const int lim = t0 < tile_end ? t0 : tile_end;
-                        if (k0 < lim && bit_at(k0)) ++k0;           // the bits alternate: the next one is a 0
-                        if (k0 < lim) trig = k0;
-                        const int cb = first_set(CBa, nzCB, 0);
-                        if (cb < trig) trig = cb;
-                    } else {
-                        // a count that started after the reset at rs: 15 alternations at rs+1 ..
-                        const int from = rs + 15 > pos ? rs + 15 : pos;
-                        trig = first_set(CBa, nzCB, from);
-                    }
-                    if (trig < tile_end) {
-                        state = ST_PREAMBLE;
-                        antallpreamble = 0;
-                        last = 0;
-                        pos = trig + 1;
-                    } else {
-                        // to the pack's end: the alternations that end there, counted from the reset / the
-                        // carried count
-                        int lastna = -1;                                   // last position with x[k] == x[k-1]
-                        for (uint32_t nz = nzNA; nz;) {
-                            const int q = 31 - clz32(nz);
-                            const uint32_t m = NAa[q * tpb];
-                            lastna = 32 * q + 31 - clz32(m);
-                            break;
-                        }
-                        int ap;
-                        if (rs < 0 && hunt0) ap = lastna < 0 ? antallpreamble + tile_end : tile_end - 1 - lastna;
-                        else {
-                            const int since = tile_end - 1 - rs, run = tile_end - 1 - lastna;
-                            ap = since < run ? since : run;
-                        }
-                        antallpreamble = ap > 15 ? 15 : ap;
-                        last = bit_at(tile_end - 1);
-                        pos = tile_end;
-                    }
-                }
+                if (state == ST_SKURR && !slow) hunt();
                 // ---- the training sequence goes on: protodec.c:1047-1048 --------------------------
                 if (state == ST_PREAMBLE && nstartsign == 0 && pos < tile_end && !slow) {
                     const int j = first_set(NAa, nzNA, pos);
@@ -565,6 +579,9 @@ __global__ __launch_bounds__(64) EV_OCC void hdlc_events_kernel(
                     if (state != st0) slow = false;
                     pos += 1;
                 }
+#if EV_HUNT_TWICE
+                if (state == ST_SKURR && !slow && pos < tile_end) hunt();
+#endif
             }
         }
         seenbase += (uint32_t) tile_end;
