@@ -262,6 +262,30 @@ def measure(cfg, args, local, rank, sync, steps, warmup, isolated=True, post=Fal
                                "what": "the timed loop again over 200 steps (not the headline: context for the "
                                        "fill + drain share of a short region)"}
 
+    if post and cfg["stage_mask"] == 0x1f and steps < 100:
+        # which stages set the period: the same loop with stages switched off (stage_mask: 1 FIR, 2 PLL, 8 deframer, 16 K3;
+        # the later stages re-read what the last full call left in the hand-off buffers, so their work is the real one) --
+        # instruction counts cannot tell a chain that is issue-bound from one that waits on two serial recurrences
+        legs = {}
+        for name, mask in (("pll_alone", 0x02), ("deframer_and_k3", 0x18), ("without_fir", 0x1e), ("fir_alone", 0x01),
+                           ("fir_and_pll", 0x03), ("all", 0x1f)):
+            b.set_option("stage_mask", mask)
+            for _ in range(8):
+                step()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(60):
+                step()
+            torch.cuda.synchronize()
+            legs[name] = (time.perf_counter() - t0) / 60 * 1e3
+        b.reset()                   # the masked legs left the receivers' state between stages inconsistent
+        for _ in range(4):
+            step()
+        torch.cuda.synchronize()
+        out["stage_masks"] = dict(legs, steps=60, what="ms per step of the pipelined loop with only the named stages running "
+                                  "(gnuais_batch_set_option stage_mask; results are discarded): the PLL stage's launches are "
+                                  "serial (they carry the receivers' state), so pll_alone is a floor under every arrangement")
+
     if post and args.e2e and cfg["stage_mask"] == 0x1f:
         # the rest of row f1 from the device: sentences AND the stdout line of every accepted frame
         # (gnuais_batch_drain_messages), one step's frames, the C call alone into buffers that exist already
@@ -409,6 +433,17 @@ def roofline_of(m, ms_per_step=None, traffic=None, n_taps=36):
                                        "as; micro-benchmarked issue costs on this chip are 2.4 (add, mul) to 4.7 (fma with a "
                                        "scalar operand, packed) cycles, so read it as an upper estimate of how full the VALU "
                                        "is: between ~0.65 x and 1 x this figure"}
+            sm = m.get("stage_masks")
+            if sm and ms_per_step:
+                # measured, not priced: if the PLL stage alone already needs most of the period, the chain waits on its
+                # recurrence, however full the VALU is
+                r["valu_chain"]["stage_masks"] = {k: v for k, v in sm.items() if k not in ("what", "steps")}
+                if sm["pll_alone"] >= 0.8 * sm["all"]:
+                    r["valu_chain"]["bound"] = "latency"
+                    r["valu_chain"]["bound_why"] = ("the PLL stage alone (serial launches of a per-channel recurrence) needs %.3f ms "
+                                                    "per step, %.0f %% of the %.3f the whole chain needs in the same loop; without "
+                                                    "the FIR %.3f, FIR alone %.3f" % (sm["pll_alone"], 100 * sm["pll_alone"] / sm["all"],
+                                                                                     sm["all"], sm["without_fir"], sm["fir_alone"]))
             r["bound"] = per[dom]["bound"] if dom in per else r["bound"]
             if r["bound"] == "latency":
                 r["latency_note"] = ("a per-channel recurrence: one wave per 16-64 channels walks the call serially "
@@ -604,6 +639,7 @@ def rank_main(rank, local, world, args, sync):
                                 n_taps=144 if cfg["wide"] else 36),
         "float_path": float_path(args, local) if (world == 1 and args.e2e and args.config == "C3") else None,
         "steady_state": m.get("steady_state"),
+        "stage_masks": m.get("stage_masks"),
         "note": "the receive path slices the sign of the filter output and never stores the pre-slicer "
                 "floats; gnuais_batch_filter() produces them (bit-exact, tests/test_hip_parity.py)",
     }
