@@ -386,8 +386,15 @@ __global__ __launch_bounds__(256) void hdlc_crc_kernel(
 {
     __shared__ uint32_t tab[256];
     __shared__ uint32_t pre[K3_CH + 1];
-    __shared__ uint32_t stage[256][HDLC_BUF_WORDS + 1];     // unstuffed frame bits per thread
-    __shared__ uint32_t rawlds[256][CAND_WORDS - CAND_HDR + 1];   // raw record per thread
+    // The two per-thread buffers are DYNAMIC shared memory (K3_DYN_LDS bytes at launch).  As static arrays (36 KB) they
+    // made the compiler derive "at most four waves per SIMD" from the workgroup's LDS and then pad the kernel's register
+    // request up to that occupancy: 104 VGPRs per wave in the descriptor for 59 in use -- beside four FIR waves and a
+    // PLL wave that is the difference between a wave that fits a SIMD's free registers and one that waits for a FIR
+    // wave to retire.
+    extern __shared__ uint32_t k3_dyn[];
+    uint32_t (*const stage)[HDLC_BUF_WORDS + 1] = reinterpret_cast<uint32_t (*)[HDLC_BUF_WORDS + 1]>(k3_dyn);   // unstuffed frame bits per thread
+    uint32_t (*const rawlds)[CAND_WORDS - CAND_HDR + 1] =                                                     // raw record per thread
+        reinterpret_cast<uint32_t (*)[CAND_WORDS - CAND_HDR + 1]>(k3_dyn + 256 * (HDLC_BUF_WORDS + 1));
     __shared__ uint32_t wave_cnt[4];
     __shared__ uint32_t pass_base;
     const int tid = threadIdx.x;
@@ -572,7 +579,8 @@ hipError_t launch_hdlc_deframe(const HdlcLaunch &a, hipStream_t stream)
 
 hipError_t launch_hdlc_crc(const HdlcLaunch &a, hipStream_t stream)
 {
-    hipLaunchKernelGGL(hdlc_crc_kernel, dim3((unsigned) ((a.N + K3_CH - 1) / K3_CH)), dim3(256), 0,
+    constexpr size_t K3_DYN_LDS = 256 * ((HDLC_BUF_WORDS + 1) + (CAND_WORDS - CAND_HDR + 1)) * sizeof(uint32_t);
+    hipLaunchKernelGGL(hdlc_crc_kernel, dim3((unsigned) ((a.N + K3_CH - 1) / K3_CH)), dim3(256), K3_DYN_LDS,
                        stream, a.cand, a.cand_first, a.cand_count, a.counters,
                        (uint32_t *) a.frames, a.frame_count, a.frame_cap, a.N, a.K, a.chunks, k3_passes(a.K_call > 0 ? a.K_call : a.K));
     return hipGetLastError();
