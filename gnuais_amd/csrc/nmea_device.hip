@@ -198,6 +198,9 @@ __device__ __forceinline__ char armor(unsigned v) { return (char) (v < 40 ? v + 
 __device__ __forceinline__ char hexdigit(unsigned v) { return (char) (v < 10 ? '0' + v : 'A' + v - 10); }
 
 constexpr int MAX_FRAME_TEXT = 164;         // two sentences of 82 bytes: 449 bits are at most 75 characters
+constexpr int NMEA_WRITE_TEXT = 256 * MAX_FRAME_TEXT + 32;             // nmea_write_kernel's LDS: the text of 256 frames ...
+constexpr int NMEA_WRITE_LDS_BYTES = NMEA_WRITE_TEXT + 256 * 17 * 4;   // ... and their records, a row of 17 words per thread
+static_assert(NMEA_WRITE_TEXT % 16 == 0, "the frame rows behind the text are dword-aligned");
 
 // 256 consecutive frames of the print order per workgroup: their text is one contiguous piece of the
 // output, built in LDS (a thread writes its own sentences byte by byte) and then stored 16 bytes per lane.
@@ -208,7 +211,11 @@ __global__ __launch_bounds__(256) void nmea_write_kernel(
     unsigned long long out_cap, uint32_t *__restrict__ totals /* [0] offset of the last frame's text, [1] its
     length, [2] sentences, [3] bad channel */, const uint32_t *__restrict__ n_dev)
 {
-    __shared__ __attribute__((aligned(16))) char buf[256 * MAX_FRAME_TEXT + 32];
+    // dynamic shared memory (NMEA_WRITE_LDS_BYTES at launch): as a static array the 42 KB made the compiler pad this
+    // kernel's register request from 32 to 136 per wave (the occupancy it derives from static LDS), and the kernel runs
+    // inside the delivery loop beside the chain's stages
+    extern __shared__ __attribute__((aligned(16))) char nmea_write_dyn[];
+    char *const buf = nmea_write_dyn;
     __shared__ uint32_t s_base, s_end, s_sent;
     const int tid = threadIdx.x;
     if (n_dev) n = (int) *n_dev;
@@ -234,8 +241,29 @@ __global__ __launch_bounds__(256) void nmea_write_kernel(
             const bool last = (j + 1 == n) || chan[j + 1] != ch;
             if (last) seq_out[ch] = (uint8_t) ((seq_in[ch] + before + (ok ? 1u : 0u)) % 10u);
             if (ok) {
-                const FrameView f = load_frame(frames, order[j]);
-                const Geo g = geometry(f.nbits());
+                // the frame's 64 bytes go to this thread's row of LDS (17 words apart: no two lanes of a wave share a
+                // bank): six() indexes the payload with a run-time byte offset, which on a register copy means
+                // scratch memory -- 75 dependent scratch loads per frame, inside the delivery loop
+                uint32_t *const fr = reinterpret_cast<uint32_t *>(buf + NMEA_WRITE_TEXT) + tid * 17;
+                {
+                    const uint4 *p = reinterpret_cast<const uint4 *>(frames + order[j]);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const uint4 v = p[q];
+                        fr[4 * q] = v.x; fr[4 * q + 1] = v.y; fr[4 * q + 2] = v.z; fr[4 * q + 3] = v.w;
+                    }
+                }
+                const int f_nbits = (int) (fr[15] >> 16);
+                auto f_byte = [&](int k) -> unsigned { return (fr[2 + (k >> 2)] >> (8 * (k & 3))) & 0xffu; };
+                auto f_six = [&](int i) -> unsigned {          // FrameView::six() on the LDS copy
+                    const int bit = 6 * i, k = bit >> 3, sh = bit & 7;
+                    const unsigned two = (f_byte(k) << 8) | (k + 1 < 53 ? f_byte(k + 1) : 0u);
+                    unsigned v = (two >> (10 - sh)) & 63u;
+                    const int valid = (f_nbits & ~7) - bit;
+                    if (valid < 6) v = valid <= 0 ? 0u : (v & ~((1u << (6 - valid)) - 1u));
+                    return v;
+                };
+                const Geo g = geometry(f_nbits);
                 const char seq = (char) ('0' + (seq_in[ch] + before) % 10u);
                 char *o = buf + shift + (off - base);
                 int done = 0;
@@ -252,7 +280,7 @@ __global__ __launch_bounds__(256) void nmea_write_kernel(
                     } else {                                            // :857-859: always 'A'
                         put(','); put('A'); put(',');
                     }
-                    for (int i = 0; i < CHARS_PER_SENTENCE && done < g.nchars; ++i, ++done) put(armor(f.six(done)));
+                    for (int i = 0; i < CHARS_PER_SENTENCE && done < g.nchars; ++i, ++done) put(armor(f_six(done)));
                     put(',');
                     put((char) ((g.parts > 1 && part == g.parts) ? '0' + g.fill : '0'));
                     o[k++] = '*'; o[k++] = hexdigit(x >> 4); o[k++] = hexdigit(x & 15u);      // :864-869
@@ -611,7 +639,8 @@ __global__ __launch_bounds__(256) void message_pack_kernel(const char *__restric
                                                            const uint32_t *__restrict__ off, int n, char *__restrict__ out,
                                                            unsigned long long out_cap, uint32_t *__restrict__ info)
 {
-    __shared__ __attribute__((aligned(16))) char buf[PACK_FRAMES * MSG_LINE_MAX + 32];
+    extern __shared__ __attribute__((aligned(16))) char message_pack_dyn[];     // MESSAGE_PACK_LDS bytes at launch (see nmea_write_kernel)
+    char *const buf = message_pack_dyn;
     __shared__ uint32_t s_lines;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int j0 = blockIdx.x * PACK_FRAMES;
@@ -1057,7 +1086,8 @@ hipError_t messages_format_enqueue(const gnuais_frame *frames, int n, int n_chan
     size_t t = lay.tmp_bytes;
     if ((e = rocprim::exclusive_scan(lay.tmp, t, len, off, 0u, (size_t) n, rocprim::plus<uint32_t>(), s)) != hipSuccess)
         return e;
-    hipLaunchKernelGGL(message_pack_kernel, dim3((n + PACK_FRAMES - 1) / PACK_FRAMES), dim3(256), 0, s, lines, len, off, n, out,
+    constexpr size_t MESSAGE_PACK_LDS = PACK_FRAMES * MSG_LINE_MAX + 32;
+    hipLaunchKernelGGL(message_pack_kernel, dim3((n + PACK_FRAMES - 1) / PACK_FRAMES), dim3(256), MESSAGE_PACK_LDS, s, lines, len, off, n, out,
                        (unsigned long long) out_cap, info2);
     return hipGetLastError();
 }
@@ -1190,7 +1220,7 @@ hipError_t nmea_format_enqueue(const gnuais_frame *frames, int n, int n_max, int
                        tri, chan, n_max);
     t = tmp_bytes;
     if ((e = rocprim::inclusive_scan(tmp, t, tri, scan, m, TriOp(), s)) != hipSuccess) return e;
-    hipLaunchKernelGGL(nmea_write_kernel, dim3(grid), dim3(256), 0, s, frames, idx2, chan, tri, scan, n, n_channels,
+    hipLaunchKernelGGL(nmea_write_kernel, dim3(grid), dim3(256), NMEA_WRITE_LDS_BYTES, s, frames, idx2, chan, tri, scan, n, n_channels,
                        seq_in, seq_out, out, (unsigned long long) out_cap, totals,
                        by_chunks ? chunk_off + n_chunks : (const uint32_t *) nullptr);
     if ((e = hipGetLastError()) != hipSuccess) return e;
