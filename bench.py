@@ -22,7 +22,9 @@ node object (gnuais_node_*: a batch and a host thread per device, merged results
 nothing shared but a start/stop barrier; launched by torch.distributed.run, the ranks it
 created are used and RCCL provides the barrier and the max-over-ranks time.
 
-Prints ONE JSON line on rank 0.
+Rank 0 prints ONE compact JSON line (< 4 KB: the contract's keys, `roofline`, `cpu_baseline`, the other
+configs' ms / frac / bound) as the LAST line of stdout; every other measurement (per-kernel VALU tables, PMC
+traffic detail, stage masks, the texts that say what each figure is) goes to bench_detail.json.
 """
 import argparse
 import json
@@ -34,6 +36,7 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+T_START = time.perf_counter()
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.3 TB/s measured)
 KERNEL_LEG_CALLS = 120         # the leg behind the timed region that `kernel_ms` comes from: events on every 2nd of
@@ -600,6 +603,127 @@ def float_path(args, local, shapes=(("C2", 256, 48000), ("C3", 16384, 48000))):
     return out
 
 
+
+COMPACT_LIMIT = 4096           # the driver keeps an 8 KB tail of stdout and parses its LAST line: stay far below
+
+
+def _r(v, nd=4):
+    """Round floats (recursively) so that the compact line spends its bytes on digits that mean something."""
+    if isinstance(v, float):
+        if v != v or v in (float("inf"), float("-inf")):
+            return None
+        return round(v, nd) if abs(v) < 1e4 else round(v, 1)
+    if isinstance(v, dict):
+        return {k: _r(x, nd) for k, x in v.items()}
+    if isinstance(v, (list, tuple)):
+        return [_r(x, nd) for x in v]
+    return v
+
+
+def _pick(d, keys):
+    return {k: d[k] for k in keys if isinstance(d, dict) and k in d and d[k] is not None}
+
+
+def compact_line(out, detail_path=None):
+    """The ONE line the driver parses: the contract's keys + `roofline` + `cpu_baseline`, nothing that is prose.
+    Everything else of `out` (per-kernel VALU tables, traffic detail, stage masks, the e2e legs, every `what`)
+    goes to the detail file.  Guaranteed shorter than COMPACT_LIMIT bytes: optional blocks are dropped, last first,
+    until it is (tests/test_bench_line.py holds it to that on canned measurements)."""
+    c = _pick(out, ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                    "vs_baseline", "dtype", "data", "valid_crc_msgs_per_s", "x_realtime_channels"))
+    c.setdefault("vs_baseline", None)
+    cfg = out.get("config") or {}
+    c["config"] = _pick(cfg, ("workload", "channels_per_gpu", "samples_per_channel", "parallelism"))
+    r = out.get("roofline") or {}
+    rr = _pick(r, ("bound", "kernel", "kernel_ms", "achieved", "peak", "unit", "frac", "traffic",
+                   "algorithmic_bytes_per_launch"))
+    rr.setdefault("traffic", None)
+    if isinstance(r.get("chain"), dict):
+        rr["chain"] = _pick(r["chain"], ("ms_per_step", "achieved", "frac"))
+    if isinstance(r.get("fir"), dict):
+        rr["fir"] = _pick(r["fir"], ("kernel_ms", "frac"))
+    if isinstance(r.get("valu"), dict):
+        rr["valu"] = _pick(r["valu"], ("insts_per_sample", "busy_frac", "issue_floor_ms"))
+    if isinstance(r.get("valu_chain"), dict):
+        rr["valu_chain"] = _pick(r["valu_chain"], ("issue_floor_ms", "bound"))
+    c["roofline"] = rr
+    cb = out.get("cpu_baseline")
+    if isinstance(cb, dict):
+        cc = _pick(cb, ("value", "unit", "cores", "cpu", "kind", "sample", "seconds"))
+        for k in ("all_cores", "all_cores_planar"):
+            if isinstance(cb.get(k), dict):
+                cc[k] = _pick(cb[k], ("value", "cores"))
+        c["cpu_baseline"] = cc
+    optional = []                   # (key, value), most dispensable LAST
+    if isinstance(out.get("kernel_ms"), dict):
+        optional.append(("kernel_ms", out["kernel_ms"]))
+    if isinstance(out.get("steady_state"), dict):
+        optional.append(("steady_state", _pick(out["steady_state"], ("steps", "ms_per_step"))))
+    if isinstance(out.get("stage_masks"), dict):
+        optional.append(("stage_masks", {k: v for k, v in out["stage_masks"].items() if k not in ("what", "steps")}))
+    oc = out.get("other_configs")
+    if isinstance(oc, dict):
+        o2 = {}
+        for name, o in oc.items():
+            e = _pick(o, ("ms_per_step", "value"))
+            orf = o.get("roofline") or {}
+            if isinstance(orf.get("chain"), dict) and "frac" in orf["chain"]:
+                e["frac"] = orf["chain"]["frac"]
+            e["bound"] = orf.get("bound")
+            e["traffic"] = orf.get("traffic")
+            e["kernel"] = orf.get("kernel")
+            o2[name] = e
+        optional.append(("other_configs", o2))
+    if isinstance(out.get("exact_chain"), dict):
+        optional.append(("exact_chain", _pick(out["exact_chain"], ("ms_per_step", "frac_of_hbm_peak",
+                                                                   "same_msgs_as_the_default_chain"))))
+    if isinstance(out.get("kernel_ms_isolated"), dict):
+        optional.append(("kernel_ms_isolated", out["kernel_ms_isolated"]))
+    if isinstance(out.get("per_gpu"), list):
+        optional.append(("per_gpu", [_pick(g, ("rank", "shard", "device", "channels", "ms_per_step"))
+                                     for g in out["per_gpu"]]))
+    if isinstance(out.get("end_to_end"), dict):
+        optional.append(("end_to_end", _pick(out["end_to_end"], ("ms_per_step", "delivered_msgs_per_s"))))
+    if out.get("bench_seconds") is not None:
+        optional.append(("bench_seconds", out["bench_seconds"]))
+    for k, v in optional:
+        c[k] = v
+    if detail_path:
+        c["detail"] = detail_path
+    c = _r(c)
+    # the texts are the only unbounded fields: cut them first, then drop optional blocks, most dispensable first
+    for holder, key in ((c["config"], "workload"), (c["config"], "parallelism"), (c.get("cpu_baseline", {}), "sample"),
+                        (c.get("cpu_baseline", {}), "cpu"), (c, "metric"), (c, "dtype")):
+        if isinstance(holder.get(key), str) and len(holder[key]) > 160:
+            holder[key] = holder[key][:157] + "..."
+    line = json.dumps(c, separators=(",", ":"))
+    while len(line) >= COMPACT_LIMIT and optional:
+        k, _ = optional.pop()
+        c.pop(k, None)
+        line = json.dumps(c, separators=(",", ":"))
+    assert len(line) < COMPACT_LIMIT, len(line)
+    return line
+
+
+def emit(out, args):
+    """Everything measured -> the detail file (bench_detail.json beside this script, and under gpurun_out/ when that
+    exists so that it comes back from the GPU box); the compact line -> stdout, LAST."""
+    detail = getattr(args, "detail", None) or os.path.join(ROOT, "bench_detail.json")
+    written = None
+    for path in [detail] + ([os.path.join(ROOT, "gpurun_out", "bench_detail.json")]
+                            if os.path.isdir(os.path.join(ROOT, "gpurun_out")) else []):
+        try:
+            with open(path, "w") as fh:
+                json.dump(out, fh, indent=1)
+            written = written or os.path.relpath(path, ROOT)
+        except OSError:
+            pass
+    if getattr(args, "print_detail", False):
+        print(json.dumps(out), flush=True)             # an EARLIER stdout line, on request only
+    sys.stderr.flush()
+    print(compact_line(out, written), flush=True)
+
+
 def rank_main(rank, local, world, args, sync):
     import torch
     torch.cuda.set_device(local)
@@ -670,12 +794,13 @@ def rank_main(rank, local, world, args, sync):
                             "kernel_ms": o["kernel_ms"], "kernel_ms_isolated": o["kernel_ms_isolated"],
                             "dominant_kernel": max(o["kernel_ms"], key=o["kernel_ms"].get),
                             "roofline": roofline_of(o, o["dt"] / o["steps"] * 1e3,
-                                                    pmc_traffic(args, name) if args.traffic else None,
+                                                    pmc_traffic(args, name) if (args.traffic and args.traffic_others) else None,
                                                     n_taps=144 if CONFIGS[name]["wide"] else 36)}
         out["other_configs"] = others
     if x_cpu is not None:
         out["cpu_baseline"] = cpu_baseline(x_cpu, args.cpu_channels, m["len"], x_wide)
-    print(json.dumps(out), flush=True)
+    out["bench_seconds"] = time.perf_counter() - T_START
+    emit(out, args)
 
 
 def node_main(world, args):
@@ -754,7 +879,8 @@ def node_main(world, args):
         x0 = slabs[0][:, : min(args.cpu_channels, slabs[0].shape[1])].cpu().numpy()
         out["cpu_baseline"] = cpu_baseline(x0, x0.shape[1], total)
     node.close()
-    print(json.dumps(out), flush=True)
+    out["bench_seconds"] = time.perf_counter() - T_START
+    emit(out, args)
 
 
 def _worker(rank, world, args, barrier, queue):
@@ -782,11 +908,21 @@ def main():
                     help="skip the 120-call leg behind the timed region that kernel_ms is averaged over")
     ap.add_argument("--no-traffic", dest="traffic", action="store_false",
                     help="skip the rocprofv3 --pmc child runs that fill roofline.traffic")
-    ap.add_argument("--no-e2e", dest="e2e", action="store_false",
-                    help="skip the message-layer legs (message_lines, end_to_end): for profile runs of the chain alone")
+    ap.add_argument("--e2e", dest="e2e", action="store_true", default=False,
+                    help="also run the message-layer legs (message_lines, end_to_end, float_path); off by default: the "
+                         "default command stays under a minute")
+    ap.add_argument("--no-e2e", dest="e2e", action="store_false", help="(the default; kept for old command lines)")
+    ap.add_argument("--traffic-others", action="store_true",
+                    help="rocprofv3 --pmc child runs for C2 and C5 too (six more passes)")
+    ap.add_argument("--full", action="store_true", help="everything: --e2e --traffic-others")
+    ap.add_argument("--detail", default="", help="where the full measurements go (default: bench_detail.json here)")
+    ap.add_argument("--print-detail", action="store_true",
+                    help="also print the full measurements as an EARLIER stdout line (the compact line stays last)")
     ap.add_argument("--no-others", dest="others", action="store_false",
                     help="skip the brief C2 / C5 measurements of a default single-GPU run")
     args = ap.parse_args()
+    if args.full:
+        args.e2e = args.traffic_others = True
 
     if "RANK" in os.environ and "WORLD_SIZE" in os.environ:
         # launched by torch.distributed.run: its ranks, RCCL for the barrier and the reductions

@@ -1,0 +1,69 @@
+"""The bench line the driver parses (bench.py: compact_line): short enough to survive the driver's 8 KB tail of
+stdout, and carrying every key the contract names -- round 4's line was 22 KB and `parsed` came back null.
+CPU only: canned measurements (the round-4 detail record under profiles/, and a synthetic worst case)."""
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402
+
+REQUIRED = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+            "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline")
+ROOFLINE = ("bound", "achieved", "peak", "unit", "frac", "traffic")
+CPU = ("value", "unit", "cores", "kind", "sample")
+
+
+def _canned():
+    with open(os.path.join(ROOT, "profiles", "r04_bench.json")) as fh:
+        return json.load(fh)
+
+
+def _check(line):
+    assert "\n" not in line
+    assert len(line) < bench.COMPACT_LIMIT, len(line)
+    c = json.loads(line)
+    for k in REQUIRED:
+        assert k in c, k
+    for k in ROOFLINE:
+        assert k in c["roofline"], k
+    for k in CPU:
+        assert k in c["cpu_baseline"], k
+    assert c["config"]["workload"] and "model" not in c["config"]
+    assert abs(c["roofline"]["frac"] - c["roofline"]["achieved"] / c["roofline"]["peak"]) < 1e-3
+    return c
+
+
+def test_round4_record_fits_and_keeps_the_contract():
+    out = _canned()
+    assert len(json.dumps(out)) > 16000            # the record that broke the driver's parser
+    c = _check(bench.compact_line(out, "bench_detail.json"))
+    assert c["detail"] == "bench_detail.json"
+    assert set(c["other_configs"]) == {"C2", "C5"}
+    for o in c["other_configs"].values():
+        assert {"ms_per_step", "frac", "bound", "traffic"} <= set(o)
+    assert c["steady_state"]["ms_per_step"] > 0
+    assert c["cpu_baseline"]["all_cores"]["cores"] >= 1
+    assert "what" not in json.dumps(c)             # no prose in the line
+
+
+def test_a_bloated_record_still_fits():
+    out = _canned()
+    out["per_gpu"] = [{"rank": g, "shard": g, "device": g, "channels": 16384, "ms_per_step": 0.5 + g * 1e-7,
+                       "pci": "0000:%02x:00.0" % g, "host_thread_pinned_to_cpus": list(range(64))} for g in range(64)]
+    out["kernel_ms"] = {"kernel_%d" % i: 0.1 * i for i in range(200)}
+    out["config"]["workload"] = "w" * 3000
+    out["cpu_baseline"]["sample"] = "s" * 3000
+    _check(bench.compact_line(out, "x.json"))
+
+
+def test_a_node_line_without_pmc_fits():
+    out = _canned()
+    out["roofline"] = {"bound": "hbm", "kernel": "chain (all devices)", "achieved": 22000.0, "peak": 64000.0,
+                       "unit": "GB/s", "frac": 22000.0 / 64000.0, "traffic": None,
+                       "algorithmic_bytes_per_launch": 8 * 1.57e9}
+    out["n_gpus"] = 8
+    out.pop("other_configs", None)
+    c = _check(bench.compact_line(out))
+    assert c["roofline"]["traffic"] is None and c["n_gpus"] == 8
