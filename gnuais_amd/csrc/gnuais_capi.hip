@@ -718,7 +718,7 @@ int gnuais_batch_set_option(gnuais_batch *b, const char *name, int value)
         b->pipeline = value != 0;
 
     } else if (!strcmp(name, "pll_variant")) {
-        if (value != 0 && value != 3 && value != 4 && value != 6 && value != 7 && value != 32 && value != 51 && value != 52)
+        if (value != 0 && value != 3 && value != 4 && value != 6 && value != 7 && value != 8 && value != 32 && value != 51 && value != 52)
             return fail(GNUAIS_E_ARG, "pll_variant must be 0 (by channel count), 3, 4, 6 (lane-per-channel forms) or 7 (time-parallel)");
         b->pll_variant = value;
     } else if (!strcmp(name, "hdlc_variant")) {

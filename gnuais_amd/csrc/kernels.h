@@ -88,6 +88,9 @@ hipError_t launch_pll(const PllLaunch &a, hipStream_t stream);           // K2
 bool pll_tp_applicable(const PllLaunch &a);
 hipError_t launch_pll_tp(const PllLaunch &a, hipStream_t stream);
 hipError_t pll_tp_read_stamps(unsigned long long *h8);                   // experiments: phase stamps of workgroup 0
+// K2 as one recurrence wave + three helper waves per 64 channels (pll_h3.hip): what the full pipeline runs
+hipError_t pll_h3_prepare_device();
+hipError_t launch_pll_h3(const PllLaunch &a, hipStream_t stream);
 constexpr int PLL_TP_MAX_CHANNELS = 512;  // launch_pll() takes the time-parallel form by itself up to this many channels
 
 // ---- K2b: HDLC deframer, K3: CRC-16 + frame delivery (hdlc_crc.hip) ---------

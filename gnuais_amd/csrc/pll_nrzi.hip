@@ -16,6 +16,23 @@
 
 namespace gnuais {
 
+#ifdef PLL6_BUDGET
+// Measurement build only (EXTRA=-DPLL6_BUDGET; scripts/pll_wave_budget.py 6): clock ticks per workgroup --
+//   0 recurrence: total   1 ... waiting for a scanner   3 ... in the rows   4 rows of four   5 blocks
+//   8 first toggler: total   9 ... waiting (pack buffer, recurrence)   10 ... in its rows
+__device__ unsigned long long pll6_budget[4096 * 16];
+#define BUDGET(i, v) do { if (lane == 0 && blockIdx.x < 4096) pll6_budget[blockIdx.x * 16 + (i)] = (v); } while (0)
+#define TICK() ((unsigned long long) clock64())
+#else
+#define BUDGET(i, v) do { } while (0)
+#define TICK() 0ull
+#pragma clang diagnostic ignored "-Wunused-variable"
+#pragma clang diagnostic ignored "-Wunused-but-set-variable"
+#endif
+#ifndef PLL_TOG_PRIO
+#define PLL_TOG_PRIO 0
+#endif
+
 // Waves of a workgroup (pll_nrzi3.hip describes the scanner, the recurrence's rows and the writer):
 //   recurrence (wave 0) six instructions per transition: it only advances the phase and writes the number of the slice
 //              the transition toggles -- relative to the block's first sample, so that it fits a byte -- over the
@@ -231,8 +248,14 @@ __global__ __launch_bounds__(64 * (2 + NSC + NTG)) __attribute__((amdgpu_waves_p
     if (role >= 3) {                              // ---- the togglers: even / odd blocks ----
         const int w = role - 3;
         int done = 0, drained = 0;
+#if PLL_TOG_PRIO
+        __builtin_amdgcn_s_setprio(PLL_TOG_PRIO);
+#endif
+        unsigned long long tg_wait = 0, tg_rows = 0;
+        const unsigned long long tg_t0 = TICK();
         for (int b = w; b < n_blk; b += NTG) {
             const int s = b / SEG_BLKS;
+            const unsigned long long q0 = TICK();
             while (drained < s - 1) {                          // pack buffer s & 1 was segment s-2's
                 drained = __builtin_amdgcn_readfirstlane((int) lds_flag_load(flag + 3));
                 if (drained < s - 1) {
@@ -247,6 +270,8 @@ __global__ __launch_bounds__(64 * (2 + NSC + NTG)) __attribute__((amdgpu_waves_p
                     __builtin_amdgcn_s_sleep(1);
                 }
             }
+            const unsigned long long q1 = TICK();
+            tg_wait += q1 - q0;
             const uint8_t *slot = slots + (b % PLL_SLOTS) * PLL_SLOT_BYTES;
             const uint32_t cnt = reinterpret_cast<const uint32_t *>(slot + 64 * PLL_STRIP)[lane];
             const uint32_t ng = (uint32_t) __builtin_amdgcn_readfirstlane(
@@ -256,8 +281,10 @@ __global__ __launch_bounds__(64 * (2 + NSC + NTG)) __attribute__((amdgpu_waves_p
                                 (uint32_t) (((s & 1) * PLL_PACKW * 64 + lane) * 4);   // LDS address of this lane's pack word 0
             if (ng) pll_toggle_rows(cnt, (uint32_t) (slot - lds) + (uint32_t) (lane * PLL_STRIP), ng, base, pb);
             lds_flag_store(flag + 5 + w, (uint32_t) (b + NTG));
+            tg_rows += TICK() - q1;
         }
         lds_flag_store(flag + 5 + w, 0x7fffffffu);
+        if (w == 0) { BUDGET(8, TICK() - tg_t0); BUDGET(9, tg_wait); BUDGET(10, tg_rows); }
         return;
     }
 
@@ -270,11 +297,14 @@ __global__ __launch_bounds__(64 * (2 + NSC + NTG)) __attribute__((amdgpu_waves_p
     const uint32_t K7 = pllinc << 7;              // p * pllinc * 2^7 < 2^32 (create refuses pllinc > 14426)
     int seen = 0;
     bool dead = false;
+    unsigned long long rc_wscan = 0, rc_rows = 0, rc_nrows = 0, rc_nblk = 0;
+    const unsigned long long rc_t0 = TICK();
     for (int s = 0; s < n_seg && !dead; ++s) {
         uint32_t segbase = 0;                                  // slices of this segment before the current block
         const int b1 = (s + 1) * SEG_BLKS < n_blk ? (s + 1) * SEG_BLKS : n_blk;
         for (int b = s * SEG_BLKS; b < b1 && !dead; ++b) {
             seen = 0;
+            const unsigned long long s0 = TICK();
             while (seen < b + 1 && !dead) {                    // scanned by the scanner of its parity
                 seen = __builtin_amdgcn_readfirstlane((int) lds_flag_load(flag + 7 + (b % NSC)));
                 if (seen < b + 1) {
@@ -283,6 +313,8 @@ __global__ __launch_bounds__(64 * (2 + NSC + NTG)) __attribute__((amdgpu_waves_p
                 }
             }
             if (dead) break;
+            const unsigned long long s1 = TICK();
+            rc_wscan += s1 - s0;
             uint8_t *slot = slots + (b % PLL_SLOTS) * PLL_SLOT_BYTES;
             const uint32_t cnt = reinterpret_cast<const uint32_t *>(slot + 64 * PLL_STRIP)[lane];
             const uint32_t ng = (uint32_t) __builtin_amdgcn_readfirstlane(
@@ -292,6 +324,11 @@ __global__ __launch_bounds__(64 * (2 + NSC + NTG)) __attribute__((amdgpu_waves_p
             reinterpret_cast<uint32_t *>(slot + 64 * PLL_STRIP + 320)[lane] = segbase;
             if (ng) pll_rows(X, cnt, (uint32_t) (slot - lds) + (uint32_t) (lane * PLL_STRIP), ng, Q, K7);
             lds_flag_store(flag + 1, (uint32_t) (b + 1));
+#ifdef PLL6_BUDGET
+            rc_rows += TICK() - s1;
+            rc_nrows += ng;
+            rc_nblk += 1;
+#endif
             const int blen = L - b * BLK_LEN < BLK_LEN ? L - b * BLK_LEN : BLK_LEN;
             X += (uint32_t) blen * K7;                         // to the next block's first sample
         }
@@ -302,7 +339,16 @@ __global__ __launch_bounds__(64 * (2 + NSC + NTG)) __attribute__((amdgpu_waves_p
         lds_flag_store(flag + 2, (uint32_t) (s + 1));
     }
     if (live && !dead) pllst[cg] = (X >> 7) & 0xffffu;
+    BUDGET(0, TICK() - rc_t0); BUDGET(1, rc_wscan); BUDGET(3, rc_rows); BUDGET(4, rc_nrows); BUDGET(5, rc_nblk);
 }
+
+#ifdef PLL6_BUDGET
+extern "C" int gnuais_debug_pll6_budget(unsigned long long *out, int n_wg)
+{
+    if (n_wg > 4096) n_wg = 4096;
+    return (int) hipMemcpyFromSymbol(out, HIP_SYMBOL(pll6_budget), sizeof(unsigned long long) * 16 * (size_t) n_wg);
+}
+#endif
 
 hipError_t pll3_prepare_device();
 hipError_t launch_pll3(const PllLaunch &a, hipStream_t stream);
@@ -313,6 +359,8 @@ hipError_t pll_prepare_device()
 {
     const hipError_t e = pll3_prepare_device();
     if (e != hipSuccess) return e;
+    const hipError_t eh = pll_h3_prepare_device();
+    if (eh != hipSuccess) return eh;
     const void *forms[] = {(const void *) pll_kernel<1, 1>, (const void *) pll_kernel<2, 1>, (const void *) pll_kernel<1, 2>,
                            (const void *) pll_kernel<2, 2>};
     for (const void *f : forms) {
@@ -333,7 +381,7 @@ int pll_form_of(const PllLaunch &a)
     if ((a.variant == 7 || (a.variant == 0 && a.N <= PLL_TP_MAX_CHANNELS)) && pll_tp_applicable(a)) return 7;
     const int n_cu = a.n_cu > 0 ? a.n_cu : 256;
     const int groups = (a.N + 63) / 64;
-    return a.variant == 3 || a.variant == 4 || a.variant == 6 || a.variant == 32 || a.variant == 51 || a.variant == 52
+    return a.variant == 3 || a.variant == 4 || a.variant == 6 || a.variant == 8 || a.variant == 32 || a.variant == 51 || a.variant == 52
                ? a.variant : (2 * groups <= n_cu ? 6 : 3);
 }
 
@@ -344,6 +392,7 @@ hipError_t launch_pll(const PllLaunch &a, hipStream_t stream)
     const int n_cu = a.n_cu > 0 ? a.n_cu : 256;
     const int groups = (a.N + 63) / 64;
     if (variant == 3 || variant == 32) return launch_pll3(a, stream);
+    if (variant == 8) return launch_pll_h3(a, stream);
     // one workgroup per CU while the channel groups fit one round; beyond that share the CUs evenly
     const int per_cu = (groups + n_cu - 1) / n_cu;
     const int lds = per_cu <= 1 ? std::max(PLL_NEED_LDS, PLL_LDS_BYTES)

@@ -45,6 +45,24 @@
 
 namespace gnuais {
 
+#ifdef PLL3_BUDGET
+// Measurement build only (make EXTRA=-DPLL3_BUDGET; scripts/pll_wave_budget.py): where the recurrence wave and the
+// scanner of every workgroup spend their clock ticks.  16 counters per workgroup:
+//   0 recurrence: ticks from the start barrier to its end   1 ... waiting for the scanner (block not published)
+//   2 ... waiting for the writer (pack buffer not drained)   3 ... inside the rows (pll3_rows)
+//   4 rows of four walked   5 blocks   6 transitions of the workgroup's lanes, summed   7 largest lane total
+//   8 scanner: ticks from the start barrier to its end   9 ... waiting for a free slot   10 ... expanding blocks
+//   11 writer: ticks to its end
+__device__ unsigned long long pll3_budget[4096 * 16];
+#define BUDGET(i, v) do { if (lane == 0 && blockIdx.x < 4096) pll3_budget[blockIdx.x * 16 + (i)] = (v); } while (0)
+#define TICK() ((unsigned long long) clock64())
+#else
+#define BUDGET(i, v) do { } while (0)
+#define TICK() 0ull
+#pragma clang diagnostic ignored "-Wunused-variable"
+#pragma clang diagnostic ignored "-Wunused-but-set-variable"
+#endif
+
 // Unit of hand-over: a "block" = 256 samples = two of the four-word pieces K1 stores side by side.
 //   scanner    (wave 1) loads a block's 32 bytes of sign bits per lane (PLL_AHEAD blocks in flight),
 //              forms the transition bits D = S ^ (S >> 1) (receiver.c:113) and expands them BYTE BY
@@ -184,6 +202,8 @@ __global__ __launch_bounds__(64 * (2 + NSC)) __attribute__((amdgpu_waves_per_eu(
                 q[j][h] = src[(size_t) ((j < n_blk ? j : 0) * BLK_QUADS + h) * (size_t) N];
         int seen = 0;
         bool dead = false;
+        unsigned long long sc_wait = 0, sc_exp = 0;
+        const unsigned long long sc_t0 = TICK();
         for (int b0 = 0; b0 < n_blk && !dead; b0 += PLL_AHEAD) {
 #pragma unroll
             for (int j = 0; j < PLL_AHEAD; ++j) {
@@ -201,6 +221,7 @@ __global__ __launch_bounds__(64 * (2 + NSC)) __attribute__((amdgpu_waves_per_eu(
                         q[j][h] = src[(size_t) ((nb < n_blk ? nb : 0) * BLK_QUADS + h) * (size_t) N];
                 }
                 if (b < n_blk && !dead) {
+                    const unsigned long long w0 = TICK();
                     while (b - seen >= SLOTS && !dead) {       // slot b % SLOTS still in use?
                         seen = __builtin_amdgcn_readfirstlane((int) lds_flag_load(flag + 1));
                         if (b - seen >= SLOTS) {
@@ -208,16 +229,20 @@ __global__ __launch_bounds__(64 * (2 + NSC)) __attribute__((amdgpu_waves_per_eu(
                             __builtin_amdgcn_s_sleep(2);
                         }
                     }
+                    const unsigned long long w1 = TICK();
+                    sc_wait += w1 - w0;
                     if (!dead) {
                         pll_expand_block(S, prev, L - b * BLK_LEN, lds, slots + (b % SLOTS) * PLL_SLOT_BYTES, lut, lane);
                         lds_flag_store(flag + 5, (uint32_t) (b + 1));
                     }
+                    sc_exp += TICK() - w1;
                 }
             }
         }
         sign1[lane] = prev;
         lds_flag_store(flag + 4, 1u);
         if (live && !dead) prevst[cg] = prev;
+        BUDGET(8, TICK() - sc_t0); BUDGET(9, sc_wait); BUDGET(10, sc_exp);
         return;
     }
 
@@ -247,6 +272,7 @@ __global__ __launch_bounds__(64 * (2 + NSC)) __attribute__((amdgpu_waves_per_eu(
         // level of the last sample (receiver.h:44 prev).
         uint32_t par = (lastbit[c] ^ sign0[lane]) & 1u;
         int seen = 0;
+        const unsigned long long wr_t0 = TICK();
         for (int s = 0; s < n_seg; ++s) {
             while (seen < s + 1) {
                 seen = __builtin_amdgcn_readfirstlane((int) lds_flag_load(flag + 2));
@@ -285,6 +311,7 @@ __global__ __launch_bounds__(64 * (2 + NSC)) __attribute__((amdgpu_waves_per_eu(
                 __hip_atomic_store(progress + blockIdx.x, progress_base + (uint32_t) n_seg_alloc, __ATOMIC_RELAXED,
                                    __HIP_MEMORY_SCOPE_AGENT);
         }
+        BUDGET(11, TICK() - wr_t0);
         return;
     }
 
@@ -297,7 +324,11 @@ __global__ __launch_bounds__(64 * (2 + NSC)) __attribute__((amdgpu_waves_per_eu(
     const uint32_t K7 = pllinc << 7;              // p * pllinc * 2^7 < 2^32 (create refuses pllinc > 14426)
     int seen = 0, drained = 0;
     bool dead = false;
+    unsigned long long rc_wscan = 0, rc_wdrain = 0, rc_rows = 0, rc_nrows = 0, rc_nblk = 0;
+    uint32_t rc_mine = 0;
+    const unsigned long long rc_t0 = TICK();
     for (int s = 0; s < n_seg && !dead; ++s) {
+        const unsigned long long d0 = TICK();
         while (drained < s - 1 && !dead) {                     // pack buffer s & 1 was segment s-2's
             drained = __builtin_amdgcn_readfirstlane((int) lds_flag_load(flag + 3));
             if (drained < s - 1) {
@@ -305,11 +336,13 @@ __global__ __launch_bounds__(64 * (2 + NSC)) __attribute__((amdgpu_waves_per_eu(
                 __builtin_amdgcn_s_sleep(1);
             }
         }
+        rc_wdrain += TICK() - d0;
         const uint32_t pb = (uint32_t) (reinterpret_cast<uint8_t *>(pack) - lds) +
                             (uint32_t) (((s & 1) * PLL_PACKW * 64 + lane) * 4);   // LDS address of this lane's pack word 0
         const int b1 = (s + 1) * SEG_BLKS < n_blk ? (s + 1) * SEG_BLKS : n_blk;
         for (int b = s * SEG_BLKS; b < b1 && !dead; ++b) {
             if (NSC == 2) seen = 0;                            // (the other scanner's counter: nothing known yet)
+            const unsigned long long s0 = TICK();
             while (seen < b + 1 && !dead) {
                 seen = __builtin_amdgcn_readfirstlane((int) lds_flag_load(flag + 5 + (b % NSC)));
                 if (seen < b + 1) {
@@ -317,6 +350,8 @@ __global__ __launch_bounds__(64 * (2 + NSC)) __attribute__((amdgpu_waves_per_eu(
                     __builtin_amdgcn_s_sleep(1);
                 }
             }
+            const unsigned long long s1 = TICK();
+            rc_wscan += s1 - s0;
             if (dead) break;
             const uint8_t *slot = slots + (b % SLOTS) * PLL_SLOT_BYTES;
             const uint32_t cnt = reinterpret_cast<const uint32_t *>(slot + 64 * PLL_STRIP)[lane];
@@ -325,6 +360,12 @@ __global__ __launch_bounds__(64 * (2 + NSC)) __attribute__((amdgpu_waves_per_eu(
             if (ng)
                 pll3_rows(X, cnt, (uint32_t) (slot - lds) + (uint32_t) (lane * PLL_STRIP), ng, Q, K7, pb);
             lds_flag_store(flag + 1, (uint32_t) (b + 1));
+#ifdef PLL3_BUDGET
+            rc_rows += TICK() - s1;
+            rc_nrows += ng;
+            rc_nblk += 1;
+            rc_mine += cnt;
+#endif
             const int blen = L - b * BLK_LEN < BLK_LEN ? L - b * BLK_LEN : BLK_LEN;
             X += (uint32_t) blen * K7;                         // to the next block's first sample
         }
@@ -335,7 +376,23 @@ __global__ __launch_bounds__(64 * (2 + NSC)) __attribute__((amdgpu_waves_per_eu(
         lds_flag_store(flag + 2, (uint32_t) (s + 1));
     }
     if (live && !dead) pllst[cg] = (X >> 7) & 0xffffu;
+#ifdef PLL3_BUDGET
+    {
+        uint32_t tot = rc_mine, mx = wave_max(rc_mine);
+        for (int o = 32; o; o >>= 1) tot += (uint32_t) __shfl_xor((int) tot, o);
+        BUDGET(0, TICK() - rc_t0); BUDGET(1, rc_wscan); BUDGET(2, rc_wdrain); BUDGET(3, rc_rows);
+        BUDGET(4, rc_nrows); BUDGET(5, rc_nblk); BUDGET(6, (unsigned long long) tot); BUDGET(7, (unsigned long long) mx);
+    }
+#endif
 }
+
+#ifdef PLL3_BUDGET
+extern "C" int gnuais_debug_pll_budget(unsigned long long *out, int n_wg)
+{
+    if (n_wg > 4096) n_wg = 4096;
+    return (int) hipMemcpyFromSymbol(out, HIP_SYMBOL(pll3_budget), sizeof(unsigned long long) * 16 * (size_t) n_wg);
+}
+#endif
 
 hipError_t pll3_prepare_device()
 {

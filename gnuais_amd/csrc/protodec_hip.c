@@ -85,6 +85,9 @@ struct d_ent {
 	int n_bits;
 	gnuais_frame *frames;
 	int cap_frames;
+	int refs;               /* under tab_lock: 1 for the table + 1 per thread that holds the entry outside tab_lock;
+	                         * whoever drops the last one frees the entry (d_unref) */
+	int released;           /* under e->lock: gnuais_protodec_release() has flushed it; d may be gone, nothing touches it */
 };
 
 /* open addressing, linear probing, backward-shift deletion; the entries themselves never move */
@@ -347,9 +350,28 @@ static struct d_ent *d_of(struct demod_state_t *d)
 				abort();
 		}
 		d_order[n_order++] = e;
+		e->refs = 1;                            /* the table's */
 	}
+	e->refs++;                                      /* the caller's: d_unref() when it is done with e */
 	pthread_mutex_unlock(&tab_lock);
 	return e;
+}
+
+/* drops a reference taken under tab_lock (d_of, flush_all's snapshot, gnuais_protodec_flush); the last one -- only
+ * after gnuais_protodec_release() has unlinked the entry and dropped the table's -- frees it */
+static void d_unref(struct d_ent *e)
+{
+	int last;
+	pthread_mutex_lock(&tab_lock);
+	last = --e->refs == 0;
+	pthread_mutex_unlock(&tab_lock);
+	if (!last)
+		return;
+	pthread_mutex_destroy(&e->lock);
+	gnuais_batch_destroy(e->b);
+	free(e->bits);
+	free(e->frames);
+	free(e);
 }
 
 /* e->lock held: the queued bits through the device deframer, the frames it closed to protodec_getdata() in time
@@ -362,7 +384,7 @@ static void flush_locked(struct d_ent *e)
 	int32_t n = e->n_bits;
 	int got = 0, pending = 0, i, j, k;
 
-	if (n == 0)
+	if (n == 0 || e->released)
 		return;
 	e->n_bits = 0;
 	if (gnuais_batch_decode_bits(e->b, e->bits, n, &n) != GNUAIS_OK)
@@ -401,21 +423,33 @@ static void flush_locked(struct d_ent *e)
 	d->bufferpos = st.bufferpos;
 }
 
-/* every decoder with queued bits, in creation order (the table lock is not held while one is served) */
+/* every decoder with queued bits, in creation order.  The order is SNAPSHOT under the table lock with a reference
+ * on every entry, so that a gnuais_protodec_release() on another thread can neither free an entry between the look-up
+ * and its lock nor shift the indices under the loop; the table lock is not held while a decoder is served. */
 static void flush_all(void)
 {
-	int i;
-	for (i = 0;; i++) {
-		struct d_ent *e;
-		pthread_mutex_lock(&tab_lock);
-		e = i < n_order ? d_order[i] : NULL;
-		pthread_mutex_unlock(&tab_lock);
-		if (!e)
-			return;
-		pthread_mutex_lock(&e->lock);
-		flush_locked(e);
-		pthread_mutex_unlock(&e->lock);
+	struct d_ent *few[16], **snap = few;
+	int i, n;
+	pthread_mutex_lock(&tab_lock);
+	n = n_order;
+	if (n > 16) {
+		snap = malloc(sizeof(*snap) * (size_t) n);
+		if (!snap)
+			abort();
 	}
+	for (i = 0; i < n; i++) {
+		snap[i] = d_order[i];
+		snap[i]->refs++;
+	}
+	pthread_mutex_unlock(&tab_lock);
+	for (i = 0; i < n; i++) {
+		pthread_mutex_lock(&snap[i]->lock);
+		flush_locked(snap[i]);
+		pthread_mutex_unlock(&snap[i]->lock);
+		d_unref(snap[i]);
+	}
+	if (snap != few)
+		free(snap);
 }
 
 void protodec_decode(char *in, int count, struct demod_state_t *d)
@@ -431,6 +465,7 @@ void protodec_decode(char *in, int count, struct demod_state_t *d)
 	if (e->n_bits >= batching)
 		flush_locked(e);
 	pthread_mutex_unlock(&e->lock);
+	d_unref(e);
 }
 
 /* additive, not reference names: how many bits may wait per decoder (1: every call returns with d current;
@@ -449,11 +484,14 @@ void gnuais_protodec_flush(struct demod_state_t *d)
 	}
 	pthread_mutex_lock(&tab_lock);
 	e = ptab_get(&d_tab, d);
+	if (e)
+		e->refs++;
 	pthread_mutex_unlock(&tab_lock);
 	if (e) {
 		pthread_mutex_lock(&e->lock);
 		flush_locked(e);
 		pthread_mutex_unlock(&e->lock);
+		d_unref(e);
 	}
 }
 
@@ -475,12 +513,12 @@ void gnuais_protodec_release(struct demod_state_t *d)
 	pthread_mutex_unlock(&tab_lock);
 	if (!e)
 		return;
+	/* unlinked: no new reference can be taken.  Flush while d is still the caller's, mark the entry so that a
+	 * flush_all() that took its reference before the unlink leaves d alone, and drop the table's reference; the
+	 * entry goes when the last holder lets go of it. */
 	pthread_mutex_lock(&e->lock);
 	flush_locked(e);
+	e->released = 1;
 	pthread_mutex_unlock(&e->lock);
-	pthread_mutex_destroy(&e->lock);
-	gnuais_batch_destroy(e->b);
-	free(e->bits);
-	free(e->frames);
-	free(e);
+	d_unref(e);
 }

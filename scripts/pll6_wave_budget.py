@@ -1,0 +1,53 @@
+"""The six-wave PLL form's recurrence wave and first toggler: where their clock ticks go (measurement build:
+EXTRA="-DPLL6_BUDGET [-DPLL_TOG_PRIO=3]" after removing build/pll_nrzi.o)."""
+import ctypes as C
+import os
+import sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+from gnuais_amd import ReceiverBatch, synth, tile_channels, lib
+
+n_ch, total = 16384, 48000
+base, _ = synth.make_base_streams(256, total)
+x = tile_channels(torch.from_numpy(base).cuda(), n_ch)
+stream = torch.cuda.current_stream().cuda_stream
+L = lib.load()
+fn = L.gnuais_debug_pll6_budget
+fn.restype, fn.argtypes = C.c_int, [C.c_void_p, C.c_int]
+n_wg = n_ch // 64
+
+
+def show(tag, ms):
+    bud = np.zeros((n_wg, 16), dtype=np.uint64)
+    assert fn(bud.ctypes.data, n_wg) == 0
+    m = bud.astype(np.float64).mean(0)
+    print(f"--- {tag}: PLL launch {ms:.3f} ms")
+    print(f"  recurrence: total {m[0]:.0f} ticks, waiting for a scanner {m[1]:.0f} ({m[1] / m[0]:.3f}), rows {m[3]:.0f} "
+          f"({m[3] / m[0]:.3f}); {m[4]:.0f} rows of four in {m[5]:.0f} blocks: {m[3] / m[4] / 4:.1f} ticks per step")
+    print(f"  first toggler: total {m[8]:.0f}, waiting {m[9]:.0f} ({m[9] / max(m[8], 1):.3f}), rows {m[10]:.0f} "
+          f"({m[10] / max(m[8], 1):.3f}): {m[10] / (m[4] / 2) / 4:.1f} ticks per step of its own blocks")
+
+
+b = ReceiverBatch(n_ch, max_len=total)
+b.set_option("pll_variant", 6)
+b.autotune(x, stream)
+for _ in range(4):
+    b.run(x, stream=stream, sync=True)
+    b.discard_frames(stream)
+b.set_timing(True)
+b.set_option("pipeline", 0)
+acc = []
+for _ in range(3):
+    b.run(x, stream=stream, sync=True)
+    acc.append(b.last_timing()["pll"])
+    b.discard_frames(stream)
+torch.cuda.synchronize()
+show("one call at a time", float(np.mean(acc)))
+b.set_option("pipeline", 1)
+b.set_option("timing_stride", 2)
+for _ in range(40):
+    b.run(x, stream=stream, sync=False)
+    b.discard_frames(stream)
+torch.cuda.synchronize()
+show("inside the pipelined loop (last launch)", float(b.mean_timing()["pll"]))

@@ -397,6 +397,88 @@ static void run_shims(const char *dir)
 	free(x);
 }
 
+
+/* ------------------------------------------------------------ 5b. the shims from two threads at once */
+
+/* Each thread owns a filter and decoders of its own (distinct objects, as the reference's threading rules allow) and
+ * drives them the way receiver.c does: protodec_decode() bit by bit, a filter_run_buf() per buffer -- which flushes
+ * EVERY decoder of the process, the other thread's included -- and, every so often, gnuais_protodec_release() of a
+ * scratch decoder while the other thread's flush may be walking the table.  A's frames must be the golden ones. */
+struct shim_job {
+	const unsigned char *bits;
+	size_t nbits;
+	char id;
+	int received, lost, lost2;
+};
+
+static void *drive_shims(void *arg)
+{
+	struct shim_job *j = arg;
+	struct demod_state_t d, *scratch = NULL;
+	float taps[36], o;
+	short s = 0;
+	size_t i;
+	struct filter *f;
+
+	gnuais_default_taps(taps);
+	f = filter_init(36, taps);
+	protodec_initialize(&d, NULL, NULL, j->id);
+	for (i = 0; i < j->nbits; i++) {
+		char b = (char) j->bits[i];
+		protodec_decode(&b, 1, &d);
+		if (i % 7 == 0) {                               /* a short-lived decoder: created, fed, released */
+			if (!scratch) {
+				scratch = malloc(sizeof *scratch);
+				protodec_initialize(scratch, NULL, NULL, (char) (j->id + 1));
+			}
+			protodec_decode(&b, 1, scratch);
+		}
+		if (i % 204 == 203)
+			filter_run_buf(f, &s, &o, 1, 1);        /* flush_all(): every decoder, both threads' */
+		if (i % 1021 == 1020 && scratch) {
+			gnuais_protodec_release(scratch);       /* while the other thread may be inside flush_all() */
+			free(scratch->buffer);
+			free(scratch->rbuffer);
+			free(scratch);
+			scratch = NULL;
+		}
+	}
+	gnuais_protodec_flush(&d);
+	j->received = d.receivedframes;
+	j->lost = d.lostframes;
+	j->lost2 = d.lostframes2;
+	gnuais_protodec_release(&d);
+	if (scratch) {
+		gnuais_protodec_release(scratch);
+		free(scratch->buffer);
+		free(scratch->rbuffer);
+		free(scratch);
+	}
+	free(d.buffer);
+	free(d.rbuffer);
+	filter_free(f);
+	return NULL;
+}
+
+static void run_shims_mt(const char *dir)
+{
+	size_t nbits;
+	unsigned char *bits = slurp(in_dir(dir, "bits_a.bin"), &nbits);
+	struct shim_job a = { bits, nbits, 'A', 0, 0, 0 }, p = { bits, nbits, 'P', 0, 0, 0 };
+	pthread_t t1, t2;
+	FILE *out = fopen(in_dir(dir, "out_shims_mt.txt"), "w");
+
+	frames_out = out;
+	pthread_create(&t1, NULL, drive_shims, &a);
+	pthread_create(&t2, NULL, drive_shims, &p);
+	pthread_join(t1, NULL);
+	pthread_join(t2, NULL);
+	fprintf(out, "A: received %d lost %d lost2 %d\n", a.received, a.lost, a.lost2);
+	fprintf(out, "P: received %d lost %d lost2 %d\n", p.received, p.lost, p.lost2);
+	fclose(out);
+	free(bits);
+}
+
 /* ------------------------------------------------------------ 6. a buffer mismatch inside a round is refused */
 
 static struct receiver *mm_a, *mm_b;
@@ -438,6 +520,7 @@ int main(int argc, char **argv)
 	run_messages_and_sinks(argv[1]);
 	run_dropin(argv[1]);
 	run_shims(argv[1]);
+	run_shims_mt(argv[1]);
 	printf("asan_host: done\n");
 	return 0;
 }

@@ -178,7 +178,7 @@ def run_both(x, chunks, n_ch, taps=None, pllinc=0, fir_T=None, pll_variant=0, op
     return o, b
 
 
-@pytest.mark.parametrize("pll_variant", [3, 32, 4, 51, 52, 6, 7])      # 7: the time-parallel form (pll_tp.hip)
+@pytest.mark.parametrize("pll_variant", [3, 32, 4, 51, 52, 6, 7, 8])      # 7: the time-parallel form (pll_tp.hip); 8: one recurrence wave + three helpers (pll_h3.hip)
 def test_chain_vs_oracle_ragged_chunks(pll_variant):
     n_ch, total = 70, 30 * 1280
     x = np.stack([synth.make_stream(total, seed=31, channel=c,
@@ -206,7 +206,7 @@ def test_chain_vs_oracle_deframer_widths_and_flag_forms(lpw, flag2):
     assert o.counters()[:, 0].sum() > 200
 
 
-@pytest.mark.parametrize("pll_variant", [3, 32, 4, 51, 52, 6, 7])
+@pytest.mark.parametrize("pll_variant", [3, 32, 4, 51, 52, 6, 7, 8])
 def test_chain_vs_oracle_noise_only_and_extremes(pll_variant):
     rng = np.random.default_rng(33)
     total = 40000

@@ -118,6 +118,22 @@ def test_reference_named_shims_over_the_test_double_under_the_sanitizers(run):
     assert "calculate_crc bad 0 nonpositive 0 0 huge 0" in got
 
 
+def _check_shims_from_two_threads(d, g):
+    """out_shims_mt.txt: both threads decoded the same golden bit stream through decoders of their own while each
+    thread's filter_run_buf() flushed the other's and scratch decoders came and went (gnuais_protodec_release)."""
+    fr = np.frombuffer(np.ascontiguousarray(g["frames"]).tobytes(), dtype=FRAME_DTYPE)
+    got = open(d / "out_shims_mt.txt").read().splitlines()
+    c = g["counters"][0]
+    for name in "AP":
+        assert [l for l in got if l.startswith(f"ch {name} ")] == [frame_line(name, f) for f in fr if int(f["channel"]) == 0]
+        assert f"{name}: received {c[0]} lost {c[1]} lost2 {c[2]}" in got
+
+
+def test_reference_named_shims_from_two_threads_under_the_sanitizers(run):
+    d, g, _ = run
+    _check_shims_from_two_threads(d, g)
+
+
 def test_buffer_mismatch_inside_a_round_is_refused_and_the_handler_may_free(run):
     """receiver_hip.c: a receiver that has not been served from the round in progress and brings a different buffer would
     make the shared batch advance every channel with the wrong samples -- it is refused loudly; the fatal handler runs with
@@ -147,3 +163,6 @@ def test_host_code_under_thread_sanitizer(run):
     mt = open(d / "out_dropin_mt.txt").read().splitlines()
     for ch, name in enumerate("AB"):
         assert [l for l in mt if l.startswith(f"ch {name} ")] == [frame_line(name, f) for f in fr if int(f["channel"]) == ch]
+    # and the reference-named shims driven from two threads (protodec_decode / filter_run_buf / gnuais_protodec_release
+    # on distinct objects: flush_all() holds a reference on every entry it serves)
+    _check_shims_from_two_threads(d, g)
