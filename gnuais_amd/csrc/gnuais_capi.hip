@@ -775,7 +775,11 @@ static void fill_hdlc(const gnuais_batch *b, HdlcLaunch &h, int k)
     h.frame_count = b->streaming ? b->ring_count[b->ring_cur] : b->frame_count;
     h.frame_cap = (uint32_t) b->frame_cap; h.N = b->N; h.n_seg = b->n_seg;
     h.seg_words = b->seg_words; h.K = b->k2b_lag * b->cand_K; h.K_call = b->cand_K;
-    h.lanes_per_wave = b->hdlc_lpw ? b->hdlc_lpw : (b->hdlc_variant ? 16 : 64);
+    // event-driven deframer: 16 channels per wave finish a small batch soonest; where the chip is full anyway (a PLL
+    // workgroup on every CU, four FIR waves per SIMD) 64 per wave -- a quarter of the waves -- cost the other stages
+    // least: C3 steady state 0.492 against 0.525 ms per call (profiles/r05_pll_h3_in_the_pipeline.txt)
+    const int ev_lpw = 2 * ((b->N + 63) / 64) > (b->n_cu > 0 ? b->n_cu : 256) ? 64 : 16;
+    h.lanes_per_wave = b->hdlc_lpw ? b->hdlc_lpw : (b->hdlc_variant ? ev_lpw : 64);
     // the chunk table describes ONE launch; a second one into the same ring would overwrite it
     h.chunks = (b->streaming && b->ring_runs[b->ring_cur] == 0) ? b->ring_chunks[b->ring_cur] : nullptr;
 }

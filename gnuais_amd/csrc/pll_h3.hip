@@ -12,14 +12,17 @@
 //     one wave of <= 96 registers per SIMD: the six-wave form (pll_nrzi.hip: two waves on two of the SIMDs) finishes a
 //     call in 0.31 ms alone and needs 0.58-0.63 inside the pipeline, waiting for FIR waves to retire in pairs.
 //
-// Hence FOUR waves, one per SIMD:
-//   recurrence (wave 0)  six instructions per transition (pll_nrzi.hip's row): advances the phase and leaves, per
-//                        transition, the number of the slice it toggles (relative to the block: a byte, in place).
-//   helpers (waves 1-3)  helper h owns blocks h, h + 3, ...: it SCANS a block (sign words -> transition positions, byte by
-//                        byte through the table: pll_common.h), and later, when the recurrence has walked it, TOGGLES
-//                        the block's bits into the segment's pack; helper 0 also takes finished packs to HBM.  Each
-//                        helper has two block slots of its own (scan b + 3 into one while b waits for the recurrence
-//                        in the other), so no slot is ever handed from one helper to another.
+//   * a block of 128 samples holds at most 30 slices (create refuses pllinc > 14426), so the toggles of a block fit ONE
+//     32-bit mask per lane: with the phase scaled by 2^8 the slice number of a transition is byte 3 of U, and
+//     `v_lshlrev_b32_sdwa bit, U.byte3, 1` + `v_xor` toggle it in a REGISTER -- two instructions instead of the five
+//     and the LDS atomic of the three-wave form, or the byte written back and a second wave's seven of the six-wave one.
+//
+// Hence FOUR waves, one per SIMD, 56 registers each:
+//   recurrence (wave 0)  seven instructions per transition: phase, nudge, and the toggle into the block's mask; the mask
+//                        goes into the segment's pack once per block (two ds_xor).  Nothing is written back per row.
+//   helpers (waves 1-3)  helper h SCANS blocks h, h + 3, ... (sign words -> transition positions, byte by byte through the
+//                        table: pll_common.h) into two block slots of its own, alternately, as far ahead as the
+//                        recurrence has freed them; helper 0 also takes finished packs to HBM.
 // A block is 128 samples (one 16-byte piece of sign words per lane): six slots of 64 x 140 bytes fit the 81 KB this
 // stage may take of a CU's LDS beside K3's and the deframer's buffers.
 #include <hip/hip_runtime.h>
@@ -35,11 +38,14 @@ constexpr int H3_BLK = 128;                    // samples per block: one uint4 o
 constexpr int H3_WORDS = H3_BLK / 32;
 constexpr int H3_STRIP = H3_BLK + 12;          // bytes per lane and slot (positions + an 8-byte store's overhang + read-ahead)
 constexpr int H3_SEG_BLKS = SEG_LEN / H3_BLK;  // 16
-constexpr int H3_NH = 3;                       // helpers
+#ifndef PLLH3_HELPERS
+#define PLLH3_HELPERS 3
+#endif
+constexpr int H3_NH = PLLH3_HELPERS;           // helpers (2 or 3; a wave each)
 constexpr int H3_SLOTS = 2 * H3_NH;            // slot of block b: b % H3_SLOTS (helper b % 3 owns slots h and h + 3)
 constexpr int H3_NPACK = 4;                    // pack buffers (segment s in buffer s & 3)
-// slot: 64 strips, cnt[64], base[64] (slices of the segment before the block), rows (one word + padding)
-constexpr int H3_OFF_CNT = 64 * H3_STRIP, H3_OFF_BASE = H3_OFF_CNT + 256, H3_OFF_NG = H3_OFF_BASE + 256;
+// slot: 64 strips, cnt[64], rows (one word + padding)
+constexpr int H3_OFF_CNT = 64 * H3_STRIP, H3_OFF_NG = H3_OFF_CNT + 256;
 constexpr int H3_SLOT_BYTES = H3_OFF_NG + 64;
 constexpr int H3_FLAG_WORDS = 32 + 2 * 64 + 4 * 64;   // counters, sign before / after the call, bit counts of four segments
 constexpr int H3_NEED_LDS = PLL_LUT_BYTES + H3_SLOTS * H3_SLOT_BYTES + H3_NPACK * PLL_PACKW * 64 * 4 + H3_FLAG_WORDS * 4;
@@ -47,12 +53,12 @@ static_assert((H3_STRIP / 4) % 2 == 1 && H3_STRIP % 4 == 0, "odd dword stride: l
 static_assert(SEG_LEN % H3_BLK == 0 && H3_NEED_LDS <= PLL_LDS_BYTES, "segments are whole blocks; the stage's LDS share");
 
 // hand-over counters (all monotonic)
-enum { F_RDONE = 1, F_SEGPUB = 2, F_WRITTEN = 3, F_LAST = 4, F_SCAN = 8 /* +h */, F_TOG = 12 /* +h */ };
+enum { F_RDONE = 1, F_SEGPUB = 2, F_WRITTEN = 3, F_LAST = 4, F_SCAN = 8 /* +h */ };
 
 #ifdef PLLH3_BUDGET
 // Measurement build only (EXTRA=-DPLLH3_BUDGET; scripts/pll_wave_budget.py h3): clock ticks per workgroup --
 //   0 recurrence: total   1 ... waiting for a helper's scan   3 ... in the rows   4 rows of four   5 blocks
-//   8 helper 0: total   9 ... scanning   10 ... waiting for the recurrence   11 ... toggling   12 ... writing packs
+//   8 helper 0: total   9 ... scanning   10 ... waiting for a free slot   12 ... writing packs
 __device__ unsigned long long pllh3_budget[4096 * 16];
 #define BUDGET(i, v) do { if (lane == 0 && blockIdx.x < 4096) pllh3_budget[blockIdx.x * 16 + (i)] = (v); } while (0)
 #define TICK() ((unsigned long long) clock64())
@@ -101,28 +107,29 @@ __device__ __forceinline__ void h3_expand_block(const uint32_t (&S)[H3_WORDS], u
     if (lane == 0) reinterpret_cast<uint32_t *>(slot + H3_OFF_NG)[0] = ng;
 }
 
-// One transition at position p (byte k of the list word E) of the current block -- the six-wave form's step
-// (pll_nrzi.hip): X = (pll0 + K + p0 * pllinc) * 2^7 + spare with p0 = the block's first sample and the slices before it
-// taken out, T = p * pllinc * 2^7, U = X + T: bit 22 is `pll >= 0x8000` (receiver.c:114), bits 31:23 the number of the
-// slice the transition toggles, counted from the block's first sample (it fits byte k of W).
-//     um = -(pll >= 0x8000);  X = (Q ^ um) + X   is  X + Q  or  X - Q - 1:
-// the -1 is taken from the seven spare bits, which are set to all ones every four steps.
+// One transition at position p (byte k of the list word E) of the current block.
+// X = (pll0 + K + p0 * pllinc) * 2^8 + spare with p0 = the block's first sample and the slices before it taken out,
+// T = p * pllinc * 2^8, U = X + T: bit 23 is `pll >= 0x8000` (receiver.c:114), BYTE 3 the number of the slice the
+// transition toggles, counted from the block's first sample (<= 30).
+//     um = -(pll >= 0x8000);  X = (Q ^ um) + X   is  X + Q  or  X - Q - 1   (receiver.c:114-117):
+// the -1 is taken from the eight spare bits, which are set to all ones every four steps.
+//     M ^= 1 << U.byte3   toggles the slice in the block's mask (v_lshlrev_b32 takes the low five bits of its count).
 #define H3_STEP(k, E, kk)                                                                 \
     "v_cmpx_lt_i32 vcc, " #kk ", %[rem]\n\t"                                              \
-    "v_mul_u32_u24_sdwa %[T], %[K7], %[" #E "] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_" #k "\n\t" \
+    "v_mul_u32_u24_sdwa %[T], %[K8], %[" #E "] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_" #k "\n\t" \
     "v_add_u32 %[U], %[X], %[T]\n\t"                                                      \
-    "v_bfe_i32 %[um], %[U], 22, 1\n\t"                                                    \
+    "v_bfe_i32 %[um], %[U], 23, 1\n\t"                                                    \
     "v_xad_u32 %[X], %[Q], %[um], %[X]\n\t"                                               \
-    "v_lshrrev_b32_sdwa %[" #E "], %[c23], %[U] dst_sel:BYTE_" #k " dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD\n\t"
+    "v_lshlrev_b32_sdwa %[T], %[U], %[one] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_3 src1_sel:DWORD\n\t" \
+    "v_xor_b32 %[M], %[M], %[T]\n\t"
 
 // `ng` rows-of-four of one block, two rows to a loop turn: this lane's list starts at LDS byte address `ad`, `cnt`
-// entries.  v_cmpx narrows EXEC monotonically (a lane whose list has ended never comes back; EXEC is restored for the
-// row's write-back and read-ahead, which every lane does); the slice numbers go back over the positions they came from,
-// in the register the row was read into.  The list words of the next two rows are read one turn ahead; LDS operations
-// complete in order, which is what the waits count.
-__device__ __forceinline__ void h3_rows(uint32_t &X, uint32_t cnt, uint32_t ad, uint32_t ng, uint32_t Q, uint32_t K7)
+// entries.  v_cmpx narrows EXEC monotonically (a lane whose list has ended never comes back; EXEC is restored at the
+// end).  The list words of the next two rows are read one turn ahead (every lane reads: the address is the lane's own).
+// Returns the block's toggle mask.
+__device__ __forceinline__ uint32_t h3_rows(uint32_t &X, uint32_t cnt, uint32_t ad, uint32_t ng, uint32_t Q, uint32_t K8)
 {
-    uint32_t U, um, T, E, F, c23 = 23;
+    uint32_t U, um, T, E, F, G, H, M = 0, one = 1;
     int32_t rem = (int32_t) cnt;
     uint32_t np = (ng + 1u) >> 1;                  // turns of two rows
     unsigned long long sv;
@@ -131,65 +138,36 @@ __device__ __forceinline__ void h3_rows(uint32_t &X, uint32_t cnt, uint32_t ad, 
         "ds_read_b32 %[E], %[ad]\n\t"
         "ds_read_b32 %[F], %[ad] offset:4\n\t"
         "1:\n\t"
-        "s_waitcnt lgkmcnt(0)\n\t"
-        "v_or_b32 %[X], 0x7f, %[X]\n\t"
+        "ds_read_b32 %[G], %[ad] offset:8\n\t"
+        "ds_read_b32 %[H], %[ad] offset:12\n\t"
+        "s_waitcnt lgkmcnt(2)\n\t"
+        "v_or_b32 %[X], 0xff, %[X]\n\t"
         H3_STEP(0, E, 0) H3_STEP(1, E, 1) H3_STEP(2, E, 2) H3_STEP(3, E, 3)
-        "v_or_b32 %[X], 0x7f, %[X]\n\t"
+        "v_or_b32 %[X], 0xff, %[X]\n\t"
         H3_STEP(0, F, 4) H3_STEP(1, F, 5) H3_STEP(2, F, 6) H3_STEP(3, F, 7)
-        "s_mov_b64 exec, %[sv]\n\t"
-        "ds_write_b32 %[ad], %[E]\n\t"
-        "ds_write_b32 %[ad], %[F] offset:4\n\t"
-        "ds_read_b32 %[E], %[ad] offset:8\n\t"
-        "ds_read_b32 %[F], %[ad] offset:12\n\t"
-        "v_add_u32 %[ad], 8, %[ad]\n\t"
-        "v_subrev_u32 %[rem], 8, %[rem]\n\t"
+        "s_sub_u32 %[np], %[np], 1\n\t"
+        "s_cmp_eq_u32 %[np], 0\n\t"
+        "s_cbranch_scc1 2f\n\t"
+        "ds_read_b32 %[E], %[ad] offset:16\n\t"
+        "ds_read_b32 %[F], %[ad] offset:20\n\t"
+        "s_waitcnt lgkmcnt(2)\n\t"
+        "v_or_b32 %[X], 0xff, %[X]\n\t"
+        H3_STEP(0, G, 8) H3_STEP(1, G, 9) H3_STEP(2, G, 10) H3_STEP(3, G, 11)
+        "v_or_b32 %[X], 0xff, %[X]\n\t"
+        H3_STEP(0, H, 12) H3_STEP(1, H, 13) H3_STEP(2, H, 14) H3_STEP(3, H, 15)
+        "v_add_u32 %[ad], 16, %[ad]\n\t"
+        "v_subrev_u32 %[rem], 16, %[rem]\n\t"
         "s_sub_u32 %[np], %[np], 1\n\t"
         "s_cmp_lg_u32 %[np], 0\n\t"
         "s_cbranch_scc1 1b\n\t"
-        "s_waitcnt lgkmcnt(0)\n\t"
-        : [X] "+v"(X), [U] "=&v"(U), [um] "=&v"(um), [T] "=&v"(T), [E] "=&v"(E), [F] "=&v"(F), [ad] "+v"(ad),
-          [rem] "+v"(rem), [np] "+s"(np), [sv] "=&s"(sv)
-        : [Q] "s"(Q), [K7] "v"(K7), [c23] "v"(c23)
-        : "vcc", "scc", "memory");
-}
-
-// The same rows, second pass (a helper): entry = slice number relative to the block; `base` = slices of the segment
-// before the block.  Bit base + entry of the lane's pack (word stride 64 dwords from `pb`) is toggled.
-#define H3_TOGGLE(k, E, kk)                                                               \
-    "v_cmpx_lt_i32 vcc, " #kk ", %[rem]\n\t"                                              \
-    "v_add_u32_sdwa %[b], %[base], %[" #E "] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_" #k "\n\t" \
-    "v_lshlrev_b32_e64 %[m], %[b], 1\n\t"                                                 \
-    "v_and_b32 %[b], 0x1e0, %[b]\n\t"                                                     \
-    "v_lshl_add_u32 %[b], %[b], 3, %[pb]\n\t"                                             \
-    "ds_xor_b32 %[b], %[m]\n\t"
-
-__device__ __forceinline__ void h3_toggle_rows(uint32_t cnt, uint32_t ad, uint32_t ng, uint32_t base, uint32_t pb)
-{
-    uint32_t b, m, E, F;
-    int32_t rem = (int32_t) cnt;
-    uint32_t np = (ng + 1u) >> 1;
-    unsigned long long sv;
-    asm volatile(
-        "s_mov_b64 %[sv], exec\n\t"
-        "ds_read_b32 %[E], %[ad]\n\t"
-        "ds_read_b32 %[F], %[ad] offset:4\n\t"
-        "1:\n\t"
-        "s_waitcnt lgkmcnt(0)\n\t"
-        H3_TOGGLE(0, E, 0) H3_TOGGLE(1, E, 1) H3_TOGGLE(2, E, 2) H3_TOGGLE(3, E, 3)
-        H3_TOGGLE(0, F, 4) H3_TOGGLE(1, F, 5) H3_TOGGLE(2, F, 6) H3_TOGGLE(3, F, 7)
+        "2:\n\t"
         "s_mov_b64 exec, %[sv]\n\t"
-        "ds_read_b32 %[E], %[ad] offset:8\n\t"
-        "ds_read_b32 %[F], %[ad] offset:12\n\t"
-        "v_add_u32 %[ad], 8, %[ad]\n\t"
-        "v_subrev_u32 %[rem], 8, %[rem]\n\t"
-        "s_sub_u32 %[np], %[np], 1\n\t"
-        "s_cmp_lg_u32 %[np], 0\n\t"
-        "s_cbranch_scc1 1b\n\t"
         "s_waitcnt lgkmcnt(0)\n\t"
-        : [b] "=&v"(b), [m] "=&v"(m), [E] "=&v"(E), [F] "=&v"(F), [ad] "+v"(ad), [rem] "+v"(rem), [np] "+s"(np),
-          [sv] "=&s"(sv)
-        : [base] "v"(base), [pb] "v"(pb)
+        : [X] "+v"(X), [U] "=&v"(U), [um] "=&v"(um), [T] "=&v"(T), [E] "=&v"(E), [F] "=&v"(F), [G] "=&v"(G), [H] "=&v"(H),
+          [M] "+v"(M), [ad] "+v"(ad), [rem] "+v"(rem), [np] "+s"(np), [sv] "=&s"(sv)
+        : [Q] "s"(Q), [K8] "v"(K8), [one] "v"(one)
         : "vcc", "scc", "memory");
+    return M;
 }
 
 // A finished pack leaves (helper 0): complement the toggle words, trim to the segment's nb bits, clear the buffer, take
@@ -219,23 +197,12 @@ __device__ __forceinline__ uint32_t h3_write_pack(uint32_t *pk, uint32_t nb, uin
     return nb ? pd : (par ^ pd);
 }
 
-// segment s is published by the recurrence and every block of it has been toggled
-__device__ __forceinline__ bool h3_seg_ready(uint32_t *flag, int s, int n_blk)
-{
-    if (__builtin_amdgcn_readfirstlane((int) lds_flag_load(flag + F_SEGPUB)) < s + 1) return false;
-    const int b1 = (s + 1) * H3_SEG_BLKS < n_blk ? (s + 1) * H3_SEG_BLKS : n_blk;
-    bool ok = true;
-#pragma unroll
-    for (int q = 0; q < H3_NH; ++q) ok = ok && __builtin_amdgcn_readfirstlane((int) lds_flag_load(flag + F_TOG + q)) >= b1;
-    return ok;
-}
-
 // LDS map (dynamic, from address 0: this kernel has no static LDS and the asm above relies on it):
 //   [0, 2048)                       lut: positions of the set bits of a byte, MSB (oldest sample) first
-//   H3_SLOTS x H3_SLOT_BYTES        block slots: 64 strips, cnt[64], base[64], rows
+//   H3_SLOTS x H3_SLOT_BYTES        block slots: 64 strips, cnt[64], rows
 //   H3_NPACK x PLL_PACKW x 64 words pack buffers (toggle words per lane)
 //   H3_FLAG_WORDS                   hand-over counters; sign before / after the call per lane; bit counts of four segments
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) void pll_h3_kernel(
+__global__ __launch_bounds__(64 * (1 + H3_NH)) __attribute__((amdgpu_waves_per_eu(4, 8))) void pll_h3_kernel(
     const uint4 *__restrict__ sgn4, uint32_t *__restrict__ pllst, uint32_t *__restrict__ prevst,
     uint32_t *__restrict__ lastbit, uint32_t *__restrict__ segbits, uint32_t *__restrict__ segcnt,
     uint32_t *__restrict__ watchdog, int N, int L, int n_seg_alloc, uint32_t pllinc)
@@ -253,11 +220,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
     const bool live = cg < N;
     const int n_seg = n_seg_cap(L);
     const int n_blk = (L + H3_BLK - 1) / H3_BLK;
-    if (threadIdx.x < 32) flag[threadIdx.x] = (threadIdx.x >= F_SCAN && threadIdx.x < F_SCAN + H3_NH)  ? threadIdx.x - F_SCAN
-                                              : (threadIdx.x >= F_TOG && threadIdx.x < F_TOG + H3_NH) ? threadIdx.x - F_TOG : 0u;
+    if (threadIdx.x < 32) flag[threadIdx.x] = (threadIdx.x >= F_SCAN && threadIdx.x < F_SCAN + H3_NH) ? threadIdx.x - F_SCAN : 0u;
     if (role == 0) sign0[lane] = prevst[c] & 1u;               // receiver.h:44 prev, before a helper rewrites it
-    pll_fill_lut(lut, (int) threadIdx.x, 256);
-    for (int q = threadIdx.x; q < H3_NPACK * PLL_PACKW * 64; q += 256) pack[q] = 0;
+    pll_fill_lut(lut, (int) threadIdx.x, 64 * (1 + H3_NH));
+    for (int q = threadIdx.x; q < H3_NPACK * PLL_PACKW * 64; q += 64 * (1 + H3_NH)) pack[q] = 0;
     __syncthreads();
     const unsigned long long t_start = wall_clock64();
     // nothing here may spin forever: a wave that waits longer than this gives up (200 ms; the waves of a workgroup
@@ -270,7 +236,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
 #define peek(f) __builtin_amdgcn_readfirstlane((int) lds_flag_load(flag + (f)))
     __builtin_amdgcn_s_setprio(3);     // every wave of this workgroup is on the call's critical path
 
-    if (role >= 1) {                   // ---- a helper: scans and toggles blocks h, h + 3, ...; helper 0 writes the packs ----
+    if (role >= 1) {                   // ---- a helper: scans blocks h, h + 3, ...; helper 0 writes the packs ----
         const int h = role - 1;
         const uint4 *__restrict__ src = sgn4 + c;                  // piece b of this lane: src[b * N]
         // the writer's state (helper 0): a transition after a segment's last slice toggles the first bit of the next
@@ -278,7 +244,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
         // Between calls it is the level at the last slice (receiver.h:38 lastbit) XOR the level of the last sample.
         uint32_t par = h == 0 ? (lastbit[c] ^ sign0[lane]) & 1u : 0u;
         int wseg = 0;
-#define H3_SEG_READY(s) h3_seg_ready(flag, (s), n_blk)
 #define H3_LOAD_BLOCK(b)           /* unconditional, clamped: the compiler counts them */                        \
     do {                                                                                                        \
         const int bb = (b) < n_blk ? (b) : 0;                                                                   \
@@ -289,14 +254,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
         uint32_t pw;
         H3_LOAD_BLOCK(h);
         bool dead = false;
-        unsigned long long hb_scan = 0, hb_wait = 0, hb_tog = 0, hb_wr = 0;
+        unsigned long long hb_scan = 0, hb_wait = 0, hb_wr = 0;
         const unsigned long long hb_t0 = TICK();
         for (int bs = h; !dead; bs += H3_NH) {
-            const int bt = bs - H3_NH;                             // scan bs, then toggle the block scanned one turn ago
-            if (bt >= n_blk && !(h == 0 && wseg < n_seg)) break;
+            if (bs >= n_blk && !(h == 0 && wseg < n_seg)) break;
             if (h == 0) {                                          // finished packs leave, in order (the only place)
                 const unsigned long long t3 = TICK();
-                while (wseg < n_seg && H3_SEG_READY(wseg)) {
+                while (wseg < n_seg && peek(F_SEGPUB) >= wseg + 1) {
                     uint32_t *pk = pack + (wseg & (H3_NPACK - 1)) * PLL_PACKW * 64 + lane;
                     const uint32_t nb = nbuf[(wseg & 3) * 64 + lane];          // slices of the segment = bits of the pack
                     par = h3_write_pack(pk, nb, par, live, segbits + ((size_t) cg * n_seg_alloc + wseg) * PACK_STRIDE,
@@ -304,14 +268,21 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
                     lds_flag_store(flag + F_WRITTEN, (uint32_t) (++wseg));
                 }
                 hb_wr += TICK() - t3;
-                if (bt >= n_blk) {                                 // nothing left but the call's last packs: wait for them
+                if (bs >= n_blk) {                                 // nothing left but the call's last packs: wait for them
                     if (expired()) dead = true;
                     __builtin_amdgcn_s_sleep(4);
                     continue;
                 }
             }
             const unsigned long long t0 = TICK();
-            if (bs < n_blk) {
+            while (peek(F_RDONE) < bs - (H3_SLOTS - 1) && !dead) { // slot bs % H3_SLOTS was block bs - H3_SLOTS's: walked?
+                if (expired()) dead = true;
+                __builtin_amdgcn_s_sleep(8);                       // (a block takes the recurrence ~2000 ticks)
+            }
+            if (dead) break;
+            const unsigned long long t1 = TICK();
+            hb_wait += t1 - t0;
+            {
                 uint32_t S[H3_WORDS] = {q.x, q.y, q.z, q.w};
                 uint32_t prev = bs == 0 ? sign0[lane] : (pw & 1u);
                 H3_LOAD_BLOCK(bs + H3_NH);                         // the next own block's words, in flight while this one is expanded
@@ -323,36 +294,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
                     if (live) prevst[cg] = prev;
                 }
             }
-            const unsigned long long t1 = TICK();
-            hb_scan += t1 - t0;
-            if (bt >= 0 && bt < n_blk) {
-                const int s = bt / H3_SEG_BLKS;
-                // pack buffer s & 3 was segment s - 4's: written long ago (its blocks were toggled sixty blocks back, and
-                // helper 0 looks after the packs at every turn) unless something is badly wrong
-                while (peek(F_WRITTEN) < s - (H3_NPACK - 1) && !dead) {
-                    if (expired()) dead = true;
-                    __builtin_amdgcn_s_sleep(2);
-                }
-                while (peek(F_RDONE) < bt + 1 && !dead) {          // walked by the recurrence
-                    if (expired()) dead = true;
-                    __builtin_amdgcn_s_sleep(1);
-                }
-                if (dead) break;
-                const unsigned long long t2 = TICK();
-                hb_wait += t2 - t1;
-                const uint8_t *slot = slots + (bt % H3_SLOTS) * H3_SLOT_BYTES;
-                const uint32_t cnt = reinterpret_cast<const uint32_t *>(slot + H3_OFF_CNT)[lane];
-                const uint32_t ng = (uint32_t) __builtin_amdgcn_readfirstlane(
-                    (int) reinterpret_cast<const uint32_t *>(slot + H3_OFF_NG)[0]);
-                const uint32_t base = reinterpret_cast<const uint32_t *>(slot + H3_OFF_BASE)[lane];
-                const uint32_t pb = (uint32_t) (reinterpret_cast<uint8_t *>(pack) - lds) +
-                                    (uint32_t) (((s & (H3_NPACK - 1)) * PLL_PACKW * 64 + lane) * 4);   // this lane's pack word 0
-                if (ng) h3_toggle_rows(cnt, (uint32_t) (slot - lds) + (uint32_t) (lane * H3_STRIP), ng, base, pb);
-                lds_flag_store(flag + F_TOG + h, (uint32_t) (bt + H3_NH));
-                hb_tog += TICK() - t2;
-            }
+            hb_scan += TICK() - t1;
         }
-        lds_flag_store(flag + F_TOG + h, 0x7fffffffu);
         if (h == 0) {
             while (lds_flag_load(flag + F_LAST) == 0 && !dead)
                 if (expired()) dead = true;
@@ -360,54 +303,75 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
                 for (int s = n_seg; s < n_seg_alloc; ++s) segcnt[(size_t) cg * n_seg_alloc + s] = 0;
                 lastbit[cg] = (sign1[lane] ^ par) & 1u;
             }
-            BUDGET(8, TICK() - hb_t0); BUDGET(9, hb_scan); BUDGET(10, hb_wait); BUDGET(11, hb_tog); BUDGET(12, hb_wr);
+            BUDGET(8, TICK() - hb_t0); BUDGET(9, hb_scan); BUDGET(10, hb_wait); BUDGET(12, hb_wr);
         }
         return;
     }
 
     // ---- the recurrence ----
-    uint32_t X = ((pllst[c] & 0xffffu) << 7) | 0x7fu;          // receiver.h:40 pll, scaled; spare bits set
-    const uint32_t Q = (uint32_t) __builtin_amdgcn_readfirstlane((int) ((pllinc / 16u) << 7));   // receiver.c:84,115,117
-    const uint32_t K7 = pllinc << 7;              // p * pllinc * 2^7 < 2^32 (create refuses pllinc > 14426)
+    uint32_t X = ((pllst[c] & 0xffffu) << 8) | 0xffu;          // receiver.h:40 pll, scaled; spare bits set
+    const uint32_t Q = (uint32_t) __builtin_amdgcn_readfirstlane((int) ((pllinc / 16u) << 8));   // receiver.c:84,115,117
+    const uint32_t K8 = pllinc << 8;              // p * pllinc * 2^8 < 2^32 and pllinc * 2^8 < 2^24 (create refuses pllinc > 14426)
     bool dead = false;
     unsigned long long rc_wscan = 0, rc_rows = 0, rc_nrows = 0, rc_nblk = 0;
     const unsigned long long rc_t0 = TICK();
     for (int s = 0; s < n_seg && !dead; ++s) {
+        while (peek(F_WRITTEN) < s - (H3_NPACK - 1) && !dead) {    // pack buffer s & 3 was segment s - 4's: long written
+            if (expired()) dead = true;
+            __builtin_amdgcn_s_sleep(2);
+        }
         uint32_t segbase = 0;                                  // slices of this segment before the current block
+        uint32_t *pk = pack + (s & (H3_NPACK - 1)) * PLL_PACKW * 64 + lane;   // this lane's pack word 0 (word stride 64)
         const int b1 = (s + 1) * H3_SEG_BLKS < n_blk ? (s + 1) * H3_SEG_BLKS : n_blk;
         for (int b = s * H3_SEG_BLKS; b < b1 && !dead; ++b) {
             const unsigned long long s0 = TICK();
-            while (peek(F_SCAN + b % H3_NH) < b + 1 && !dead) {    // scanned by its helper
-                if (expired()) dead = true;
+            // the helper's counter, the lane's count and the block's rows in ONE trip to the LDS: the three reads are
+            // executed in this order, so a counter that says "scanned" vouches for the two values read behind it
+            const uint8_t *slot = slots + (b % H3_SLOTS) * H3_SLOT_BYTES;
+            uint32_t cnt, ng;
+            for (;;) {
+                uint32_t f, g;
+                asm volatile("ds_read_b32 %0, %3\n\tds_read_b32 %1, %4\n\tds_read_b32 %2, %5\n\ts_waitcnt lgkmcnt(0)"
+                             : "=&v"(f), "=&v"(cnt), "=&v"(g)
+                             : "v"((uint32_t) (reinterpret_cast<uint8_t *>(flag + F_SCAN + b % H3_NH) - lds)),
+                               "v"((uint32_t) (slot + H3_OFF_CNT - lds) + (uint32_t) lane * 4u),
+                               "v"((uint32_t) (slot + H3_OFF_NG - lds))
+                             : "memory");
+                ng = (uint32_t) __builtin_amdgcn_readfirstlane((int) g);
+                if (__builtin_amdgcn_readfirstlane((int) f) >= b + 1) break;       // scanned by its helper
+                if (expired()) { dead = true; break; }
                 __builtin_amdgcn_s_sleep(1);
             }
             if (dead) break;
             const unsigned long long s1 = TICK();
             rc_wscan += s1 - s0;
-            uint8_t *slot = slots + (b % H3_SLOTS) * H3_SLOT_BYTES;
-            const uint32_t cnt = reinterpret_cast<const uint32_t *>(slot + H3_OFF_CNT)[lane];
-            const uint32_t ng = (uint32_t) __builtin_amdgcn_readfirstlane(
-                (int) reinterpret_cast<const uint32_t *>(slot + H3_OFF_NG)[0]);
-            segbase += X >> 23;                                // slice numbers inside the block start at 0
-            X &= 0x007fffffu;
-            reinterpret_cast<uint32_t *>(slot + H3_OFF_BASE)[lane] = segbase;
-            if (ng) h3_rows(X, cnt, (uint32_t) (slot - lds) + (uint32_t) (lane * H3_STRIP), ng, Q, K7);
-            lds_flag_store(flag + F_RDONE, (uint32_t) (b + 1));
+            segbase += X >> 24;                                // slice numbers inside the block start at 0
+            X &= 0x00ffffffu;
+            if (ng) {
+                const uint32_t M = h3_rows(X, cnt, (uint32_t) (slot - lds) + (uint32_t) (lane * H3_STRIP), ng, Q, K8);
+                lds_flag_store(flag + F_RDONE, (uint32_t) (b + 1));        // the slot is its helper's again
+                // bit i of M = the toggle of slice segbase + i of the segment: into the pack (two words; <= 465 < 512 bits)
+                const uint32_t sh = segbase & 31u, w = segbase >> 5;
+                atomicXor(pk + w * 64, M << sh);                           // (this lane's own words: a plain read-modify-write
+                atomicXor(pk + w * 64 + 64, (M >> 1) >> (31u - sh));       //  would do; ds_xor is the one-instruction form)
+            } else {
+                lds_flag_store(flag + F_RDONE, (uint32_t) (b + 1));
+            }
 #ifdef PLLH3_BUDGET
             rc_rows += TICK() - s1;
             rc_nrows += ng;
             rc_nblk += 1;
 #endif
             const int blen = L - b * H3_BLK < H3_BLK ? L - b * H3_BLK : H3_BLK;
-            X += (uint32_t) blen * K7;                         // to the next block's first sample
+            X += (uint32_t) blen * K8;                         // to the next block's first sample
         }
         if (dead) break;
-        X |= 0x7fu;
-        nbuf[(s & 3) * 64 + lane] = segbase + (X >> 23);       // slices so far = bits of the segment
-        X = (X & 0x007fff80u) | 0x7fu;                         // receiver.c:133 pll &= 0xffff
+        X |= 0xffu;
+        nbuf[(s & 3) * 64 + lane] = segbase + (X >> 24);       // slices so far = bits of the segment
+        X = (X & 0x00ffff00u) | 0xffu;                         // receiver.c:133 pll &= 0xffff
         lds_flag_store(flag + F_SEGPUB, (uint32_t) (s + 1));
     }
-    if (live && !dead) pllst[cg] = (X >> 7) & 0xffffu;
+    if (live && !dead) pllst[cg] = (X >> 8) & 0xffffu;
     BUDGET(0, TICK() - rc_t0); BUDGET(1, rc_wscan); BUDGET(3, rc_rows); BUDGET(4, rc_nrows); BUDGET(5, rc_nblk);
 }
 
@@ -431,7 +395,7 @@ hipError_t launch_pll_h3(const PllLaunch &a, hipStream_t stream)
     const int groups = (a.N + 63) / 64, per_cu = (groups + n_cu - 1) / n_cu;
     const int lds = per_cu <= 1 ? std::max(H3_NEED_LDS, PLL_LDS_BYTES) : std::max(H3_NEED_LDS, (160 * 1024 / per_cu) & ~1023);
     if (lds > 160 * 1024) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(pll_h3_kernel, dim3(groups), dim3(256), lds, stream, (const uint4 *) a.sgn, a.pll, a.prev, a.lastbit,
+    hipLaunchKernelGGL(pll_h3_kernel, dim3(groups), dim3(64 * (1 + H3_NH)), lds, stream, (const uint4 *) a.sgn, a.pll, a.prev, a.lastbit,
                        a.segbits, a.segcnt, a.watchdog, a.N, a.L, a.n_seg, a.pllinc);
     return hipGetLastError();
 }

@@ -382,7 +382,7 @@ int pll_form_of(const PllLaunch &a)
     const int n_cu = a.n_cu > 0 ? a.n_cu : 256;
     const int groups = (a.N + 63) / 64;
     return a.variant == 3 || a.variant == 4 || a.variant == 6 || a.variant == 8 || a.variant == 32 || a.variant == 51 || a.variant == 52
-               ? a.variant : (2 * groups <= n_cu ? 6 : 3);
+               ? a.variant : (2 * groups <= n_cu ? 6 : 8);
 }
 
 hipError_t launch_pll(const PllLaunch &a, hipStream_t stream)

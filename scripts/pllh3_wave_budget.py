@@ -25,9 +25,8 @@ def show(tag, ms):
     print(f"--- {tag}: PLL launch {ms:.3f} ms")
     print(f"  recurrence: total {m[0]:.0f} ticks (max {bud[:, 0].max()}), waiting for a scan {m[1]:.0f} ({m[1] / m[0]:.3f}), rows "
           f"{m[3]:.0f} ({m[3] / m[0]:.3f}); {m[4]:.0f} rows of four in {m[5]:.0f} blocks: {m[3] / m[4] / 4:.1f} ticks per step")
-    print(f"  helper 0: total {m[8]:.0f}, scanning {m[9]:.0f} ({m[9] / m[8]:.3f}), waiting for the recurrence {m[10]:.0f} "
-          f"({m[10] / m[8]:.3f}), toggling {m[11]:.0f} ({m[11] / m[8]:.3f}), packs {m[12]:.0f} ({m[12] / m[8]:.3f}); per own "
-          f"block: scan {m[9] / (m[5] / 3):.0f}, toggle {m[11] / (m[5] / 3):.0f}")
+    print(f"  helper 0: total {m[8]:.0f}, scanning {m[9]:.0f} ({m[9] / m[8]:.3f}), waiting for a free slot {m[10]:.0f} "
+          f"({m[10] / m[8]:.3f}), packs {m[12]:.0f} ({m[12] / m[8]:.3f}); per own block: scan {m[9] / (m[5] / 3):.0f}")
 
 
 b = ReceiverBatch(n_ch, max_len=total)
