@@ -493,7 +493,7 @@ def pmc_traffic(args, config):
         return {"error": "rocprofv3 not found"}
     child = [sys.executable, os.path.join(ROOT, "bench.py"), "--config", config, "--no-cpu", "--no-others", "--no-e2e",
              "--no-traffic", "--no-kernel-leg", "--steps", "6", "--warmup", "1", "--base", str(args.base)]
-    short = (("fir_sign", "fir_slice"), ("fir_slice_generic", "fir_slice"), ("fir_slice", "fir_slice"), ("pll_h3_kernel", "pll"), ("pll3_kernel", "pll"), ("pll_kernel", "pll"), ("pll_tp_kernel", "pll"),
+    short = (("fir_sign", "fir_slice"), ("fir_slice_generic", "fir_slice"), ("fir_slice", "fir_slice"), ("pll_h3_kernel", "pll"), ("pll_tp_kernel", "pll"),
              ("hdlc_events", "hdlc_deframe"), ("hdlc_deframe", "hdlc_deframe"), ("hdlc_crc", "hdlc_crc"))
     env = dict(os.environ, TMPDIR="/tmp")
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):

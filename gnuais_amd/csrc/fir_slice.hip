@@ -33,8 +33,8 @@
 #include "kernels.h"
 
 #ifndef FIR_VARIANT
-#define FIR_VARIANT scalar      // Makefile builds this file twice: scalar (-fno-slp-vectorize,
-#endif                          // v_mul_f32/v_add_f32) and packed (v_pk_mul_f32/v_pk_add_f32)
+#define FIR_VARIANT scalar      // the exact kernel's namespace (built with -fno-slp-vectorize: v_mul_f32 / v_add_f32,
+#endif                          // every product and every sum rounded as filter.h:40-49 rounds them)
 
 namespace gnuais {
 
@@ -64,23 +64,6 @@ __device__ __forceinline__ void touch16(float *a)
                       "+v"(a[12]), "+v"(a[13]), "+v"(a[14]), "+v"(a[15]));
 }
 
-#ifdef FIR_USE_MFMA
-// Products on the matrix pipe.  v_mfma_f32_4x4x1_16b_f32 multiplies, in each of
-// its 16 blocks of 4 lanes, a 4-vector A (one element per lane of the block) by
-// a 4-vector B (one element per lane) : D[reg i] at lane j of the block =
-// A[lane i] * B[lane j] + C.  With A = four taps (lane i of every block holds tap
-// 4g+i), B = the lane's own sample and C = +0, register i of every lane receives
-// te[4g+i] * x(lane): K = 1, so the result is fma(a, b, +0) = the correctly
-// rounded product -- bit-identical to v_mul_f32 (and a -0 product becomes +0,
-// which the ordered sum cannot distinguish).  Eight of these per sample give all
-// 32 products on the MFMA pipe and leave only the 31 additions to the VALU.
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ void touch8q(f32x4 *q)
-{
-    asm volatile("" : "+v"(q[0]), "+v"(q[1]), "+v"(q[2]), "+v"(q[3]), "+v"(q[4]), "+v"(q[5]),
-                      "+v"(q[6]), "+v"(q[7]));
-}
-#endif
 
 // grid: x = channel group (64 channels), y = time segment of T outputs
 // (T a multiple of 32).  block = 64 threads = one wave.
@@ -107,19 +90,6 @@ __global__ __launch_bounds__(64) void fir_slice_kernel(
     float acc[NE];
 #pragma unroll
     for (int s = 0; s < NE; ++s) acc[s] = 0.0f;
-#ifdef FIR_USE_MFMA
-    float tapq[NE / 4];                         // lane l: te[4g + (l & 3)]
-    {
-        const int li = lane & 3;
-#pragma unroll
-        for (int g = 0; g < NE / 4; ++g) {
-            const float a0 = taps.te[4 * g], a1 = taps.te[4 * g + 1];
-            const float a2 = taps.te[4 * g + 2], a3 = taps.te[4 * g + 3];
-            tapq[g] = li == 0 ? a0 : (li == 1 ? a1 : (li == 2 ? a2 : a3));
-        }
-    }
-    const f32x4 zero4 = {0.0f, 0.0f, 0.0f, 0.0f};
-#endif
 
     int peak = 0;
     // local sample index i <-> m = t0 - d + i ; sample i feeds output o = i - j
@@ -138,23 +108,6 @@ __global__ __launch_bounds__(64) void fir_slice_kernel(
 #pragma unroll
         for (int i = 0; i < NE - 1; ++i) {
             const float xs = (float) xw[i];
-#ifdef FIR_USE_MFMA
-#pragma unroll
-            for (int g = 0; 4 * g <= i; ++g) {
-                const f32x4 pr = __builtin_amdgcn_mfma_f32_4x4x1f32(tapq[g], xs, zero4, 0, 0, 0);
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const int j = 4 * g + q;
-                    if (j <= i) {               // o = i - j >= 0 only
-                        const int s = (i - j) & (NE - 1);
-                        if (j == 0) acc[s] = pr[q]; else acc[s] = acc[s] + pr[q];
-                    }
-                }
-            }
-            touch16(acc);
-            touch16(acc + 16);
-            __builtin_amdgcn_sched_barrier(0);
-#else
 #pragma unroll
             for (int j = 0; j <= i; ++j) {      // o = i - j >= 0 only
                 const int s = (i - j) & (NE - 1);
@@ -163,7 +116,6 @@ __global__ __launch_bounds__(64) void fir_slice_kernel(
                 const float p = taps.te[jm] * xs;
                 if (j == 0) acc[s] = p + 0.0f; else acc[s] = acc[s] + p;
             }
-#endif
         }
     }
 
@@ -208,50 +160,6 @@ __global__ __launch_bounds__(64) void fir_slice_kernel(
             peak = bp > peak ? bp : peak;
         }
         uint32_t w = 0;
-#ifdef FIR_USE_MFMA
-        // two-stage software pipeline: the eight MFMAs of sample p+1 are issued
-        // together with the 31 additions of sample p (different pipes); the
-        // sched_barrier keeps hipcc from hoisting every MFMA of the block to the top
-        f32x4 prA[NE / 4], prB[NE / 4];
-        {
-            const float x0 = (float) xi[0];
-#pragma unroll
-            for (int g = 0; g < NE / 4; ++g)
-                prA[g] = __builtin_amdgcn_mfma_f32_4x4x1f32(tapq[g], x0, zero4, 0, 0, 0);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int p = 0; p < 32; ++p) {
-            if (p + 1 < 32) {
-                const float xn = (float) xi[p + 1];
-#pragma unroll
-                for (int g = 0; g < NE / 4; ++g) {
-                    const f32x4 v = __builtin_amdgcn_mfma_f32_4x4x1f32(tapq[g], xn, zero4, 0, 0, 0);
-                    if (p & 1) prA[g] = v; else prB[g] = v;
-                }
-            }
-#pragma unroll
-            for (int g = 0; g < NE / 4; ++g) {
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const int j = 4 * g + q;
-                    const int s = (NE - 1 + p - j) & (NE - 1);
-                    const float pv = (p & 1) ? prB[g][q] : prA[g][q];
-                    if (j == 0) acc[s] = pv; else acc[s] = acc[s] + pv;
-                }
-            }
-            if (p + 1 < 32) { if (p & 1) touch8q(prA); else touch8q(prB); }
-            touch16(acc);
-            touch16(acc + 16);
-            const float y = acc[p & (NE - 1)];  // output o = obase + p is complete
-            w = (w << 1) | (y > 0.0f ? 1u : 0u);
-            if (DUMP) {
-                const int n = t0 + obase + p;
-                if (live && n < t1) dump[(size_t) n * (size_t) N + cg] = y;
-            }
-            __builtin_amdgcn_sched_barrier(0);
-        }
-#else
 #pragma unroll
         for (int p = 0; p < 32; ++p) {
             const float xs = (float) xi[p];
@@ -281,7 +189,6 @@ __global__ __launch_bounds__(64) void fir_slice_kernel(
                 if (live && n < t1) dump[(size_t) n * (size_t) N + cg] = y;
             }
         }
-#endif
         // partial last word: outputs beyond t1 are garbage -> clear them; valid
         // bits stay left-aligned (bit 31 = oldest)
         const int valid = t1 - (t0 + obase);
@@ -1090,7 +997,7 @@ int launch_fir_sign_quantum(int NC)
 
 hipError_t launch_fir_sign(const FirLaunch &a, hipStream_t stream)
 {
-    if (a.dump || a.T % launch_fir_sign_quantum(a.NC) || !a.te_mem || (a.NC != 10 && a.NC != 12 && a.NC != 48) || a.NE < a.NC || (a.NE - a.NC) % 2)
+    if (a.dump || a.T % launch_fir_sign_quantum(a.NC) || !a.te_mem || (a.NC != 12 && a.NC != 48) || a.NE < a.NC || (a.NE - a.NC) % 2)
         return hipErrorInvalidValue;
     if (a.T > 65280) return hipErrorInvalidValue;       // the kernel notes open outputs as 16-bit offsets into the segment
     dim3 grid((a.N + 63) / 64, (a.L + a.T - 1) / a.T), block(64);
@@ -1106,19 +1013,7 @@ hipError_t launch_fir_sign(const FirLaunch &a, hipStream_t stream)
     if (a.persist > 0 && (long) gx * gy > a.persist) grid = dim3((a.persist + 7) & ~7);   // a multiple of 8: a workgroup's items stay on its XCD
     // the stamp buffer (a debugging option) is written by workgroup id: a grid it has no room for gets none
     unsigned long long *const stamps_ok = ((size_t) grid.x * grid.y <= a.stamps_waves) ? a.stamps : nullptr;
-    if (a.NC == 10 && a.NE == 32) {
-        // ten central taps: one symmetric pair less per output than twelve, an ambiguity band three times as wide
-        FirTaps<32> t;
-        for (int j = 0; j < 32; ++j) t.te[j] = a.te[j];
-        if (a.fscale > 0.0f)
-            hipLaunchKernelGGL((fir_sign_kernel<32, 10, 32, false, true>), grid, block, a.lds_pad, stream, a.x, a.hist, a.sgn, a.maxval,
-                               a.hist_out, a.maxval_next, a.te_mem, a.N, a.L, a.T, a.d, a.NT, a.NE, eps_up, map, t, stamps_ok, n_big, T2, a.eps_seen, a.eps_ahead, gx, gy, a.fscale);
-        else
-        hipLaunchKernelGGL((fir_sign_kernel<32, 10, 32>), grid, block, a.lds_pad, stream, a.x, a.hist, a.sgn, a.maxval,
-                           a.hist_out, a.maxval_next, a.te_mem, a.N, a.L, a.T, a.d, a.NT, a.NE, eps_up, map, t, stamps_ok, n_big, T2, a.eps_seen, a.eps_ahead, gx, gy, a.fscale);
-    } else if (a.NC == 10) {
-        return hipErrorInvalidValue;
-    } else if (a.NC == 12 && a.NE == 32) {
+    if (a.NC == 12 && a.NE == 32) {
         FirTaps<32> t;
         for (int j = 0; j < 32; ++j) t.te[j] = a.te[j];
         if (a.fscale > 0.0f)
@@ -1238,9 +1133,6 @@ hipError_t launch_fir_slice(const FirLaunch &a, hipStream_t stream)
         memcpy(&u1, &a.te[31 - j], 4);
         sym = sym && (u0 == u1);
     }
-#ifdef FIR_USE_MFMA
-    sym = false;                                // the MFMA build computes all 32 products anyway
-#endif
 #define FIR_LAUNCH(D, S)                                                                     \
     hipLaunchKernelGGL((fir_slice_kernel<32, D, S>), grid, block, 0, stream, a.x, a.hist, a.sgn, \
                        a.dump, a.maxval, a.hist_out, a.maxval_next, a.N, a.L, a.T, a.d, a.NT, t)

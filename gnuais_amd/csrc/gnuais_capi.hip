@@ -26,8 +26,6 @@ using namespace gnuais;
 
 namespace gnuais {
 namespace scalar { hipError_t launch_fir_slice(const FirLaunch &a, hipStream_t stream); }
-namespace packed { hipError_t launch_fir_slice(const FirLaunch &a, hipStream_t stream); }
-namespace mfma { hipError_t launch_fir_slice(const FirLaunch &a, hipStream_t stream); }
 }
 
 static thread_local std::string g_err;
@@ -67,8 +65,8 @@ struct gnuais_batch {
     // device state
     // The FIR's carry (the last NT input rows) and the per-call peak buffers rotate over HB buffers: call i reads
     // hist[i % HB], writes hist[(i + 1) % HB], gathers its peaks in maxval[i % HB] and clears maxval[(i + 2) % HB].
-    // Two would do for FIR launches that run one after the other; four let launch i + 1 start while launch i is
-    // still running (fir_streams = 2): nothing launch i + 1 writes is read by launch i.
+    // (Two would do for FIR launches that run one after the other; four keep the writer of a buffer two calls away
+    // from its readers.)
     static constexpr int HB = 4;
     int16_t *hist[HB] = {};
     int hist_cur = 0;
@@ -89,8 +87,7 @@ struct gnuais_batch {
     int n_seg = 0, seg_words = 0;
     // stage pipeline: K1 on the caller's stream and one internal stream per later
     // kernel, so that the short-on-parallelism stages of call i overlap the FIR of
-    // call i+1 (and each other).  NBUF = 4 measured best: 3 starves the FIR (1.0 ms per C3 call),
-    // 5..8 let it run further ahead and the stages get in each other's way more (0.84).
+    // call i+1 (and each other).
     hipStream_t s_k[4] = {nullptr, nullptr, nullptr, nullptr};   // K2, (spare), K2b, K3 (entries of pool[])
     hipStream_t s_k_default[4] = {nullptr, nullptr, nullptr, nullptr};
     static constexpr int POOL = 12;
@@ -166,38 +163,19 @@ struct gnuais_batch {
     // options
     int fir_T = 512;
     int fir_map = 1;                            // K1s workgroup mapping (fir_slice.hip): XCD-contiguous channel groups
-    int fir_T2 = 128;                           // K1s: segment length of the launch's tail (0: all segments alike)
-    int fir_persist = 0;                        // K1s (scalar forms): > 0 = that many workgroups per SIMD, each looping over the launch's items
-    int fir_tail = 0;                           //   how much of the launch, in tenths of a full round of resident waves, takes the short segments
-    int fir_cpl = 1;                            // K1s channels per lane: 1 (fir_slice.hip), 2 or 4 (fir_sign_wide.hip; even / 4-divisible N)
-    unsigned long long *d_stamps = nullptr;     // experiment (fir_stamps): start / end clock of every K1s wave of the last call
-    size_t stamps_waves = 0;
-    int fir_dbg = 0, fir_lds = 0;               // experiments: FirLaunch::dbg / lds_pad
-    int fir_form = 0;                           // fir_sign_wide.hip: bit 0 packed fp32, bit 1 prefetch, bits 4.. rows per group
     int stage_mask = 0x1f;                      // experiments only: bit s = launch stage s
     int fir_variant = 3;            // 3 sign-exact slicer (default when the table allows);
-                                    // 0 exact scalar VALU, 1 exact packed, 2 exact MFMA products
+                                    // 0 the exact ordered sum for every sample
     bool sign_ok = false;           // table is 32 symmetric effective taps: K1s applicable
     float sign_eps = 0.0f;
     float sign_eps_pk = 0.0f;       // the same for the packed transposed kernel's order of operations
-    int fir_pk = -1;                // K1s on register pairs (fir_sign_pk.hip): 1 where the table allows, 0 never, -1 where it is
-                                    // faster: the 48-tap sum (C5: 4.3 against 5.1 ms), not the 12-tap one (0.47 against 0.42-0.45)
     float sign_eps_seen = 0.0f, sign_eps_ahead = 0.0f;   // sign_eps split: what scales with the samples seen / what cannot
     int fir_inloop = 1;             // 48-tap K1s: running window maximum in the loop (0: the per-segment pre-pass)
     int sign_NC = 12;               // central taps K1s evaluates
-    int sign_NC_lo = 0;             // ... and the shorter sum the one-channel-per-lane 12-tap kernel may take instead (0: none)
-    float sign_eps_lo = 0.0f;       //     with its bound
-    // 12: the twelve central taps; 0: the shorter sum (ten) where the table allows one.  Ten taps take two instructions
-    // off every output and leave a band four times as wide (0.5 against 0.125 with FL2): four times the open signs,
-    // each of which re-reads its 32 rows -- FIR traffic 2.18 against 1.84 GB per C3 call, the launch 0.37 against 0.325 ms
-    // alone, the chain 1-1.5 % slower (profiles/r04_fir_twelve_taps_again.txt).  Since the flags cost one instruction
-    // per output the launch is bound by its memory accesses, not its instructions: twelve is the default again.
-    int fir_nc = 12;
     int fir_flag2 = 1;              // the direct-form K1s gathers sign and threshold bit with one instruction per output (FL2)
     float sign_fscale = 0.0f;       //   the power of two its central taps are scaled by (0: the table does not allow it)
-    float sign_fscale_lo = 0.0f;    //   ... for the shorter sum
     int k0 = 0;                     // first effective tap
-    int pll_variant = 0;            // 0: by channel count; 3 / 6 (kernels.h: PllLaunch::variant)
+    int pll_variant = 0;            // 0: by channel count; 7 / 8 (kernels.h: PllLaunch::variant)
     int hdlc_lpw = 0;               // channels per wave in K2b; 0 = the variant's own default (16 event-driven, 64 bit-serial)
     int hdlc_variant = 1;           // 1: the event-driven deframer (hdlc_events.hip), 0: window by window (hdlc_crc.hip)
     bool timing = false;
@@ -211,30 +189,10 @@ struct gnuais_batch {
     bool timed_last = false;
     hipStream_t last_stream = nullptr;
     int last_len = 0;
-    // FIR launches on two streams alternately (fir_streams = 2): launch i + 1 may begin while launch i's last
-    // workgroups are still running, so the FIR stage has no gap and no tail between calls.  What launch i + 1 needs of
-    // launch i -- the last NT input rows -- is copied by a small kernel queued IN FRONT of launch i.
-    int fir_streams = 1;
-    hipStream_t s_fir2 = nullptr;
     // K3 on the deframer's stream: at ring lag 1 the two never overlap (deframer(i) -> K3(i) -> deframer(i+1)), so the two
     // cross-stream event waits per call in the loop that sets the period become stream order: 20-step 0.550 -> 0.544,
     // steady 0.527 -> 0.522 (three A/B pairs, profiles/r04_k3_on_the_deframers_stream.txt).  0 = a stream of its own.
     int k3_same = 1;
-    hipEvent_t e_hist[2] = {nullptr, nullptr};  // the carry of the call on FIR stream q is written
-    hipEvent_t e_order = nullptr;               // the caller's stream has reached this call (its input is there)
-    // cold start: a call that finds the pipeline empty is followed by a FIR launch that would otherwise be dispatched
-    // before the first call's PLL stage and keep it waiting for a whole FIR launch; cold_hold_us >= 0 holds that
-    // second FIR launch back on the host until the first one has ended, plus this many microseconds
-    // K2b started beside the PLL launch of its own call and fed segment by segment (kernels.h: PllLaunch::progress): a
-    // call's latency loses one stage.  Bit-exact (GPU suite + fuzz with it on), and measured a LOSS except at depth 2
-    // (profiles/r04_k2b_dataflow.txt: 20 steps 0.606 against 0.556 at depth 3, 0.636 against 0.729 at depth 2): the
-    // deframer's waves are then resident for the whole PLL launch, throttled at its front, and what a stage costs the
-    // others is the time its waves hold their registers.  Off; kept as an option for that measurement.
-    int k2b_dataflow = 0;
-    uint32_t *progress = nullptr;               // [groups of 64 channels] segments of the running call in HBM, + call * n_seg
-    int cold_hold_us = -1;
-    unsigned long long cold_call = ~0ull;
-    uint32_t *h_started = nullptr;              // pinned: the PLL launch of a cold call writes its stamp here when it has its place
 };
 
 static int set_device(const gnuais_batch *b)
@@ -274,7 +232,7 @@ void gnuais_batch_destroy(gnuais_batch *b)
     }
     void *ptrs[] = {b->hist[0], b->hist[1], b->hist[2], b->hist[3], b->pll, b->lastbit, b->prev, b->ctl, b->cand,
                     b->frame_count, b->counters, b->maxval[0], b->maxval[1], b->maxval[2], b->maxval[3], b->frames, b->d_taps,
-                    b->stage_x, b->d_seq[0], b->d_seq[1], b->d_text, b->nmea_scratch, b->d_msg, b->d_word, b->d_stamps, b->stage_f, b->vt, b->vt_fslot};
+                    b->stage_x, b->d_seq[0], b->d_seq[1], b->d_text, b->nmea_scratch, b->d_msg, b->d_word, b->stage_f, b->vt, b->vt_fslot};
     for (void *p : ptrs)
         if (p) (void) hipFree(p);
     for (auto &set : b->evr)
@@ -285,11 +243,6 @@ void gnuais_batch_destroy(gnuais_batch *b)
             if (e) (void) hipEventDestroy(e);
     for (auto &st : b->pool)
         if (st) (void) hipStreamDestroy(st);
-    if (b->s_fir2) (void) hipStreamDestroy(b->s_fir2);
-    if (b->h_started) (void) hipHostFree(b->h_started);
-    if (b->progress) (void) hipFree(b->progress);
-    for (hipEvent_t e : {b->e_hist[0], b->e_hist[1], b->e_order})
-        if (e) (void) hipEventDestroy(e);
     for (int q = 0; q < gnuais_batch::NRING; ++q) {
         if (q > 0 && b->ring[q]) (void) hipFree(b->ring[q]);          // ring 0 is frames / frame_count
         if (q > 0 && b->ring_count[q]) (void) hipFree(b->ring_count[q]);
@@ -421,23 +374,6 @@ int gnuais_batch_create(gnuais_batch **out, int device, int n_channels, const fl
                     ahead += std::fabs((double) b->te[i - 1]) * (1.0 + (std::pow(1 + u, NE - i + 2) - 1));
                 b->sign_eps_ahead = (float) (X * ahead * 1.1 + 1e-30);
                 b->sign_eps_seen = (float) ((bound - X * ahead) * 1.1);
-                // Since the open signs are settled lane-parallel (fir_sign_kernel, round 4) an open sign costs a
-                // fraction of what it did, and the outermost pair of the twelve weighs 3.7e-6: ten central taps leave
-                // a band three times as wide (0.41 against 0.136: 2.5e-4 of a noisy channel's outputs open instead of
-                // 0.9e-4) and take two instructions off every output.  Same derivation, NC - 2.
-                if (NC == 12 && NE == 32 && K1S_DIRECT(10)) {
-                    const int NL = 10, JL = (NE - NL) / 2;
-                    double out_lo = 0, cen = 0;
-                    for (int j = 0; j < NE; ++j)
-                        if (j < JL || j >= JL + NL) out_lo += std::fabs((double) b->te[j]);
-                    for (int i = 1; i <= NL / 2; ++i)
-                        cen += 2.0 * std::fabs((double) b->te[JL + i - 1]) * (std::pow(1 + u, i == 1 ? NL / 2 : NL / 2 - i + 2) - 1);
-                    const double bound_lo = X * (ordered(0, NE) + cen + out_lo) + 1e-30;
-                    if (std::isfinite(bound_lo) && bound_lo < 2.0) {
-                        b->sign_NC_lo = NL;
-                        b->sign_eps_lo = (float) (bound_lo * 1.1);
-                    }
-                }
                 // FL2 (fir_sign_kernel): the direct form's central taps times k = 2 / P, P = the power of two at or above
                 // eps.  k is a power of two >= 1, so every product, pre-add and partial sum of the scaled evaluation is
                 // exactly k times the unscaled one (nothing overflows: |y'| <= 2 X sum|t| / eps < 1e9; an underflow the
@@ -459,7 +395,6 @@ int gnuais_batch_create(gnuais_batch **out, int device, int n_channels, const fl
                 };
                 if (NC == 12) {
                     b->sign_fscale = flag_scale(b->sign_eps, 12);
-                    if (b->sign_NC_lo) b->sign_fscale_lo = flag_scale(b->sign_eps_lo, b->sign_NC_lo);
                 }
             }
         }
@@ -495,7 +430,6 @@ int gnuais_batch_create(gnuais_batch **out, int device, int n_channels, const fl
     alloc((void **) &b->lastbit, sizeof(uint32_t) * N);
     alloc((void **) &b->prev, sizeof(uint32_t) * N);
     alloc((void **) &b->ctl, sizeof(uint32_t) * N * HDLC_CTL_WORDS);
-    alloc((void **) &b->progress, sizeof(uint32_t) * ((N + 63) / 64 + 1));
     // candidate ring, per channel and call.  The deframer cannot open frames faster than one per
     // 30 bits (16 alternating bits to leave ST_SKURR, protodec.c:1030-1043, six ones each for the
     // opening and the closing flag, a bit in ST_STOPSIGN), so this many slots hold whatever a call
@@ -519,9 +453,6 @@ int gnuais_batch_create(gnuais_batch **out, int device, int n_channels, const fl
     for (auto &pair : b->e_done)
         for (auto &ev : pair)
             if (e == hipSuccess) e = hipEventCreateWithFlags(&ev, hipEventDisableTiming);
-    for (auto &ev : b->e_hist)
-        if (e == hipSuccess) e = hipEventCreateWithFlags(&ev, hipEventDisableTiming);
-    if (e == hipSuccess) e = hipEventCreateWithFlags(&b->e_order, hipEventDisableTiming);
     {
         // the sequential stages are short on parallelism, long on latency: give them
         // dispatch priority over the FIR's tens of thousands of workgroups
@@ -561,10 +492,7 @@ int gnuais_batch_create(gnuais_batch **out, int device, int n_channels, const fl
     }
     if (const char *v = getenv("GNUAIS_K3_SAME")) b->k3_same = atoi(v) != 0;
     if (const char *v = getenv("GNUAIS_PLL_VARIANT")) b->pll_variant = atoi(v);
-    if (const char *v = getenv("GNUAIS_K2B_DATAFLOW")) b->k2b_dataflow = atoi(v) != 0;
     if (const char *v = getenv("GNUAIS_NBUF")) b->nbuf = std::min((int) gnuais_batch::NBUF, std::max(2, atoi(v)));
-    if (const char *v = getenv("GNUAIS_COLD_HOLD_US")) b->cold_hold_us = atoi(v);
-    if (const char *v = getenv("GNUAIS_FIR_STREAMS")) b->fir_streams = atoi(v) == 2 ? 2 : 1;
     if (const char *v = getenv("GNUAIS_PIPELINE")) b->pipeline = atoi(v) != 0;
     if (const char *v = getenv("GNUAIS_HDLC_VARIANT")) b->hdlc_variant = atoi(v) != 0;
     if (const char *v = getenv("GNUAIS_HDLC_LPW")) b->hdlc_lpw = std::min(64, std::max(1, atoi(v)));
@@ -573,12 +501,7 @@ int gnuais_batch_create(gnuais_batch **out, int device, int n_channels, const fl
         return fail(GNUAIS_E_HIP, "create: device allocation", e);
     }
     if (const char *v = getenv("GNUAIS_FIR_VARIANT")) b->fir_variant = atoi(v);
-    if (const char *v = getenv("GNUAIS_FIR_NC")) b->fir_nc = atoi(v) == 12 ? 12 : 0;
     if (const char *v = getenv("GNUAIS_FIR_FLAG2")) b->fir_flag2 = atoi(v) != 0;
-    if (const char *v = getenv("GNUAIS_FIR_PK")) b->fir_pk = atoi(v) < 0 ? -1 : (atoi(v) != 0);
-    if (const char *v = getenv("GNUAIS_FIR_CPL")) { const int c = atoi(v); if (c == 1 || c == 2 || c == 4) b->fir_cpl = c; }
-    if (const char *v = getenv("GNUAIS_FIR_FORM")) b->fir_form = atoi(v);
-    if (const char *v = getenv("GNUAIS_FIR_PERSIST")) b->fir_persist = std::min(16, std::max(0, atoi(v)));
     if (const char *v = getenv("GNUAIS_FIR_T")) b->fir_T = std::max(64, atoi(v) / 32 * 32);
     *out = b;
     int rc = gnuais_batch_reset(b);
@@ -605,12 +528,10 @@ int gnuais_batch_reset(gnuais_batch *b)
         HIP_TRY(hipMemset(b->segcnt[k], 0, sizeof(uint32_t) * N * (size_t) b->n_seg));
     b->calls = 0;
     b->hdlc_calls = 0;
-    HIP_TRY(hipMemset(b->progress, 0, sizeof(uint32_t) * ((N + 63) / 64 + 1)));
     HIP_TRY(hipMemset(b->counters, 0, sizeof(int32_t) * N * 3));      // protodec.c:62-64
     for (int q = 0; q < gnuais_batch::HB; ++q) HIP_TRY(hipMemset(b->maxval[q], 0, sizeof(int) * N));
     b->max_cur = 0;
     b->max_last = 0;
-    b->cold_call = ~0ull;
     HIP_TRY(hipMemset(b->frame_count, 0, sizeof(uint32_t) * 4));
     for (int q = 1; q < gnuais_batch::NRING; ++q)
         if (b->ring_count[q]) HIP_TRY(hipMemset(b->ring_count[q], 0, sizeof(uint32_t) * 4));
@@ -635,22 +556,11 @@ int gnuais_batch_set_option(gnuais_batch *b, const char *name, int value)
     if (!strcmp(name, "fir_T")) {
         if (value < 64 || value % 32) return fail(GNUAIS_E_ARG, "fir_T must be a multiple of 32, >= 64");
         b->fir_T = value;
-    } else if (!strcmp(name, "fir_map")) {
-        b->fir_map = value;
     } else if (!strcmp(name, "nbuf")) {             // hand-off sets in use: the calls that may be in flight
         if (value < 2 || value > gnuais_batch::NBUF) return fail(GNUAIS_E_ARG, "nbuf must be 2..8");
         if (int rc = gnuais_batch_sync(b)) return rc;
         HIP_TRY(hipDeviceSynchronize());
         b->nbuf = value;
-    } else if (!strcmp(name, "fir_streams")) {
-        if (value != 1 && value != 2) return fail(GNUAIS_E_ARG, "fir_streams must be 1 or 2");
-        if (int rc = gnuais_batch_sync(b)) return rc;
-        b->fir_streams = value;
-    } else if (!strcmp(name, "k2b_dataflow")) {
-        if (int rc = gnuais_batch_sync(b)) return rc;
-        b->k2b_dataflow = value != 0;
-    } else if (!strcmp(name, "cold_hold_us")) {
-        b->cold_hold_us = value < 0 ? -1 : value;
     } else if (!strcmp(name, "streaming")) {
         // 0: leave the streamed delivery (gnuais_batch_stream_nmea / autotune_delivery switch it on): everything in
         // flight is flushed and DROPPED, K3 goes back to ring 0, the drain-type calls work again.  The rings, texts
@@ -669,47 +579,11 @@ int gnuais_batch_set_option(gnuais_batch *b, const char *name, int value)
             b->hdlc_calls = 0;
             b->streaming = false;
         }
-    } else if (!strcmp(name, "fir_T2")) {
-        if (value < 0 || value % 32) return fail(GNUAIS_E_ARG, "fir_T2 must be a multiple of 32 (0: off)");
-        b->fir_T2 = value;
-    } else if (!strcmp(name, "fir_persist")) {
-        if (value < 0 || value > 16) return fail(GNUAIS_E_ARG, "fir_persist: workgroups per SIMD, 0 (off) .. 16");
-        b->fir_persist = value;
-    } else if (!strcmp(name, "fir_tail")) {
-        b->fir_tail = value < 0 ? 0 : value;
-    } else if (!strcmp(name, "fir_cpl")) {
-        if (value != 1 && value != 2 && value != 4) return fail(GNUAIS_E_ARG, "fir_cpl must be 1, 2 or 4");
-        b->fir_cpl = value;
-    } else if (!strcmp(name, "fir_form")) {
-        b->fir_form = value;
-    } else if (!strcmp(name, "k3_same")) {           // K3 on the deframer's stream (1, default) or on its own
-        if (value != 0 && value != 1) return fail(GNUAIS_E_ARG, "k3_same: 0 or 1");
-        if (int rc = gnuais_batch_sync(b)) return rc;
-        b->k3_same = value;
     } else if (!strcmp(name, "fir_flag2")) {         // 0: |y| - eps and two alignbits per output (rounds 1-4)
         if (value != 0 && value != 1) return fail(GNUAIS_E_ARG, "fir_flag2: 0 or 1");
         b->fir_flag2 = value;
-    } else if (!strcmp(name, "fir_nc")) {
-        if (value != 0 && value != 12) return fail(GNUAIS_E_ARG, "fir_nc: 0 (the shortest certified central sum) or 12");
-        b->fir_nc = value;
-    } else if (!strcmp(name, "fir_pk")) {
-        b->fir_pk = value < 0 ? -1 : (value != 0);
-    } else if (!strcmp(name, "fir_inloop")) {
-        b->fir_inloop = value != 0;
-    } else if (!strcmp(name, "fir_dbg")) {
-        b->fir_dbg = value;
-    } else if (!strcmp(name, "fir_lds")) {
-        b->fir_lds = value;
-    } else if (!strcmp(name, "fir_stamps")) {
-        if (value && !b->d_stamps) {
-            // one pair of stamps per workgroup of the largest grid the launcher can make: the shortest segment it
-            // accepts is 64 outputs (fir_T >= 64; the short tail segments fir_T2 are multiples of the same quantum)
-            b->stamps_waves = (size_t) (b->N / 64 + 1) * (size_t) (b->max_len / 64 + 2);
-            HIP_TRY(hipMalloc((void **) &b->d_stamps, b->stamps_waves * 16));
-            HIP_TRY(hipMemset(b->d_stamps, 0, b->stamps_waves * 16));
-        }
     } else if (!strcmp(name, "fir_variant")) {
-        if (value < 0 || value > 3) return fail(GNUAIS_E_ARG, "fir_variant must be 0..3");
+        if (value != 0 && value != 3) return fail(GNUAIS_E_ARG, "fir_variant must be 0 (the exact sum for every sample) or 3 (the sign-exact slicer)");
         b->fir_variant = value;
     } else if (!strcmp(name, "timing_stride")) {
         if (value < 1) return fail(GNUAIS_E_ARG, "timing_stride must be >= 1");
@@ -718,8 +592,8 @@ int gnuais_batch_set_option(gnuais_batch *b, const char *name, int value)
         b->pipeline = value != 0;
 
     } else if (!strcmp(name, "pll_variant")) {
-        if (value != 0 && value != 3 && value != 4 && value != 6 && value != 7 && value != 8 && value != 32 && value != 51 && value != 52)
-            return fail(GNUAIS_E_ARG, "pll_variant must be 0 (by channel count), 3, 4, 6 (lane-per-channel forms) or 7 (time-parallel)");
+        if (value != 0 && value != 7 && value != 8)
+            return fail(GNUAIS_E_ARG, "pll_variant must be 0 (by channel count), 7 (time-parallel, pll_tp.hip) or 8 (pll_h3.hip)");
         b->pll_variant = value;
     } else if (!strcmp(name, "hdlc_variant")) {
         b->hdlc_variant = value != 0;
@@ -760,10 +634,6 @@ static void fill_fir(const gnuais_batch *b, FirLaunch &f, const int16_t *x, int 
         for (int j = 0; j < b->sign_NC; ++j) f.ctaps[j] = b->te[(b->NE - b->sign_NC) / 2 + j];
     f.te_mem = b->d_taps + b->k0;
     f.map = b->fir_map;
-    f.dbg = b->fir_dbg;
-    f.stamps = b->d_stamps;
-    f.stamps_waves = b->stamps_waves;
-    f.lds_pad = b->fir_lds;
 }
 
 static void fill_hdlc(const gnuais_batch *b, HdlcLaunch &h, int k)
@@ -784,19 +654,12 @@ static void fill_hdlc(const gnuais_batch *b, HdlcLaunch &h, int k)
     h.chunks = (b->streaming && b->ring_runs[b->ring_cur] == 0) ? b->ring_chunks[b->ring_cur] : nullptr;
 }
 
-// does the receive path run the shorter central sum?  (only the one-channel-per-lane scalar kernel is built for it)
 // the stream K3 runs on (and everything that has to come behind the last K3)
 static hipStream_t k3_stream(const gnuais_batch *b)
 {
     // not while the batch is streaming: K3 then waits for the delivery side (a frame ring to come free), and on the
     // deframer's stream that wait would hold the next deframer launch too (0.89 against 0.62 ms per delivered step)
     return (b->k3_same && b->k2b_lag == 1 && !b->streaming) ? b->s_k[2] : b->s_k[3];
-}
-
-static bool sign_lo(const gnuais_batch *b)
-{
-    return b->sign_ok && b->sign_NC == 12 && b->sign_NC_lo > 0 && b->fir_nc != 12 && b->fir_variant == 3 &&
-           b->fir_pk != 1 && b->fir_cpl <= 1;
 }
 
 // K1 + carry.  The specialised kernel updates the history and clears the next peak
@@ -808,15 +671,13 @@ static int run_fir(gnuais_batch *b, const int16_t *x, int len, float *dump, hipS
     if (b->fir_variant == 3 && b->sign_ok && !dump) {
         const int q = launch_fir_sign_quantum(f.NC);        // whole loop turns of the kernel's unrolled body
         f.T = std::min((f.T + q - 1) / q * q, 65280 / q * q);       // K1s notes open outputs as 16-bit offsets into the segment
-        // several adjacent channels per lane (wide typed loads) where the table, the channel count and the
-        // buffer's alignment allow; one channel per lane otherwise
-        if ((b->fir_pk == 1 || (b->fir_pk < 0 && f.NC == 48)) &&
-            ((f.NC == 12 && f.NE == 32) || (f.NC == 48 && f.NE - f.NC <= 98 && f.eps_seen > 0.0f))) {
+        // 48 central taps (the 192 kHz table): the transposed sum on register pairs (fir_sign_pk.hip)
+        if (f.NC == 48 && f.NE - f.NC <= 98 && f.eps_seen > 0.0f) {
             const int qp = launch_fir_sign_pk_quantum();
             // 48 taps: a segment's warm-up is 47 pair steps' worth of samples; longer segments (there are plenty of
             // waves: 16384 x 192000 is 16000 segments of 3072) cut its share (round 4: 3072 against 1536, 4.29 against
             // 4.39 ms per C5 call in steady state, profiles/r04_c5_ring_and_segments.txt)
-            f.T = ((f.NC == 48 && b->fir_T <= 768 ? 3072 : b->fir_T) + qp - 1) / qp * qp;
+            f.T = ((b->fir_T <= 768 ? 3072 : b->fir_T) + qp - 1) / qp * qp;
             f.T = std::min(f.T, 65280 / qp * qp);           // the kernel notes open outputs as 16-bit offsets into the segment
             HIP_TRY(launch_fir_sign_pk(f, s));
             b->hist_cur = (b->hist_cur + 1) % gnuais_batch::HB;
@@ -824,40 +685,13 @@ static int run_fir(gnuais_batch *b, const int16_t *x, int len, float *dump, hipS
             b->max_cur = (b->max_cur + 1) % gnuais_batch::HB;
             return GNUAIS_OK;
         }
-        const int cpl = (f.NC == 12 && f.NE == 32 && b->fir_cpl > 1 && b->N % b->fir_cpl == 0 &&
-                         ((uintptr_t) x & (uintptr_t) (2 * b->fir_cpl - 1)) == 0) ? b->fir_cpl : 1;
-        // The launch's last round of waves takes short segments (fir_slice.hip: fir_sign_kernel): as many long
-        // segments as leave fir_tail / 10 rounds of resident waves (five per SIMD) of work for the short ones
-        if (f.NC == 12 && b->fir_T2 > 0 && b->fir_tail > 0) {
-            const int groups = (b->N / cpl + 63) / 64, nseg = (len + f.T - 1) / f.T;
-            const int per_round = std::max(1, b->n_cu * 20 / std::max(1, groups));      // long segments one round covers
-            const int tail_segs = (per_round * b->fir_tail + 9) / 10;
-            f.T2 = (b->fir_T2 + q - 1) / q * q;
-            f.n_big = std::max(0, nseg - tail_segs);
-            if (f.T2 >= f.T) f.T2 = 0;
-        }
-        f.persist = b->fir_persist * 4 * b->n_cu;
-        if (cpl > 1) {
-            HIP_TRY(launch_fir_sign_wide(f, cpl, b->fir_form, s));
-        } else {
-            if (f.NC == 12 && b->fir_flag2) f.fscale = b->sign_fscale;
-            if (sign_lo(b)) {                   // the one-channel-per-lane kernel: ten central taps where the table allows
-                f.NC = b->sign_NC_lo;
-                f.eps = b->sign_eps_lo;
-                f.fscale = b->fir_flag2 ? b->sign_fscale_lo : 0.0f;
-                for (int j = 0; j < f.NC; ++j) f.ctaps[j] = b->te[(b->NE - f.NC) / 2 + j];
-            }
-            HIP_TRY(launch_fir_sign(f, s));
-        }
+        if (f.NC == 12 && b->fir_flag2) f.fscale = b->sign_fscale;
+        HIP_TRY(launch_fir_sign(f, s));
     } else if (b->NE != 32) {
         HIP_TRY(hipMemsetAsync(b->maxval[(b->max_cur + 2) % gnuais_batch::HB], 0, sizeof(int) * (size_t) b->N, s));
         HIP_TRY(launch_fir_generic(f, s));
         HIP_TRY(launch_fir_history(x, b->hist[b->hist_cur], b->hist[(b->hist_cur + 1) % gnuais_batch::HB], b->N, len,
                                    b->NT, s));
-    } else if (b->fir_variant == 1) {
-        HIP_TRY(packed::launch_fir_slice(f, s));
-    } else if (b->fir_variant == 2) {
-        HIP_TRY(mfma::launch_fir_slice(f, s));
     } else {
         HIP_TRY(scalar::launch_fir_slice(f, s));
     }
@@ -880,14 +714,12 @@ static void fill_pll(const gnuais_batch *b, PllLaunch &p, int k, int len)
 // K2b, K3 of one call, each on its own stream (pipeline) or all on s0, after `after`
 // (the event that says this call's PLL stage is done; null = stream order on s0).
 static int run_tail(gnuais_batch *b, int k, int len, bool tm, hipEvent_t *ev,
-                    hipStream_t s0, hipEvent_t after, const uint32_t *progress = nullptr, uint32_t progress_base = 0)
+                    hipStream_t s0, hipEvent_t after)
 {
     const bool pl = b->pipeline;
     hipStream_t sC = pl ? b->s_k[2] : s0, sD = pl ? k3_stream(b) : s0;
     HdlcLaunch h;
     fill_hdlc(b, h, k);
-    h.progress = progress;                      // K2b beside the PLL launch (`after` is then the FIR's event, not the PLL's)
-    h.progress_base = progress_base;
     // K2b: needs segbits[k]; fills cand_first/count[k] (read by K3 of call - NBUF).  It also writes
     // the per-channel candidate ring that K3 of the PREVIOUS call may still be reading: slots are
     // reused after cand_K frame starts, which one call cannot exceed but two could
@@ -923,24 +755,6 @@ int gnuais_batch_run(gnuais_batch *b, const int16_t *d_samples, int len, void *s
 
     {
         hipStream_t sA = pl ? b->s_k[0] : s0;
-        // Cold start.  A call that finds the pipeline empty has its PLL stage ready when its FIR launch ends, but the
-        // next call's FIR launch is queued right behind and its 24 000 workgroups are dispatched first: the PLL stage
-        // then starts a whole FIR launch late (profiles/r03_region_timeline_20steps.txt: ready at 438 us, started at
-        // 848), and everything behind it with it.  So the launch that follows a cold call is held back on the host until
-        // the cold call's FIR has ended (+ cold_hold_us); it would have started ~50 us after that anyway.
-        if (pl && b->cold_hold_us >= 0 && b->calls > 0 && b->calls == b->cold_call + 1 && b->h_started) {
-            // ... until the cold call's PLL launch has placed its last workgroup (it says so itself), at most 3 ms
-            const uint32_t want = (uint32_t) b->cold_call + 1u;
-            const double until = now_ms() + 3.0;
-            while (__atomic_load_n(b->h_started, __ATOMIC_RELAXED) != want && now_ms() < until) {}
-            if (b->cold_hold_us > 0) {
-                const double more = now_ms() + b->cold_hold_us * 1e-3;
-                while (now_ms() < more) {}
-            }
-        }
-        if (pl && b->cold_hold_us >= 0 &&
-            (b->calls == 0 || hipEventQuery(b->e_done[4][b->last_k]) == hipSuccess))
-            b->cold_call = b->calls;            // nothing of an earlier call is left on the device
         // Hand-off set k was last used by call i-nbuf.  Its last user is that call's K3; wait for
         // it on the HOST (normally long done): five stream-wait packets per call, each ~20 us of
         // queue time on the stream it sits in, for a condition that is practically always true.
@@ -951,25 +765,7 @@ int gnuais_batch_run(gnuais_batch *b, const int16_t *d_samples, int len, void *s
         // K1 carries the FIR history and the peak buffers from call to call in stream order: a caller
         // that changes streams between calls gets the old stream drained first
         if (b->calls > 0 && s0 != b->last_stream) HIP_TRY(hipStreamSynchronize(b->last_stream));
-        // fir_streams = 2: the FIR launches alternate between the caller's stream and an internal one.  The launch on
-        // the internal stream starts once the caller's stream has reached this call (its input is there); the caller's
-        // stream waits for it to end (the caller may reuse the input after the call, in stream order).  Launch i needs
-        // of launch i-1 only the carry, which a small kernel in front of launch i-1 has written (e_hist).
-        const bool two = pl && b->fir_streams == 2 && b->fir_variant == 3 && b->sign_ok && (b->stage_mask & 1);
-        const int q = two ? (int) (b->calls & 1) : 0;
         hipStream_t sF = s0;
-        if (two) {
-            if (!b->s_fir2) HIP_TRY(hipStreamCreateWithFlags(&b->s_fir2, hipStreamNonBlocking));
-            if (q) {
-                sF = b->s_fir2;
-                HIP_TRY(hipEventRecord(b->e_order, s0));
-                HIP_TRY(hipStreamWaitEvent(sF, b->e_order, 0));
-            }
-            if (b->calls > 0) HIP_TRY(hipStreamWaitEvent(sF, b->e_hist[q ^ 1], 0));
-            HIP_TRY(launch_fir_history(d_samples, b->hist[b->hist_cur], b->hist[(b->hist_cur + 1) % gnuais_batch::HB],
-                                       b->N, len, b->NT, sF));
-            HIP_TRY(hipEventRecord(b->e_hist[q], sF));
-        }
         if (tm) HIP_TRY(hipEventRecord(ev[0], sF));
         if (b->stage_mask & 1)
             if (int rc = run_fir(b, d_samples, len, nullptr, sF, k)) return rc;
@@ -979,33 +775,16 @@ int gnuais_batch_run(gnuais_batch *b, const int16_t *d_samples, int len, void *s
             b->e_in_hook = nullptr;
         }
         if (pl) HIP_TRY(hipEventRecord(b->e_done[0][k], sF));
-        if (two && q) HIP_TRY(hipStreamWaitEvent(s0, b->e_done[0][k], 0));
         // K2: this call's sign words -> bit packs segbits[k] (read by K2b of call i-nbuf); in order
         // across calls (it carries the receivers' pll / prev / lastbit)
         PllLaunch p;
         fill_pll(b, p, k, len);
-        if (pl && b->cold_hold_us >= 0 && b->cold_call == b->calls) {
-            if (!b->h_started) {
-                HIP_TRY(hipHostMalloc((void **) &b->h_started, 64, hipHostMallocDefault));
-                *b->h_started = 0;
-            }
-            p.started = b->h_started;
-            p.stamp = (uint32_t) b->calls + 1u;
-        }
         if (pl) HIP_TRY(hipStreamWaitEvent(sA, b->e_done[0][k], 0));
-        // K2b of this call starts with the PLL launch (behind the same FIR event) and takes the packs segment by segment
-        // as the PLL stage's writer publishes them, where the PLL form that runs has the hand-over (the three-wave one)
-        const bool flow = pl && b->k2b_dataflow && !b->streaming && b->hdlc_variant == 1 && (b->stage_mask & 0x0a) == 0x0a && pll_form_of(p) == 3;
-        if (flow) {
-            p.progress = b->progress;
-            p.progress_base = (uint32_t) (b->calls * (unsigned long long) b->n_seg);
-        }
         if (tm) HIP_TRY(hipEventRecord(ev[2], sA));
         if (b->stage_mask & 2) HIP_TRY(launch_pll(p, sA));
         if (tm) HIP_TRY(hipEventRecord(ev[6], sA));
         if (pl) HIP_TRY(hipEventRecord(b->e_done[1][k], sA));
-        if (int rc = run_tail(b, k, len, tm, ev, s0, pl ? (flow ? b->e_done[0][k] : b->e_done[1][k]) : nullptr,
-                              flow ? b->progress : nullptr, p.progress_base)) return rc;
+        if (int rc = run_tail(b, k, len, tm, ev, s0, pl ? b->e_done[1][k] : nullptr)) return rc;
     }
 
     b->timed_last = tm;
@@ -1115,7 +894,6 @@ int gnuais_batch_sync(gnuais_batch *b)
     if (!b) return fail(GNUAIS_E_ARG, "sync: NULL batch");
     if (int rc = set_device(b)) return rc;
     HIP_TRY(hipStreamSynchronize(b->last_stream));
-    if (b->s_fir2) HIP_TRY(hipStreamSynchronize(b->s_fir2));
     for (auto &st : b->s_k) HIP_TRY(hipStreamSynchronize(st));
     return GNUAIS_OK;
 }
@@ -1924,13 +1702,13 @@ int gnuais_batch_info(const gnuais_batch *b, const char *name, double *value)
     if (!b || !name || !value) return fail(GNUAIS_E_ARG, "info: argument");
     if (!strcmp(name, "sign_exact")) *value = b->sign_ok && b->fir_variant == 3;
     else if (!strcmp(name, "sign_eps")) {            // of the kernel the options select; FL2: the power of two it works with
-        const float fs = !b->fir_flag2 || b->fir_cpl > 1 || b->fir_pk == 1 ? 0.0f : sign_lo(b) ? b->sign_fscale_lo : b->sign_NC == 12 ? b->sign_fscale : 0.0f;
-        *value = fs > 0.0f ? 2.0f / fs : sign_lo(b) ? b->sign_eps_lo : b->sign_eps;
+        const float fs = !b->fir_flag2 ? 0.0f : b->sign_NC == 12 ? b->sign_fscale : 0.0f;
+        *value = fs > 0.0f ? 2.0f / fs : b->sign_eps;
     }
-    else if (!strcmp(name, "sign_flag_scale")) *value = !b->fir_flag2 ? 0.0f : sign_lo(b) ? b->sign_fscale_lo : b->sign_NC == 12 ? b->sign_fscale : 0.0f;
+    else if (!strcmp(name, "sign_flag_scale")) *value = !b->fir_flag2 ? 0.0f : b->sign_NC == 12 ? b->sign_fscale : 0.0f;
     else if (!strcmp(name, "sign_eps_seen")) *value = b->sign_eps_seen;
     else if (!strcmp(name, "sign_eps_ahead")) *value = b->sign_eps_ahead;
-    else if (!strcmp(name, "sign_central_taps")) *value = sign_lo(b) ? b->sign_NC_lo : b->sign_NC;
+    else if (!strcmp(name, "sign_central_taps")) *value = b->sign_NC;
     else if (!strcmp(name, "first_effective_tap")) *value = b->k0;
     else if (!strcmp(name, "n_effective_taps")) *value = b->NE;
     else if (!strcmp(name, "compute_units")) *value = b->n_cu;
@@ -1943,26 +1721,6 @@ int gnuais_batch_info(const gnuais_batch *b, const char *name, double *value)
 
 int gnuais_batch_n_channels(const gnuais_batch *b) { return b ? b->N : 0; }
 int gnuais_batch_n_taps(const gnuais_batch *b) { return b ? b->NT : 0; }
-
-// experiments only (not in the header): wall-clock (100 MHz) start / end of every K1s wave of the last call
-int gnuais_debug_fir_stamps(gnuais_batch *b, unsigned long long *h_out, size_t max_waves)
-{
-    if (!b || !b->d_stamps || !h_out) return fail(GNUAIS_E_ARG, "debug_fir_stamps: set_option fir_stamps first");
-    if (int rc = set_device(b)) return rc;
-    HIP_TRY(hipDeviceSynchronize());
-    HIP_TRY(hipMemcpy(h_out, b->d_stamps, std::min(max_waves, b->stamps_waves) * 16, hipMemcpyDeviceToHost));
-    return GNUAIS_OK;
-}
-
-// experiments only (not in the header): wall-clock (100 MHz) stamps of the time-parallel PLL's phases, workgroup 0, last launch
-int gnuais_debug_pll_tp_stamps(gnuais_batch *b, unsigned long long *h8)
-{
-    if (!b || !h8) return fail(GNUAIS_E_ARG, "debug_pll_tp_stamps: argument");
-    if (int rc = set_device(b)) return rc;
-    HIP_TRY(hipDeviceSynchronize());
-    HIP_TRY(pll_tp_read_stamps(h8));
-    return GNUAIS_OK;
-}
 
 int gnuais_batch_set_timing(gnuais_batch *b, int on)
 {

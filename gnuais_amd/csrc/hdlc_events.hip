@@ -81,8 +81,7 @@ __global__ __launch_bounds__(64) EV_OCC void hdlc_events_kernel(
     const uint32_t *__restrict__ segbits, const uint32_t *__restrict__ segcnt,
     uint32_t *__restrict__ ctl, uint32_t *__restrict__ cand, uint32_t *__restrict__ cand_first,
     uint32_t *__restrict__ cand_count, int32_t *__restrict__ counters,
-    uint32_t *__restrict__ flags, int N, int n_seg, int seg_words, int K,
-    const uint32_t *__restrict__ progress, uint32_t progress_base)
+    uint32_t *__restrict__ flags, int N, int n_seg, int seg_words, int K)
 {
     __builtin_amdgcn_s_setprio(3);      // latency-bound chain: take every issue slot it can use
     extern __shared__ uint32_t lds[];
@@ -220,38 +219,12 @@ __global__ __launch_bounds__(64) EV_OCC void hdlc_events_kernel(
     };
 
     const uint32_t *__restrict__ rows = segbits + c * (size_t) n_seg * (size_t) PACK_STRIDE;
-    // Hand-over by segment (progress != NULL): this launch runs BESIDE the PLL launch that writes its packs.  Segment s
-    // of a 64-channel group is there once the group's counter has passed progress_base + s (agent-scope release by the
-    // PLL stage's writer wave, acquire here); the next pack is requested early only when it is already there.  A
-    // counter that does not move for 200 ms means the PLL launch gave up (its own watchdog): say so and go on.
-    const uint32_t *const prog = progress ? progress + (c >> 6) : nullptr;
-    const unsigned long long t_start = wall_clock64();
-    auto published = [&](int seg) -> bool {      // the lane's group has segment `seg` in HBM
-        return (int32_t) (__hip_atomic_load(prog, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - (progress_base + (uint32_t) seg + 1u)) >= 0;
-    };
-    auto await = [&](int seg) {
-        if (!prog) return;
-        while (!__all((int) published(seg))) {
-            if (wall_clock64() - t_start > 20000000ull) { if (tx == 0) atomicOr(&flags[3], 1u); break; }
-            __builtin_amdgcn_s_sleep(64);       // ~2 us: a segment takes the PLL stage ~20; every poll goes past the L2
-            __builtin_amdgcn_s_sleep(64);
-        }
-        asm volatile("" ::: "memory");          // nothing of the pack is asked for before the counter has been seen
-    };
     uint32_t pf[EW];
     int pf_cnt = 0;
     bool pf_ready = false;                      // pf / pf_cnt hold the pack of the segment the loop is about to take
     auto fetch = [&](int seg) {
         const uint32_t *__restrict__ row = rows + (size_t) seg * (size_t) PACK_STRIDE;
-        if (prog) {
-            // written by a launch that is still running, on whatever XCD: agent-scope loads (past this XCD's L2),
-            // issued once the counter has been seen -- no cache is invalidated
-            uint32_t *cnt_p = const_cast<uint32_t *>(segcnt) + c * (size_t) n_seg + seg;
-            pf_cnt = live ? (int) __hip_atomic_load(cnt_p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
-#pragma unroll
-            for (int q = 0; q < EW; ++q)
-                pf[q] = __hip_atomic_load(const_cast<uint32_t *>(row) + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        } else {
+        {
             pf_cnt = live ? (int) segcnt[c * (size_t) n_seg + seg] : 0;
 #pragma unroll
             for (int q = 0; q < EW / 4; ++q) {
@@ -263,10 +236,7 @@ __global__ __launch_bounds__(64) EV_OCC void hdlc_events_kernel(
     };
 
     for (int seg = 0; seg < n_seg; ++seg) {
-        if (!pf_ready) {
-            await(seg);
-            fetch(seg);
-        }
+        if (!pf_ready) fetch(seg);
         int tile_end = pf_cnt;
         if (tile_end > seg_words * 32) tile_end = seg_words * 32;
 
@@ -280,13 +250,7 @@ __global__ __launch_bounds__(64) EV_OCC void hdlc_events_kernel(
 #pragma unroll
         for (int q = 0; q < EW; ++q) XW(q) = pf[q];
         pf_ready = false;
-        if (seg + 1 < n_seg) {              // the next pack is on its way while this one is walked -- if it exists yet
-            if (!prog) {
-                fetch(seg + 1);
-            } else if (__all((int) published(seg + 1))) {
-                fetch(seg + 1);
-            }
-        }
+        if (seg + 1 < n_seg) fetch(seg + 1);    // the next pack is on its way while this one is walked
         const int nwq = __builtin_amdgcn_readfirstlane((int) wave_max_i((tile_end + 31) >> 5, tpb, tx));
 #if EV_BITMAPS32
         // Every "bit i of (v << d) is bit i-d of v" below takes the bits that come in from the word before out of THAT
@@ -623,7 +587,7 @@ hipError_t launch_hdlc_events(const HdlcLaunch &a, hipStream_t stream)
     const size_t lds = EV_ROWS * lpw * sizeof(uint32_t);
 #define EV_LAUNCH(T)                                                                                                  \
     hipLaunchKernelGGL(hdlc_events_kernel<T>, grid, block, lds, stream, a.segbits, a.segcnt, a.ctl, a.cand, a.cand_first, \
-                       a.cand_count, a.counters, a.frame_count, a.N, a.n_seg, a.seg_words, a.K, a.progress, a.progress_base)
+                       a.cand_count, a.counters, a.frame_count, a.N, a.n_seg, a.seg_words, a.K)
     switch (lpw) {
     case 8: EV_LAUNCH(8); break;
     case 16: EV_LAUNCH(16); break;

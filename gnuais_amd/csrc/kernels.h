@@ -36,8 +36,6 @@ struct FirLaunch {
 };
 int launch_fir_sign_quantum(int NC);           // T must be a multiple of this
 hipError_t launch_fir_sign(const FirLaunch &a, hipStream_t stream);
-// K1s with cpl = 2 / 4 adjacent channels per lane (fir_sign_wide.hip): 12 central taps of a 32-tap table only
-hipError_t launch_fir_sign_wide(const FirLaunch &a, int cpl, int form, hipStream_t stream);
 // K1s in transposed form on register pairs (fir_sign_pk.hip): NC 12 (32-tap table) or 48
 int launch_fir_sign_pk_quantum();
 hipError_t launch_fir_sign_pk(const FirLaunch &a, hipStream_t stream);
@@ -45,7 +43,7 @@ hipError_t launch_fir_generic(const FirLaunch &a, hipStream_t stream);
 hipError_t launch_fir_history(const int16_t *x, const int16_t *hist_in, int16_t *hist_out,
                               int N, int L, int NT, hipStream_t stream);
 
-// ---- K2: PLL clock recovery, slice + NRZI (pll_nrzi.hip) --------------------------
+// ---- K2: PLL clock recovery, slice + NRZI (pll_h3.hip, pll_tp.hip) ----------------
 constexpr int PLL_LDS_BYTES = 81 * 1024;   // > half of a CU's LDS: one PLL workgroup per CU
 constexpr int SEG_WORDS = 64;        // segment (one bit pack per channel): 64 sign words
 constexpr int SEG_LEN = SEG_WORDS * 32;    //   = 2048 samples
@@ -72,25 +70,15 @@ struct PllLaunch {
     int N, L, n_seg, seg_words;
     uint32_t pllinc;
     int n_cu;              // compute units of the batch's device
-    int variant = 0;       // 0: by channel count; 3 / 6: the three- / six-wave form; 7: the time-parallel form (pll_tp.hip)
-    uint32_t *started = nullptr;   // host-visible word (or NULL): the launch's last workgroup writes `stamp` when it starts
-    uint32_t stamp = 0;
-    // segment-level hand-over to K2b (the three-wave form only): progress[group of 64 channels] is raised to
-    // progress_base + s + 1 (agent-scope release) once segment s of the call is in HBM, to progress_base + n_seg at the end
-    uint32_t *progress = nullptr;
-    uint32_t progress_base = 0;
+    int variant = 0;       // 0: by channel count; 7: the time-parallel form (pll_tp.hip); 8: one recurrence wave + three helpers (pll_h3.hip)
 };
-int pll_form_of(const PllLaunch &a);                                     // the form launch_pll() will take: 3, 32, 4, 51, 52, 6, 7
+int pll_form_of(const PllLaunch &a);                                     // the form launch_pll() will take: 7 or 8
 int pll_need_lds();                                                      // bytes of LDS a PLL workgroup cannot do without
 hipError_t pll_prepare_device();                                         // once per device, after hipSetDevice
 hipError_t launch_pll(const PllLaunch &a, hipStream_t stream);           // K2
 // K2 in its time-parallel form (pll_tp.hip): a workgroup per channel, lanes = candidate phases; small batches
 bool pll_tp_applicable(const PllLaunch &a);
 hipError_t launch_pll_tp(const PllLaunch &a, hipStream_t stream);
-hipError_t pll_tp_read_stamps(unsigned long long *h8);                   // experiments: phase stamps of workgroup 0
-// K2 as one recurrence wave + three helper waves per 64 channels (pll_h3.hip): what the full pipeline runs
-hipError_t pll_h3_prepare_device();
-hipError_t launch_pll_h3(const PllLaunch &a, hipStream_t stream);
 constexpr int PLL_TP_MAX_CHANNELS = 512;  // launch_pll() takes the time-parallel form by itself up to this many channels
 
 // ---- K2b: HDLC deframer, K3: CRC-16 + frame delivery (hdlc_crc.hip) ---------
@@ -112,10 +100,6 @@ struct HdlcLaunch {
     int N, n_seg, seg_words, K;   // K: slots of a channel's candidate ring
     int K_call = 0;        // most frame starts one call can have (<= K; 0: K); sizes the chunk table
     int lanes_per_wave;    // channels per wave in K2b (blockDim)
-    // K2b started TOGETHER with the PLL launch that writes its packs: segment s of 64-channel group g may be read once
-    // progress[g] - progress_base > s (agent-scope acquire); NULL: the packs are complete when K2b starts
-    const uint32_t *progress = nullptr;
-    uint32_t progress_base = 0;
     uint2 *chunks = nullptr;   // optional [blocks of K3][k3_passes(K)]: where each pass of each K3 block put its
                            // frames in the ring (start, count).  (block, pass, position) is the reference's
                            // print order -- channel, then time -- so a ring that holds ONE call needs no sort

@@ -1,17 +1,40 @@
-// pll_h3.hip -- K2, the form the full pipeline runs from round 5 on: bit-clock recovery PLL, slice and NRZI decode for
-// gfx950 (gnuais src/receiver.c:109-135) as ONE recurrence wave and THREE uniform helper waves per 64 channels.
+// pll_h3.hip -- K2: bit-clock recovery PLL, slice and NRZI decode for gfx950, ONE recurrence wave and THREE helper waves
+// per 64 channels.  Stands in for the per-sample loop of receiver_run(), gnuais src/receiver.c:109-135, for a whole
+// batch of channels.
 //
-// What is computed, and why a transition toggles exactly one output bit (bits = ~XOR_j 1 << floor(U(t_j) / 2^16)), is
-// derived in pll_nrzi3.hip.  What this form is about is measured in profiles/r05_pll_wave_budget.txt:
+// The reference touches the phase on every sample, but only a sign change of the filter output (a "transition",
+// receiver.c:113) makes it do anything that is not linear:
+//
+//     transition at sample t :  pll += (pll < 0x8000) ? +pllinc/16 : -pllinc/16     receiver.c:114-117
+//     every sample           :  pll += pllinc;  overflow -> slice, pll &= 0xffff    receiver.c:122-133
+//
+// Write the phase without the `& 0xffff`: U(t) = pll0 + t * pllinc + K(t), K = the nudges so far.  U only grows
+// (pllinc > pllinc/16), a nudge never crosses a multiple of 2^16 (pll < 0x8000 -> +q stays below 0x10000,
+// pll >= 0x8000 -> -q stays above 0), and pllinc + q < 2^16, so the slices are exactly the times U crosses a multiple
+// of 2^16: floor(U / 2^16) slices have happened before sample t, and the nudge at a transition needs U mod 2^16 there,
+// nothing else.  The bit the reference emits at a slice is 1 if the level (the sign of the filter output) is the same
+// as at the previous slice, 0 if it differs (receiver.c:126-132), i.e. NOT the parity of the transitions since the
+// previous slice.  A transition at sample t (the level a slice AT t sees is already the new one) therefore toggles
+// exactly one bit of the output: number floor(U(t) / 2^16).  So
+//
+//     bits = ~( XOR over the transitions of  1 << floor(U(t_j) / 2^16) )
+//
+// which turns 48 000 dependent steps per channel and call into ~13 000: one per transition of the busiest of a wave's
+// 64 channels, re-synchronised every 128 samples (the busiest single channel has 8 000; lanes that ran ahead freely
+// would need rings of thousands of entries: profiles/r05_pll_wave_budget.txt).
+// Output: one pack of <= PACK_STRIDE words + a bit count per (channel, 2048-sample segment); bit k of a pack is at
+// word k/32, bit k%32.
+//
+// How it is laid out follows from three measurements (profiles/r05_pll_wave_budget.txt, r05_ubench_pll_rows_sched.txt,
+// r05_pll_h3_in_the_pipeline.txt):
 //
 //   * a lone wave issues ONE instruction per ~6.5 clock ticks, whatever the dependencies between them (reordering a row
-//     for instruction-level parallelism changes nothing, profiles/r05_ubench_pll_rows_sched.txt): the recurrence wave
-//     of the three-wave form spends 92 % of the launch inside its rows, 77 ticks per transition for twelve
-//     instructions.  Its time is its instruction count; everything that is not the recurrence has to leave that wave.
+//     for instruction-level parallelism changes nothing): the recurrence wave of round 4's three-wave form spent 92 % of
+//     the launch inside its rows, 77 ticks per transition for twelve instructions.  Its time is its instruction count;
+//     everything that is not the recurrence has to leave that wave.
 //   * beside the FIR (four waves of 104 registers per SIMD, 96 left) a workgroup is placed at once only if it asks for
-//     one wave of <= 96 registers per SIMD: the six-wave form (pll_nrzi.hip: two waves on two of the SIMDs) finishes a
-//     call in 0.31 ms alone and needs 0.58-0.63 inside the pipeline, waiting for FIR waves to retire in pairs.
-//
+//     one wave of <= 96 registers per SIMD: round 4's six-wave form (two waves on two of the SIMDs) finished a call in
+//     0.31 ms alone and needed 0.58-0.63 inside the pipeline, waiting for FIR waves to retire in pairs.
 //   * a block of 128 samples holds at most 30 slices (create refuses pllinc > 14426), so the toggles of a block fit ONE
 //     32-bit mask per lane: with the phase scaled by 2^8 the slice number of a transition is byte 3 of U, and
 //     `v_lshlrev_b32_sdwa bit, U.byte3, 1` + `v_xor` toggle it in a REGISTER -- two instructions instead of the five
@@ -30,7 +53,7 @@
 
 #include <algorithm>
 #include "kernels.h"
-#include "pll_common.h"      // LDS hand-over primitives, the byte table, the writer's way out of a pack
+#include "pll_common.h"      // LDS hand-over primitives, the byte table, the pack geometry
 
 namespace gnuais {
 
@@ -69,7 +92,7 @@ __device__ unsigned long long pllh3_budget[4096 * 16];
 #pragma clang diagnostic ignored "-Wunused-but-set-variable"
 #endif
 
-// One block's transition lists (pll_common.h: pll_expand_block, for a block of H3_WORDS sign words): D = S ^ (S >> 1)
+// One block's transition lists: D = S ^ (S >> 1)
 // (receiver.c:113) expanded byte by byte through the table, one unaligned ds_write_b64 per byte into the lane's strip.
 // `prev` = the sign before the block, updated to the sign of its last valid sample; nv = valid samples.
 __device__ __forceinline__ void h3_expand_block(const uint32_t (&S)[H3_WORDS], uint32_t &prev, int nv, uint8_t *lds,
@@ -171,8 +194,7 @@ __device__ __forceinline__ uint32_t h3_rows(uint32_t &X, uint32_t cnt, uint32_t 
 }
 
 // A finished pack leaves (helper 0): complement the toggle words, trim to the segment's nb bits, clear the buffer, take
-// the toggle that fell on the NEXT slice (pll_common.h: pll_pack_out / pll_pack_store, four words at a time so that the
-// helper's other roles keep their registers).  `par` = the parity carried from pack to pack (receiver.c:128: a transition
+// the toggle that fell on the NEXT slice (four words at a time: the helper's other role keeps its registers).  `par` = the parity carried from pack to pack (receiver.c:128: a transition
 // after a segment's last slice toggles the first bit of the next segment that has one, or of a later call); returns it.
 __device__ __forceinline__ uint32_t h3_write_pack(uint32_t *pk, uint32_t nb, uint32_t par, bool live,
                                                   uint32_t *__restrict__ dst, uint32_t *__restrict__ dcnt)
@@ -383,13 +405,24 @@ extern "C" int gnuais_debug_pllh3_budget(unsigned long long *out, int n_wg)
 }
 #endif
 
-hipError_t pll_h3_prepare_device()
+int pll_need_lds() { return H3_NEED_LDS; }
+
+hipError_t pll_prepare_device()
 {
     return hipFuncSetAttribute((const void *) pll_h3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
 }
 
-hipError_t launch_pll_h3(const PllLaunch &a, hipStream_t stream)
+// Which form: the time-parallel one (pll_tp.hip: a workgroup per channel, 64 x the instructions, a fifth of the latency)
+// where the batch leaves the chip nearly empty and that implementation applies; this one otherwise.
+int pll_form_of(const PllLaunch &a)
 {
+    if ((a.variant == 7 || (a.variant == 0 && a.N <= PLL_TP_MAX_CHANNELS)) && pll_tp_applicable(a)) return 7;
+    return 8;
+}
+
+hipError_t launch_pll(const PllLaunch &a, hipStream_t stream)
+{
+    if (pll_form_of(a) == 7) return launch_pll_tp(a, stream);
     // one workgroup per CU while the channel groups fit one round; beyond that share the CUs evenly
     const int n_cu = a.n_cu > 0 ? a.n_cu : 256;
     const int groups = (a.N + 63) / 64, per_cu = (groups + n_cu - 1) / n_cu;

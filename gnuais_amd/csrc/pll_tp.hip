@@ -131,14 +131,12 @@ __device__ __forceinline__ int tp_popc(const uint64_t d[4])
 
 } // namespace
 
-// experiments only: wall-clock (100 MHz) stamps of workgroup 0's phases of the last launch (gnuais_debug_pll_tp_stamps)
-__device__ unsigned long long tp_stamps[8];
 
 // One workgroup per channel.  LDS: the chunk's table, per-block transition counts / true c_in / last signs, the bit packs.
 __global__ __launch_bounds__(64 * TP_WAVES) void pll_tp_kernel(
     const uint32_t *__restrict__ sgn, uint32_t *__restrict__ pllst, uint32_t *__restrict__ prevst,
     uint32_t *__restrict__ lastbit, uint32_t *__restrict__ segbits, uint32_t *__restrict__ segcnt,
-    int N, int L, int n_seg_alloc, uint32_t pllinc, uint32_t *__restrict__ started, uint32_t stamp)
+    int N, int L, int n_seg_alloc, uint32_t pllinc)
 {
     extern __shared__ uint32_t tp_lds[];
     const int n_blk = (L + TP_BLK - 1) / TP_BLK;
@@ -155,11 +153,7 @@ __global__ __launch_bounds__(64 * TP_WAVES) void pll_tp_kernel(
     const uint32_t q = pllinc / 16u;                          // receiver.c:84,115,117
     const uint32_t pll0 = pllst[c] & 0xffffu;                 // receiver.h:40
     const uint32_t prev0 = prevst[c] & 1u;                    // receiver.h:44
-    const bool stamps = blockIdx.x == 0 && threadIdx.x == 0;
-    if (stamps) tp_stamps[0] = wall_clock64();
 
-    if (started && blockIdx.x == gridDim.x - 1 && threadIdx.x == 0)
-        __hip_atomic_store(started, stamp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     for (int i = (int) threadIdx.x; i < n_seg * PACK_STRIDE; i += 64 * TP_WAVES) pack[i] = 0;
 
     // ---- pre-pass, lane = block: the number of transitions and the sign of the block's last sample (a block's
@@ -189,7 +183,6 @@ __global__ __launch_bounds__(64 * TP_WAVES) void pll_tp_kernel(
         if (threadIdx.x == 0) cin[0] = 0;                     // c = 0 at the call's first sample, by definition
     }
     __syncthreads();
-    if (stamps) tp_stamps[1] = wall_clock64();
 
     // ---- chunks: pass 1 (all waves), walk (one wave)
     for (int b0 = 0; b0 < n_blk; b0 += TP_CHUNK) {
@@ -208,7 +201,6 @@ __global__ __launch_bounds__(64 * TP_WAVES) void pll_tp_kernel(
             tab[(b - b0) * 64 + lane] = tp_run_block(d, base, pllinc, q, cc + odd + 2 * (lane - TP_HALF));
         }
         __syncthreads();
-        if (stamps) tp_stamps[2 + (b0 ? 2 : 0)] = wall_clock64();      // (first chunk: [2] pass 1, [3] walk; later ones overwrite [4], [5])
         if (wave == 0) {
             // the walk: uniform over the wave (every lane carries the same value); one dependent LDS read per block --
             // the blocks' parities come as a ballot, lane i = block b0 + i
@@ -233,7 +225,6 @@ __global__ __launch_bounds__(64 * TP_WAVES) void pll_tp_kernel(
             if (b0 + lane < b1) cin[b0 + lane + 1] = res;
         }
         __syncthreads();
-        if (stamps) tp_stamps[3 + (b0 ? 2 : 0)] = wall_clock64();
     }
 
     // ---- pass 3: lane = block.  Toggle bit floor(U(t) / 2^16) - (slices before the segment) of the segment's pack for
@@ -262,7 +253,6 @@ __global__ __launch_bounds__(64 * TP_WAVES) void pll_tp_kernel(
         }
     }
     __syncthreads();
-    if (stamps) tp_stamps[6] = wall_clock64();
 
     // ---- the packs leave: one lane per segment forms its words, lane 0 carries the parity from segment to segment
     // (pll_nrzi3.hip's writer: a transition after a segment's last slice toggles the first bit of the next segment that
@@ -308,13 +298,8 @@ __global__ __launch_bounds__(64 * TP_WAVES) void pll_tp_kernel(
         segbits[((size_t) c * n_seg_alloc + (size_t) (i / PACK_STRIDE)) * PACK_STRIDE + (size_t) (i % PACK_STRIDE)] = pack[i];
     for (int s = (int) threadIdx.x; s < n_seg_alloc; s += 64 * TP_WAVES)
         segcnt[(size_t) c * n_seg_alloc + s] = s < n_seg ? nbs[s] : 0u;
-    if (stamps) tp_stamps[7] = wall_clock64();
 }
 
-hipError_t pll_tp_read_stamps(unsigned long long *h8)
-{
-    return hipMemcpyFromSymbol(h8, HIP_SYMBOL(tp_stamps), sizeof(unsigned long long) * 8);
-}
 
 // The time-parallel form is exact for any input; these are the limits of THIS implementation: whole 32-bit unwrapped
 // phase (U = pll0 + L * pllinc + q * c < 2^32 with |c| <= L), its LDS tables, and a call long enough to be worth it.
@@ -342,7 +327,7 @@ hipError_t launch_pll_tp(const PllLaunch &a, hipStream_t stream)
         raised[dev] = true;
     }
     hipLaunchKernelGGL(pll_tp_kernel, dim3(a.N), dim3(64 * TP_WAVES), lds, stream, a.sgn, a.pll, a.prev, a.lastbit,
-                       a.segbits, a.segcnt, a.N, a.L, a.n_seg, a.pllinc, a.started, a.stamp);
+                       a.segbits, a.segcnt, a.N, a.L, a.n_seg, a.pllinc);
     return hipGetLastError();
 }
 

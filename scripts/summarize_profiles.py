@@ -16,7 +16,7 @@ root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 out = sys.argv[3] if len(sys.argv) > 3 else os.path.join(root, "profiles")      # the GPU box writes next to the raw files
 os.makedirs(out, exist_ok=True)
 
-SHORT = [("fir_sign_pk", "fir_slice"), ("fir_sign_wide", "fir_slice"), ("fir_sign_kernel", "fir_slice"), ("fir_slice_kernel", "fir_slice"), ("pll_kernel", "pll"), ("pll3_kernel", "pll"), ("pll_tp_kernel", "pll"),
+SHORT = [("fir_sign_pk", "fir_slice"), ("fir_sign_kernel", "fir_slice"), ("fir_slice_kernel", "fir_slice"), ("pll_h3_kernel", "pll"), ("pll_tp_kernel", "pll"),
          ("hdlc_events_kernel", "hdlc_deframe"), ("hdlc_deframe_kernel", "hdlc_deframe"),
          ("hdlc_crc_kernel", "hdlc_crc")]
 

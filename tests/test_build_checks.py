@@ -45,5 +45,5 @@ def test_only_the_named_kernels_are_judged(tmp_path):
 
 def test_the_makefile_runs_the_check_on_the_chain_kernels():
     mk = open(os.path.join(ROOT, "gnuais_amd", "csrc", "Makefile")).read()
-    for obj in ("hdlc_events.s", "hdlc_crc.s", "pll_nrzi3.s"):
+    for obj in ("hdlc_events.s", "hdlc_crc.s", "pll_h3.s"):
         assert f"$(CHECK_RES) $(BUILD)/{obj}" in mk
