@@ -89,7 +89,6 @@ def one_case(seed):
         b.set_option("fir_variant", int(os.environ["FIR_VARIANT"]))
     if rng.integers(0, 3) == 0:
         b.set_option("fir_T", int(rng.choice([96, 128, 256, 512, 2048])))
-    b.set_option("fir_nc", int(rng.choice([0, 0, 12])))             # ten central taps or twelve (the default) where the table is the reference's
     b.set_option("pll_variant", int((int(os.environ["PLL_VARIANT"]) if os.environ.get("PLL_VARIANT") else rng.choice([0, 7, 8]))))
     host_input = rng.integers(0, 4) == 0          # gnuais_batch_run_host: the drop-in's entry point
     reset_at = int(rng.integers(0, len(chunks))) if rng.integers(0, 6) == 0 else -1

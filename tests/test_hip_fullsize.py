@@ -312,11 +312,11 @@ def test_node_of_eight_shards_at_once_equals_one_unsharded_batch():
         node.run([xb[d][lo:hi, f:f + n].contiguous() for d, f, n in node.shards])
         node.sync()
         want, got = one.drain_frames(), node.drain_frames()
-        assert len(want) > 1000 and got.tobytes() == want.tobytes()
+        assert (len(want) > 1000 or hi - lo == 1) and got.tobytes() == want.tobytes()
         assert node.counters().tobytes() == one.counters().tobytes()
         assert node.pll_state().tobytes() == one.pll_state().tobytes()
         assert np.array_equal(node.maxval(), one.maxval())
-    assert node.total_received() == one.total_received()
+    assert node.total_received() == one.total_received() > 50000
     st = node.shard_stats()
     assert len(st) == 8 and [s_["first_channel"] for s_ in st] == [2048 * g for g in range(8)]
 
