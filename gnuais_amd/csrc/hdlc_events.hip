@@ -83,7 +83,7 @@ __global__ __launch_bounds__(64) EV_OCC void hdlc_events_kernel(
     uint32_t *__restrict__ cand_count, int32_t *__restrict__ counters,
     uint32_t *__restrict__ flags, int N, int n_seg, int seg_words, int K)
 {
-    __builtin_amdgcn_s_setprio(3);      // latency-bound chain: take every issue slot it can use
+    __builtin_amdgcn_s_setprio(3);      // latency-bound chain: take every issue slot it can use (priority 0 / 1: level, profiles/r05_pll_h3_in_the_pipeline.txt)
     extern __shared__ uint32_t lds[];
     const int tpb = TPB > 0 ? TPB : (int) blockDim.x, tx = (int) threadIdx.x;
     const int cg = blockIdx.x * blockDim.x + threadIdx.x;
