@@ -79,6 +79,7 @@ struct gnuais_batch {
     // better (0.53-0.55), 2 starves (0.70); a short timed region ends sooner with fewer calls in flight to drain
     // (20 steps: 0.574 against 0.583), so 3.
     int nbuf = 3;
+    int sets_alloc = 0;                         // hand-off sets that exist (>= nbuf)
     uint32_t *sgn[NBUF] = {};                   // K1 -> K2
     uint32_t *pll = nullptr, *lastbit = nullptr, *prev = nullptr;   // receiver.h:38-44, carried by K2
     int n_cu = 256;
@@ -219,6 +220,27 @@ int gnuais_default_taps(float *out36)
         out36[35 - k] = (float) k_tap_half[k];
     }
     return 36;
+}
+
+// hand-off sets [sets_alloc, n): sign words, bit packs and their counts, K2b -> K3 slot ranges (zeroed)
+static hipError_t alloc_sets(gnuais_batch *b, int n)
+{
+    const size_t N = (size_t) b->N;
+    for (int k = b->sets_alloc; k < n && k < gnuais_batch::NBUF; ++k) {
+        struct { void **p; size_t bytes; } want[] = {
+            {(void **) &b->sgn[k], sizeof(uint32_t) * sgn_words_alloc(b->sgn_words, b->N)},
+            {(void **) &b->segbits[k], sizeof(uint32_t) * N * (size_t) b->n_seg * PACK_STRIDE},
+            {(void **) &b->segcnt[k], sizeof(uint32_t) * N * (size_t) b->n_seg},
+            {(void **) &b->cand_first[k], sizeof(uint32_t) * N},
+            {(void **) &b->cand_count[k], sizeof(uint32_t) * N}};
+        for (auto &w : want) {
+            hipError_t e = hipMalloc(w.p, w.bytes);
+            if (e == hipSuccess) e = hipMemset(*w.p, 0, w.bytes);
+            if (e != hipSuccess) return e;
+        }
+        b->sets_alloc = k + 1;
+    }
+    return hipSuccess;
 }
 
 void gnuais_batch_destroy(gnuais_batch *b)
@@ -417,15 +439,9 @@ int gnuais_batch_create(gnuais_batch **out, int device, int n_channels, const fl
         gnuais_batch_destroy(b);
         return fail(GNUAIS_E_ARG, "create: pllinc too large (more than one slice per ~4.6 samples)");
     }
-    for (int k = 0; k < gnuais_batch::NBUF; ++k) {
-        alloc((void **) &b->sgn[k], sizeof(uint32_t) * sgn_words_alloc(b->sgn_words, b->N));
-        alloc((void **) &b->segbits[k], sizeof(uint32_t) * N * (size_t) b->n_seg * PACK_STRIDE);
-        alloc((void **) &b->segcnt[k], sizeof(uint32_t) * N * (size_t) b->n_seg);
-    }
-    for (int k = 0; k < gnuais_batch::NBUF; ++k) {
-        alloc((void **) &b->cand_first[k], sizeof(uint32_t) * N);
-        alloc((void **) &b->cand_count[k], sizeof(uint32_t) * N);
-    }
+    // the hand-off sets in use (`nbuf`; more are allocated when set_option raises it: a C5 set is 0.4 GB of sign words)
+    if (const char *v = getenv("GNUAIS_NBUF")) b->nbuf = std::min((int) gnuais_batch::NBUF, std::max(2, atoi(v)));
+    if (e == hipSuccess) e = alloc_sets(b, b->nbuf);
     alloc((void **) &b->pll, sizeof(uint32_t) * N);
     alloc((void **) &b->lastbit, sizeof(uint32_t) * N);
     alloc((void **) &b->prev, sizeof(uint32_t) * N);
@@ -492,7 +508,6 @@ int gnuais_batch_create(gnuais_batch **out, int device, int n_channels, const fl
     }
     if (const char *v = getenv("GNUAIS_K3_SAME")) b->k3_same = atoi(v) != 0;
     if (const char *v = getenv("GNUAIS_PLL_VARIANT")) b->pll_variant = atoi(v);
-    if (const char *v = getenv("GNUAIS_NBUF")) b->nbuf = std::min((int) gnuais_batch::NBUF, std::max(2, atoi(v)));
     if (const char *v = getenv("GNUAIS_PIPELINE")) b->pipeline = atoi(v) != 0;
     if (const char *v = getenv("GNUAIS_HDLC_VARIANT")) b->hdlc_variant = atoi(v) != 0;
     if (const char *v = getenv("GNUAIS_HDLC_LPW")) b->hdlc_lpw = std::min(64, std::max(1, atoi(v)));
@@ -524,7 +539,7 @@ int gnuais_batch_reset(gnuais_batch *b)
     HIP_TRY(hipMemset(b->pll, 0, sizeof(uint32_t) * N));              // receiver.c:66-71
     HIP_TRY(hipMemset(b->lastbit, 0, sizeof(uint32_t) * N));
     HIP_TRY(hipMemset(b->prev, 0, sizeof(uint32_t) * N));
-    for (int k = 0; k < gnuais_batch::NBUF; ++k)
+    for (int k = 0; k < b->sets_alloc; ++k)
         HIP_TRY(hipMemset(b->segcnt[k], 0, sizeof(uint32_t) * N * (size_t) b->n_seg));
     b->calls = 0;
     b->hdlc_calls = 0;
@@ -560,6 +575,7 @@ int gnuais_batch_set_option(gnuais_batch *b, const char *name, int value)
         if (value < 2 || value > gnuais_batch::NBUF) return fail(GNUAIS_E_ARG, "nbuf must be 2..8");
         if (int rc = gnuais_batch_sync(b)) return rc;
         HIP_TRY(hipDeviceSynchronize());
+        HIP_TRY(alloc_sets(b, value));
         b->nbuf = value;
     } else if (!strcmp(name, "streaming")) {
         // 0: leave the streamed delivery (gnuais_batch_stream_nmea / autotune_delivery switch it on): everything in
