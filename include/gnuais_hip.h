@@ -304,23 +304,19 @@ int  gnuais_batch_last_timing(gnuais_batch *b, float *ms5);
  * stage pipeline on, these are the durations WHILE the stages of neighbouring
  * calls overlap */
 int  gnuais_batch_mean_timing(gnuais_batch *b, float *ms5, int *n_calls);
-/* tunables: "fir_T" (outputs per wave in K1, multiple of 32), "fir_variant"
- * (3 = sign-exact slicer, the default on the receive path; 0 = exact v_mul/v_add K1,
- * 1 = its v_pk build, 2 = its MFMA-product build), "fir_map" (1 = workgroups of one XCD
- * walk neighbouring channel groups, the default; 0 = plain blockIdx order), "pipeline",
- * "pll_variant" (0 = by channel count, the default: the six-wave PLL workgroup where fewer channel
- * groups than half the CUs leave the chip room, the three-wave one otherwise; 3 / 6 force one;
- * measurement forms, all bit-exact: 32 = three waves + a second scanner, 4 = one scanner / short
- * recurrence / one toggler / writer, 51 / 52 = the six-wave form less one toggler / one scanner),
- * "hdlc_variant" (1 = the event-driven deframer, the default; 0 = the bit-serial one),
- * "hdlc_lpw" (channels per wave in the bit-serial deframer, 1..64), "timing_stride" (with
- * set_timing on, time every n-th call only: the event records of a timed call cost ~0.05 ms
- * of stream time), "stage_mask" (experiments: bit 0 = FIR/slicer, bit 1 = PLL/NRZI, bit 3 =
- * deframer, bit 4 = unstuff/CRC; results are wrong unless 0x1f), "nbuf" (hand-off sets in use = calls that
- * may be in flight, 2..8, default 3), "fir_flag2" (1 = the sign-exact slicer reads sign and threshold of an output
- * off one scaled sum with one instruction, the default; 0 = subtract + two gathers), "fir_nc" (12 = twelve
- * central taps certify the sign, the default; 0 = the shortest certified sum, ten for the reference table),
- * "pll_variant" 7 (time-parallel PLL: automatic up to 512 channels).  Every setting is bit-exact. */
+/* Options (every setting is bit-exact):
+ *   "pipeline"      1 (default): every stage on its own stream, the stages of consecutive calls overlap; 0: one stream
+ *   "nbuf"          hand-off sets in use = calls that may be in flight, 2..8 (default 3; more are allocated on demand)
+ *   "fir_T"         outputs per wave in K1 (multiple of 32; default 512)
+ *   "fir_variant"   3 = the sign-exact slicer (default where the table allows); 0 = the exact ordered sum for every sample
+ *   "fir_flag2"     1 = the slicer reads sign and threshold of an output off one scaled sum (default); 0 = subtract + two gathers
+ *   "pll_variant"   0 = by channel count (default: the time-parallel form, pll_tp.hip, up to 512 channels; pll_h3.hip above);
+ *                   7 / 8 force one
+ *   "hdlc_variant"  1 = the event-driven deframer (default); 0 = the bit-serial one
+ *   "hdlc_lpw"      channels per deframer wave, 1..64 (default: 16, or 64 where the batch fills the chip)
+ *   "streaming"     0 leaves the streamed delivery (gnuais_batch_stream_nmea switches it on)
+ *   "timing_stride" with set_timing on, time every n-th call only (the event records of a timed call cost stream time)
+ *   "stage_mask"    measurement only: bit 0 FIR/slicer, 1 PLL/NRZI, 3 deframer, 4 unstuff/CRC; results are wrong unless 0x1f */
 int  gnuais_batch_set_option(gnuais_batch *b, const char *name, int value);
 /* Optional, once, before real work: time the stage -> stream assignments on `d_samples` (about 1.3 s
  * of pipelined calls: two greedy searches and a longer head-to-head with the default) and keep the fastest; RESETS the batch.  Which hardware queue a stream gets
