@@ -477,7 +477,7 @@ def cpu_model():
     return "unknown"
 
 
-def pmc_traffic(args, config):
+def pmc_traffic(args, config, device=0):
     """PMC counters per launch, collected as MI355X_MICROARCH.md's HBM / rocprofv3 section prescribes: separate
     rocprofv3 passes with --kernel-trace only, each over a 6-step child run of this same script.
       * HBM bytes: --pmc FETCH_SIZE and --pmc WRITE_SIZE (KiB; FETCH_SIZE doubled: gfx950 tallies 128-byte requests at 64);
@@ -498,6 +498,9 @@ def pmc_traffic(args, config):
     env = dict(os.environ, TMPDIR="/tmp")
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
+    # the child is a one-GPU run on THIS rank's device (a multi-GPU job: rank 0's; every GPU runs the same workload)
+    vis = [v for v in os.environ.get("HIP_VISIBLE_DEVICES", "").split(",") if v.strip()]
+    env["HIP_VISIBLE_DEVICES"] = vis[device] if device < len(vis) else str(device)
     res, raw = {}, {}
     tmp = tempfile.mkdtemp(prefix="gnuais_pmc_", dir="/tmp")
 
@@ -762,7 +765,7 @@ def rank_main(rank, local, world, args, sync):
         "end_to_end": m.get("end_to_end"),
         "message_lines": m.get("message_lines"),
         "roofline": roofline_of(m, dt / args.steps * 1e3,
-                                pmc_traffic(args, args.config) if (world == 1 and args.traffic) else None,
+                                pmc_traffic(args, args.config, local) if args.traffic else None,
                                 n_taps=144 if cfg["wide"] else 36),
         "float_path": float_path(args, local) if (world == 1 and args.e2e and args.config == "C3") else None,
         "steady_state": m.get("steady_state"),
@@ -877,6 +880,12 @@ def node_main(world, args):
                         "algorithmic_bytes_per_launch": alg,
                         "what": "N*L*2 bytes of all shards / ms_per_step against 8 TB/s per distinct device; per-kernel "
                                 "figures come from the single-GPU line"}}
+    if args.traffic and not args.channels and not args.len:
+        # HBM bytes of one device's workload (PMC child passes on the first device) x the shards: every shard runs it
+        t = pmc_traffic(args, args.config, devs[0])
+        if t and not t.get("error"):
+            out["roofline"]["traffic"] = t["chain_bytes_per_call"] * world
+            out["roofline"]["traffic_what"] = "PMC bytes per call of ONE shard's workload (a one-GPU child run on device %d) x %d shards" % (devs[0], world)
     if args.cpu:
         # the reference's own code on this host beside it (a bounded sample of shard 0's input; one core)
         x0 = slabs[0][:, : min(args.cpu_channels, slabs[0].shape[1])].cpu().numpy()
