@@ -102,7 +102,6 @@ struct gnuais_batch {
     uint32_t *cand_first[NBUF] = {}, *cand_count[NBUF] = {};   // K2b -> K3
     uint32_t *frame_count = nullptr;
     int cand_K = 64;
-    int k2b_lag = 1;                // K2b of a call waits for K3 of the call this many calls before it
     int32_t *counters = nullptr;
     int *maxval[HB] = {};                  // rotate with the history buffers
     int max_cur = 0, max_last = 0;
@@ -451,11 +450,7 @@ int gnuais_batch_create(gnuais_batch **out, int device, int n_channels, const fl
     // opening and the closing flag, a bit in ST_STOPSIGN), so this many slots hold whatever a call
     // can produce, adversarial bit streams included (real traffic: <= 38 frames per second)
     b->cand_K = std::max(64, b->bits_words * 32 / 30 + 2);
-    // k2b_lag 2 (experiment, GNUAIS_K2B_LAG): two calls' worth of slots, so that K2b of call i+1 cannot reach the
-    // slots K3 of call i still reads and only has to wait for K3 of call i-1 -- K2b(i) -> K3(i) -> K2b(i+1) is
-    // otherwise a serial loop.  Measured: the loop goes, the period does not fall.
-    if (const char *v = getenv("GNUAIS_K2B_LAG")) b->k2b_lag = atoi(v) == 2 ? 2 : 1;
-    alloc((void **) &b->cand, sizeof(uint32_t) * N * (size_t) (b->k2b_lag * b->cand_K) * CAND_WORDS);
+    alloc((void **) &b->cand, sizeof(uint32_t) * N * (size_t) b->cand_K * CAND_WORDS);
     alloc((void **) &b->frame_count, sizeof(uint32_t) * 4);
     alloc((void **) &b->counters, sizeof(int32_t) * N * 3);
     for (int q = 0; q < gnuais_batch::HB; ++q) alloc((void **) &b->maxval[q], sizeof(int) * N);
@@ -660,7 +655,7 @@ static void fill_hdlc(const gnuais_batch *b, HdlcLaunch &h, int k)
     h.frames = b->streaming ? b->ring[b->ring_cur] : b->frames;
     h.frame_count = b->streaming ? b->ring_count[b->ring_cur] : b->frame_count;
     h.frame_cap = (uint32_t) b->frame_cap; h.N = b->N; h.n_seg = b->n_seg;
-    h.seg_words = b->seg_words; h.K = b->k2b_lag * b->cand_K; h.K_call = b->cand_K;
+    h.seg_words = b->seg_words; h.K = b->cand_K; h.K_call = b->cand_K;
     // event-driven deframer: 16 channels per wave finish a small batch soonest; where the chip is full anyway (a PLL
     // workgroup on every CU, four FIR waves per SIMD) 64 per wave -- a quarter of the waves -- cost the other stages
     // least: C3 steady state 0.492 against 0.525 ms per call (profiles/r05_pll_h3_in_the_pipeline.txt)
@@ -675,7 +670,7 @@ static hipStream_t k3_stream(const gnuais_batch *b)
 {
     // not while the batch is streaming: K3 then waits for the delivery side (a frame ring to come free), and on the
     // deframer's stream that wait would hold the next deframer launch too (0.89 against 0.62 ms per delivered step)
-    return (b->k3_same && b->k2b_lag == 1 && !b->streaming) ? b->s_k[2] : b->s_k[3];
+    return (b->k3_same && !b->streaming) ? b->s_k[2] : b->s_k[3];
 }
 
 // K1 + carry.  The specialised kernel updates the history and clears the next peak
@@ -740,8 +735,8 @@ static int run_tail(gnuais_batch *b, int k, int len, bool tm, hipEvent_t *ev,
     // the per-channel candidate ring that K3 of the PREVIOUS call may still be reading: slots are
     // reused after cand_K frame starts, which one call cannot exceed but two could
     if (pl && after) HIP_TRY(hipStreamWaitEvent(sC, after, 0));
-    if (pl && b->calls >= (unsigned) b->k2b_lag && sD != sC)
-        HIP_TRY(hipStreamWaitEvent(sC, b->e_done[4][(k + b->nbuf - b->k2b_lag) % b->nbuf], 0));
+    if (pl && b->calls >= 1 && sD != sC)
+        HIP_TRY(hipStreamWaitEvent(sC, b->e_done[4][(k + b->nbuf - 1) % b->nbuf], 0));
     if (tm) HIP_TRY(hipEventRecord(ev[5], sC));
     if (b->stage_mask & 8) HIP_TRY(b->hdlc_variant ? launch_hdlc_events(h, sC) : launch_hdlc_deframe(h, sC));
     if (tm) HIP_TRY(hipEventRecord(ev[7], sC));
