@@ -389,7 +389,7 @@ def roofline_of(m, ms_per_step=None, traffic=None, n_taps=36):
     km = {k: v for k, v in m["kernel_ms"].items() if v and v > 0}
     dom = max(km, key=km.get)
     ach = alg / (km[dom] * 1e-3) / 1e9
-    r = {"bound": "hbm", "kernel": dom, "kernel_ms": km[dom], "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+    r = {"bound": "hbm" if (traffic and not traffic.get("error")) else None, "kernel": dom, "kernel_ms": km[dom], "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
          "frac": ach / HBM_PEAK_GBS, "traffic": None, "algorithmic_bytes_per_launch": alg,
          "algorithmic_flops_per_launch": m["n_ch"] * m["len"] * 2.0 * n_taps,
          "kernel_ms_samples": m.get("kernel_ms_calls"),
@@ -553,11 +553,16 @@ def pmc_traffic(args, config, device=0):
                 clock = SPEC_CLOCK_HZ
                 if c.get("GRBM_GUI_ACTIVE"):
                     clock = c["GRBM_GUI_ACTIVE"] / 8.0 / (ms * 1e-3)         # the counter sums the 8 XCDs
-                floor_ms = c["SQ_ACTIVE_INST_VALU"] * 4.0 / (N_SIMD * clock) * 1e3
+                # what an instruction costs its SIMD: 4 cycles is what SQ_ACTIVE_INST_VALU counts and what VOP3 / packed
+                # forms take (1.9 ns at four waves per SIMD); the 12-tap direct-form stream of fir_sign_kernel is VOP2
+                # adds, muls and fmacs and was measured at 1.02 ns per instruction = 2.45 cycles
+                # (profiles/r05_ubench_valu_op_rates.txt: direct12_now_8out)
+                inst_cycles = 2.45 if (k == "fir_slice" and config in ("C2", "C3")) else 4.0
+                floor_ms = c["SQ_ACTIVE_INST_VALU"] * inst_cycles / (N_SIMD * clock) * 1e3
                 valu[k] = {"insts_per_launch": c.get("SQ_INSTS_VALU"), "active_quad_cycles": c["SQ_ACTIVE_INST_VALU"],
                            "waves": c.get("SQ_WAVES"), "launch_ms_in_this_pass": ms, "clock_ghz": clock / 1e9,
                            "clock_from": "GRBM_GUI_ACTIVE / 8 XCDs / duration" if c.get("GRBM_GUI_ACTIVE") else "spec",
-                           "issue_floor_ms": floor_ms, "busy_frac": floor_ms / ms,
+                           "issue_floor_ms": floor_ms, "busy_frac": floor_ms / ms, "cycles_per_instruction_priced": inst_cycles,
                            "valu_share_of_wave_cycles": (c["SQ_ACTIVE_INST_VALU"] / c["SQ_WAVE_CYCLES"]) if c.get("SQ_WAVE_CYCLES") else None}
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
