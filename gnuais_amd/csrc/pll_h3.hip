@@ -81,6 +81,7 @@ enum { F_RDONE = 1, F_SEGPUB = 2, F_WRITTEN = 3, F_LAST = 4, F_SCAN = 8 /* +h */
 #ifdef PLLH3_BUDGET
 // Measurement build only (EXTRA=-DPLLH3_BUDGET; scripts/pll_wave_budget.py h3): clock ticks per workgroup --
 //   0 recurrence: total   1 ... waiting for a helper's scan   3 ... in the rows   4 rows of four   5 blocks
+//   6 recurrence: its span on the constant 100 MHz clock (core clock = [0] / [6] x 100 MHz)
 //   8 helper 0: total   9 ... scanning   10 ... waiting for a free slot   12 ... writing packs
 __device__ unsigned long long pllh3_budget[4096 * 16];
 #define BUDGET(i, v) do { if (lane == 0 && blockIdx.x < 4096) pllh3_budget[blockIdx.x * 16 + (i)] = (v); } while (0)
@@ -337,6 +338,9 @@ __global__ __launch_bounds__(64 * (1 + H3_NH)) __attribute__((amdgpu_waves_per_e
     bool dead = false;
     unsigned long long rc_wscan = 0, rc_rows = 0, rc_nrows = 0, rc_nblk = 0;
     const unsigned long long rc_t0 = TICK();
+#ifdef PLLH3_BUDGET
+    const unsigned long long rc_w0 = wall_clock64();
+#endif
     for (int s = 0; s < n_seg && !dead; ++s) {
         while (peek(F_WRITTEN) < s - (H3_NPACK - 1) && !dead) {    // pack buffer s & 3 was segment s - 4's: long written
             if (expired()) dead = true;
@@ -395,6 +399,9 @@ __global__ __launch_bounds__(64 * (1 + H3_NH)) __attribute__((amdgpu_waves_per_e
     }
     if (live && !dead) pllst[cg] = (X >> 8) & 0xffffu;
     BUDGET(0, TICK() - rc_t0); BUDGET(1, rc_wscan); BUDGET(3, rc_rows); BUDGET(4, rc_nrows); BUDGET(5, rc_nblk);
+#ifdef PLLH3_BUDGET
+    BUDGET(6, wall_clock64() - rc_w0);           // the same span on the constant 100 MHz clock: ticks / this = the core clock
+#endif
 }
 
 #ifdef PLLH3_BUDGET

@@ -25,6 +25,7 @@ def show(tag, ms):
     print(f"--- {tag}: PLL launch {ms:.3f} ms")
     print(f"  recurrence: total {m[0]:.0f} ticks (max {bud[:, 0].max()}), waiting for a scan {m[1]:.0f} ({m[1] / m[0]:.3f}), rows "
           f"{m[3]:.0f} ({m[3] / m[0]:.3f}); {m[4]:.0f} rows of four in {m[5]:.0f} blocks: {m[3] / m[4] / 4:.1f} ticks per step")
+    print(f"  core clock while the recurrence wave ran: {m[0] / max(m[6], 1) * 0.1:.3f} GHz (clock ticks / 100 MHz ticks)")
     print(f"  helper 0: total {m[8]:.0f}, scanning {m[9]:.0f} ({m[9] / m[8]:.3f}), waiting for a free slot {m[10]:.0f} "
           f"({m[10] / m[8]:.3f}), packs {m[12]:.0f} ({m[12] / m[8]:.3f}); per own block: scan {m[9] / (m[5] / 3):.0f}")
 
@@ -46,8 +47,25 @@ torch.cuda.synchronize()
 show("one call at a time", float(np.mean(acc)))
 b.set_option("pipeline", 1)
 b.set_option("timing_stride", 2)
-for _ in range(40):
+for _ in range(80):
     b.run(x, stream=stream, sync=False)
     b.discard_frames(stream)
+# NOT synchronised: the host is at most `nbuf` calls ahead, so the counters read now (a copy on the null stream, which
+# the library's non-blocking streams do not wait for) are those of a launch in the middle of the running loop
+snap = np.zeros((n_wg, 16), dtype=np.uint64)
+assert fn(snap.ctypes.data, n_wg) == 0
 torch.cuda.synchronize()
-show("inside the pipelined loop (last launch)", float(b.mean_timing()["pll"]))
+live = float(b.mean_timing()["pll"])
+
+
+def show_snap(tag, ms, bud):
+    m = bud.astype(np.float64).mean(0)
+    print(f"--- {tag}: PLL launch {ms:.3f} ms (mean of the loop)")
+    print(f"  recurrence: total {m[0]:.0f} ticks, waiting for a scan {m[1]:.0f} ({m[1] / m[0]:.3f}), rows {m[3]:.0f} ({m[3] / m[0]:.3f}): "
+          f"{m[3] / m[4] / 4:.1f} ticks per step")
+    print(f"  core clock while the recurrence wave ran: {m[0] / max(m[6], 1) * 0.1:.3f} GHz; its span {m[6] / 100:.1f} us")
+    print(f"  helper 0: total {m[8]:.0f}, scanning {m[9]:.0f} ({m[9] / m[8]:.3f}), waiting for a free slot {m[10]:.0f} ({m[10] / m[8]:.3f}), "
+          f"packs {m[12]:.0f} ({m[12] / m[8]:.3f}); per own block: scan {m[9] / (m[5] / 3):.0f}")
+
+
+show_snap("inside the pipelined loop (a launch in the middle of it, read while the loop runs)", live, snap)
