@@ -1,8 +1,8 @@
 """pll_h3 with more channel groups than CUs (two / three workgroups per CU): 33 000 and 50 000 channels against the oracle
 on the channels at both ends and in the middle."""
 import sys, os, numpy as np, torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "tests"))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
 from gnuais_amd import synth, ReceiverBatch, tile_channels
 from oracle_lib import Oracle
 for n_ch, total in ((33000, 9000), (50001, 5000)):
