@@ -41,6 +41,14 @@ namespace gnuais {
 template <int NE>
 struct FirTaps { float te[NE]; };
 
+// A typed buffer load: descriptor (base, span, DST_SEL_X = R | NUM_FORMAT = SSCALED | DATA_FORMAT = 16) in SGPRs, the
+// lane's byte offset in a VGPR, the row in the scalar offset -- the memory pipeline delivers the int16 sample as a float
+// (exactly), with no 64-bit address arithmetic and no conversion in the VALU stream.
+// clang has no builtin for llvm.amdgcn.raw.buffer.load.format; the intrinsic is reached by name
+typedef int fir_v4i __attribute__((ext_vector_type(4)));
+extern "C" __device__ float fir_load_format_f32(fir_v4i rsrc, int voffset, int soffset, int aux)
+    __asm("llvm.amdgcn.raw.buffer.load.format.f32");
+
 __device__ __forceinline__ int load_sample(const int16_t *__restrict__ x,
                                            const int16_t *__restrict__ hist,
                                            int m, int N, int NT, int c)
@@ -92,6 +100,7 @@ __global__ __launch_bounds__(64) void fir_slice_kernel(
     for (int s = 0; s < NE; ++s) acc[s] = 0.0f;
 
     int peak = 0;
+    int peakbits = 0;                           // the blocks' peak as float bits (see there)
     // local sample index i <-> m = t0 - d + i ; sample i feeds output o = i - j
     // (o = n - t0); output o is complete after sample i = o + NE - 1.
     const int m0 = t0 - d;
@@ -119,17 +128,28 @@ __global__ __launch_bounds__(64) void fir_slice_kernel(
         }
     }
 
+    // interior blocks read through a typed descriptor based at the segment's first interior row (as K1s does): every row
+    // this segment reads lies within [row0, row0 + T + NE + 32) rows of it
+    const int row0 = m0 + NE - 1 > 0 ? m0 + NE - 1 : 0;
+    const uint32_t rowbytes = (uint32_t) N * 2u;
+    const unsigned long long span = (unsigned long long) (L - row0) * rowbytes;
+    const unsigned long long xbase = (unsigned long long) (x + (size_t) row0 * (size_t) N);
+    const fir_v4i rsrc_f = {(int) (xbase & 0xffffffffull), (int) ((xbase >> 32) & 0xffffull),
+                            (int) (span > 0xffffffffull ? 0xffffffffull : span), 0x13004};
+    const bool typed_ok = (unsigned long long) (T + NE + 64) * rowbytes < 0x7fffffffull;   // the scalar offset is 32 bits
+    const int coff = c * 2;
+
     const int nblk = (t1 - t0 + 31) >> 5;
     for (int b = 0; b < nblk; ++b) {
         const int obase = b * 32;               // outputs obase .. obase+31
-        int xi[32];
+        float xf[32];                           // the block's samples as floats (int16 values: exact)
         // the 32 samples of this block: i = NE-1+obase+p  ->  m = mb + p
         const int mb = m0 + NE - 1 + obase;
-        const bool interior = (mb >= 0) && (mb + 31 < L);
+        const bool interior = (mb >= 0) && (mb + 31 < L) && typed_ok;
         if (interior) {
-            const int16_t *row = x + (size_t) mb * (size_t) N + c;
 #pragma unroll
-            for (int p = 0; p < 32; ++p) xi[p] = (int) row[(size_t) p * (size_t) N];
+            for (int p = 0; p < 32; ++p)
+                xf[p] = fir_load_format_f32(rsrc_f, coff, (int) ((uint32_t) (mb - row0 + p) * rowbytes), 0);
         } else {
             // first block of a call (3 history samples) or the last, partial block
             // (addresses clamped; those outputs are masked out below)
@@ -137,32 +157,33 @@ __global__ __launch_bounds__(64) void fir_slice_kernel(
             for (int p = 0; p < 32; ++p) {
                 int m = mb + p;
                 m = (m < L) ? m : L - 1;
-                xi[p] = load_sample(x, hist, m, N, NT, c);
+                xf[p] = (float) load_sample(x, hist, m, N, NT, c);
             }
         }
         // filter.c:118-119: peak positive input sample of this call.  The block's
         // samples are n = mb .. mb+31; over all segments they cover [-shift, L-shift)
         // (shift = d-NE+1 trailing zero taps), so history samples (n < 0) are
         // masked here and the last `shift` samples are added after the loop.
-        {
+        {   // (for values >= 0 the order of floats is the order of their bit patterns as signed integers, and negative
+            // floats are negative integers: an integer max against 0 is the float max; converted back once, below)
             int bp = 0;
             if (interior) {
 #pragma unroll
-                for (int p = 0; p < 32; ++p) bp = xi[p] > bp ? xi[p] : bp;
+                for (int p = 0; p < 32; ++p) bp = __float_as_int(xf[p]) > bp ? __float_as_int(xf[p]) : bp;
             } else {
 #pragma unroll
                 for (int p = 0; p < 32; ++p) {
                     const int m = mb + p;
-                    const int v = (m >= 0 && m < L) ? xi[p] : 0;
+                    const int v = (m >= 0 && m < L) ? __float_as_int(xf[p]) : 0;
                     bp = v > bp ? v : bp;
                 }
             }
-            peak = bp > peak ? bp : peak;
+            peakbits = bp > peakbits ? bp : peakbits;
         }
         uint32_t w = 0;
 #pragma unroll
         for (int p = 0; p < 32; ++p) {
-            const float xs = (float) xi[p];
+            const float xs = xf[p];
             if (SYM) {
 #pragma unroll
                 for (int j = 0; j < NE / 2; ++j) {
@@ -196,6 +217,7 @@ __global__ __launch_bounds__(64) void fir_slice_kernel(
         if (live) sgn[sgn_index((t0 + obase) >> 5, N, cg)] = w;
     }
 
+    peak = (int) __int_as_float(peakbits);      // (an int16 value as a float: exact)
     // the last segment also owns the final `shift` samples of the call
     if (t1 == L) {
         const int shift = d - NE + 1;
@@ -282,10 +304,6 @@ __global__ __launch_bounds__(64) void fir_slice_kernel(
 #ifndef FIR_BUFFER_LOADS
 #define FIR_BUFFER_LOADS 2
 #endif
-typedef int fir_v4i __attribute__((ext_vector_type(4)));
-// clang has no builtin for llvm.amdgcn.raw.buffer.load.format; the intrinsic is reached by name
-extern "C" __device__ float fir_load_format_f32(fir_v4i rsrc, int voffset, int soffset, int aux)
-    __asm("llvm.amdgcn.raw.buffer.load.format.f32");
 // zero-instruction fence (see touch16): bounds how many samples the scheduler interleaves,
 // i.e. how many products are alive at once; without it the kernel needs 98 VGPRs (4 waves per
 // SIMD) instead of <= 88 (5 waves)
