@@ -334,12 +334,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NC == 48 ? 4
     const int NE = NES > 0 ? NES : NE_rt;
     const int wave_id = (int) (blockIdx.y * gridDim.x + blockIdx.x);
     if (stamps && threadIdx.x == 0) stamps[2 * wave_id] = wall_clock64();
-    // (gx, gy) = the logical grid: channel groups x segments.  Launched with exactly that grid a workgroup does one
-    // item.  Launched with FEWER workgroups (a one-dimensional grid, option fir_persist = workgroups per SIMD) each
-    // takes the items id, id + gridDim.x, ...: measured, bit-exact, slower (C3: FIR 0.53 instead of 0.46 ms inside the
-    // pipeline, period 0.53 instead of 0.51 with five per SIMD; four: 0.56) -- the hardware's own placement of 24 000
-    // short-lived workgroups balances the launch better than a static split, and resident waves that never leave give
-    // the other stages' workgroups no turn.  Kept as an option for that measurement.
+    // (gx, gy) = the logical grid: channel groups x segments; the launch uses exactly that grid, a workgroup does one item.
+    // (A grid of fewer, persistent workgroups looping over the items was measured slower: the hardware's own placement of
+    // 24 000 short-lived workgroups balances the launch better, and waves that never leave give the other stages no turn.)
     const int items = gx * gy, stride = (int) (gridDim.x * gridDim.y);
     auto work = [&](const int item) {
     const int J0 = (NE - NC) / 2;               // first central tap (10 of 32 for the reference table)
@@ -1019,26 +1016,19 @@ hipError_t launch_fir_sign(const FirLaunch &a, hipStream_t stream)
         return hipErrorInvalidValue;
     if (a.T > 65280) return hipErrorInvalidValue;       // the kernel notes open outputs as 16-bit offsets into the segment
     dim3 grid((a.N + 63) / 64, (a.L + a.T - 1) / a.T), block(64);
-    int n_big = 1 << 30, T2 = a.T;
-    if (a.T2 > 0 && a.T2 < a.T && a.T2 % launch_fir_sign_quantum(a.NC) == 0 && a.n_big < (int) grid.y) {
-        n_big = a.n_big > 0 ? a.n_big : 0;
-        T2 = a.T2;
-        grid.y = n_big + (a.L - n_big * a.T + T2 - 1) / T2;
-    }
+    const int n_big = 1 << 30, T2 = a.T;        // (the kernel can give a launch's last segments another length: not used)
     const float eps_up = __builtin_nextafterf(a.eps, INFINITY);
     const int map = (a.map == 1 && grid.x % 8 == 0) ? 1 : 0;
     const int gx = (int) grid.x, gy = (int) grid.y;
-    if (a.persist > 0 && (long) gx * gy > a.persist) grid = dim3((a.persist + 7) & ~7);   // a multiple of 8: a workgroup's items stay on its XCD
-    // the stamp buffer (a debugging option) is written by workgroup id: a grid it has no room for gets none
-    unsigned long long *const stamps_ok = ((size_t) grid.x * grid.y <= a.stamps_waves) ? a.stamps : nullptr;
+    unsigned long long *const stamps_ok = nullptr;
     if (a.NC == 12 && a.NE == 32) {
         FirTaps<32> t;
         for (int j = 0; j < 32; ++j) t.te[j] = a.te[j];
         if (a.fscale > 0.0f)
-            hipLaunchKernelGGL((fir_sign_kernel<32, 12, 32, false, true>), grid, block, a.lds_pad, stream, a.x, a.hist, a.sgn, a.maxval,
+            hipLaunchKernelGGL((fir_sign_kernel<32, 12, 32, false, true>), grid, block, 0, stream, a.x, a.hist, a.sgn, a.maxval,
                                a.hist_out, a.maxval_next, a.te_mem, a.N, a.L, a.T, a.d, a.NT, a.NE, eps_up, map, t, stamps_ok, n_big, T2, a.eps_seen, a.eps_ahead, gx, gy, a.fscale);
         else
-        hipLaunchKernelGGL((fir_sign_kernel<32, 12, 32>), grid, block, a.lds_pad, stream, a.x, a.hist, a.sgn, a.maxval,
+        hipLaunchKernelGGL((fir_sign_kernel<32, 12, 32>), grid, block, 0, stream, a.x, a.hist, a.sgn, a.maxval,
                            a.hist_out, a.maxval_next, a.te_mem, a.N, a.L, a.T, a.d, a.NT, a.NE, eps_up, map, t, stamps_ok, n_big, T2, a.eps_seen, a.eps_ahead, gx, gy, a.fscale);
     } else if (a.NC == 12) {
         FirTaps<12> t;

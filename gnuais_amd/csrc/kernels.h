@@ -18,7 +18,6 @@ struct FirLaunch {
     const float *d_taps;   // device copy of all NT taps (generic kernel)
     float te[64];          // trimmed taps (specialised kernel)
     int N, L, T;           // T: outputs per wave, multiple of 32
-    int n_big = 1 << 30, T2 = 0;   // K1s: segments 0 .. n_big-1 are T outputs long, the rest T2 (the launch's tail, see run_fir)
     int NT, NE, d;         // out[n] = sum_j te[j] * x[n - d + j], j < NE
     float eps;             // sign-exact slicer: |central sum| > eps certifies the sign
     float fscale = 0;      // K1s direct form: > 0 = a power of two the central taps are scaled by so that the certified distance
@@ -28,11 +27,7 @@ struct FirLaunch {
     int NC;                //   central taps used (12 or 48)
     float ctaps[48];       //   te[(NE-NC)/2 .. +NC)
     const float *te_mem;   //   the NE effective taps in device memory (exact re-evaluation)
-    unsigned long long *stamps = nullptr;   // experiments: [waves][2] wall-clock start / end of every K1s wave
-    size_t stamps_waves = 0;                //   how many waves the buffer has room for (a larger grid gets no stamps)
-    int dbg = 0, lds_pad = 0;   // experiments (fir_sign_wide.hip): elimination switches, LDS claimed per wave to cap the occupancy
     int map;               // K1s workgroup -> (channel group, segment) mapping, see fir_sign_kernel
-    int persist = 0;       // K1s: > 0 = launch this many workgroups, each looping over the (group, segment) items
 };
 int launch_fir_sign_quantum(int NC);           // T must be a multiple of this
 hipError_t launch_fir_sign(const FirLaunch &a, hipStream_t stream);

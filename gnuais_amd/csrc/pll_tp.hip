@@ -7,7 +7,7 @@
 //   * at a sign change at sample t (receiver.c:113-118):   c += 1 if bit 15 of U(t) is clear, else c -= 1;
 //   * it slices whenever U crosses a multiple of 2^16 (:124): floor(U / 2^16) slices lie before sample t, and a sign
 //     change at t toggles output bit number floor(U(t) / 2^16) of   bits = ~XOR_j (1 << floor(U(t_j) / 2^16))
-//     (pll_nrzi3.hip has the derivation).
+//     (pll_h3.hip has the derivation).
 // Everything nonlinear is the one integer c, and c moves by +-1 per transition with a KNOWN parity (the number of
 // transitions so far).  That is what makes an exact block-parallel form affordable:
 //
@@ -21,7 +21,7 @@
 //           centred on the value the walk ended with, so that this stays rare.
 //   pass 3  LANE = BLOCK: every block runs once more from its now known c_in, per-lane bit scan, and XORs its toggles
 //           into the segment's bit pack in LDS; then the packs leave as the lane-per-channel kernels write them
-//           (complement, trim, parity carried from segment to segment and call to call: pll_nrzi3.hip's writer).
+//           (complement, trim, parity carried from segment to segment and call to call: pll_h3.hip's pack writer).
 //
 // Exact for every input: pass 1 computes the true block map on its window, the walk composes maps or falls back to the
 // map's definition, pass 3 is the reference's loop restricted to one block.  Work is 64 x the serial kernel's vector
@@ -255,7 +255,7 @@ __global__ __launch_bounds__(64 * TP_WAVES) void pll_tp_kernel(
     __syncthreads();
 
     // ---- the packs leave: one lane per segment forms its words, lane 0 carries the parity from segment to segment
-    // (pll_nrzi3.hip's writer: a transition after a segment's last slice toggles the first bit of the next segment that
+    // (pll_h3.hip's pack writer: a transition after a segment's last slice toggles the first bit of the next segment that
     // has one, or of a later call)
     uint32_t *nbs = reinterpret_cast<uint32_t *>(tab);        // [n_seg] bits of the segment; [n_seg .. 2 n_seg) its pending toggle
     const uint32_t Kend = q * (uint32_t) cin[n_blk];
