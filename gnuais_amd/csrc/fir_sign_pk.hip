@@ -57,6 +57,9 @@ __device__ __forceinline__ void pk_expand_void(F &&f, std::integer_sequence<int,
 template <class F, int... Is>
 __device__ __forceinline__ bool pk_expand_and(F &&f, std::integer_sequence<int, Is...>) { return (f(PkIc<Is>{}) && ...); }
 
+constexpr int pk_gcd(int a, int b) { return b == 0 ? a : pk_gcd(b, a % b); }
+constexpr int pk_unroll(int nc) { return 48 % nc == 0 ? 48 : nc * 16 / pk_gcd(nc, 16); }
+
 template <int NC>
 struct PkTaps {
     pk_f2 E[NC / 4];            // E[j] = { tc[2j], tc[2j+1] },   j < NC/4
@@ -70,6 +73,10 @@ struct PkTaps {
 #endif
 #define PK_PEND 8           // noted outputs per lane (1 KB of LDS per wave); more than that are settled on the spot
 template <int NES> struct PkExact { float te[NES > 0 ? NES : 1]; };
+// INLOOP: eps = seen * M / 32768 + ahead with M the running maximum of |x| over the rows behind AND the rest of the
+// output's own 16-row group; [0..3]: the output completes >= 6, 4, 2, 0 rows before the group's end (pair steps 0-4, 5,
+// 6, 7) -- the taps that reach beyond those rows are priced with |x| = 32768 in `ahead` (gnuais_capi.hip)
+struct PkEps { float seen[4], ahead[4]; };
 
 // the next group's rows are requested before this group's steps run
 #ifndef PK_PREFETCH_12
@@ -91,10 +98,11 @@ __device__ __forceinline__ void fir_sign_pk_body(
     uint32_t *__restrict__ sgn, int *__restrict__ maxval,
     int16_t *__restrict__ hist_out, int *__restrict__ maxval_next,
     const float *__restrict__ te_mem, int N, int L, int T, int d, int NTaps, int NE_rt, float eps_up,
-    float eps_seen, float eps_ahead, int map, PkTaps<NC> tp, PkExact<NES> ex)
+    PkEps ek, int map, PkTaps<NC> tp, PkExact<NES> ex)
 {
-    static_assert(NC % 4 == 0 && 48 % NC == 0, "48 unrolled phases must hold whole turns of the accumulator ring");
-    constexpr int GROUP = 16, UNROLL = 48, NG = UNROLL / GROUP, NP = NC / 2;
+    // the unrolled body holds whole turns of the accumulator ring AND whole 16-row groups: 48 phases for 12 and 48 taps, 80 for 40
+    constexpr int GROUP = 16, UNROLL = 48 % NC == 0 ? 48 : NC * GROUP / pk_gcd(NC, GROUP), NG = UNROLL / GROUP, NP = NC / 2;
+    static_assert(NC % 4 == 0 && UNROLL % NC == 0 && UNROLL % GROUP == 0 && UNROLL <= 96, "whole turns of the ring, whole groups");
     const int NE = NES > 0 ? NES : NE_rt;
     const int J0 = (NE - NC) / 2;
     const int lane = threadIdx.x;
@@ -196,11 +204,7 @@ __device__ __forceinline__ void fir_sign_pk_body(
     // The accumulator ring (and, for 48 taps, the odd tap pairs) sits in fixed registers above PK_VGPR_BASE, outside
     // the compiler's budget; everything that touches it is one of the generated instruction streams.
     (void) NP;
-    if constexpr (NC == 12) asm volatile(PK12_ZERO ::: PK12_CLOBBERS);
-    else {
-        asm volatile(PK48_ZERO ::: PK48_CLOBBERS);
-        pk48_load_o(tp);
-    }
+    pk_zero_ring<NC>(tp);
     // warm-up: samples i = 0 .. NC-2 (ring phase i + 1); nothing they complete is an output of this segment.  The loads
     // of up to eight steps go out together (the steps are volatile asm: a load issued between two of them would be
     // waited for there, one round trip per step)
@@ -220,12 +224,12 @@ __device__ __forceinline__ void fir_sign_pk_body(
                 w[k][1] = (float) pk_load_sample(x, hist, m0 + P, N, NTaps, c);
             }
             if constexpr (s0 == 0) {
-                if constexpr (NC == 12) pk12_warm<0, true>(w0, tp); else pk48_warm<0, true>(w0, tp);   // phase 0 is empty, phase 1 = sample 0
+                pk_warm<NC, 0, true>(w0, tp);                   // phase 0 is empty, phase 1 = sample 0
             }
             auto warm = [&](auto S) __attribute__((always_inline)) {
                 constexpr int k = decltype(S)::value;
                 constexpr int P = 2 + 2 * (s0 + k);
-                if constexpr (NC == 12) pk12_warm<P, false>(w[k], tp); else pk48_warm<P, false>(w[k], tp);
+                pk_warm<NC, P, false>(w[k], tp);
             };
             pk_expand(warm, std::make_integer_sequence<int, n>{});
         };
@@ -235,9 +239,11 @@ __device__ __forceinline__ void fir_sign_pk_body(
     int peakbits = 0;
     uint32_t neg = 0, amb = 0, zor = 0;
     bool zprev_known = false, zprev = false;
-    float eps_w = eps_up;
-    constexpr int NHIST = 3;                    // maxima of |x|: [0] this turn of three groups so far, [1] the turn before, [2] the one before
-    static_assert(NG == 3, "two whole turns of three 16-row groups = the 96 rows behind a group cover NC - 1 + J0 for J0 <= 49");
+    float eps_w = eps_up, Mn = 0.0f;            // INLOOP: Mn = the running maximum / 32768, eps_w follows the pair step's class
+    // maxima of |x|: [0] this turn of NG groups so far, [1] the turn before, ...: whole turns that hold the 96 rows behind a
+    // group, which cover NC - 1 + J0 (48 taps: J0 <= 49, 40 taps: J0 <= 57)
+    constexpr int NHIST = 1 + (96 + UNROLL - 1) / UNROLL;
+    static_assert(NHIST == 3, "v_max3 of three maxima");
     float hmax[NHIST];
     if constexpr (INLOOP) {
         float Pm = 0.0f;
@@ -415,13 +421,13 @@ __device__ __forceinline__ void fir_sign_pk_body(
                 }
                 const float M = __builtin_fmaxf(__builtin_fmaxf(hmax[0], hmax[1]), hmax[2]);
                 gmax_group = gm;
-                eps_w = __builtin_fmaf(eps_seen, M * (1.0f / 32768.0f), eps_ahead);
+                Mn = M * (1.0f / 32768.0f);
             }
             auto pairs = [&](auto S) __attribute__((always_inline)) {
                 constexpr int s = decltype(S)::value;
                 constexpr int P = (g * GROUP + 2 * s) % NC;
-                if constexpr (NC == 12) pk12_step<P>(neg, amb, xp[s], eps_w, tp);
-                else pk48_step<P>(neg, amb, xp[s], eps_w, tp);
+                if constexpr (INLOOP && (s == 0 || s >= 5)) eps_w = __builtin_fmaf(ek.seen[s <= 4 ? 0 : s - 4], Mn, ek.ahead[s <= 4 ? 0 : s - 4]);
+                pk_step<NC, P>(neg, amb, xp[s], eps_w, tp);
             };
             pk_expand_void(pairs, std::make_integer_sequence<int, GROUP / 2>{});
             if constexpr (INLOOP) {
@@ -470,48 +476,66 @@ __device__ __forceinline__ void fir_sign_pk_body(
         const int16_t *__restrict__ x, const int16_t *__restrict__ hist, uint32_t *__restrict__ sgn,                 \
         int *__restrict__ maxval, int16_t *__restrict__ hist_out, int *__restrict__ maxval_next,                     \
         const float *__restrict__ te_mem, int N, int L, int T, int d, int NTaps, int NE_rt, float eps_up,            \
-        float eps_seen, float eps_ahead, int map, PkTaps<NCV> tp, PkExact<0> ex)                                     \
+        PkEps ek, int map, PkTaps<NCV> tp, PkExact<0> ex)                                                            \
     {                                                                                                                 \
         fir_sign_pk_body<0, NCV, INL>(x, hist, sgn, maxval, hist_out, maxval_next, te_mem, N, L, T, d, NTaps, NE_rt,  \
-                                      eps_up, eps_seen, eps_ahead, map, tp, ex);                                      \
+                                      eps_up, ek, map, tp, ex);                                                       \
     }
 PK_KERNEL(fir_sign_pk12_kernel, 12, false, PK12_VGPR_BUDGET)
+PK_KERNEL(fir_sign_pk40_kernel, 40, true, PK40_VGPR_BUDGET)
 PK_KERNEL(fir_sign_pk48_kernel, 48, true, PK48_VGPR_BUDGET)
 #undef PK_KERNEL
 
 } // namespace
 
-int launch_fir_sign_pk_quantum() { return 384; }
+// whole unrolled turns and whole 16-byte sign stores per segment: lcm(unrolled phases, 128)
+int launch_fir_sign_pk_quantum(int NC) { return pk_unroll(NC) * 128 / pk_gcd(pk_unroll(NC), 128); }
 
-// NC = 12 with the reference's 32 effective taps, or NC = 48 (any symmetric table of up to 146 effective taps)
+namespace {
+
+template <int NC, class K>
+hipError_t pk_launch_long(K kern, const FirLaunch &a, dim3 grid, dim3 block, float eps_up, int map, hipStream_t stream)
+{
+    PkTaps<NC> tp;
+    PkExact<0> ex;
+    auto tc = [&](int q) { return a.ctaps[((q % NC) + NC) % NC]; };
+    for (int j = 0; j < NC / 4; ++j) tp.E[j] = pk_f2{tc(2 * j), tc(2 * j + 1)};
+    for (int j = 0; j <= NC / 4; ++j) tp.O[j] = pk_f2{tc(2 * j), tc(2 * j - 1)};
+    ex.te[0] = 0.0f;
+    PkEps ek;
+    for (int q = 0; q < 4; ++q) {
+        ek.seen[q] = a.eps_seen_k[q];
+        ek.ahead[q] = a.eps_ahead_k[q];
+        if (!(ek.seen[q] > 0.0f)) return hipErrorInvalidValue;
+    }
+    hipLaunchKernelGGL(kern, grid, block, 0, stream, a.x, a.hist, a.sgn, a.maxval, a.hist_out, a.maxval_next, a.te_mem, a.N, a.L,
+                       a.T, a.d, a.NT, a.NE, eps_up, ek, map, tp, ex);
+    return hipGetLastError();
+}
+
+} // namespace
+
+// NC = 12 with the reference's 32 effective taps, or NC = 40 / 48 (any symmetric table whose window behind a group, NC - 1 +
+// (NE - NC) / 2 rows, is at most 96 rows long)
 hipError_t launch_fir_sign_pk(const FirLaunch &a, hipStream_t stream)
 {
-    if (a.dump || a.T % 384 || (a.NC != 12 && a.NC != 48) || a.NE < a.NC || (a.NE - a.NC) % 2 || !a.te_mem ||
-        (a.NC == 12 && a.NE != 32) || (a.NC == 48 && (a.NE - a.NC > 98 || a.eps_seen <= 0.0f)))
+    if (a.dump || (a.NC != 12 && a.NC != 40 && a.NC != 48) || a.T % launch_fir_sign_pk_quantum(a.NC) || a.NE < a.NC ||
+        (a.NE - a.NC) % 2 || !a.te_mem || (a.NC == 12 && a.NE != 32) ||
+        (a.NC != 12 && (a.NC - 1 + (a.NE - a.NC) / 2 > 96 || a.eps_seen <= 0.0f)))
         return hipErrorInvalidValue;
     dim3 grid((a.N + 63) / 64, (a.L + a.T - 1) / a.T), block(64);
     const float eps_up = __builtin_nextafterf(a.eps_pk > 0.0f ? a.eps_pk : a.eps, INFINITY);
     const int map = (a.map == 1 && grid.x % 8 == 0) ? 1 : 0;
-    if (a.NC == 12) {
-        PkTaps<12> tp;
-        PkExact<0> ex;
-        ex.te[0] = 0.0f;
-        auto tc = [&](int q) { return a.ctaps[((q % 12) + 12) % 12]; };
-        for (int j = 0; j < 3; ++j) tp.E[j] = pk_f2{tc(2 * j), tc(2 * j + 1)};
-        for (int j = 0; j <= 3; ++j) tp.O[j] = pk_f2{tc(2 * j), tc(2 * j - 1)};
-        hipLaunchKernelGGL(fir_sign_pk12_kernel, grid, block, 0, stream, a.x, a.hist, a.sgn, a.maxval,
-                           a.hist_out, a.maxval_next, a.te_mem, a.N, a.L, a.T, a.d, a.NT, a.NE, eps_up, 0.0f, 0.0f, map, tp, ex);
-    } else {
-        PkTaps<48> tp;
-        PkExact<0> ex;
-        auto tc = [&](int q) { return a.ctaps[((q % 48) + 48) % 48]; };
-        for (int j = 0; j < 12; ++j) tp.E[j] = pk_f2{tc(2 * j), tc(2 * j + 1)};
-        for (int j = 0; j <= 12; ++j) tp.O[j] = pk_f2{tc(2 * j), tc(2 * j - 1)};
-        ex.te[0] = 0.0f;
-        hipLaunchKernelGGL(fir_sign_pk48_kernel, grid, block, 0, stream, a.x, a.hist, a.sgn, a.maxval,
-                           a.hist_out, a.maxval_next, a.te_mem, a.N, a.L, a.T, a.d, a.NT, a.NE, eps_up, a.eps_seen,
-                           a.eps_ahead, map, tp, ex);
-    }
+    if (a.NC == 40) return pk_launch_long<40>(fir_sign_pk40_kernel, a, grid, block, eps_up, map, stream);
+    if (a.NC == 48) return pk_launch_long<48>(fir_sign_pk48_kernel, a, grid, block, eps_up, map, stream);
+    PkTaps<12> tp;
+    PkExact<0> ex;
+    ex.te[0] = 0.0f;
+    auto tc = [&](int q) { return a.ctaps[((q % 12) + 12) % 12]; };
+    for (int j = 0; j < 3; ++j) tp.E[j] = pk_f2{tc(2 * j), tc(2 * j + 1)};
+    for (int j = 0; j <= 3; ++j) tp.O[j] = pk_f2{tc(2 * j), tc(2 * j - 1)};
+    hipLaunchKernelGGL(fir_sign_pk12_kernel, grid, block, 0, stream, a.x, a.hist, a.sgn, a.maxval,
+                       a.hist_out, a.maxval_next, a.te_mem, a.N, a.L, a.T, a.d, a.NT, a.NE, eps_up, PkEps{}, map, tp, ex);
     return hipGetLastError();
 }
 

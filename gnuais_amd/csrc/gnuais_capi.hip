@@ -170,6 +170,12 @@ struct gnuais_batch {
     float sign_eps = 0.0f;
     float sign_eps_pk = 0.0f;       // the same for the packed transposed kernel's order of operations
     float sign_eps_seen = 0.0f, sign_eps_ahead = 0.0f;   // sign_eps split: what scales with the samples seen / what cannot
+    bool pk40_ok = false;           // the table allows 40 central taps where sign_NC is 48 (fir_sign_pk.hip)
+    float pk40_eps_pk = 0.0f, pk40_eps_seen = 0.0f, pk40_eps_ahead = 0.0f;
+    // the packed kernel's bound per output position in its 16-row group: the group's later rows are under the running
+    // maximum too, so an output that completes k rows before the group's end has k rows fewer "ahead" ([0..3]: k >= 6, 4, 2, 0)
+    float pk_seen_k[2][4] = {}, pk_ahead_k[2][4] = {};      // [0]: 48 central taps, [1]: 40
+    int fir_pk_taps = 0;            // 0: 40 where the table allows it; 48: never 40
     int fir_inloop = 1;             // 48-tap K1s: running window maximum in the loop (0: the per-segment pre-pass)
     int sign_NC = 12;               // central taps K1s evaluates
     int fir_flag2 = 1;              // the direct-form K1s gathers sign and threshold bit with one instruction per output (FL2)
@@ -343,11 +349,13 @@ int gnuais_batch_create(gnuais_batch **out, int device, int n_channels, const fl
         // sign-exact slicer (fir_slice.hip K1s): error budget of the NC central taps against the
         // reference's ordered NE-term fp32 sum, for |x| <= 32768.  The smallest NC the kernel is
         // built for (12, 48) whose bound stays small enough is used: 12 for the reference table
-        // (32 effective taps, bound 0.23), 48 for the 192 kHz table (126 taps, bound 0.87).
+        // (32 effective taps, bound 0.23), 48 for the 192 kHz table (126 taps, bound 0.87).  40 is
+        // evaluated on the way as the packed kernel's alternative to 48 (fir_sign_pk.hip; the 192 kHz
+        // table: bound 1.4, a sixth fewer multiply-adds).
         const int NE = b->NE;
         bool sym = NE <= 128;
         for (int j = 0; sym && j < NE; ++j) sym = memcmp(&b->te[j], &b->te[NE - 1 - j], 4) == 0;
-        for (int NC : {12, 48}) {
+        for (int NC : {12, 40, 48}) {
             if (!sym || b->sign_ok || NE < NC || (NE - NC) % 2) continue;
             const double u = 5.9604644775390625e-8, X = 32768.0;
             const int J0 = (NE - NC) / 2;
@@ -380,6 +388,26 @@ int gnuais_batch_create(gnuais_batch **out, int device, int n_channels, const fl
             };
             const double central = K1S_DIRECT(NC) ? paired() : ordered(J0, NC);
             const double bound = X * (ordered(0, NE) + central + sum_out) + 1e-30;
+            if (NC == 40) {
+                // the packed kernel only (running window maximum: its window behind a group is 96 rows)
+                if (std::isfinite(bound) && bound < 2.0 && NC - 1 + J0 <= 96) {
+                    double ahead = 0;
+                    for (int i = J0 + NC + 1; i <= NE; ++i)
+                        ahead += std::fabs((double) b->te[i - 1]) * (1.0 + (std::pow(1 + u, NE - i + 2) - 1));
+                    b->pk40_ok = true;
+                    b->pk40_eps_pk = (float) (bound * 1.1);
+                    b->pk40_eps_ahead = (float) (X * ahead * 1.1 + 1e-30);
+                    b->pk40_eps_seen = (float) ((bound - X * ahead) * 1.1);
+                    for (int q = 0; q < 4; ++q) {
+                        double ah = 0;
+                        for (int i = J0 + NC + 1 + (6 - 2 * q); i <= NE; ++i)
+                            ah += std::fabs((double) b->te[i - 1]) * (1.0 + (std::pow(1 + u, NE - i + 2) - 1));
+                        b->pk_ahead_k[1][q] = (float) (X * ah * 1.1 + 1e-30);
+                        b->pk_seen_k[1][q] = (float) ((bound - X * ah) * 1.1);
+                    }
+                }
+                continue;
+            }
             if (std::isfinite(bound) && bound < 2.0) {
                 b->sign_eps = (float) (bound * 1.1);
                 b->sign_eps_pk = (float) ((X * (ordered(0, NE) + ordered(J0, NC) + sum_out) + 1e-30) * 1.1);   // transposed sum (fir_sign_pk.hip)
@@ -395,6 +423,13 @@ int gnuais_batch_create(gnuais_batch **out, int device, int n_channels, const fl
                     ahead += std::fabs((double) b->te[i - 1]) * (1.0 + (std::pow(1 + u, NE - i + 2) - 1));
                 b->sign_eps_ahead = (float) (X * ahead * 1.1 + 1e-30);
                 b->sign_eps_seen = (float) ((bound - X * ahead) * 1.1);
+                for (int q = 0; q < 4; ++q) {
+                    double ah = 0;
+                    for (int i = J0 + NC + 1 + (6 - 2 * q); i <= NE; ++i)
+                        ah += std::fabs((double) b->te[i - 1]) * (1.0 + (std::pow(1 + u, NE - i + 2) - 1));
+                    b->pk_ahead_k[0][q] = (float) (X * ah * 1.1 + 1e-30);
+                    b->pk_seen_k[0][q] = (float) ((bound - X * ah) * 1.1);
+                }
                 // FL2 (fir_sign_kernel): the direct form's central taps times k = 2 / P, P = the power of two at or above
                 // eps.  k is a power of two >= 1, so every product, pre-add and partial sum of the scaled evaluation is
                 // exactly k times the unscaled one (nothing overflows: |y'| <= 2 X sum|t| / eps < 1e9; an underflow the
@@ -593,6 +628,9 @@ int gnuais_batch_set_option(gnuais_batch *b, const char *name, int value)
     } else if (!strcmp(name, "fir_flag2")) {         // 0: |y| - eps and two alignbits per output (rounds 1-4)
         if (value != 0 && value != 1) return fail(GNUAIS_E_ARG, "fir_flag2: 0 or 1");
         b->fir_flag2 = value;
+    } else if (!strcmp(name, "fir_pk_taps")) {       // long tables: 0 = 40 central taps where the table allows them, 48 = never 40
+        if (value != 0 && value != 48) return fail(GNUAIS_E_ARG, "fir_pk_taps: 0 or 48");
+        b->fir_pk_taps = value;
     } else if (!strcmp(name, "fir_variant")) {
         if (value != 0 && value != 3) return fail(GNUAIS_E_ARG, "fir_variant must be 0 (the exact sum for every sample) or 3 (the sign-exact slicer)");
         b->fir_variant = value;
@@ -683,8 +721,19 @@ static int run_fir(gnuais_batch *b, const int16_t *x, int len, float *dump, hipS
         const int q = launch_fir_sign_quantum(f.NC);        // whole loop turns of the kernel's unrolled body
         f.T = std::min((f.T + q - 1) / q * q, 65280 / q * q);       // K1s notes open outputs as 16-bit offsets into the segment
         // 48 central taps (the 192 kHz table): the transposed sum on register pairs (fir_sign_pk.hip)
-        if (f.NC == 48 && f.NE - f.NC <= 98 && f.eps_seen > 0.0f) {
-            const int qp = launch_fir_sign_pk_quantum();
+        if (f.NC == 48 && b->pk40_ok && b->fir_pk_taps != 48 && f.eps_seen > 0.0f) {
+            f.NC = 40;
+            f.eps_pk = b->pk40_eps_pk;
+            f.eps_seen = b->pk40_eps_seen;
+            f.eps_ahead = b->pk40_eps_ahead;
+            for (int j = 0; j < 40; ++j) f.ctaps[j] = b->te[(b->NE - 40) / 2 + j];
+        }
+        for (int q = 0; q < 4; ++q) {
+            f.eps_seen_k[q] = b->pk_seen_k[f.NC == 40][q];
+            f.eps_ahead_k[q] = b->pk_ahead_k[f.NC == 40][q];
+        }
+        if ((f.NC == 48 || f.NC == 40) && f.NC - 1 + (f.NE - f.NC) / 2 <= 96 && f.eps_seen > 0.0f) {
+            const int qp = launch_fir_sign_pk_quantum(f.NC);
             // 48 taps: a segment's warm-up is 47 pair steps' worth of samples; longer segments (there are plenty of
             // waves: 16384 x 192000 is 16000 segments of 3072) cut its share (round 4: 3072 against 1536, 4.29 against
             // 4.39 ms per C5 call in steady state, profiles/r04_c5_ring_and_segments.txt)
@@ -1717,9 +1766,11 @@ int gnuais_batch_info(const gnuais_batch *b, const char *name, double *value)
         *value = fs > 0.0f ? 2.0f / fs : b->sign_eps;
     }
     else if (!strcmp(name, "sign_flag_scale")) *value = !b->fir_flag2 ? 0.0f : b->sign_NC == 12 ? b->sign_fscale : 0.0f;
-    else if (!strcmp(name, "sign_eps_seen")) *value = b->sign_eps_seen;
-    else if (!strcmp(name, "sign_eps_ahead")) *value = b->sign_eps_ahead;
-    else if (!strcmp(name, "sign_central_taps")) *value = b->sign_NC;
+    else if (!strcmp(name, "sign_eps_seen") || !strcmp(name, "sign_eps_ahead")) {
+        const bool pk40 = b->sign_NC == 48 && b->pk40_ok && b->fir_pk_taps != 48 && b->fir_inloop;
+        *value = name[9] == 's' ? (pk40 ? b->pk40_eps_seen : b->sign_eps_seen) : (pk40 ? b->pk40_eps_ahead : b->sign_eps_ahead);
+    }
+    else if (!strcmp(name, "sign_central_taps")) *value = (b->sign_NC == 48 && b->pk40_ok && b->fir_pk_taps != 48 && b->fir_inloop) ? 40 : b->sign_NC;
     else if (!strcmp(name, "first_effective_tap")) *value = b->k0;
     else if (!strcmp(name, "n_effective_taps")) *value = b->NE;
     else if (!strcmp(name, "compute_units")) *value = b->n_cu;

@@ -24,6 +24,8 @@ struct FirLaunch {
                            //   is |y'| >= 2.0 and one v_alignbit_b32 gathers sign and exponent bit (fir_sign_kernel FL2); eps is then unused
     float eps_pk = 0;      // fir_sign_pk.hip, 12 taps: the bound for the transposed fused sum (the direct form's is eps)
     float eps_seen = 0, eps_ahead = 0;     // 48-tap K1s with the running maximum (eps_seen > 0): eps = eps_seen * M / 32768 + eps_ahead
+    float eps_seen_k[4] = {}, eps_ahead_k[4] = {};   // fir_sign_pk.hip, 40 / 48 taps: the same for an output that completes >= 6, 4, 2, 0 rows
+                                                     //   before the end of its 16-row group (those rows are under the maximum M as well)
     int NC;                //   central taps used (12 or 48)
     float ctaps[48];       //   te[(NE-NC)/2 .. +NC)
     const float *te_mem;   //   the NE effective taps in device memory (exact re-evaluation)
@@ -31,8 +33,8 @@ struct FirLaunch {
 };
 int launch_fir_sign_quantum(int NC);           // T must be a multiple of this
 hipError_t launch_fir_sign(const FirLaunch &a, hipStream_t stream);
-// K1s in transposed form on register pairs (fir_sign_pk.hip): NC 12 (32-tap table) or 48
-int launch_fir_sign_pk_quantum();
+// K1s in transposed form on register pairs (fir_sign_pk.hip): NC 12 (32-tap table), 40 or 48
+int launch_fir_sign_pk_quantum(int NC);
 hipError_t launch_fir_sign_pk(const FirLaunch &a, hipStream_t stream);
 hipError_t launch_fir_generic(const FirLaunch &a, hipStream_t stream);
 hipError_t launch_fir_history(const int16_t *x, const int16_t *hist_in, int16_t *hist_out,

@@ -1,4 +1,4 @@
-"""fir_sign_pk.hip keeps its accumulator ring (and, for 48 taps, its tap pairs) in fixed VGPRs above what the compiler
+"""fir_sign_pk.hip keeps its accumulator ring (and, for 40 and 48 taps, its tap pairs) in fixed VGPRs above what the compiler
 uses.  The asm statements list them as clobbers (so the compiler keeps nothing of its own there ACROSS a statement and
 counts them into the wave's allocation), but a clobber list cannot protect state BETWEEN two statements, so the ISA is
 scanned: (1) no compiler-generated instruction (anything outside the ASMSTART/ASMEND blocks) of the two kernels may name
@@ -13,10 +13,10 @@ import os, re, subprocess, sys, tempfile
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = os.path.join(root, "gnuais_amd", "csrc", "fir_sign_pk.hip")
 inc = open(os.path.join(root, "gnuais_amd", "csrc", "fir_sign_pk_asm.inc")).read()
-base = {nc: int(re.search(rf"#define PK{nc}_VGPR_BASE (\d+)", inc).group(1)) for nc in (12, 48)}
+base = {nc: int(re.search(rf"#define PK{nc}_VGPR_BASE (\d+)", inc).group(1)) for nc in (12, 40, 48)}
 # the highest register the generated streams name: the wave must have been allocated at least that many
 ring_top = {nc: max(int(r) for r in re.findall(r'"v(\d+)"', re.search(rf"#define PK{nc}_CLOBBERS (.*)", inc).group(1)))
-            for nc in (12, 48)}
+            for nc in (12, 40, 48)}
 if len(sys.argv) > 1:
     text = open(sys.argv[1]).read().splitlines()
 else:
@@ -27,7 +27,7 @@ else:
                                "-w", src, "-o", out])
         text = open(out).read().splitlines()
 bad = 0
-for nc in (12, 48):
+for nc in (12, 40, 48):
     inside = in_asm = found = False
     top = -1                     # highest register of the compiler's own code below the streams' block
     above = -1                   # ... and above it

@@ -89,6 +89,8 @@ def one_case(seed):
         b.set_option("fir_variant", int(os.environ["FIR_VARIANT"]))
     if rng.integers(0, 3) == 0:
         b.set_option("fir_T", int(rng.choice([96, 128, 256, 512, 2048])))
+    if rng.integers(0, 3) == 0:
+        b.set_option("fir_pk_taps", 48)                          # long tables: 48 central taps instead of 40
     b.set_option("pll_variant", int((int(os.environ["PLL_VARIANT"]) if os.environ.get("PLL_VARIANT") else rng.choice([0, 7, 8]))))
     host_input = rng.integers(0, 4) == 0          # gnuais_batch_run_host: the drop-in's entry point
     reset_at = int(rng.integers(0, len(chunks))) if rng.integers(0, 6) == 0 else -1

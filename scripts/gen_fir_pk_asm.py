@@ -8,21 +8,21 @@ the flags of the output that has just completed (|y| - eps -> amb, sign -> neg, 
 
 Operands of a full step:   %0 neg (+v)  %1 amb (+v)  %2 sample pair (v)  %3 eps (v)  %4.. tap pairs
   NC = 12: %4..%6 = E[0..2], %7..%10 = O[0..3]   (SGPR pairs)
-  NC = 48: no tap operands: O[j] sits in v[B+NC+2+2j : +1], E[j] in v[B+NC+28+2j : +1] (PK48_LOAD_O puts them there)
+  NC = 40, 48: no tap operands: O[j] (NC/4 + 1 pairs) sits in v[B+NC+2+2j : +1], E[j] (NC/4 pairs) right above them
+  (PK40_LOAD_O / PK48_LOAD_O put them there)
 A warm-up step (no outputs): %0 sample pair, %1.. tap pairs.
 Order inside a half: the pair whose slot is read next goes first and the pair that was just cleared goes last, so that
 no packed instruction sits next to an instruction that depends on it (the assembler adds no wait states in inline asm).
 """
 import os
-BASE = {12: 72, 48: int(os.environ.get("PK48_BASE", "44"))}      # first register of the ring per instantiation
+NCS = (12, 40, 48)
+BASE = {12: 72, 40: int(os.environ.get("PK40_BASE", "44")), 48: int(os.environ.get("PK48_BASE", "44"))}      # first register of the ring per instantiation
 GAP = 8     # what the compiler's own code may use ends at least GAP registers below the ring (PK*_VGPR_BUDGET, for the
             # record: nothing enforces it in the language -- scripts/check_pk_registers.py, run by the Makefile on every
             # build, scans the generated ISA for compiler code that touches the ring and checks the wave's allocation)
 
-E48_SGPR = os.environ.get("PK48_E", "vgpr") == "sgpr"
-
-def tap_e(nc, idx, first):      # operand text of E[idx]
-    return f"%{first + idx}"
+def e_base(nc):                 # first register of E[0] (NC >= 40: the tap pairs live in registers)
+    return BASE[nc] + nc + 2 + 2 * (nc // 4 + 1)
 
 def gen(nc, warm):
     B = BASE[nc]
@@ -71,7 +71,7 @@ def gen(nc, warm):
                     src, swap = j, 1
                 else:
                     src, swap = nc // 2 - 1 - j, 0
-                tap = f"%{e_first + src}" if (nc == 12 or E48_SGPR) else f"v[{B + nc + 28 + 2 * src}:{B + nc + 29 + 2 * src}]"
+                tap = f"%{e_first + src}" if nc == 12 else f"v[{e_base(nc) + 2 * src}:{e_base(nc) + 1 + 2 * src}]"
                 lines.append(f"v_pk_fma_f32 {acc(a)}, {tap}, {x}, {acc(a)} op_sel:[{swap},1,0] op_sel_hi:[{1 - swap},1,1]")
             lines += flags((P + 2) % nc)
             name = f"PK{nc}_{'WARM' if warm else 'STEP'}_{P}" + ("_HALF" if half_only else "")
@@ -81,14 +81,14 @@ def gen(nc, warm):
 def clobbers(nc):
     B = BASE[nc]
     regs = list(range(B, B + nc + 2))
-    if nc == 48:
-        regs += list(range(B + nc + 2, B + nc + 2 + 26 + 24))
+    if nc != 12:
+        regs += list(range(B + nc + 2, B + nc + 2 + 2 * (nc // 4 + 1) + 2 * (nc // 4)))
     return ", ".join(f'"v{r}"' for r in regs)
 
 path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gnuais_amd", "csrc", "fir_sign_pk_asm.inc")
 with open(path, "w") as f:
     f.write("// GENERATED by scripts/gen_fir_pk_asm.py -- do not edit.  See that script for the layout.\n")
-    for nc in (12, 48):
+    for nc in NCS:
         B = BASE[nc]
         f.write(f"#define PK{nc}_VGPR_BASE {B}\n")
         f.write(f"#define PK{nc}_VGPR_BUDGET {B - GAP}\n")
@@ -98,20 +98,20 @@ with open(path, "w") as f:
         for warm in (True, False):
             for name, lines in gen(nc, warm).items():
                 f.write(f'#define {name} "' + "\\n\\t".join(lines) + '"\n')
-    # NC = 48: the tap pairs into their registers, operands %0..%12 = O[0..12], %13..%24 = E[0..11] (SGPR pairs)
-    ld = []
-    B = BASE[48]
-    for j in range(13):
-        ld.append(f"v_mov_b64 v[{B + 50 + 2 * j}:{B + 51 + 2 * j}], %{j}")
-    for j in range(12):
-        ld.append(f"v_mov_b64 v[{B + 76 + 2 * j}:{B + 77 + 2 * j}], %{13 + j}")
-    f.write('#define PK48_LOAD_O "' + "\\n\\t".join(ld) + '"\n')
+    # NC = 40, 48: the tap pairs into their registers, operands %0.. = O[0..NC/4], then E[0..NC/4-1] (SGPR pairs)
+    for nc in NCS:
+        if nc == 12:
+            continue
+        B, no, ne = BASE[nc], nc // 4 + 1, nc // 4
+        ld = [f"v_mov_b64 v[{B + nc + 2 + 2 * j}:{B + nc + 3 + 2 * j}], %{j}" for j in range(no)]
+        ld += [f"v_mov_b64 v[{e_base(nc) + 2 * j}:{e_base(nc) + 1 + 2 * j}], %{no + j}" for j in range(ne)]
+        f.write(f'#define PK{nc}_LOAD_O "' + "\\n\\t".join(ld) + '"\n')
     # C++ dispatch: one function template per kind, the ring phase as template argument
-    for nc in (12, 48):
+    for nc in NCS:
         ne, no = nc // 4, nc // 4 + 1
         taps_e = ", ".join(f'"s"(tp.E[{j}])' for j in range(ne))
         taps_o = ", ".join(f'"s"(tp.O[{j}])' for j in range(no))
-        taps = (taps_e + ", " + taps_o) if nc == 12 else (taps_e if E48_SGPR else "")
+        taps = (taps_e + ", " + taps_o) if nc == 12 else ""
         tapsc = (", " + taps) if taps else ""
         f.write(f"template <int P> __device__ __forceinline__ void pk{nc}_step(uint32_t &neg, uint32_t &amb, pk_f2 x, float eps, const PkTaps<{nc}> &tp)\n{{\n")
         for i, P in enumerate(range(0, nc, 2)):
@@ -122,6 +122,23 @@ with open(path, "w") as f:
         for P in range(0, nc, 2):
             f.write(f"    else if constexpr (P == {P}) asm volatile(PK{nc}_WARM_{P} :: \"v\"(x){tapsc} : PK{nc}_CLOBBERS);\n")
         f.write("}\n")
-    f.write("__device__ __forceinline__ void pk48_load_o(const PkTaps<48> &tp)\n{\n    asm volatile(PK48_LOAD_O :: " +
-            ", ".join([f'\"s\"(tp.O[{j}])' for j in range(13)] + [f'\"s\"(tp.E[{j}])' for j in range(12)]) + " : PK48_CLOBBERS);\n}\n")
+    for nc in NCS:
+        if nc == 12:
+            continue
+        no, ne = nc // 4 + 1, nc // 4
+        f.write(f"__device__ __forceinline__ void pk{nc}_load_o(const PkTaps<{nc}> &tp)\n{{\n    asm volatile(PK{nc}_LOAD_O :: " +
+                ", ".join([f'\"s\"(tp.O[{j}])' for j in range(no)] + [f'\"s\"(tp.E[{j}])' for j in range(ne)]) + f" : PK{nc}_CLOBBERS);\n}}\n")
+    # one name for all instantiations
+    f.write("template <int NC, int P> __device__ __forceinline__ void pk_step(uint32_t &neg, uint32_t &amb, pk_f2 x, float eps, const PkTaps<NC> &tp)\n{\n")
+    for i, nc in enumerate(NCS):
+        f.write(f"    {'if' if i == 0 else 'else if'} constexpr (NC == {nc}) pk{nc}_step<P>(neg, amb, x, eps, tp);\n")
+    f.write("}\n")
+    f.write("template <int NC, int P, bool HALF> __device__ __forceinline__ void pk_warm(pk_f2 x, const PkTaps<NC> &tp)\n{\n")
+    for i, nc in enumerate(NCS):
+        f.write(f"    {'if' if i == 0 else 'else if'} constexpr (NC == {nc}) pk{nc}_warm<P, HALF>(x, tp);\n")
+    f.write("}\n")
+    f.write("template <int NC> __device__ __forceinline__ void pk_zero_ring(const PkTaps<NC> &tp)\n{\n")
+    for i, nc in enumerate(NCS):
+        f.write(f"    {'if' if i == 0 else 'else if'} constexpr (NC == {nc}) {{ asm volatile(PK{nc}_ZERO ::: PK{nc}_CLOBBERS);" + (f" pk{nc}_load_o(tp);" if nc != 12 else "") + " }\n")
+    f.write("}\n")
 print("wrote", path)

@@ -146,7 +146,7 @@ def test_c5_full_size():
     xb = tile_channels(dev(base), n_ch)
     taps = params.taps_192k()
     b = batch(n_ch, taps=taps, pllinc=params.PLLINC_192K, max_len=total)
-    assert b.info("sign_exact") == 1 and b.info("sign_central_taps") == 48
+    assert b.info("sign_exact") == 1 and b.info("sign_central_taps") == 40
     b.run(xb)
     frames = b.drain_frames()
     cnt = counters_of(b)

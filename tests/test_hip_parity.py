@@ -261,7 +261,7 @@ def test_chain_vs_oracle_digital_silence_patterns():
     run_both(x, [total], x.shape[1])
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("kernel", ["scalar12", "packed48"])
+@pytest.mark.parametrize("kernel", ["scalar12", "packed40", "packed48"])
 def test_open_signs_settled_in_bulk(kernel):
     """K1s notes the outputs whose sign its central sum cannot certify and settles them lane-parallel after the segment
     (eight per lane; more are settled on the spot, all lanes together).  Sparse +-1 / +-2 dither makes most outputs of a
@@ -271,8 +271,9 @@ def test_open_signs_settled_in_bulk(kernel):
     sample, and the chain behind them == oracle."""
     rng = np.random.default_rng(77)
     n_ch, total = 70, 9000
-    taps = params.taps_192k() if kernel == "packed48" else None
-    pllinc = params.PLLINC_192K if kernel == "packed48" else 0
+    taps = params.taps_192k() if kernel != "scalar12" else None
+    pllinc = params.PLLINC_192K if kernel != "scalar12" else 0
+    opts = {"fir_pk_taps": 48} if kernel == "packed48" else {}      # the 192 kHz table: 40 central taps unless told otherwise
     cols = []
     for c in range(n_ch):
         p = (0.0005, 0.003, 0.02, 0.1, 0.4, 0.9)[c % 6]
@@ -286,6 +287,8 @@ def test_open_signs_settled_in_bulk(kernel):
     xd = dev(x)
     for chunks in ([total], [4096, 3000, 1, 1903], [511] * 17 + [313]):
         b = batch(n_ch, taps=taps, pllinc=pllinc, max_len=max(chunks))
+        for k, v in opts.items():
+            b.set_option(k, v)
         assert b.info("sign_exact") == 1 and b.info("sign_central_taps") == int(kernel[-2:])
         got, pos = [], 0
         for n in chunks:
@@ -294,7 +297,7 @@ def test_open_signs_settled_in_bulk(kernel):
             pos += n
         got = np.concatenate(got, axis=1)
         assert np.array_equal(got, want), (chunks[0], np.argwhere(got != want)[:5])
-    run_both(x, [4096, 4904], n_ch, taps=taps, pllinc=pllinc)
+    run_both(x, [4096, 4904], n_ch, taps=taps, pllinc=pllinc, options=opts)
 
 
 def test_more_channel_groups_than_cus():
@@ -354,14 +357,16 @@ def test_chain_vs_oracle_other_symmetric_tables(n_taps, shape):
     run_both(x, [2048, 2048, 2048, 300], 9, taps=taps)
 
 
-def test_chain_192k_vs_oracle():
+@pytest.mark.parametrize("pk_taps", [0, 48])             # central taps of the packed slicer: 40 (default for this table) or 48
+def test_chain_192k_vs_oracle(pk_taps):
     total = 6 * 5120
     x = np.stack([synth.make_stream(total, seed=35, channel=c, sps=20, sigma=1500.0,
                                     occupancy=0.8)[0] for c in range(5)], axis=1)
-    run_both(x, [4096, total - 4096], 5, taps=params.taps_192k(), pllinc=params.PLLINC_192K)
+    run_both(x, [4096, total - 4096], 5, taps=params.taps_192k(), pllinc=params.PLLINC_192K, options={"fir_pk_taps": pk_taps})
 
 
-def test_chain_192k_sparse_impulses_and_ragged_ends():
+@pytest.mark.parametrize("pk_taps", [0, 48])
+def test_chain_192k_sparse_impulses_and_ragged_ends(pk_taps):
     """Impulses in digital silence under the 144-tap table: nearly every sample is undecidable from
     the central taps, the silence shortcut must see every sample a window touches -- also in a last
     word that ends in its first half (found by scripts/fuzz_parity.py, seed 218)."""
@@ -376,7 +381,7 @@ def test_chain_192k_sparse_impulses_and_ragged_ends():
     cols.append(np.zeros(total, dtype=np.int16))
     x = np.stack(cols, axis=1)
     for chunks in ([96, 1020, 9999, 1020, 3000], [4111, 4113, 4127, total - 12351]):   # lengths = 15, 17, 31 mod 32
-        run_both(x, chunks, x.shape[1], taps=params.taps_192k(), pllinc=params.PLLINC_192K)
+        run_both(x, chunks, x.shape[1], taps=params.taps_192k(), pllinc=params.PLLINC_192K, options={"fir_pk_taps": pk_taps})
 
 
 def test_shards_equal_whole():
