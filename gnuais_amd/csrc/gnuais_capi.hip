@@ -737,7 +737,9 @@ static int run_fir(gnuais_batch *b, const int16_t *x, int len, float *dump, hipS
             // 48 taps: a segment's warm-up is 47 pair steps' worth of samples; longer segments (there are plenty of
             // waves: 16384 x 192000 is 16000 segments of 3072) cut its share (round 4: 3072 against 1536, 4.29 against
             // 4.39 ms per C5 call in steady state, profiles/r04_c5_ring_and_segments.txt)
-            f.T = ((b->fir_T <= 768 ? 3072 : b->fir_T) + qp - 1) / qp * qp;
+            // 40 taps: 1920 (FIR alone 3.34-3.40 ms against 3.43-3.49 at 3200 and 3.85 at 6400: the lists of open outputs a
+            // segment settles at its end grow with it; profiles/r05_c5_forty_central_taps.txt)
+            f.T = ((b->fir_T <= 768 ? (f.NC == 40 ? 1920 : 3072) : b->fir_T) + qp - 1) / qp * qp;
             f.T = std::min(f.T, 65280 / qp * qp);           // the kernel notes open outputs as 16-bit offsets into the segment
             HIP_TRY(launch_fir_sign_pk(f, s));
             b->hist_cur = (b->hist_cur + 1) % gnuais_batch::HB;
