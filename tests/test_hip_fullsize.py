@@ -487,7 +487,7 @@ def test_bench_two_workers_prints_n_gpus_2():
     for mode in (["--procs"], []):                          # worker processes; the in-process node object
         out = subprocess.check_output([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--devices", devs,
                                        "--steps", "6", "--warmup", "2", "--channels", "2048", "--len", "9600",
-                                       "--base", "64", "--no-cpu"] + mode, timeout=600)
+                                       "--base", "64", "--no-cpu", "--no-traffic"] + mode, timeout=600)
         line = json.loads(out.decode().strip().splitlines()[-1])
         assert line["n_gpus"] == 2 and len(line["per_gpu"]) == 2
         assert line["value"] > 0 and line["valid_crc_msgs_per_s"] > 0
@@ -749,8 +749,10 @@ def test_c4_full_size_shard_by_shard():
     """BASELINE C4 -- 131072 channels x 48000 samples over 8 GPUs -- is eight independent C3-sized
     batches (receivers share nothing).  All eight shards of that size, each with input of
     its own, one after another through the product path on the visible device(s) (shard r on device
-    r % device_count, as `bench.py --gpus 8` places them), every channel of every shard against the
-    oracle: frames, counters, PLL carry.  What an 8-GPU node adds is only that the shards run at once."""
+    r % device_count, as `bench.py --gpus 8` places them) against the oracle: frames, counters, PLL carry -- every
+    channel of the first and the last shard, every fourth channel of the six between (the oracle is two seconds of
+    host time per 16384 channels; GNUAIS_TEST_FULL=1: every channel of all eight).  What an 8-GPU node adds is only
+    that the shards run at once."""
     import torch
     from gnuais_amd import tile_channels
     world, per, total, k = 8, 16384, 48000, 128
@@ -766,13 +768,20 @@ def test_c4_full_size_shard_by_shard():
         b = batch(per, max_len=total, device=d)
         b.run(xb)
         frames = b.drain_frames()
-        o = Oracle(per)
-        o.run(xb.cpu().numpy(), threads=host_threads())
+        every = r in (0, world - 1) or os.environ.get("GNUAIS_TEST_FULL") == "1"
+        pick = np.arange(per) if every else np.arange(r % 4, per, 4)
+        o = Oracle(len(pick))
+        o.run(np.ascontiguousarray(xb[:, torch.from_numpy(pick).to(xb.device)].cpu().numpy()), threads=host_threads())
         want = o.frames()
-        assert len(want) > 200000
-        assert frames.tobytes() == want.tobytes(), r
-        assert np.array_equal(counters_of(b), o.counters()), r
-        assert pll_of(b) == [o.pll(c) for c in range(per)], r
+        assert len(want) > 200000 * len(pick) // per
+        sel = frames if every else frames[np.isin(frames["channel"], pick)].copy()
+        if not every:
+            sel["channel"] = sel["channel"] // 4
+        assert sel.tobytes() == want.tobytes(), r
+        assert np.array_equal(counters_of(b)[pick], o.counters()), r
+        p = pll_of(b)
+        assert [p[int(c)] for c in pick] == [o.pll(i) for i in range(len(pick))], r
+        assert len(frames) > 200000
         received += len(frames)
         del b, o, xb
     torch.cuda.set_device(0)
