@@ -222,9 +222,10 @@ def test_chain_vs_oracle_noise_only_and_extremes(pll_variant):
 
 def test_time_parallel_pll_walks_out_of_its_window():
     """pll_tp.hip: a block's map is tabulated on a window of +-64 nudges around the chunk's first value; a channel whose
-    phase diffuses further inside a chunk (long stretches of loud noise: one nudge per transition, either way) makes the
-    walker run blocks itself from the true value.  48 000 samples of noise at several levels, with and without
-    messages, one call and ragged calls, the 192 kHz parameter set too: bits, frames, counters, PLL carry == oracle."""
+    phase diffuses further inside a chunk (long stretches of loud noise: one nudge per transition, either way) ends the
+    chunk where the value leaves the window, and the next chunk is centred on it.  48 000 samples of noise at several
+    levels, with and without messages, one call and ragged calls, the 192 kHz parameter set too: bits, frames,
+    counters, PLL carry == oracle."""
     rng = np.random.default_rng(77)
     total = 48000
     cols = [rng.normal(0, s, total) for s in (200, 1000, 5000, 20000)]
@@ -233,6 +234,31 @@ def test_time_parallel_pll_walks_out_of_its_window():
     run_both(x, [total], x.shape[1], pll_variant=7)
     run_both(x, [16384, 300, 256, 257, total - 17197], x.shape[1], pll_variant=7)
     run_both(x[:40000], [40000], x.shape[1], taps=params.taps_192k(), pllinc=params.PLLINC_192K, pll_variant=7)
+
+
+@pytest.mark.parametrize("pll_variant", [7, 8])
+def test_pll_with_a_sign_change_at_every_sample(pll_variant):
+    """A table that passes the input through (one tap) and inputs that change sign at every sample, at every second,
+    third ... sample, in bursts between silences, and at random: up to 256 transitions and as many nudges per 256-sample
+    block.  The time-parallel form's value then leaves its +-64 window inside ONE block, chunk after chunk (each chunk
+    still advances by a block: the worst case of its walk); the lane-per-channel form's 128-sample blocks hold their
+    maximum of transitions.  Several pllinc (slices every 4.7 to 20 samples).  == oracle, bit for bit."""
+    rng = np.random.default_rng(123)
+    total = 12000
+    taps = np.zeros(9, dtype=np.float32)
+    taps[4] = 1.0
+    t = np.arange(total)
+    cols = [np.where(t % 2, 900.0, -900.0),                                   # a transition at every sample
+            np.where(t // 2 % 2, 900.0, -900.0), np.where(t // 3 % 2, 900.0, -900.0),
+            np.where(t // 7 % 2, 900.0, -900.0),
+            np.where((t // 700) % 2, np.where(t % 2, 900.0, -900.0), 0.0),     # bursts of them between silences
+            np.where((t // 1500) % 2, np.where(t % 2, 900.0, -900.0), np.where(t // 5 % 2, 900.0, -900.0)),
+            rng.choice([-500.0, 500.0], total),                                # a fair coin per sample
+            np.where(rng.random(total) < 0.9, np.where(t % 2, 300.0, -300.0), 300.0)]
+    x = np.stack(cols, axis=1).astype(np.int16)
+    for pllinc in (0, 0x10000 // 20, 14000):
+        run_both(x, [total], x.shape[1], taps=taps, pllinc=pllinc, pll_variant=pll_variant)
+        run_both(x, [4097, 255, 1, 2048, total - 6401], x.shape[1], taps=taps, pllinc=pllinc, pll_variant=pll_variant)
 
 
 def test_chain_vs_oracle_digital_silence_patterns():
