@@ -697,7 +697,13 @@ static void fill_hdlc(const gnuais_batch *b, HdlcLaunch &h, int k)
     // event-driven deframer: 16 channels per wave finish a small batch soonest; where the chip is full anyway (a PLL
     // workgroup on every CU, four FIR waves per SIMD) 64 per wave -- a quarter of the waves -- cost the other stages
     // least: C3 steady state 0.492 against 0.525 ms per call (profiles/r05_pll_h3_in_the_pipeline.txt)
-    const int ev_lpw = 2 * ((b->N + 63) / 64) > (b->n_cu > 0 ? b->n_cu : 256) ? 64 : 16;
+    // small batches: a lane's walk through its events is the stage's latency, and the fewer lanes share a wave the less
+    // they wait for each other -- as few per wave as keep the launch at <= 512 waves (256 channels: 0.148 ms with one
+    // lane per wave against 0.243 with 16; 1024 channels: 0.180 with two, 0.216 with one; time_pll_forms.py, round 5)
+    int small_lpw = 1;
+    while (small_lpw < 16 && (b->N + small_lpw - 1) / small_lpw > 512) small_lpw *= 2;
+    if (b->N > PLL_TP_MAX_CHANNELS) small_lpw = 16;      // beside the lane-per-channel PLL more deframer waves cost more than they save (2048 channels: 0.346 against 0.336 ms per call)
+    const int ev_lpw = 2 * ((b->N + 63) / 64) > (b->n_cu > 0 ? b->n_cu : 256) ? 64 : small_lpw;
     h.lanes_per_wave = b->hdlc_lpw ? b->hdlc_lpw : (b->hdlc_variant ? ev_lpw : 64);
     // the chunk table describes ONE launch; a second one into the same ring would overwrite it
     h.chunks = (b->streaming && b->ring_runs[b->ring_cur] == 0) ? b->ring_chunks[b->ring_cur] : nullptr;

@@ -76,7 +76,7 @@ hipError_t launch_pll(const PllLaunch &a, hipStream_t stream);           // K2
 // K2 in its time-parallel form (pll_tp.hip): a workgroup per channel, lanes = candidate phases; small batches
 bool pll_tp_applicable(const PllLaunch &a);
 hipError_t launch_pll_tp(const PllLaunch &a, hipStream_t stream);
-constexpr int PLL_TP_MAX_CHANNELS = 512;  // launch_pll() takes the time-parallel form by itself up to this many channels
+constexpr int PLL_TP_MAX_CHANNELS = 1536; // launch_pll() takes the time-parallel form by itself up to this many channels (48 000 samples: 0.066 / 0.118 / 0.219 / 0.423 ms at 512 / 1024 / 2048 / 4096 against pll_h3's 0.32)
 
 // ---- K2b: HDLC deframer, K3: CRC-16 + frame delivery (hdlc_crc.hip) ---------
 constexpr int HDLC_CTL_WORDS = 6;

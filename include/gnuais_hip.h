@@ -311,7 +311,7 @@ int  gnuais_batch_mean_timing(gnuais_batch *b, float *ms5, int *n_calls);
  *   "fir_variant"   3 = the sign-exact slicer (default where the table allows); 0 = the exact ordered sum for every sample
  *   "fir_pk_taps"   long tables (192 kHz): 0 = 40 central taps where the table's bound allows (default), 48 = 48 of them
  *   "fir_flag2"     1 = the slicer reads sign and threshold of an output off one scaled sum (default); 0 = subtract + two gathers
- *   "pll_variant"   0 = by channel count (default: the time-parallel form, pll_tp.hip, up to 512 channels; pll_h3.hip above);
+ *   "pll_variant"   0 = by channel count (default: the time-parallel form, pll_tp.hip, up to 1536 channels; pll_h3.hip above);
  *                   7 / 8 force one
  *   "hdlc_variant"  1 = the event-driven deframer (default); 0 = the bit-serial one
  *   "hdlc_lpw"      channels per deframer wave, 1..64 (default: 16, or 64 where the batch fills the chip)

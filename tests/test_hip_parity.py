@@ -151,7 +151,7 @@ def run_both(x, chunks, n_ch, taps=None, pllinc=0, fir_T=None, pll_variant=0, op
         b.set_option("fir_T", fir_T)
     for k, v in (options or {}).items():
         b.set_option(k, v)
-    b.set_option("pll_variant", pll_variant)      # 0: by channel count (the time-parallel form up to 512 channels)
+    b.set_option("pll_variant", pll_variant)      # 0: by channel count (the time-parallel form up to 1536 channels)
     pos = 0
     gbits = [[] for _ in range(n_ch)]
     obits = [[] for _ in range(n_ch)]
