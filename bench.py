@@ -407,7 +407,9 @@ def roofline_of(m, ms_per_step=None, traffic=None, n_taps=36):
                       "measured_peak": MEASURED_HBM_GBS, "ms_per_step": ms_per_step,
                       "what": "N*L*2 bytes / ms_per_step of this line (whole chain, as the driver clocks it)"}
     if traffic and not traffic.get("error"):
-        r["traffic"] = traffic.get("chain_bytes_per_call")
+        # `traffic`: HBM bytes of the kernel `achieved` is quoted on, per launch; the whole chain's beside it
+        r["traffic"] = traffic.get("bytes_per_launch", {}).get(dom, traffic.get("chain_bytes_per_call"))
+        r["traffic_chain"] = traffic.get("chain_bytes_per_call")
         r["traffic_detail"] = {k: v for k, v in traffic.items() if k != "valu"}
         valu = traffic.get("valu") or {}
         wave_samples = m["n_ch"] * m["len"] / 64.0
@@ -643,7 +645,7 @@ def compact_line(out, detail_path=None):
     cfg = out.get("config") or {}
     c["config"] = _pick(cfg, ("workload", "channels_per_gpu", "samples_per_channel", "parallelism"))
     r = out.get("roofline") or {}
-    rr = _pick(r, ("bound", "kernel", "kernel_ms", "achieved", "peak", "unit", "frac", "traffic",
+    rr = _pick(r, ("bound", "kernel", "kernel_ms", "achieved", "peak", "unit", "frac", "traffic", "traffic_chain",
                    "algorithmic_bytes_per_launch"))
     rr.setdefault("traffic", None)
     if isinstance(r.get("chain"), dict):
