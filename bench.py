@@ -525,15 +525,24 @@ def pmc_traffic(args, config, device=0):
                         name = next((s_ for pat, s_ in short if pat in row["Kernel_Name"]), None)
                         if not name:
                             continue
-                        acc.setdefault(name, {}).setdefault(row["Counter_Name"], []).append(float(row["Counter_Value"]))
+                        # a stage may be more than one kernel per call (C5's FIR: the call's first segment and the rest):
+                        # the mean per launch of each distinct kernel, summed over the kernels of the stage
+                        full = row["Kernel_Name"]
+                        acc.setdefault(name, {}).setdefault(full, {}).setdefault(row["Counter_Name"], []).append(float(row["Counter_Value"]))
                         try:
-                            dur.setdefault(name, {})[row["Dispatch_Id"]] = (int(row["End_Timestamp"]) - int(row["Start_Timestamp"])) / 1e6
+                            dur.setdefault(name, {}).setdefault(full, {})[row["Dispatch_Id"]] = (int(row["End_Timestamp"]) - int(row["Start_Timestamp"])) / 1e6
                         except (KeyError, ValueError):
                             pass
         if not acc:
             return None
-        return ({k: {c: sum(v) / len(v) for c, v in cs.items()} for k, cs in acc.items()},
-                {k: sum(v.values()) / len(v) for k, v in dur.items() if v})
+        out_c, out_d = {}, {}
+        for k, per in acc.items():
+            for cs in per.values():
+                for c, v in cs.items():
+                    out_c.setdefault(k, {})[c] = out_c.get(k, {}).get(c, 0.0) + sum(v) / len(v)
+        for k, per in dur.items():
+            out_d[k] = sum(sum(v.values()) / len(v) for v in per.values() if v)
+        return out_c, out_d
 
     try:
         for counter in ("FETCH_SIZE", "WRITE_SIZE"):

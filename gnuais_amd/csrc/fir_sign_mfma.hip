@@ -1,0 +1,450 @@
+// fir_sign_mfma.hip -- K1s for LONG tables on the matrix pipe (gfx950): the sign-exact slicer standing in for
+// filter_run_buf() + the `out > 0` test of receiver_run() (gnuais src/filter.c:106-143, src/receiver.c:109-111,126), 48
+// central taps, as an EXACT INTEGER Toeplitz product on v_mfma_i32_32x32x16_i8.
+//
+// Same contract as fir_sign_pk.hip (bit-identical sign words, peak, history carry); what changes is how y_c, the sum over
+// the 48 central taps, is formed -- and what it costs: the packed kernel issues 20-24 v_pk_fma_f32 per sample and is
+// VALU-bound (3.4 ms per C5 call); here a step of 32 outputs x 64 channels is 60 matrix instructions and ~13 vector
+// instructions per sample row.
+//
+//   y_c[n] = sum_q tc[q] * x[n - dc + q],  q < 48.   Taps as 24-bit integers tq = round(tc * S) (S a power of two, sum |tq| <
+//   2^23), three signed int8 digits t2 t1 t0; samples as two int8 digits, x = 256 hs + l' + 128 (hs = x >> 8, l' = (x & 255)
+//   - 128).  With Y = sum tq x (exact, |Y| < 2^38):
+//       y' = A3 2^16 + A2 2^8 + A1 + (A0 >> 8) = floor(Y / 256),
+//       A3 = sum t2 hs,  A2 = sum t2 l' + t1 hs,  A1 = sum t1 l' + t0 hs,  A0 = sum t0 l' + 128 sum tq
+//   -- six matrix products per block of 16 window rows, int32 accumulators, no rounding anywhere: the only error against
+//   the real central sum is the taps' quantisation (|tq / S - tc| <= 0.5 / S each), which the host adds to the
+//   certification bound, and the floor (< 1 unit of 256 / S).
+//   A step of 32 outputs reads window rows n0 - dc .. n0 - dc + 79: five blocks of 16, the first three are the previous
+//   step's last three.  A[i][k] = tq[16 b + k - i] (Toeplitz, constant: 30 VGPRs), B[k][n] = a sample digit of row k, channel n.
+//   A wave owns 64 channels as 32 PAIRS (lanes n and n + 32 hold the pair 2n, 2n+1 -- one dword per row -- for rows r0 + 8 hh
+//   + j, hh = lane / 32) and T outputs.
+//
+// The certification threshold follows a running maximum M of |x| over EVERY row a reference window of the step touches
+// (behind AND ahead: the rows of the next step are loaded and converted one step early), so nothing is priced at full
+// scale; a channel whose M is 0 has y = +0 exactly (bit 0, nothing to settle).  Outputs with |y'| below the threshold are
+// noted per lane and settled with the reference's ordered sum (filter.h:40-49) lane-parallel, as in fir_sign_pk.hip.
+//
+// Only segments whose windows lie inside the call's input run here (t0 >= T); the call's first segment, with its
+// history rows, is the packed kernel's (launch_fir_sign_pk with max_segments = 1).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <math.h>
+#include "kernels.h"
+
+namespace gnuais {
+
+namespace {
+
+typedef int mf_v16i __attribute__((ext_vector_type(16)));
+typedef int mf_v4i __attribute__((ext_vector_type(4)));
+extern "C" __device__ int mf_ld_b32(mf_v4i, int, int, int) __asm("llvm.amdgcn.raw.buffer.load.i32");
+extern "C" __device__ float mf_load_format_f32(mf_v4i rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.load.format.f32");
+
+constexpr int MF_NC = 48, MF_NB = 5, MF_PEND = 8, MF_EXACT_BATCH = 8;
+
+struct Blk {                 // one block of 16 window rows, this lane's 8 rows x 2 channels
+    long l[2], h[2];         // [set]: the eight l' / hs digits of the even / odd channel of the pair
+};
+
+// d[j] = row j: bytes (l' even, hs even, l' odd, hs odd)  ->  per digit the eight rows' bytes
+__device__ __forceinline__ void mf_transpose8(const uint32_t *d, Blk &o)
+{
+    uint32_t e[2][4];
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+        const uint32_t d0 = d[4 * g], d1 = d[4 * g + 1], d2 = d[4 * g + 2], d3 = d[4 * g + 3];
+        // v_perm_b32(a, b, sel): selector bytes 0-3 pick from b, 4-7 from a
+        const uint32_t t0 = __builtin_amdgcn_perm(d1, d0, 0x05010400u);   // d0.b0 d1.b0 d0.b1 d1.b1
+        const uint32_t t1 = __builtin_amdgcn_perm(d1, d0, 0x07030602u);   // d0.b2 d1.b2 d0.b3 d1.b3
+        const uint32_t t2 = __builtin_amdgcn_perm(d3, d2, 0x05010400u);
+        const uint32_t t3 = __builtin_amdgcn_perm(d3, d2, 0x07030602u);
+        e[g][0] = __builtin_amdgcn_perm(t2, t0, 0x05040100u);             // b0 of rows 0..3
+        e[g][1] = __builtin_amdgcn_perm(t2, t0, 0x07060302u);             // b1
+        e[g][2] = __builtin_amdgcn_perm(t3, t1, 0x05040100u);             // b2
+        e[g][3] = __builtin_amdgcn_perm(t3, t1, 0x07060302u);             // b3
+    }
+    o.l[0] = (long) (((unsigned long) e[1][0] << 32) | e[0][0]);
+    o.h[0] = (long) (((unsigned long) e[1][1] << 32) | e[0][1]);
+    o.l[1] = (long) (((unsigned long) e[1][2] << 32) | e[0][2]);
+    o.h[1] = (long) (((unsigned long) e[1][3] << 32) | e[0][3]);
+}
+
+__device__ __forceinline__ uint32_t mf_spread16(uint32_t p)     // nibbles n3 n2 n1 n0 -> 0 n3 0 n2 0 n1 0 n0
+{
+    p &= 0xffffu;
+    p = (p | (p << 8)) & 0x00ff00ffu;
+    return (p | (p << 4)) & 0x0f0f0f0fu;
+}
+
+typedef short mf_v2s __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t mf_pk_max(uint32_t a, uint32_t b)
+{
+    return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(mf_v2s, a), __builtin_bit_cast(mf_v2s, b)));
+}
+__device__ __forceinline__ uint32_t mf_pk_min(uint32_t a, uint32_t b)
+{
+    return __builtin_bit_cast(uint32_t, __builtin_elementwise_min(__builtin_bit_cast(mf_v2s, a), __builtin_bit_cast(mf_v2s, b)));
+}
+
+} // namespace
+
+// One wave per (64 channels, segment of T outputs).  PF: steps the loads run ahead of the step that converts them.
+template <int PF>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void fir_sign_mfma_kernel(
+    const int16_t *__restrict__ x, uint32_t *__restrict__ sgn, int *__restrict__ maxval, int16_t *__restrict__ hist_out,
+    int *__restrict__ maxval_next, const float *__restrict__ te_mem, const MfmaTaps *__restrict__ cs, int N, int L, int T, int d,
+    int NTaps, int NE, int seg0, float eps_seen_u, float eps_abs_u)
+{
+    const int lane = (int) threadIdx.x, n = lane & 31, hh = lane >> 5;
+    const int t0 = ((int) blockIdx.y + seg0) * T;
+    if (t0 >= L) return;
+    const int g = (int) blockIdx.x;
+    const int t1 = (t0 + T < L) ? t0 + T : L;
+    const int c = g * 64 + 2 * n + hh;                 // the channel whose words this lane assembles and stores
+    const int J0 = (NE - MF_NC) / 2, dc = d - J0;      // y_c[o] = sum_q tc[q] * x[o - dc + q]
+    const uint32_t rowb = (uint32_t) N * 2u;
+
+    // the Toeplitz operands wait in LDS (in registers they are 30 of a wave's 256; the compiler keeps what fits)
+    __shared__ long As[MF_NB * 3][64];
+#pragma unroll
+    for (int q = 0; q < MF_NB * 3; ++q) As[q][lane] = cs->a[q / 3][q % 3][lane];
+#define MF_A(b, dgt) As[(b) * 3 + (dgt)][lane]
+    const int K0 = cs->k0;                             // 128 * sum tq
+
+    // the window rows through a descriptor based at the segment's first row (the whole input may exceed 4 GB); rows past
+    // the call read as zero
+    const int row0 = t0 - dc - 48;                     // first row of pair k0 - 3 (>= 0: t0 >= T >= dc + 48, launcher)
+    mf_v4i rs;
+    {
+        const unsigned long long p = (unsigned long long) (x + (size_t) row0 * (size_t) N);
+        const unsigned long long span = (unsigned long long) (L - row0) * rowb;
+        rs[0] = (int) (uint32_t) p;
+        rs[1] = (int) (uint32_t) ((p >> 32) & 0xffffull);
+        rs[2] = (int) (span > 0xffffffffull ? 0xffffffffu : (uint32_t) span);
+        rs[3] = 0x00020000;
+    }
+    const int voff = (g * 64 + 2 * n) * 2 + hh * 8 * (int) rowb;
+    auto load_block = [&](int r0, uint32_t *dd) __attribute__((always_inline)) {      // rows r0 + 8 hh + j (relative to row0)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) dd[j] = (uint32_t) mf_ld_b32(rs, voff, (int) ((uint32_t) (r0 + j) * rowb), 0);
+    };
+    // a block's digits and the packed maxima / minima of its 16 rows (both halves of the wave), even channel in the low half
+    uint32_t peak_pk = 0;                              // packed running maximum of the samples seen (filter.c:118-119)
+    auto maxima = [&](const uint32_t *d0, const uint32_t *d1, uint32_t &pmx, uint32_t &pmn) __attribute__((always_inline)) {   // of a pair of blocks
+        uint32_t mx = d0[0], mn = d0[0];
+#pragma unroll
+        for (int j = 1; j < 8; ++j) {
+            mx = mf_pk_max(mx, d0[j]);
+            mn = mf_pk_min(mn, d0[j]);
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            mx = mf_pk_max(mx, d1[j]);
+            mn = mf_pk_min(mn, d1[j]);
+        }
+        mx = mf_pk_max(mx, (uint32_t) __shfl_xor((int) mx, 32));
+        mn = mf_pk_min(mn, (uint32_t) __shfl_xor((int) mn, 32));
+        peak_pk = mf_pk_max(peak_pk, mx);
+        pmx = mx;
+        pmn = mn;
+    };
+    auto digits = [&](const uint32_t *dd, Blk &o) __attribute__((always_inline)) {
+        uint32_t f[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) f[j] = dd[j] ^ 0x00800080u;       // low byte -> l' (offset binary -> two's complement)
+        mf_transpose8(f, o);
+    };
+    // largest |x| of the even (s = 0) / odd channel in a packed (max, min) pair
+    auto absmax = [&](uint32_t pmx, uint32_t pmn, int s) __attribute__((always_inline)) -> int {
+        const int mx = s ? ((int) pmx >> 16) : (int) (short) (pmx & 0xffffu);
+        const int mn = s ? ((int) pmn >> 16) : (int) (short) (pmn & 0xffffu);
+        return mx > -mn ? mx : -mn;
+    };
+
+    // exact re-evaluation of one output of ANY channel of the group (filter.h:40-49 order), window through a typed
+    // descriptor (16-bit SSCALED) based at the segment's first reference row
+    const int e_row = t0 - d;                          // >= 0 (launcher)
+    mf_v4i rsrc_e;
+    {
+        const unsigned long long p = (unsigned long long) (x + (size_t) e_row * (size_t) N);
+        const unsigned long long span = (unsigned long long) (L - e_row) * rowb;
+        rsrc_e[0] = (int) (uint32_t) p;
+        rsrc_e[1] = (int) (uint32_t) ((p >> 32) & 0xffffull);
+        rsrc_e[2] = (int) (span > 0xffffffffull ? 0xffffffffu : (uint32_t) span);
+        rsrc_e[3] = 0x13004;
+    }
+    auto exact_positive = [&](int o) __attribute__((always_inline)) -> bool {      // output t0 + o of channel c
+        float sum = 0.0f;
+        const int voe = o * (int) rowb + c * 2;
+        for (int j0 = 0; j0 < NE; j0 += MF_EXACT_BATCH) {
+            float xs[MF_EXACT_BATCH];
+#pragma unroll
+            for (int j = 0; j < MF_EXACT_BATCH; ++j) {
+                const int jj = j0 + j < NE ? j0 + j : NE - 1;
+                xs[j] = mf_load_format_f32(rsrc_e, voe, (int) ((uint32_t) jj * rowb), 0);
+            }
+#pragma unroll
+            for (int j = 0; j < MF_EXACT_BATCH; ++j)
+                if (j0 + j < NE) sum = sum + te_mem[j0 + j] * xs[j];
+        }
+        return sum > 0.0f;
+    };
+
+    // ---- prologue: pairs k0 - 3 .. k0 + 1 (rows row0 .. row0 + 159); B[0..4] = the first step's blocks, B[5..6] the next step's.
+    // Pair k = the two blocks that step k is the first to use (as its B[3], B[4]).  A step's reference windows reach from the
+    // first row of pair k - 3 (J0 <= 48 rows before its first central row) to less than 65 rows past its last central row:
+    // the last row of pair k + 2.
+    Blk B[7];
+    uint32_t pmx[6], pmn[6];                           // packed maxima / minima of pairs k - 3 .. k + 2 ([5] = the newest)
+    {
+        uint32_t r0[8], r1[8];
+#pragma unroll
+        for (int p = 0; p < 5; ++p) {
+            load_block(32 * p, r0);
+            load_block(32 * p + 16, r1);
+            maxima(r0, r1, pmx[p], pmn[p]);
+            // pair k0 - 3 + p: blocks are B operands from pair k0 - 2's second block on
+            if (p == 1) { digits(r1, B[0]); }
+            else if (p == 2) { digits(r0, B[1]); digits(r1, B[2]); }
+            else if (p == 3) { digits(r0, B[3]); digits(r1, B[4]); }
+            else if (p == 4) { digits(r0, B[5]); digits(r1, B[6]); }
+        }
+    }
+    uint32_t raw[PF][2][8];
+#pragma unroll
+    for (int p = 0; p < PF; ++p) {                     // pairs k0 + 2 .. : rows row0 + 160 + 32 p
+        load_block(160 + 32 * p, raw[p][0]);
+        load_block(160 + 32 * p + 16, raw[p][1]);
+    }
+
+    uint32_t wq[4] = {0u, 0u, 0u, 0u};
+    __shared__ uint16_t pend[MF_PEND * 64];
+    int n_pend = 0;
+    auto flush = [&](int obase, uint32_t w, uint32_t amb) __attribute__((always_inline)) {     // outputs obase .. obase + 31 of channel c
+        const int valid = t1 - (t0 + obase);
+        if (valid < 32) {
+            w &= ~0u << (32 - valid);
+            amb &= ~0u << (32 - valid);
+        }
+        w &= ~amb;
+        const int slot = (obase >> 5) & 3;
+        const bool last = t0 + obase + 32 >= t1;
+        while (amb && n_pend < MF_PEND) {
+            const int pos = __clz((int) amb);
+            amb &= ~(0x80000000u >> pos);
+            pend[n_pend * 64 + lane] = (uint16_t) (obase + pos);
+            ++n_pend;
+        }
+        if (slot == 0) wq[0] = w; else if (slot == 1) wq[1] = w; else if (slot == 2) wq[2] = w; else wq[3] = w;
+        if (__any(amb != 0) || (last && __any(n_pend != 0))) {
+            const int held = (obase >> 5) - slot;                   // first word that is still in wq[]
+            for (int k = 0;; ++k) {
+                int o = -1;
+                if (k < n_pend) {
+                    o = (int) pend[k * 64 + lane];
+                } else if (amb) {
+                    const int pos = __clz((int) amb);
+                    amb &= ~(0x80000000u >> pos);
+                    o = obase + pos;
+                }
+                if (!__any(o >= 0)) break;
+                if (o < 0 || !exact_positive(o)) continue;
+                const uint32_t bit = 0x80000000u >> (o & 31);
+                const int wi = (o >> 5) - held;
+                if (wi < 0) {
+                    atomicOr(sgn + sgn_index((t0 + o) >> 5, N, c), bit);
+                } else {
+                    wq[0] |= wi == 0 ? bit : 0u;
+                    wq[1] |= wi == 1 ? bit : 0u;
+                    wq[2] |= wi == 2 ? bit : 0u;
+                    wq[3] |= wi == 3 ? bit : 0u;
+                }
+            }
+            n_pend = 0;
+        }
+        if (slot == 3 || last) {
+            uint32_t *dst = sgn + sgn_index(((t0 + obase) >> 5) - slot, N, c);
+            if (slot == 3) {
+                *reinterpret_cast<uint4 *>(dst) = make_uint4(wq[0], wq[1], wq[2], wq[3]);
+            } else {
+                dst[0] = wq[0];
+                if (slot >= 1) dst[1] = wq[1];
+                if (slot >= 2) dst[2] = wq[2];
+            }
+        }
+    };
+
+    // ---- steps of 32 outputs.  Measured (profiles/r05_c5_matrix_pipe.txt): the matrix pipe is busy 32 cycles per product =
+    // 1.2 ms per C5 call, but the kernel is bound by its ~17 vector instructions per output (digits, maxima, and 8 per output to
+    // put four int32 accumulators together and read sign and threshold off them): two waves per SIMD take 3.0 ms.  One wave
+    // per SIMD with the products software-pipelined beside the previous set's flags (sched_group_barrier) took 3.65 ms
+    // (accumulators in AccVGPRs: a copy per element read), eight-wave workgroups whose SIMD partners alternate products
+    // and flags between s_barriers 3.6 ms.
+    auto products = [&](int s, mf_v16i &a3, mf_v16i &a2, mf_v16i &a1, mf_v16i &a0) __attribute__((always_inline)) {
+        // four accumulators, six products per block, no product straight behind one on the same accumulator
+#pragma unroll
+        for (int v = 0; v < 16; ++v) {
+            a3[v] = 0; a2[v] = 0; a1[v] = 0; a0[v] = K0;
+        }
+#pragma unroll
+        for (int b = 0; b < MF_NB; ++b) {
+            a3 = __builtin_amdgcn_mfma_i32_32x32x16_i8(MF_A(b, 2), B[b].h[s], a3, 0, 0, 0);
+            a2 = __builtin_amdgcn_mfma_i32_32x32x16_i8(MF_A(b, 2), B[b].l[s], a2, 0, 0, 0);
+            a1 = __builtin_amdgcn_mfma_i32_32x32x16_i8(MF_A(b, 1), B[b].l[s], a1, 0, 0, 0);
+            a0 = __builtin_amdgcn_mfma_i32_32x32x16_i8(MF_A(b, 0), B[b].l[s], a0, 0, 0, 0);
+            a2 = __builtin_amdgcn_mfma_i32_32x32x16_i8(MF_A(b, 1), B[b].h[s], a2, 0, 0, 0);
+            a1 = __builtin_amdgcn_mfma_i32_32x32x16_i8(MF_A(b, 0), B[b].h[s], a1, 0, 0, 0);
+        }
+    };
+    // sixteen outputs' sign and threshold bits, spread to their places in the 32-output word, + the partner lane's half
+    auto flags = [&](const mf_v16i &a3, const mf_v16i &a2, const mf_v16i &a1, const mf_v16i &a0, float eps, uint32_t &word, uint32_t &ambw)
+        __attribute__((always_inline)) {
+        uint32_t neg = 0, amb = 0;
+#pragma unroll
+        for (int v = 0; v < 16; ++v) {
+            const int y = (int) ((((uint32_t) a3[v] << 8) + (uint32_t) a2[v]) << 8) + a1[v] + (a0[v] >> 8);   // floor(Y / 256)
+            const float yf = (float) y;
+            neg = __builtin_amdgcn_alignbit(neg, (uint32_t) y, 31);
+            amb = __builtin_amdgcn_alignbit(amb, __float_as_uint(__builtin_fabsf(yf) - eps), 31);
+        }
+        // this lane: outputs (v % 4) + 8 (v / 4) + 4 hh, v = 0 first = bit 15
+        const uint32_t sn = mf_spread16(~neg), sa = mf_spread16(amb);
+        const uint32_t pn = (uint32_t) __shfl_xor((int) sn, 32), pa = (uint32_t) __shfl_xor((int) sa, 32);
+        word = hh == 0 ? (sn << 4) | pn : (pn << 4) | sn;
+        ambw = hh == 0 ? (sa << 4) | pa : (pa << 4) | sa;
+    };
+
+    for (int n0 = t0; n0 < t1; n0 += 32 * PF) {
+#pragma unroll
+        for (int j = 0; j < PF; ++j) {
+            const int p = j;
+            if (n0 + 32 * j < t1) {
+                mf_v16i a3, a2, a1, a0;
+                uint32_t word0 = 0, amb0 = 0, word1 = 0, amb1 = 0;
+                int M0 = 0, M1 = 0;
+                products(0, a3, a2, a1, a0);
+                {
+                    maxima(raw[p][0], raw[p][1], pmx[5], pmn[5]);     // pair k + 2: asked for PF steps ago
+                    // the running maximum over pairs k - 3 .. k + 2: every row a reference window of this step's outputs touches
+                    uint32_t mx = pmx[0], mn = pmn[0];
+#pragma unroll
+                    for (int q = 1; q < 6; ++q) {
+                        mx = mf_pk_max(mx, pmx[q]);
+                        mn = mf_pk_min(mn, pmn[q]);
+                    }
+                    M0 = absmax(mx, mn, 0);
+                    M1 = absmax(mx, mn, 1);
+                    flags(a3, a2, a1, a0, __builtin_fmaf(eps_seen_u, (float) M0, eps_abs_u), word0, amb0);
+                }
+                products(1, a3, a2, a1, a0);
+                {
+                    flags(a3, a2, a1, a0, __builtin_fmaf(eps_seen_u, (float) M1, eps_abs_u), word1, amb1);
+                    // lane hh = 0 keeps the even channel's word, hh = 1 the odd one's; a channel without a nonzero sample in
+                    // reach has y = +0 exactly: not positive (receiver.c:111), nothing to settle
+                    uint32_t w = hh == 0 ? word0 : word1, am = hh == 0 ? amb0 : amb1;
+                    if ((hh == 0 ? M0 : M1) == 0) {
+                        w = 0;
+                        am = 0;
+                    }
+                    flush(n0 + 32 * j - t0, w, am);
+#pragma unroll
+                    for (int q = 0; q < 5; ++q) {
+                        pmx[q] = pmx[q + 1];
+                        pmn[q] = pmn[q + 1];
+                    }
+                    // shift: the next step's blocks (a ring of eight blocks walked by a four-step loop turn saves these moves and
+                    // costs the registers they save: 3.06 against 2.87-3.03 ms); pair k + 2's digits
+#pragma unroll
+                    for (int b = 0; b < 5; ++b) B[b] = B[b + 2];
+                    digits(raw[p][0], B[5]);
+                    digits(raw[p][1], B[6]);
+                    // (no condition around the loads: rows past the end read as zero through the descriptor)
+                    const int rel = (n0 + 32 * j - t0) + 160 + 32 * PF;
+                    load_block(rel, raw[p][0]);
+                    load_block(rel + 16, raw[p][1]);
+                }
+            }
+        }
+    }
+
+    // ---- peak, carry
+    int peak = hh ? ((int) peak_pk >> 16) : (int) (short) (peak_pk & 0xffffu);
+    if (t1 == L) {                                     // the call's last rows, which no window of this segment has read
+        for (int m = (L - 64 > t0 ? L - 64 : t0); m < L; ++m) {
+            const int v = (int) x[(size_t) m * (size_t) N + c];
+            peak = v > peak ? v : peak;
+        }
+    }
+    if (peak > 0) atomicMax(&maxval[c], peak);
+    if (t1 == L) {                                     // carry for the next call (filter.c:129-134 restated); L >= NTaps (launcher)
+        for (int k = 0; k < NTaps; ++k)
+            hist_out[(size_t) k * (size_t) N + c] = x[(size_t) (L - NTaps + k) * (size_t) N + c];
+        maxval_next[c] = 0;
+    }
+}
+
+// 24-bit integer taps in three signed int8 digits, laid out as the A operands of the five blocks; false when the table
+// does not fit (a tap too large for the scale).  bound_q: sum |tq / S - tc| (what the quantisation adds to the
+// certification bound, per unit of |x|); scale: S.
+bool fir_sign_mfma_taps(const float *tc48, MfmaTaps *out, double *scale, double *bound_q)
+{
+    double sabs = 0;
+    for (int q = 0; q < MF_NC; ++q) sabs += fabs((double) tc48[q]);
+    if (!(sabs > 0) || !isfinite(sabs)) return false;
+    int e = 0;
+    (void) frexp(8388608.0 / sabs * 0.999, &e);        // the largest power of two at or below 2^23 / sum |tc| (a power of two:
+    const double S = ldexp(1.0, e - 1);                //  tq / S is then exact in double and fp32 alike)
+    long tq[MF_NC], sumtq = 0, sumabs = 0;
+    double bq = 0;
+    for (int q = 0; q < MF_NC; ++q) {
+        tq[q] = lround((double) tc48[q] * S);
+        sumtq += tq[q];
+        sumabs += labs(tq[q]);
+        bq += fabs((double) tq[q] / S - (double) tc48[q]);
+    }
+    if (sumabs >= 8388608 - 64) return false;
+    for (int b = 0; b < MF_NB; ++b)
+        for (int lane = 0; lane < 64; ++lane) {
+            const int i = lane & 31;
+            unsigned long v[3] = {0, 0, 0};
+            for (int j = 0; j < 8; ++j) {
+                const int k = 8 * (lane >> 5) + j, q = 16 * b + k - i;
+                long t = (q >= 0 && q < MF_NC) ? tq[q] : 0;
+                // signed digits: t = 65536 t2 + 256 t1 + t0, each in [-128, 127]
+                const long t0 = ((t + 128) & 255) - 128; t = (t - t0) >> 8;
+                const long t1 = ((t + 128) & 255) - 128; t = (t - t1) >> 8;
+                const long t2 = t;
+                if (t2 < -128 || t2 > 127) return false;
+                v[0] |= (unsigned long) (uint8_t) (int8_t) t0 << (8 * j);
+                v[1] |= (unsigned long) (uint8_t) (int8_t) t1 << (8 * j);
+                v[2] |= (unsigned long) (uint8_t) (int8_t) t2 << (8 * j);
+            }
+            for (int dgt = 0; dgt < 3; ++dgt) out->a[b][dgt][lane] = (long) v[dgt];
+        }
+    out->k0 = (int) (128 * sumtq);
+    *scale = S;
+    *bound_q = bq;
+    return true;
+}
+
+int launch_fir_sign_mfma_quantum() { return 128; }
+
+// segments seg0 .. of T outputs (the packed kernel has run segment 0): a.mfma = the device copy of the taps, a.eps_seen /
+// a.eps_ahead = the threshold in units of y' per unit of |x| / absolute
+hipError_t launch_fir_sign_mfma(const FirLaunch &a, int seg0, hipStream_t stream)
+{
+    const int J0 = (a.NE - MF_NC) / 2, dc = a.d - J0;
+    if (a.dump || a.NC != MF_NC || a.T % 128 || a.NE < MF_NC || (a.NE - MF_NC) % 2 || !a.te_mem || !a.mfma || a.N % 64 || seg0 < 1 ||
+        a.T < dc + 48 || a.T < a.d || a.L < a.NT || a.T > 65280 || !(a.eps_seen > 0.0f) || dc < 0 || J0 > 48 ||
+        (unsigned long long) (a.T + a.NE + 512) * (unsigned long long) a.N * 2ull >= 0x7fffffffull)
+        return hipErrorInvalidValue;
+    const int segs = (a.L + a.T - 1) / a.T - seg0;
+    if (segs <= 0) return hipSuccess;
+    dim3 grid(a.N / 64, segs), block(64);
+    hipLaunchKernelGGL(fir_sign_mfma_kernel<2>, grid, block, 0, stream, a.x, a.sgn, a.maxval, a.hist_out, a.maxval_next, a.te_mem,
+                       a.mfma, a.N, a.L, a.T, a.d, a.NT, a.NE, seg0, a.eps_seen, a.eps_ahead);
+    return hipGetLastError();
+}
+
+} // namespace gnuais

@@ -524,6 +524,7 @@ hipError_t launch_fir_sign_pk(const FirLaunch &a, hipStream_t stream)
         (a.NC != 12 && (a.NC - 1 + (a.NE - a.NC) / 2 > 96 || a.eps_seen <= 0.0f)))
         return hipErrorInvalidValue;
     dim3 grid((a.N + 63) / 64, (a.L + a.T - 1) / a.T), block(64);
+    if (a.max_segments > 0 && (int) grid.y > a.max_segments) grid.y = a.max_segments;
     const float eps_up = __builtin_nextafterf(a.eps_pk > 0.0f ? a.eps_pk : a.eps, INFINITY);
     const int map = (a.map == 1 && grid.x % 8 == 0) ? 1 : 0;
     if (a.NC == 40) return pk_launch_long<40>(fir_sign_pk40_kernel, a, grid, block, eps_up, map, stream);

@@ -107,6 +107,11 @@ struct gnuais_batch {
     int max_cur = 0, max_last = 0;
     gnuais_frame *frames = nullptr;
     float *d_taps = nullptr;
+    MfmaTaps *d_mfma = nullptr;     // fir_sign_mfma.hip: the 48 central taps as integer Toeplitz operands (long tables)
+    bool mfma_ok = false;
+    MfmaTaps mfma_host;
+    float mfma_eps_seen_u = 0.0f, mfma_eps_abs_u = 0.0f;     // its threshold in units of y' = floor(sum tq x / 256): per unit of max |x|, absolute
+    int fir_mfma = 1;               // 1: long tables run their inner segments on the matrix pipe where the batch allows it
     // f1 on the device (gnuais_batch_drain_nmea): allocated on first use
     uint8_t *d_seq[2] = {nullptr, nullptr};
     char *d_text = nullptr;
@@ -258,7 +263,7 @@ void gnuais_batch_destroy(gnuais_batch *b)
             if (p) (void) hipFree(p);
     }
     void *ptrs[] = {b->hist[0], b->hist[1], b->hist[2], b->hist[3], b->pll, b->lastbit, b->prev, b->ctl, b->cand,
-                    b->frame_count, b->counters, b->maxval[0], b->maxval[1], b->maxval[2], b->maxval[3], b->frames, b->d_taps,
+                    b->frame_count, b->counters, b->maxval[0], b->maxval[1], b->maxval[2], b->maxval[3], b->frames, b->d_taps, b->d_mfma,
                     b->stage_x, b->d_seq[0], b->d_seq[1], b->d_text, b->nmea_scratch, b->d_msg, b->d_word, b->stage_f, b->vt, b->vt_fslot};
     for (void *p : ptrs)
         if (p) (void) hipFree(p);
@@ -430,6 +435,20 @@ int gnuais_batch_create(gnuais_batch **out, int device, int n_channels, const fl
                     b->pk_ahead_k[0][q] = (float) (X * ah * 1.1 + 1e-30);
                     b->pk_seen_k[0][q] = (float) ((bound - X * ah) * 1.1);
                 }
+                if (NC == 48 && J0 <= 48) {
+                    // fir_sign_mfma.hip: the central sum in exact integer arithmetic on quantised taps -- the bound is the
+                    // reference's own rounding + the omitted taps + the quantisation, ALL of it per unit of the largest
+                    // |x| in reach of a window (its running maximum covers the rows behind and ahead), + 1 for the floor
+                    double S = 0, bq = 0;
+                    if (fir_sign_mfma_taps(&b->te[J0], &b->mfma_host, &S, &bq)) {
+                        const double rel = ordered(0, NE) + sum_out + bq;          // per unit of |x|, in units of y
+                        if (X * rel < 2.0) {
+                            b->mfma_ok = true;
+                            b->mfma_eps_seen_u = (float) (rel * (S / 256.0) * 1.1);
+                            b->mfma_eps_abs_u = 3.0f;
+                        }
+                    }
+                }
                 // FL2 (fir_sign_kernel): the direct form's central taps times k = 2 / P, P = the power of two at or above
                 // eps.  k is a power of two >= 1, so every product, pre-add and partial sum of the scaled evaluation is
                 // exactly k times the unscaled one (nothing overflows: |y'| <= 2 X sum|t| / eps < 1e9; an underflow the
@@ -491,6 +510,10 @@ int gnuais_batch_create(gnuais_batch **out, int device, int n_channels, const fl
     for (int q = 0; q < gnuais_batch::HB; ++q) alloc((void **) &b->maxval[q], sizeof(int) * N);
     alloc((void **) &b->frames, sizeof(gnuais_frame) * (size_t) b->frame_cap);
     alloc((void **) &b->d_taps, sizeof(float) * b->NT);
+    if (b->mfma_ok) {
+        alloc((void **) &b->d_mfma, sizeof(MfmaTaps));
+        if (e == hipSuccess) e = hipMemcpy(b->d_mfma, &b->mfma_host, sizeof(MfmaTaps), hipMemcpyHostToDevice);
+    }
     if (e == hipSuccess)
         e = hipMemcpy(b->d_taps, b->taps.data(), sizeof(float) * b->NT, hipMemcpyHostToDevice);
     for (auto &set : b->evr)
@@ -631,6 +654,9 @@ int gnuais_batch_set_option(gnuais_batch *b, const char *name, int value)
     } else if (!strcmp(name, "fir_pk_taps")) {       // long tables: 0 = 40 central taps where the table allows them, 48 = never 40
         if (value != 0 && value != 48) return fail(GNUAIS_E_ARG, "fir_pk_taps: 0 or 48");
         b->fir_pk_taps = value;
+    } else if (!strcmp(name, "fir_mfma")) {          // long tables: 1 = inner segments on the matrix pipe (fir_sign_mfma.hip), 0 = the packed kernel throughout
+        if (value != 0 && value != 1) return fail(GNUAIS_E_ARG, "fir_mfma: 0 or 1");
+        b->fir_mfma = value;
     } else if (!strcmp(name, "fir_variant")) {
         if (value != 0 && value != 3) return fail(GNUAIS_E_ARG, "fir_variant must be 0 (the exact sum for every sample) or 3 (the sign-exact slicer)");
         b->fir_variant = value;
@@ -747,7 +773,21 @@ static int run_fir(gnuais_batch *b, const int16_t *x, int len, float *dump, hipS
             // segment settles at its end grow with it; profiles/r05_c5_forty_central_taps.txt)
             f.T = ((b->fir_T <= 768 ? (f.NC == 40 ? 1920 : 3072) : b->fir_T) + qp - 1) / qp * qp;
             f.T = std::min(f.T, 65280 / qp * qp);           // the kernel notes open outputs as 16-bit offsets into the segment
+            // the matrix-pipe kernel takes every segment but the call's first (whose windows reach into the history)
+            const int dc48 = f.d - (f.NE - 48) / 2;
+            const bool mfma = b->fir_mfma && b->mfma_ok && b->N % 64 == 0 && f.T % launch_fir_sign_mfma_quantum() == 0 && len > f.T &&
+                              len >= b->NT && f.T >= dc48 + 48 && f.T >= f.d &&
+                              (unsigned long long) (f.T + f.NE + 512) * (unsigned long long) b->N * 2ull < 0x7fffffffull;
+            if (mfma) f.max_segments = 1;
             HIP_TRY(launch_fir_sign_pk(f, s));
+            if (mfma) {
+                FirLaunch m = f;
+                m.NC = 48;
+                m.mfma = b->d_mfma;
+                m.eps_seen = b->mfma_eps_seen_u;
+                m.eps_ahead = b->mfma_eps_abs_u;
+                HIP_TRY(launch_fir_sign_mfma(m, 1, s));
+            }
             b->hist_cur = (b->hist_cur + 1) % gnuais_batch::HB;
             b->max_last = b->max_cur;
             b->max_cur = (b->max_cur + 1) % gnuais_batch::HB;
@@ -1778,6 +1818,7 @@ int gnuais_batch_info(const gnuais_batch *b, const char *name, double *value)
         const bool pk40 = b->sign_NC == 48 && b->pk40_ok && b->fir_pk_taps != 48 && b->fir_inloop;
         *value = name[9] == 's' ? (pk40 ? b->pk40_eps_seen : b->sign_eps_seen) : (pk40 ? b->pk40_eps_ahead : b->sign_eps_ahead);
     }
+    else if (!strcmp(name, "sign_matrix_pipe")) *value = (b->fir_mfma && b->mfma_ok && b->N % 64 == 0 && b->sign_NC == 48 && b->fir_variant == 3) ? 1 : 0;
     else if (!strcmp(name, "sign_central_taps")) *value = (b->sign_NC == 48 && b->pk40_ok && b->fir_pk_taps != 48 && b->fir_inloop) ? 40 : b->sign_NC;
     else if (!strcmp(name, "first_effective_tap")) *value = b->k0;
     else if (!strcmp(name, "n_effective_taps")) *value = b->NE;

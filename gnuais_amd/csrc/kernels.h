@@ -30,11 +30,18 @@ struct FirLaunch {
     float ctaps[48];       //   te[(NE-NC)/2 .. +NC)
     const float *te_mem;   //   the NE effective taps in device memory (exact re-evaluation)
     int map;               // K1s workgroup -> (channel group, segment) mapping, see fir_sign_kernel
+    int max_segments = 0;  // fir_sign_pk.hip: > 0 = only the call's first segments (the rest is fir_sign_mfma.hip's)
+    const struct MfmaTaps *mfma = nullptr;   // fir_sign_mfma.hip: the device copy of its integer taps; eps_seen / eps_ahead are then in ITS units
 };
 int launch_fir_sign_quantum(int NC);           // T must be a multiple of this
 hipError_t launch_fir_sign(const FirLaunch &a, hipStream_t stream);
 // K1s in transposed form on register pairs (fir_sign_pk.hip): NC 12 (32-tap table), 40 or 48
 int launch_fir_sign_pk_quantum(int NC);
+// K1s, 48 central taps as an exact integer Toeplitz product on the matrix pipe (fir_sign_mfma.hip): segments seg0 .. of a call
+struct MfmaTaps { long a[5][3][64]; int k0; };      // [block of 16 window rows][tap digit 0..2][lane]: the A operands; 128 * sum of the integer taps
+bool fir_sign_mfma_taps(const float *tc48, MfmaTaps *out, double *scale, double *bound_q);
+int launch_fir_sign_mfma_quantum();
+hipError_t launch_fir_sign_mfma(const FirLaunch &a, int seg0, hipStream_t stream);
 hipError_t launch_fir_sign_pk(const FirLaunch &a, hipStream_t stream);
 hipError_t launch_fir_generic(const FirLaunch &a, hipStream_t stream);
 hipError_t launch_fir_history(const int16_t *x, const int16_t *hist_in, int16_t *hist_out,

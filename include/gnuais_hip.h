@@ -309,6 +309,8 @@ int  gnuais_batch_mean_timing(gnuais_batch *b, float *ms5, int *n_calls);
  *   "nbuf"          hand-off sets in use = calls that may be in flight, 2..8 (default 3; more are allocated on demand)
  *   "fir_T"         outputs per wave in K1 (multiple of 32; default 512)
  *   "fir_variant"   3 = the sign-exact slicer (default where the table allows); 0 = the exact ordered sum for every sample
+ *   "fir_mfma"      long tables (192 kHz), whole groups of 64 channels, calls longer than a segment: 1 = every segment but a call's
+ *                   first runs its 48 central taps as an exact integer Toeplitz product on the matrix pipe (default), 0 = packed kernel only
  *   "fir_pk_taps"   long tables (192 kHz): 0 = 40 central taps where the table's bound allows (default), 48 = 48 of them
  *   "fir_flag2"     1 = the slicer reads sign and threshold of an output off one scaled sum (default); 0 = subtract + two gathers
  *   "pll_variant"   0 = by channel count (default: the time-parallel form, pll_tp.hip, up to 1536 channels; pll_h3.hip above);

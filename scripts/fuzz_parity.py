@@ -74,7 +74,7 @@ def one_case(seed):
     rng = np.random.default_rng(seed)
     taps, pllinc, tname = table(rng)
     sps = 20 if tname == "192k" else 5
-    n_ch = int(rng.choice([1, 2, 3, 63, 64, 65, 130, 257]))
+    n_ch = int(rng.choice([1, 2, 3, 63, 64, 65, 128, 130, 192, 257]))     # whole groups of 64: long tables on the matrix pipe
     total = int(rng.integers(1, 30000))
     x = np.stack([column(rng, total, sps) for _ in range(n_ch)], axis=1)
     chunks = []
@@ -91,6 +91,8 @@ def one_case(seed):
         b.set_option("fir_T", int(rng.choice([96, 128, 256, 512, 2048])))
     if rng.integers(0, 3) == 0:
         b.set_option("fir_pk_taps", 48)                          # long tables: 48 central taps instead of 40
+    if rng.integers(0, 4) == 0:
+        b.set_option("fir_mfma", 0)                              # ... and the packed kernel for every segment
     b.set_option("pll_variant", int((int(os.environ["PLL_VARIANT"]) if os.environ.get("PLL_VARIANT") else rng.choice([0, 7, 8]))))
     host_input = rng.integers(0, 4) == 0          # gnuais_batch_run_host: the drop-in's entry point
     reset_at = int(rng.integers(0, len(chunks))) if rng.integers(0, 6) == 0 else -1

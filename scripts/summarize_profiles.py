@@ -16,7 +16,7 @@ root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 out = sys.argv[3] if len(sys.argv) > 3 else os.path.join(root, "profiles")      # the GPU box writes next to the raw files
 os.makedirs(out, exist_ok=True)
 
-SHORT = [("fir_sign_pk", "fir_slice"), ("fir_sign_kernel", "fir_slice"), ("fir_slice_kernel", "fir_slice"), ("pll_h3_kernel", "pll"), ("pll_tp_kernel", "pll"),
+SHORT = [("fir_sign_pk", "fir_slice"), ("fir_sign_mfma", "fir_slice"), ("fir_sign_kernel", "fir_slice"), ("fir_slice_kernel", "fir_slice"), ("pll_h3_kernel", "pll"), ("pll_tp_kernel", "pll"),
          ("hdlc_events_kernel", "hdlc_deframe"), ("hdlc_deframe_kernel", "hdlc_deframe"),
          ("hdlc_crc_kernel", "hdlc_crc")]
 
@@ -30,15 +30,23 @@ def short(name):
 
 def per_launch(path, n_ch=16384):
     """mean counter value per launch, bench-sized launches only (grid of the C3 workload)"""
-    acc = defaultdict(lambda: defaultdict(list))
+    acc = defaultdict(lambda: defaultdict(lambda: defaultdict(list)))
     with open(path) as f:
         for r in csv.DictReader(f):
             s = short(r["Kernel_Name"])
             if s is None:
                 continue
-            acc[s][r["Counter_Name"]].append(float(r["Counter_Value"]))
-    # the three isolated + warm-up launches are the same size as the timed ones: plain mean
-    return {k: {c: sum(v) / len(v) for c, v in d.items()} for k, d in acc.items()}
+            acc[s][r["Kernel_Name"]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    # the three isolated + warm-up launches are the same size as the timed ones: plain mean per distinct kernel; a stage
+    # that is two kernels per call (C5's FIR: the call's first segment, the rest) is their sum
+    out = {}
+    for k, per in acc.items():
+        out[k] = defaultdict(float)
+        for d in per.values():
+            for c, v in d.items():
+                out[k][c] += sum(v) / len(v)
+        out[k] = dict(out[k])
+    return out
 
 
 def find(rel):

@@ -410,6 +410,51 @@ def test_chain_192k_sparse_impulses_and_ragged_ends(pk_taps):
         run_both(x, chunks, x.shape[1], taps=params.taps_192k(), pllinc=params.PLLINC_192K, options={"fir_pk_taps": pk_taps})
 
 
+@pytest.mark.parametrize("n_ch", [64, 192])
+def test_chain_192k_on_the_matrix_pipe(n_ch):
+    """fir_sign_mfma.hip: with whole groups of 64 channels and calls longer than a segment, the 144-tap table's slicer
+    runs every segment but a call's first as an integer Toeplitz product on the matrix pipe.  Messages at several noise
+    levels, noise alone from 3 to 20 000 rms, full-scale random samples, digital silence with sparse impulses, silence
+    that ends and begins inside a segment, constant levels: bits, frames, counters, PLL carry == oracle; calls of one
+    and of several segments, ragged, and short calls in between (the packed kernel alone)."""
+    rng = np.random.default_rng(4242)
+    total = 4 * 1920 + 777
+    cols = []
+    for c in range(n_ch):
+        k = c % 16
+        if k < 6:
+            v = synth.make_stream(total, seed=57, channel=c, sps=20, sigma=(0.0, 300.0, 1500.0, 6000.0, 20000.0, 1000.0)[k],
+                                  occupancy=0.8)[0].astype(np.float64)
+        elif k < 10:
+            v = rng.normal(0, (3.0, 40.0, 1000.0, 20000.0)[k - 6], total)
+        elif k == 10:
+            v = rng.integers(-32768, 32768, total).astype(np.float64)
+        elif k == 11:
+            v = np.zeros(total)
+            at = rng.integers(0, total, total // 90)
+            v[at] = rng.integers(-32768, 32768, len(at))
+        elif k == 12:
+            v = rng.normal(0, 2000.0, total)
+            v[2500:5200] = 0                                          # silence inside segments
+            v[6100:6140] = 0
+        elif k == 13:
+            v = np.zeros(total)
+        elif k == 14:
+            v = np.full(total, (32767.0, -32768.0, 1.0, -1.0)[(c // 16) % 4])
+        else:
+            v = np.where(rng.random(total) < 0.02, rng.integers(-2, 3, total), 0).astype(np.float64)   # +-1 / +-2 dither in silence
+        cols.append(v)
+    x = np.clip(np.rint(np.stack(cols, axis=1)), -32768, 32767).astype(np.int16)
+    kw = dict(taps=params.taps_192k(), pllinc=params.PLLINC_192K)
+    b = batch(n_ch, max_len=total, **kw)
+    assert b.info("sign_matrix_pipe") == 1
+    b.close()
+    run_both(x, [total], n_ch, **kw)
+    run_both(x, [1921, 1920, 100, 3841, total - 7782], n_ch, **kw)
+    run_both(x, [total], n_ch, options={"fir_pk_taps": 48}, **kw)
+    run_both(x, [total], n_ch, options={"fir_mfma": 0}, **kw)
+
+
 def test_shards_equal_whole():
     """channels are independent -- two half batches == one batch."""
     n_ch, total = 128, 8 * 1280
