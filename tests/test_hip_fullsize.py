@@ -750,7 +750,7 @@ def test_c4_full_size_shard_by_shard():
     batches (receivers share nothing).  All eight shards of that size, each with input of
     its own, one after another through the product path on the visible device(s) (shard r on device
     r % device_count, as `bench.py --gpus 8` places them) against the oracle: frames, counters, PLL carry -- every
-    channel of the first and the last shard, every fourth channel of the six between (the oracle is two seconds of
+    channel of the first and the last shard, every eighth channel of the six between (the oracle is two seconds of
     host time per 16384 channels; GNUAIS_TEST_FULL=1: every channel of all eight).  What an 8-GPU node adds is only
     that the shards run at once."""
     import torch
@@ -769,14 +769,14 @@ def test_c4_full_size_shard_by_shard():
         b.run(xb)
         frames = b.drain_frames()
         every = r in (0, world - 1) or os.environ.get("GNUAIS_TEST_FULL") == "1"
-        pick = np.arange(per) if every else np.arange(r % 4, per, 4)
+        pick = np.arange(per) if every else np.arange(r % 8, per, 8)
         o = Oracle(len(pick))
         o.run(np.ascontiguousarray(xb[:, torch.from_numpy(pick).to(xb.device)].cpu().numpy()), threads=host_threads())
         want = o.frames()
         assert len(want) > 200000 * len(pick) // per
         sel = frames if every else frames[np.isin(frames["channel"], pick)].copy()
         if not every:
-            sel["channel"] = sel["channel"] // 4
+            sel["channel"] = sel["channel"] // 8
         assert sel.tobytes() == want.tobytes(), r
         assert np.array_equal(counters_of(b)[pick], o.counters()), r
         p = pll_of(b)

@@ -641,13 +641,13 @@ def test_randomised_soak_short():
     import sys
     sys.path.insert(0, os.path.join(os.path.dirname(G), "..", "scripts"))
     import fuzz_parity
-    for seed in list(range(1000, 1020)) + [218, 219]:
+    for seed in list(range(1000, 1012)) + [218, 219]:
         res = fuzz_parity.one_case(seed)
         assert res.startswith("ok"), (seed, res)
     for seed in (3, 4, 5):
         res = fuzz_parity.pipelined_case(seed)
         assert res.startswith("ok"), (seed, res)
-    for seed in range(2000, 2012):
+    for seed in range(2000, 2008):
         res = fuzz_parity.deframer_case(seed)
         assert res.startswith("ok"), (seed, res)
 
