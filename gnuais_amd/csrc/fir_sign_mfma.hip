@@ -281,29 +281,38 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     // per SIMD with the products software-pipelined beside the previous set's flags (sched_group_barrier) took 3.65 ms
     // (accumulators in AccVGPRs: a copy per element read), eight-wave workgroups whose SIMD partners alternate products
     // and flags between s_barriers 3.6 ms.
-    auto products = [&](int s, mf_v16i &a3, mf_v16i &a2, mf_v16i &a1, mf_v16i &a0) __attribute__((always_inline)) {
-        // four accumulators, six products per block, no product straight behind one on the same accumulator
+    // y' = ((A3 2^8 + A2) 2^8) + (A1 + (A0 >> 8)): the outer accumulators first (ten products, alternating), their shifted values
+    // are what the inner accumulators start from (twenty products, alternating) -- two accumulators per output instead of four,
+    // three vector instructions per output to form y' instead of four; no product straight behind one on the same accumulator
+    auto products = [&](int s, mf_v16i &c2, mf_v16i &c1) __attribute__((always_inline)) {
+        mf_v16i a3 = {0}, a0;
 #pragma unroll
-        for (int v = 0; v < 16; ++v) {
-            a3[v] = 0; a2[v] = 0; a1[v] = 0; a0[v] = K0;
-        }
+        for (int v = 0; v < 16; ++v) a0[v] = K0;
 #pragma unroll
         for (int b = 0; b < MF_NB; ++b) {
             a3 = __builtin_amdgcn_mfma_i32_32x32x16_i8(MF_A(b, 2), B[b].h[s], a3, 0, 0, 0);
-            a2 = __builtin_amdgcn_mfma_i32_32x32x16_i8(MF_A(b, 2), B[b].l[s], a2, 0, 0, 0);
-            a1 = __builtin_amdgcn_mfma_i32_32x32x16_i8(MF_A(b, 1), B[b].l[s], a1, 0, 0, 0);
             a0 = __builtin_amdgcn_mfma_i32_32x32x16_i8(MF_A(b, 0), B[b].l[s], a0, 0, 0, 0);
-            a2 = __builtin_amdgcn_mfma_i32_32x32x16_i8(MF_A(b, 1), B[b].h[s], a2, 0, 0, 0);
-            a1 = __builtin_amdgcn_mfma_i32_32x32x16_i8(MF_A(b, 0), B[b].h[s], a1, 0, 0, 0);
+        }
+#pragma unroll
+        for (int v = 0; v < 16; ++v) {
+            c2[v] = (int) ((uint32_t) a3[v] << 8);
+            c1[v] = a0[v] >> 8;
+        }
+#pragma unroll
+        for (int b = 0; b < MF_NB; ++b) {
+            c2 = __builtin_amdgcn_mfma_i32_32x32x16_i8(MF_A(b, 2), B[b].l[s], c2, 0, 0, 0);
+            c1 = __builtin_amdgcn_mfma_i32_32x32x16_i8(MF_A(b, 1), B[b].l[s], c1, 0, 0, 0);
+            c2 = __builtin_amdgcn_mfma_i32_32x32x16_i8(MF_A(b, 1), B[b].h[s], c2, 0, 0, 0);
+            c1 = __builtin_amdgcn_mfma_i32_32x32x16_i8(MF_A(b, 0), B[b].h[s], c1, 0, 0, 0);
         }
     };
     // sixteen outputs' sign and threshold bits, spread to their places in the 32-output word, + the partner lane's half
-    auto flags = [&](const mf_v16i &a3, const mf_v16i &a2, const mf_v16i &a1, const mf_v16i &a0, float eps, uint32_t &word, uint32_t &ambw)
+    auto flags = [&](const mf_v16i &c2, const mf_v16i &c1, float eps, uint32_t &word, uint32_t &ambw)
         __attribute__((always_inline)) {
         uint32_t neg = 0, amb = 0;
 #pragma unroll
         for (int v = 0; v < 16; ++v) {
-            const int y = (int) ((((uint32_t) a3[v] << 8) + (uint32_t) a2[v]) << 8) + a1[v] + (a0[v] >> 8);   // floor(Y / 256)
+            const int y = (int) ((uint32_t) c2[v] << 8) + c1[v];                                           // floor(Y / 256)
             const float yf = (float) y;
             neg = __builtin_amdgcn_alignbit(neg, (uint32_t) y, 31);
             amb = __builtin_amdgcn_alignbit(amb, __float_as_uint(__builtin_fabsf(yf) - eps), 31);
@@ -320,10 +329,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
         for (int j = 0; j < PF; ++j) {
             const int p = j;
             if (n0 + 32 * j < t1) {
-                mf_v16i a3, a2, a1, a0;
+                mf_v16i c2, c1;
                 uint32_t word0 = 0, amb0 = 0, word1 = 0, amb1 = 0;
                 int M0 = 0, M1 = 0;
-                products(0, a3, a2, a1, a0);
+                products(0, c2, c1);
                 {
                     maxima(raw[p][0], raw[p][1], pmx[5], pmn[5]);     // pair k + 2: asked for PF steps ago
                     // the running maximum over pairs k - 3 .. k + 2: every row a reference window of this step's outputs touches
@@ -335,11 +344,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
                     }
                     M0 = absmax(mx, mn, 0);
                     M1 = absmax(mx, mn, 1);
-                    flags(a3, a2, a1, a0, __builtin_fmaf(eps_seen_u, (float) M0, eps_abs_u), word0, amb0);
+                    flags(c2, c1, __builtin_fmaf(eps_seen_u, (float) M0, eps_abs_u), word0, amb0);
                 }
-                products(1, a3, a2, a1, a0);
+                products(1, c2, c1);
                 {
-                    flags(a3, a2, a1, a0, __builtin_fmaf(eps_seen_u, (float) M1, eps_abs_u), word1, amb1);
+                    flags(c2, c1, __builtin_fmaf(eps_seen_u, (float) M1, eps_abs_u), word1, amb1);
                     // lane hh = 0 keeps the even channel's word, hh = 1 the odd one's; a channel without a nonzero sample in
                     // reach has y = +0 exactly: not positive (receiver.c:111), nothing to settle
                     uint32_t w = hh == 0 ? word0 : word1, am = hh == 0 ? amb0 : amb1;
