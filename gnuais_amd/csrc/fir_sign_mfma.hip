@@ -4,15 +4,16 @@
 //
 // Same contract as fir_sign_pk.hip (bit-identical sign words, peak, history carry); what changes is how y_c, the sum over
 // the 48 central taps, is formed -- and what it costs: the packed kernel issues 20-24 v_pk_fma_f32 per sample and is
-// VALU-bound (3.4 ms per C5 call); here a step of 32 outputs x 64 channels is 60 matrix instructions and ~13 vector
-// instructions per sample row.
+// VALU-bound (3.4 ms per C5 call); here a step of 32 outputs x 64 channels is 60 matrix instructions and ~16 vector
+// instructions per output and channel (2.9 ms; what binds it is in the step loop's comment).
 //
 //   y_c[n] = sum_q tc[q] * x[n - dc + q],  q < 48.   Taps as 24-bit integers tq = round(tc * S) (S a power of two, sum |tq| <
 //   2^23), three signed int8 digits t2 t1 t0; samples as two int8 digits, x = 256 hs + l' + 128 (hs = x >> 8, l' = (x & 255)
 //   - 128).  With Y = sum tq x (exact, |Y| < 2^38):
 //       y' = A3 2^16 + A2 2^8 + A1 + (A0 >> 8) = floor(Y / 256),
 //       A3 = sum t2 hs,  A2 = sum t2 l' + t1 hs,  A1 = sum t1 l' + t0 hs,  A0 = sum t0 l' + 128 sum tq
-//   -- six matrix products per block of 16 window rows, int32 accumulators, no rounding anywhere: the only error against
+//   -- six matrix products per block of 16 window rows, int32 accumulators (A3 and A0 first; A3 2^8 and A0 >> 8 are what A2
+//   and A1 accumulate on), no rounding anywhere: the only error against
 //   the real central sum is the taps' quantisation (|tq / S - tc| <= 0.5 / S each), which the host adds to the
 //   certification bound, and the floor (< 1 unit of 256 / S).
 //   A step of 32 outputs reads window rows n0 - dc .. n0 - dc + 79: five blocks of 16, the first three are the previous
@@ -276,8 +277,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     };
 
     // ---- steps of 32 outputs.  Measured (profiles/r05_c5_matrix_pipe.txt): the matrix pipe is busy 32 cycles per product =
-    // 1.2 ms per C5 call, but the kernel is bound by its ~17 vector instructions per output (digits, maxima, and 8 per output to
-    // put four int32 accumulators together and read sign and threshold off them): two waves per SIMD take 3.0 ms.  One wave
+    // 1.2 ms per C5 call, but the kernel is bound by its ~16 vector instructions per output (digits, maxima, and 7 per output to
+    // put the int32 accumulators together and read sign and threshold off them): two waves per SIMD take 2.9 ms.  One wave
     // per SIMD with the products software-pipelined beside the previous set's flags (sched_group_barrier) took 3.65 ms
     // (accumulators in AccVGPRs: a copy per element read), eight-wave workgroups whose SIMD partners alternate products
     // and flags between s_barriers 3.6 ms.
