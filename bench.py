@@ -557,7 +557,7 @@ def pmc_traffic(args, config, device=0):
             res[k] = (2.0 * raw["FETCH_SIZE"][k] + raw["WRITE_SIZE"].get(k, 0.0)) * 1024.0
         valu = None
         sq = ["SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "SQ_WAVE_CYCLES", "SQ_WAVES"]
-        got = one_pass("SQ", sq + ["GRBM_GUI_ACTIVE"]) or one_pass("SQ2", sq)
+        got = one_pass("SQ", sq + ["SQ_VALU_MFMA_BUSY_CYCLES", "GRBM_GUI_ACTIVE"]) or one_pass("SQ1", sq + ["GRBM_GUI_ACTIVE"]) or one_pass("SQ2", sq)
         if got:
             valu = {}
             for k, c in got[0].items():
@@ -573,10 +573,15 @@ def pmc_traffic(args, config, device=0):
                 # (profiles/r05_ubench_valu_op_rates.txt: direct12_now_8out)
                 inst_cycles = 2.45 if (k == "fir_slice" and config in ("C2", "C3")) else 4.0
                 floor_ms = c["SQ_ACTIVE_INST_VALU"] * inst_cycles / (N_SIMD * clock) * 1e3
+                # a kernel that also runs matrix products (C5's slicer): the pipe's busy cycles (32 per product, summed over
+                # the SIMDs) on top -- its two waves per SIMD run in phase, products and vector work do not overlap
+                # (profiles/r05_c5_matrix_pipe.txt)
+                mfma_ms = c.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / (N_SIMD * clock) * 1e3
+                floor_ms += mfma_ms
                 valu[k] = {"insts_per_launch": c.get("SQ_INSTS_VALU"), "active_quad_cycles": c["SQ_ACTIVE_INST_VALU"],
                            "waves": c.get("SQ_WAVES"), "launch_ms_in_this_pass": ms, "clock_ghz": clock / 1e9,
                            "clock_from": "GRBM_GUI_ACTIVE / 8 XCDs / duration" if c.get("GRBM_GUI_ACTIVE") else "spec",
-                           "issue_floor_ms": floor_ms, "busy_frac": floor_ms / ms, "cycles_per_instruction_priced": inst_cycles,
+                           "issue_floor_ms": floor_ms, "mfma_busy_ms": mfma_ms, "busy_frac": floor_ms / ms, "cycles_per_instruction_priced": inst_cycles,
                            "valu_share_of_wave_cycles": (c["SQ_ACTIVE_INST_VALU"] / c["SQ_WAVE_CYCLES"]) if c.get("SQ_WAVE_CYCLES") else None}
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
