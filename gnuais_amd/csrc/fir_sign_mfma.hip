@@ -381,7 +381,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     // ---- peak, carry
     int peak = hh ? ((int) peak_pk >> 16) : (int) (short) (peak_pk & 0xffffu);
     if (t1 == L) {                                     // the call's last rows, which no window of this segment has read
-        for (int m = (L - 64 > t0 ? L - 64 : t0); m < L; ++m) {
+        // (the loop's maxima reach row L - dc + 111 at least; dc = d - J0 grows with trailing zero taps, so the rescan
+        // follows it -- 96 for the 192 kHz table, where 64 rows do)
+        const int J0p = (NE - MF_NC) / 2, back = (d - J0p) > 64 ? (d - J0p) : 64;
+        for (int m = (L - back > t0 ? L - back : t0); m < L; ++m) {
             const int v = (int) x[(size_t) m * (size_t) N + c];
             peak = v > peak ? v : peak;
         }

@@ -65,29 +65,15 @@ struct PkTaps {
     pk_f2 E[NC / 4];            // E[j] = { tc[2j], tc[2j+1] },   j < NC/4
     pk_f2 O[NC / 4 + 1];        // O[j] = { tc[2j], tc[2j-1] },   j <= NC/4, tc[-1] = tc[NC-1]
 };
-#ifndef PK_DEFER
-#define PK_DEFER 1          // 0: every open sign is settled where it is found (rounds 3-4; kept for the A/B)
-#endif
-#ifndef PK_EXACT_BATCH
-#define PK_EXACT_BATCH 6          // loads in flight in the ordered sum (8 cost the 48-tap kernel a 145th register: 152 per wave instead of 144)
-#endif
-#define PK_PEND 8           // noted outputs per lane (1 KB of LDS per wave); more than that are settled on the spot
+constexpr int PK_EXACT_BATCH = 6;   // loads in flight in the ordered sum (8 cost the 48-tap kernel a 145th register: 152 per wave instead of 144)
+constexpr int PK_PEND = 8;          // noted outputs per lane (1 KB of LDS per wave); more than that are settled on the spot
 template <int NES> struct PkExact { float te[NES > 0 ? NES : 1]; };
 // INLOOP: eps = seen * M / 32768 + ahead with M the running maximum of |x| over the rows behind AND the rest of the
 // output's own 16-row group; [0..3]: the output completes >= 6, 4, 2, 0 rows before the group's end (pair steps 0-4, 5,
 // 6, 7) -- the taps that reach beyond those rows are priced with |x| = 32768 in `ahead` (gnuais_capi.hip)
 struct PkEps { float seen[4], ahead[4]; };
 
-// the next group's rows are requested before this group's steps run
-#ifndef PK_PREFETCH_12
-#define PK_PREFETCH_12 1
-#endif
-#ifndef PK_PREFETCH_48
-#define PK_PREFETCH_48 0
-#endif
-#ifndef PK_WARM_BATCH
-#define PK_WARM_BATCH 8
-#endif
+constexpr int PK_WARM_BATCH = 8;    // warm-up rows loaded at a time
 #include "fir_sign_pk_asm.inc"       // generated: the pair steps as fixed-register instruction streams (scripts/gen_fir_pk_asm.py)
 
 // NES > 0: the table's NES effective taps travel in SGPRs for the exact re-evaluation (reference table: 32);
@@ -297,7 +283,7 @@ __device__ __forceinline__ void fir_sign_pk_body(
         w &= ~amb;
         const int slot = (obase >> 5) & 3;
         const bool last = t0 + obase + 32 >= t1;
-        if (PK_DEFER) {
+        {
             while (amb && n_pend < PK_PEND) {
                 const int pos = __clz((int) amb);
                 amb &= ~(0x80000000u >> pos);
@@ -306,7 +292,7 @@ __device__ __forceinline__ void fir_sign_pk_body(
             }
         }
         if (slot == 0) wq[0] = w; else if (slot == 1) wq[1] = w; else if (slot == 2) wq[2] = w; else wq[3] = w;
-        if (__any(amb != 0) || (PK_DEFER && last && __any(n_pend != 0))) {
+        if (__any(amb != 0) || (last && __any(n_pend != 0))) {
             const int held = (obase >> 5) - slot;                   // first word that is still in wq[]
             for (int k = 0;; ++k) {
                 int o = -1;
@@ -369,7 +355,7 @@ __device__ __forceinline__ void fir_sign_pk_body(
             }
         }
     };
-    constexpr bool PF = NC == 12 ? (PK_PREFETCH_12 != 0) : (PK_PREFETCH_48 != 0);
+    constexpr bool PF = false;      // (the next group's rows requested a group ahead: level for the long tables, profiles/r04_c5_ring_and_segments.txt)
     pk_f2 xn[GROUP / 2];
     if constexpr (PF) load_group(m0 + NC - 1, xn);
     for (int b = 0; b * NG < ngroups; ++b) {
@@ -481,7 +467,6 @@ __device__ __forceinline__ void fir_sign_pk_body(
         fir_sign_pk_body<0, NCV, INL>(x, hist, sgn, maxval, hist_out, maxval_next, te_mem, N, L, T, d, NTaps, NE_rt,  \
                                       eps_up, ek, map, tp, ex);                                                       \
     }
-PK_KERNEL(fir_sign_pk12_kernel, 12, false, PK12_VGPR_BUDGET)
 PK_KERNEL(fir_sign_pk40_kernel, 40, true, PK40_VGPR_BUDGET)
 PK_KERNEL(fir_sign_pk48_kernel, 48, true, PK48_VGPR_BUDGET)
 #undef PK_KERNEL
@@ -515,29 +500,20 @@ hipError_t pk_launch_long(K kern, const FirLaunch &a, dim3 grid, dim3 block, flo
 
 } // namespace
 
-// NC = 12 with the reference's 32 effective taps, or NC = 40 / 48 (any symmetric table whose window behind a group, NC - 1 +
-// (NE - NC) / 2 rows, is at most 96 rows long)
+// NC = 40 / 48: any symmetric table whose window behind a group, NC - 1 + (NE - NC) / 2 rows, is at most 96 rows long.
+// (The reference's 32-tap table with 12 central taps in this form was slower than the direct form of fir_slice.hip --
+// v_pk_fma_f32 issues at half the rate of v_fmac_f32 -- and left with round 5: profiles/r05_ubench_valu_op_rates.txt.)
 hipError_t launch_fir_sign_pk(const FirLaunch &a, hipStream_t stream)
 {
-    if (a.dump || (a.NC != 12 && a.NC != 40 && a.NC != 48) || a.T % launch_fir_sign_pk_quantum(a.NC) || a.NE < a.NC ||
-        (a.NE - a.NC) % 2 || !a.te_mem || (a.NC == 12 && a.NE != 32) ||
-        (a.NC != 12 && (a.NC - 1 + (a.NE - a.NC) / 2 > 96 || a.eps_seen <= 0.0f)))
+    if (a.dump || (a.NC != 40 && a.NC != 48) || a.T % launch_fir_sign_pk_quantum(a.NC) || a.NE < a.NC ||
+        (a.NE - a.NC) % 2 || !a.te_mem || a.NC - 1 + (a.NE - a.NC) / 2 > 96 || a.eps_seen <= 0.0f)
         return hipErrorInvalidValue;
     dim3 grid((a.N + 63) / 64, (a.L + a.T - 1) / a.T), block(64);
     if (a.max_segments > 0 && (int) grid.y > a.max_segments) grid.y = a.max_segments;
     const float eps_up = __builtin_nextafterf(a.eps_pk > 0.0f ? a.eps_pk : a.eps, INFINITY);
     const int map = (a.map == 1 && grid.x % 8 == 0) ? 1 : 0;
     if (a.NC == 40) return pk_launch_long<40>(fir_sign_pk40_kernel, a, grid, block, eps_up, map, stream);
-    if (a.NC == 48) return pk_launch_long<48>(fir_sign_pk48_kernel, a, grid, block, eps_up, map, stream);
-    PkTaps<12> tp;
-    PkExact<0> ex;
-    ex.te[0] = 0.0f;
-    auto tc = [&](int q) { return a.ctaps[((q % 12) + 12) % 12]; };
-    for (int j = 0; j < 3; ++j) tp.E[j] = pk_f2{tc(2 * j), tc(2 * j + 1)};
-    for (int j = 0; j <= 3; ++j) tp.O[j] = pk_f2{tc(2 * j), tc(2 * j - 1)};
-    hipLaunchKernelGGL(fir_sign_pk12_kernel, grid, block, 0, stream, a.x, a.hist, a.sgn, a.maxval,
-                       a.hist_out, a.maxval_next, a.te_mem, a.N, a.L, a.T, a.d, a.NT, a.NE, eps_up, PkEps{}, map, tp, ex);
-    return hipGetLastError();
+    return pk_launch_long<48>(fir_sign_pk48_kernel, a, grid, block, eps_up, map, stream);
 }
 
 } // namespace gnuais

@@ -32,10 +32,6 @@
 #include <math.h>
 #include "kernels.h"
 
-#ifndef FIR_VARIANT
-#define FIR_VARIANT scalar      // the exact kernel's namespace (built with -fno-slp-vectorize: v_mul_f32 / v_add_f32,
-#endif                          // every product and every sum rounded as filter.h:40-49 rounds them)
-
 namespace gnuais {
 
 template <int NE>
@@ -59,7 +55,9 @@ __device__ __forceinline__ int load_sample(const int16_t *__restrict__ x,
     return (int) *p;
 }
 
-namespace FIR_VARIANT {
+// the exact kernel (built with -fno-slp-vectorize: v_mul_f32 / v_add_f32, every product and every sum rounded as
+// filter.h:40-49 rounds them)
+namespace scalar {
 
 // Zero-instruction ordering fence.  hipcc's DAG scheduler is free to hoist the
 // multiplies (or sink the additions) of many samples of the unrolled block and
@@ -242,9 +240,8 @@ __global__ __launch_bounds__(64) void fir_slice_kernel(
     }
 }
 
-} // namespace FIR_VARIANT
+} // namespace scalar
 
-#ifdef FIR_PRIMARY
 // ---------------------------------------------------------------------------
 // K1s -- sign-exact slicer (the default on the receive path).
 //
@@ -269,41 +266,15 @@ __global__ __launch_bounds__(64) void fir_slice_kernel(
 //
 // Same mapping as K1 (lane = channel, wave = 64 channels x one time segment), but
 // 12 accumulators rotate, so 96 phases (three sign words) are unrolled.
-#ifndef FIR_SIGN_DEFER
-#define FIR_SIGN_DEFER 1        // 0: every open sign is settled where it is found (rounds 1-4; kept for the A/B)
-#endif
-#define FIR_SIGN_PEND 8         // noted outputs per lane (1 KB of LDS per wave); more than that are settled on the spot
-#ifndef FIR_SIGN_CLAIM
-#define FIR_SIGN_CLAIM "v103"       // the highest VGPR the 12-tap kernel pretends to use (see fir_sign_kernel; profiles/r04_fir_claim.txt)
-#endif
-#ifndef FIR_SIGN_FENCE
-#define FIR_SIGN_FENCE 4
-#endif
-// main-loop loads of the 12-tap instantiation: 0 plain global loads, 1 buffer loads (no VALU address
-// adds), 2 typed buffer loads (16-bit SSCALED descriptor: the memory pipeline also does the int16 ->
-// float conversion, exactly -- scripts/ubench/fmt_load.hip checks all 65536 values)
-#ifndef FIR_TYPED_LOADS_48
-#define FIR_TYPED_LOADS_48 1
-#endif
-// 48-tap instantiation: ask for the next group's rows before working on this group's (16 registers)
-#ifndef FIR_VTAPS_12
-#define FIR_VTAPS_12 0
-#endif
-#ifndef FIR_VTAPS_48
-#define FIR_VTAPS_48 0       // measured: 5.14 ms with the taps in VGPRs against 5.10 (C5 FIR alone); the isolated rates do not carry over
-#endif
-#ifndef FIR_PREFETCH_48
-#define FIR_PREFETCH_48 0       // measured: 5.10 ms either way (C5 FIR alone) -- the kernel is not waiting for its loads
-#endif
-// words per loop turn of the direct form; with 4 a lane stores its four sign words of 128 outputs as ONE
-// 16-byte store (sgn_index() keeps them adjacent): a wave's store covers 1 KB densely instead of four
-// stores of 4 bytes in every 16 (PMC: 0.30 GB of write traffic per C3 call for 0.10 GB of sign words)
-#ifndef FIR_DIRECT_UNROLL
-#define FIR_DIRECT_UNROLL 4
-#endif
-#ifndef FIR_BUFFER_LOADS
-#define FIR_BUFFER_LOADS 2
-#endif
+constexpr int FIR_SIGN_PEND = 8;    // noted outputs per lane (1 KB of LDS per wave); more than that are settled on the spot
+constexpr int FIR_SIGN_FENCE = 4;   // transposed form: the scheduling fence (touch12) after every fourth sample
+// words per loop turn of the direct form: a lane stores its four sign words of 128 outputs as ONE 16-byte store
+// (sgn_index() keeps them adjacent): a wave's store covers 1 KB densely instead of four stores of 4 bytes in every 16
+// (PMC: 0.30 GB of write traffic per C3 call for 0.10 GB of sign words)
+constexpr int FIR_DIRECT_UNROLL = 4;
+// Main-loop loads are typed buffer loads (16-bit SSCALED descriptor): no VALU address adds, and the memory pipeline also
+// does the int16 -> float conversion, exactly -- scripts/ubench/fmt_load.hip checks all 65536 values.  (Plain global loads,
+// untyped buffer loads, the taps in vector registers, a software prefetch of the 48-tap groups: measured, git history.)
 // zero-instruction fence (see touch16): bounds how many samples the scheduler interleaves,
 // i.e. how many products are alive at once; without it the kernel needs 98 VGPRs (4 waves per
 // SIMD) instead of <= 88 (5 waves)
@@ -327,29 +298,24 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NC == 48 ? 4
     uint32_t *__restrict__ sgn, int *__restrict__ maxval,
     int16_t *__restrict__ hist_out, int *__restrict__ maxval_next,
     const float *__restrict__ te_mem, int N, int L, int T, int d, int NTaps, int NE_rt, float eps_up,
-    int map, FirTaps<NT> taps, unsigned long long *stamps, int n_big, int T2, float eps_seen, float eps_ahead,
-    int gx, int gy, float fscale)
+    int map, FirTaps<NT> taps, float eps_seen, float eps_ahead, float fscale)
 {
     static_assert(!FL2 || K1S_DIRECT(NC), "the two-bit flag gather belongs to the direct form");
     const int NE = NES > 0 ? NES : NE_rt;
-    const int wave_id = (int) (blockIdx.y * gridDim.x + blockIdx.x);
-    if (stamps && threadIdx.x == 0) stamps[2 * wave_id] = wall_clock64();
-    // (gx, gy) = the logical grid: channel groups x segments; the launch uses exactly that grid, a workgroup does one item.
-    // (A grid of fewer, persistent workgroups looping over the items was measured slower: the hardware's own placement of
-    // 24 000 short-lived workgroups balances the launch better, and waves that never leave give the other stages no turn.)
-    const int items = gx * gy, stride = (int) (gridDim.x * gridDim.y);
-    auto work = [&](const int item) {
+    // the grid is channel groups x segments, a workgroup does one item.  (A grid of fewer, persistent workgroups looping
+    // over the items was measured slower: the hardware's own placement of 24 000 short-lived workgroups balances the
+    // launch better, and waves that never leave give the other stages no turn.)
+    const int gx = (int) gridDim.x;
+    const int item = (int) (blockIdx.y * gridDim.x + blockIdx.x);
     const int J0 = (NE - NC) / 2;               // first central tap (10 of 32 for the reference table)
     auto ctap = [&](int q) -> float { return NES > 0 ? taps.te[(NES - NC) / 2 + q] : taps.te[q]; };
-#if FIR_SIGN_FENCE > 0
     if constexpr (NC <= 12)
     // Claim 104 VGPRs although the fenced code needs 68: four waves per SIMD then leave 96
     // registers for waves of the stages that run beside us (the PLL stage needs 64).  At seven
     // waves per SIMD this kernel would fill the register file and they would wait for FIR
     // waves to retire before they could even be placed.  88 (five waves, 72 left: rounds 1-3) gives the same 20-call
     // figure and a steady state 5-7 % slower; 96, 112 and 128 are worse than both (profiles/r04_fir_claim.txt).
-    asm volatile("" ::: FIR_SIGN_CLAIM);
-#endif
+    asm volatile("" ::: "v103");
     static_assert((K1S_DIRECT(NC) || 96 % NC == 0) && NC % 2 == 0, "96 unrolled phases must hold whole turns of the accumulator ring");
     const int lane = threadIdx.x;
     // Workgroup -> (channel group, time segment).  The dispatcher deals consecutive workgroup ids
@@ -365,12 +331,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NC == 48 ? 4
     const int cg = bx * 64 + lane;
     const int c = cg < N ? cg : N - 1;
     const bool live = cg < N;
-    // Segments of two lengths: the first n_big are T outputs long, the rest T2.  Workgroups are dispatched in
-    // id order, so the short ones are the launch's last: with equal segments the launch ends in a tail of one wave
-    // lifetime (70 us of 410) during which the occupancy falls linearly to zero (scripts/fir_wave_timeline.py).
-    const int t0 = by < n_big ? by * T : n_big * T + (by - n_big) * T2;
-    const int t1e = t0 + (by < n_big ? T : T2);
-    const int t1 = t1e < L ? t1e : L;
+    // (shorter segments at the launch's end -- its tail is one wave lifetime, 70 us of 410, during which the occupancy
+    // falls linearly to zero -- were measured level: profiles/r03_fir_wave_timeline_short_tail.txt)
+    const int t0 = by * T;
+    const int t1 = t0 + T < L ? t0 + T : L;
     if (t0 >= L) return;
     const int dc = d - J0;                      // y_c[n] = sum_q tc[q] * x[n - dc + q]
 
@@ -486,16 +450,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NC == 48 ? 4
     const int row0 = m0 > 0 ? m0 : 0;
     const uint32_t rowbytes = (uint32_t) N * 2u;
     const unsigned long long span = (unsigned long long) (L - row0) * rowbytes;
-    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<int16_t *>(x) + (size_t) row0 * (size_t) N, 0,
-        (int) (span > 0xffffffffull ? 0xffffffffull : span), 0x00020000);
     const int coff = c * 2;
-    // the same range as a typed descriptor: DST_SEL_X = R, NUM_FORMAT = SSCALED, DATA_FORMAT = 16
+    // a typed descriptor: DST_SEL_X = R, NUM_FORMAT = SSCALED, DATA_FORMAT = 16
     const unsigned long long xbase = (unsigned long long) (x + (size_t) row0 * (size_t) N);
     const fir_v4i rsrc_f = {(int) (xbase & 0xffffffffull), (int) ((xbase >> 32) & 0xffffull),
                             (int) (span > 0xffffffffull ? 0xffffffffull : span), 0x13004};
-    (void) rsrc_f;
-    (void) rsrc;
 
   if constexpr (NC % 32 != 16) {
         // words unrolled per loop turn: three for the transposed form (whole turns of its accumulator
@@ -520,20 +479,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NC == 48 ? 4
                     // row in the scalar offset, the lane's constant byte offset in the vector offset -- no
                     // per-load 64-bit VALU address add (a sixth of this kernel's issue cycles otherwise);
                     // typed, the load also delivers the sample as a float
-#if FIR_BUFFER_LOADS == 2
     #pragma unroll
                     for (int p = 0; p < 32; ++p)
                         xf[p] = fir_load_format_f32(rsrc_f, coff, (int) ((uint32_t) (mb - row0 + p) * rowbytes), 0);
-#elif FIR_BUFFER_LOADS == 1
-    #pragma unroll
-                    for (int p = 0; p < 32; ++p)
-                        xf[p] = (float) (int) (int16_t) __builtin_amdgcn_raw_buffer_load_b16(
-                            rsrc, coff, (int) ((uint32_t) (mb - row0 + p) * rowbytes), 0);
-#else
-                    const int16_t *row = x + (size_t) mb * (size_t) N + c;
-    #pragma unroll
-                    for (int p = 0; p < 32; ++p) xf[p] = (float) (int) row[(size_t) p * (size_t) N];
-#endif
                 } else {
     #pragma unroll
                     for (int p = 0; p < 32; ++p) {
@@ -567,15 +515,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NC == 48 ? 4
                 //        exactly when |y_c| <= eps (a - b is negative or -0 iff a < b).
                 uint32_t neg = 0, amb = 0;
                 uint32_t fe = 0, fo = 0;                        // FL2: (sign, exponent bit 7) of the even / the odd outputs
-                // FIR_VTAPS_12: the direct form's taps in vector registers (see FIR_VTAPS_48 below for the rates)
                 float dtap[NC / 2];
     #pragma unroll
-                for (int q = 0; q < NC / 2; ++q) {
-                    dtap[q] = FL2 ? ctap(q) * fscale : ctap(q);
-#if FIR_VTAPS_12
-                    asm volatile("" : "+v"(dtap[q]));
-#endif
-                }
+                for (int q = 0; q < NC / 2; ++q) dtap[q] = FL2 ? ctap(q) * fscale : ctap(q);
     #pragma unroll
                 for (int p = 0; p < 32; ++p) {
                     const int P = w3 * 32 + p;                  // phase 0..95, P % 12 static
@@ -608,12 +550,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NC == 48 ? 4
                         }
                         y = acc[P % NC];                    // y_c of output obase + p
                     }
-#ifdef FIR_PAD
-                    // experiment: FIR_PAD extra VALU instructions per sample (does the pipeline's period follow the
-                    // chain's instruction count?)
-    #pragma unroll
-                    for (int pd = 0; pd < FIR_PAD; ++pd) asm volatile("v_mov_b32 %0, %0" : "+v"(peakbits));
-#endif
                     if constexpr (FL2) {
                         if (p & 1) fo = __builtin_amdgcn_alignbit(fo, __float_as_uint(y), 30);
                         else fe = __builtin_amdgcn_alignbit(fe, __float_as_uint(y), 30);
@@ -621,12 +557,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NC == 48 ? 4
                     neg = __builtin_amdgcn_alignbit(neg, __float_as_uint(y), 31);
                     amb = __builtin_amdgcn_alignbit(amb, __float_as_uint(__builtin_fabsf(y) - eps_up), 31);
                     }
-    #if FIR_SIGN_FENCE > 0
                     if (p % FIR_SIGN_FENCE == FIR_SIGN_FENCE - 1 && !K1S_DIRECT(NC)) {
     #pragma unroll
                         for (int g = 0; g < NC; g += 12) touch12(acc + g);
                     }
-    #endif
                 }
                 if constexpr (K1S_DIRECT(NC)) {
     #pragma unroll
@@ -671,7 +605,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NC == 48 ? 4
                 const int wi = b * UW + w3;                     // word of the segment (wave-uniform; static mod 4 for UW = 4)
                 const int slot = WIDE ? (wi & 3) : 0;
                 const bool last = t0 + obase + 32 >= t1;        // the segment's last word
-                if constexpr (WIDE && FIR_SIGN_DEFER) {
+                if constexpr (WIDE) {
                     while (amb && n_pend < FIR_SIGN_PEND) {
                         const int pos = __clz((int) amb);
                         amb &= ~(0x80000000u >> pos);
@@ -682,7 +616,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NC == 48 ? 4
                 if constexpr (WIDE) {
                     if (slot == 0) wq[0] = w; else if (slot == 1) wq[1] = w; else if (slot == 2) wq[2] = w; else wq[3] = w;
                 }
-                if (__any(amb != 0) || (WIDE && FIR_SIGN_DEFER && last && __any(n_pend != 0))) {
+                if (__any(amb != 0) || (WIDE && last && __any(n_pend != 0))) {
                     const int held = wi - slot;                 // first word that is still in registers
                     for (int k = 0;; ++k) {
                         int o = -1;
@@ -734,18 +668,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NC == 48 ? 4
         // 16 samples are 31 KB, and a word is flushed after every second group.
         constexpr int GROUP = 16;
         constexpr int UNROLL = NC;
-        // The central taps in VECTOR registers (FIR_VTAPS_48): v_fmac_f32 with its multiplier in an SGPR issues at
-        // 2.0 ns per wave-instruction and SIMD, with all three operands in VGPRs at 1.1 (four waves per SIMD; 1.4-1.5
-        // with three or five) -- scripts/ubench/valu_rate.hip.  The 48-tap kernel is 48 of them per sample.  The empty
-        // asm hides that the value is wave-uniform, or the compiler would move it back into SGPRs.
         float vtap[NC / 2];
 #pragma unroll
-        for (int q = 0; q < NC / 2; ++q) {
-            vtap[q] = ctap(q);
-#if FIR_VTAPS_48
-            asm volatile("" : "+v"(vtap[q]));
-#endif
-        }
+        for (int q = 0; q < NC / 2; ++q) vtap[q] = ctap(q);
         constexpr int NG = UNROLL / GROUP;
         static_assert(UNROLL % NC == 0 && UNROLL % GROUP == 0, "whole ring turns, whole groups");
         // Two flag bits per sample, each gathered with ONE v_alignbit_b32 (shift the word
@@ -865,7 +790,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NC == 48 ? 4
         // rows mbx .. mbx + GROUP - 1 of the lane's channel as floats
         auto load_group48 = [&](int mbx, float *dst) {
             if ((mbx >= 0) && (mbx + GROUP - 1 < L)) {
-#if FIR_TYPED_LOADS_48
                 // typed buffer loads as in the 12-tap path, but with the row in the VECTOR offset (one
                 // two-operand add per load): this instantiation has no SGPRs to spare for 16 row offsets
                 // -- with them it lost 6.8 vs 6.6 ms -- and still sheds the 64-bit address add and the
@@ -874,11 +798,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NC == 48 ? 4
     #pragma unroll
                 for (int p = 0; p < GROUP; ++p)
                     dst[p] = fir_load_format_f32(rsrc_f, voff0 + (int) ((uint32_t) p * rowbytes), 0, 0);
-#else
-                const int16_t *row = x + (size_t) mbx * (size_t) N + c;
-    #pragma unroll
-                for (int p = 0; p < GROUP; ++p) dst[p] = (float) (int) row[(size_t) p * (size_t) N];
-#endif
             } else {
     #pragma unroll
                 for (int p = 0; p < GROUP; ++p) {
@@ -888,10 +807,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NC == 48 ? 4
                 }
             }
         };
-#if FIR_PREFETCH_48
-        float xn[GROUP];
-        load_group48(m0 + NC - 1, xn);
-#endif
         for (int b = 0; b * NG < ngroups; ++b) {
     #pragma unroll
             for (int g = 0; g < NG; ++g) {
@@ -901,17 +816,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NC == 48 ? 4
                 float xf[GROUP];                                // the group's samples as floats (exact)
                 const int mb = m0 + NC - 1 + gbase;             // sample of the group's first phase
                 const bool interior = (mb >= 0) && (mb + GROUP - 1 < L);
-#if FIR_PREFETCH_48
-                // the rows of this group were asked for one group ago; the next group's go out now, before this
-                // group's 880 instructions, so that a wave's loads are in flight while it computes (four waves per
-                // SIMD do not cover a load's latency for each other when each of them waits at the same point)
-    #pragma unroll
-                for (int p = 0; p < GROUP; ++p) xf[p] = xn[p];
-                if (gi + 1 < ngroups) load_group48(mb + GROUP, xn);
-                __builtin_amdgcn_sched_barrier(0);
-#else
                 load_group48(mb, xf);
-#endif
                 {   // filter.c:118-119 peak, on the float bit patterns (see the 12-tap path)
                     int bp = 0;
                     if (interior) {
@@ -957,12 +862,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NC == 48 ? 4
                     const float y = acc[P % NC];                // y_c of output gbase + p
                     neg = __builtin_amdgcn_alignbit(neg, __float_as_uint(y), 31);
                     amb = __builtin_amdgcn_alignbit(amb, __float_as_uint(__builtin_fabsf(y) - eps_w), 31);
-    #if FIR_SIGN_FENCE > 0
                     if (p % FIR_SIGN_FENCE == FIR_SIGN_FENCE - 1) {
     #pragma unroll
                         for (int gg = 0; gg < NC; gg += 12) touch12(acc + gg);
                     }
-    #endif
                 }
                 // zor = OR of the word's samples, for the silence test in flush(), which only looks at
                 // it when the word has >= 8 ambiguous samples.  A first half without any cannot belong
@@ -998,16 +901,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NC == 48 ? 4
         }
         maxval_next[cg] = 0;
     }
-    };
-    for (int item = wave_id; item < items; item += stride) work(item);
-    if (stamps && threadIdx.x == 0) stamps[2 * wave_id + 1] = wall_clock64();
 }
 
 int launch_fir_sign_quantum(int NC)
 {
     // the 12-tap kernel stores four sign words at once: segments start on a multiple of 128 outputs
     // (the 48-tap one too, and its unrolled body is three words: 384)
-    return NC <= 12 ? ((FIR_DIRECT_UNROLL == 4 || FIR_DIRECT_UNROLL == 2 || FIR_DIRECT_UNROLL == 1) ? 128 : 32 * FIR_DIRECT_UNROLL) : 384;
+    return NC <= 12 ? 128 : 384;
 }
 
 hipError_t launch_fir_sign(const FirLaunch &a, hipStream_t stream)
@@ -1016,38 +916,35 @@ hipError_t launch_fir_sign(const FirLaunch &a, hipStream_t stream)
         return hipErrorInvalidValue;
     if (a.T > 65280) return hipErrorInvalidValue;       // the kernel notes open outputs as 16-bit offsets into the segment
     dim3 grid((a.N + 63) / 64, (a.L + a.T - 1) / a.T), block(64);
-    const int n_big = 1 << 30, T2 = a.T;        // (the kernel can give a launch's last segments another length: not used)
     const float eps_up = __builtin_nextafterf(a.eps, INFINITY);
     const int map = (a.map == 1 && grid.x % 8 == 0) ? 1 : 0;
-    const int gx = (int) grid.x, gy = (int) grid.y;
-    unsigned long long *const stamps_ok = nullptr;
     if (a.NC == 12 && a.NE == 32) {
         FirTaps<32> t;
         for (int j = 0; j < 32; ++j) t.te[j] = a.te[j];
         if (a.fscale > 0.0f)
             hipLaunchKernelGGL((fir_sign_kernel<32, 12, 32, false, true>), grid, block, 0, stream, a.x, a.hist, a.sgn, a.maxval,
-                               a.hist_out, a.maxval_next, a.te_mem, a.N, a.L, a.T, a.d, a.NT, a.NE, eps_up, map, t, stamps_ok, n_big, T2, a.eps_seen, a.eps_ahead, gx, gy, a.fscale);
+                               a.hist_out, a.maxval_next, a.te_mem, a.N, a.L, a.T, a.d, a.NT, a.NE, eps_up, map, t, a.eps_seen, a.eps_ahead, a.fscale);
         else
         hipLaunchKernelGGL((fir_sign_kernel<32, 12, 32>), grid, block, 0, stream, a.x, a.hist, a.sgn, a.maxval,
-                           a.hist_out, a.maxval_next, a.te_mem, a.N, a.L, a.T, a.d, a.NT, a.NE, eps_up, map, t, stamps_ok, n_big, T2, a.eps_seen, a.eps_ahead, gx, gy, a.fscale);
+                           a.hist_out, a.maxval_next, a.te_mem, a.N, a.L, a.T, a.d, a.NT, a.NE, eps_up, map, t, a.eps_seen, a.eps_ahead, a.fscale);
     } else if (a.NC == 12) {
         FirTaps<12> t;
         for (int j = 0; j < 12; ++j) t.te[j] = a.ctaps[j];
         if (a.fscale > 0.0f)
             hipLaunchKernelGGL((fir_sign_kernel<0, 12, 12, false, true>), grid, block, 0, stream, a.x, a.hist, a.sgn, a.maxval,
-                               a.hist_out, a.maxval_next, a.te_mem, a.N, a.L, a.T, a.d, a.NT, a.NE, eps_up, map, t, stamps_ok, n_big, T2, a.eps_seen, a.eps_ahead, gx, gy, a.fscale);
+                               a.hist_out, a.maxval_next, a.te_mem, a.N, a.L, a.T, a.d, a.NT, a.NE, eps_up, map, t, a.eps_seen, a.eps_ahead, a.fscale);
         else
         hipLaunchKernelGGL((fir_sign_kernel<0, 12, 12>), grid, block, 0, stream, a.x, a.hist, a.sgn, a.maxval,
-                           a.hist_out, a.maxval_next, a.te_mem, a.N, a.L, a.T, a.d, a.NT, a.NE, eps_up, map, t, stamps_ok, n_big, T2, a.eps_seen, a.eps_ahead, gx, gy, a.fscale);
+                           a.hist_out, a.maxval_next, a.te_mem, a.N, a.L, a.T, a.d, a.NT, a.NE, eps_up, map, t, a.eps_seen, a.eps_ahead, a.fscale);
     } else {
         FirTaps<48> t;
         for (int j = 0; j < 48; ++j) t.te[j] = a.ctaps[j];
         if (a.eps_seen > 0.0f && a.NE - a.NC <= 98)
             hipLaunchKernelGGL((fir_sign_kernel<0, 48, 48, true>), grid, block, 0, stream, a.x, a.hist, a.sgn, a.maxval,
-                               a.hist_out, a.maxval_next, a.te_mem, a.N, a.L, a.T, a.d, a.NT, a.NE, eps_up, map, t, stamps_ok, n_big, T2, a.eps_seen, a.eps_ahead, gx, gy, a.fscale);
+                               a.hist_out, a.maxval_next, a.te_mem, a.N, a.L, a.T, a.d, a.NT, a.NE, eps_up, map, t, a.eps_seen, a.eps_ahead, a.fscale);
         else
         hipLaunchKernelGGL((fir_sign_kernel<0, 48, 48>), grid, block, 0, stream, a.x, a.hist, a.sgn, a.maxval,
-                           a.hist_out, a.maxval_next, a.te_mem, a.N, a.L, a.T, a.d, a.NT, a.NE, eps_up, map, t, stamps_ok, n_big, T2, a.eps_seen, a.eps_ahead, gx, gy, a.fscale);
+                           a.hist_out, a.maxval_next, a.te_mem, a.N, a.L, a.T, a.d, a.NT, a.NE, eps_up, map, t, a.eps_seen, a.eps_ahead, a.fscale);
     }
     return hipGetLastError();
 }
@@ -1123,9 +1020,7 @@ hipError_t launch_fir_history(const int16_t *x, const int16_t *hist_in, int16_t 
     return hipGetLastError();
 }
 
-#endif // FIR_PRIMARY
-
-namespace FIR_VARIANT {
+namespace scalar {
 // NE == 32 only (the reference table after trimming); anything else goes to
 // launch_fir_generic.
 hipError_t launch_fir_slice(const FirLaunch &a, hipStream_t stream)
@@ -1149,6 +1044,6 @@ hipError_t launch_fir_slice(const FirLaunch &a, hipStream_t stream)
 #undef FIR_LAUNCH
     return hipGetLastError();
 }
-} // namespace FIR_VARIANT
+} // namespace scalar
 
 } // namespace gnuais

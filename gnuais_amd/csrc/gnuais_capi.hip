@@ -244,9 +244,14 @@ static hipError_t alloc_sets(gnuais_batch *b, int n)
             {(void **) &b->cand_first[k], sizeof(uint32_t) * N},
             {(void **) &b->cand_count[k], sizeof(uint32_t) * N}};
         for (auto &w : want) {
+            if (*w.p) continue;                 // left by an earlier attempt that failed further down this set
             hipError_t e = hipMalloc(w.p, w.bytes);
             if (e == hipSuccess) e = hipMemset(*w.p, 0, w.bytes);
-            if (e != hipSuccess) return e;
+            if (e != hipSuccess) {
+                if (*w.p) (void) hipFree(*w.p);
+                *w.p = nullptr;
+                return e;
+            }
         }
         b->sets_alloc = k + 1;
     }
@@ -560,7 +565,10 @@ int gnuais_batch_create(gnuais_batch **out, int device, int n_channels, const fl
             if (e == hipSuccess) e = hipStreamCreateWithPriority(&b->pool[made], hipStreamNonBlocking, made < 8 ? hi : 0);
     }
     if (const char *v = getenv("GNUAIS_K3_SAME")) b->k3_same = atoi(v) != 0;
-    if (const char *v = getenv("GNUAIS_PLL_VARIANT")) b->pll_variant = atoi(v);
+    if (const char *v = getenv("GNUAIS_PLL_VARIANT")) {      // the values set_option takes, nothing else
+        const int pv = atoi(v);
+        if (pv == 0 || pv == 7 || pv == 8) b->pll_variant = pv;
+    }
     if (const char *v = getenv("GNUAIS_PIPELINE")) b->pipeline = atoi(v) != 0;
     if (const char *v = getenv("GNUAIS_HDLC_VARIANT")) b->hdlc_variant = atoi(v) != 0;
     if (const char *v = getenv("GNUAIS_HDLC_LPW")) b->hdlc_lpw = std::min(64, std::max(1, atoi(v)));
@@ -568,7 +576,10 @@ int gnuais_batch_create(gnuais_batch **out, int device, int n_channels, const fl
         gnuais_batch_destroy(b);
         return fail(GNUAIS_E_HIP, "create: device allocation", e);
     }
-    if (const char *v = getenv("GNUAIS_FIR_VARIANT")) b->fir_variant = atoi(v);
+    if (const char *v = getenv("GNUAIS_FIR_VARIANT")) {
+        const int fv = atoi(v);
+        if (fv == 0 || fv == 3) b->fir_variant = fv;
+    }
     if (const char *v = getenv("GNUAIS_FIR_FLAG2")) b->fir_flag2 = atoi(v) != 0;
     if (const char *v = getenv("GNUAIS_FIR_T")) b->fir_T = std::max(64, atoi(v) / 32 * 32);
     *out = b;
@@ -983,14 +994,20 @@ int gnuais_batch_autotune(gnuais_batch *b, const int16_t *d_samples, int len, vo
         for (int q = 0; q < 4; ++q) cand_set[n_sets][q] = b->pool[chosen[q]];
         ++n_sets;
     }
+    // The default assignment (creation order, see gnuais_batch_create) is the best one wherever the process has created no
+    // streams of its own (round 6, three boxes: un-calibrated within 1 % of the best calibrated run) and a 40-call leg
+    // still carries +-2 % of noise, so a searched assignment only replaces it when it is at least 3 % faster: what a
+    // plain gnuais_batch_run() caller gets is then never worse than what this call leaves behind.
     int best_set = 0;
     best_all = 1e30;
+    double ms_set[3] = {0, 0, 0};
     for (int k = 0; k < n_sets; ++k) {
         for (int q = 0; q < 4; ++q) b->s_k[q] = cand_set[k][q];
-        double ms = 0;
-        if (int rc = measure(ms, 40)) return rc;
-        if (ms < best_all) { best_all = ms; best_set = k; }
+        if (int rc = measure(ms_set[k], 40)) return rc;
     }
+    best_all = ms_set[0];
+    for (int k = 1; k < n_sets; ++k)
+        if (ms_set[k] < 0.97 * ms_set[0] && ms_set[k] < best_all) { best_all = ms_set[k]; best_set = k; }
     for (int q = 0; q < 4; ++q) b->s_k[q] = cand_set[best_set][q];
     b->timing = timing;
     if (ms_per_call) *ms_per_call = (float) best_all;
@@ -1777,6 +1794,58 @@ int gnuais_batch_fsm_state(gnuais_batch *b, gnuais_fsm_state *h_out)
         h_out[c].last = (w >> 15) & 1;
         h_out[c].bufferpos = (w >> 16) & 511;
     }
+    return GNUAIS_OK;
+}
+
+// protodec_reset() (protodec.c:87-100) for every receiver's decoder: the machine back to ST_SKURR with its counts
+// cleared, a frame in progress dropped; receivedframes / lostframes / lostframes2 stay, as in the reference
+int gnuais_batch_protodec_reset(gnuais_batch *b)
+{
+    if (!b) return fail(GNUAIS_E_ARG, "protodec_reset: NULL batch");
+    if (int rc = gnuais_batch_sync(b)) return rc;
+    HIP_TRY(launch_hdlc_fsm_reset(b->ctl, b->N, nullptr));
+    HIP_TRY(hipStreamSynchronize(nullptr));
+    return GNUAIS_OK;
+}
+
+// d->buffer (protodec.h:52, written at protodec.c:1019): the stored bits -- one per byte, stuffed 0s dropped -- of the
+// frame a channel's decoder is in (ST_DATA / ST_STOPSIGN) or, between frames, of the last frame that reached its stop
+// bit; *n_bits = -1 when neither is on record (no frame yet, or the last one was given up at 449 bits).  Rebuilt on the host from
+// the candidate record the deframer keeps (raw bits incl. stuffing) and its partial word.
+int gnuais_batch_frame_bits(gnuais_batch *b, int channel, uint8_t *h_bits, int cap, int *n_bits)
+{
+    if (!b || !h_bits || !n_bits || channel < 0 || channel >= b->N || cap < 0)
+        return fail(GNUAIS_E_ARG, "frame_bits: argument");
+    if (int rc = gnuais_batch_sync(b)) return rc;
+    uint32_t w[HDLC_CTL_WORDS];
+    for (int q = 0; q < HDLC_CTL_WORDS; ++q)
+        HIP_TRY(hipMemcpy(&w[q], b->ctl + (size_t) q * (size_t) b->N + channel, 4, hipMemcpyDeviceToHost));
+    *n_bits = -1;
+    const uint32_t state = w[0] & 7, nstart = w[3];
+    if (nstart == 0) return GNUAIS_OK;
+    uint32_t rec[CAND_WORDS];
+    HIP_TRY(hipMemcpy(rec, b->cand + ((size_t) channel * b->cand_K + (nstart - 1) % (uint32_t) b->cand_K) * CAND_WORDS,
+                      sizeof rec, hipMemcpyDeviceToHost));
+    int rawlen;
+    const bool open = state == 4 || state == 5;             // ST_DATA, ST_STOPSIGN (protodec.h:33-34)
+    if (open) {
+        rawlen = (int) w[4];
+        if ((rawlen >> 5) < CAND_WORDS - CAND_HDR) rec[CAND_HDR + (rawlen >> 5)] = w[1];   // the word being filled
+    } else if (rec[0] >> 17) {                              // closed with a stop bit, good (CAND_VALID) or bad: its length is on record
+        rawlen = (int) ((rec[0] >> 17) & 0x3ffu);
+    } else {
+        return GNUAIS_OK;                                   // given up at 449 bits (protodec.c:1024-1026), or overwritten
+    }
+    if (rawlen < 0 || rawlen > 32 * (CAND_WORDS - CAND_HDR)) return fail(GNUAIS_E_STATE, "frame_bits: record length");
+    int n = 0, ones = 0;
+    for (int i = 0; i < rawlen; ++i) {
+        const uint8_t x = (rec[CAND_HDR + (i >> 5)] >> (i & 31)) & 1u;
+        if (ones == 5) { ones = 0; continue; }              // the 0 after five 1s: protodec.c:1002-1006
+        if (n < cap) h_bits[n] = x;
+        ++n;
+        ones = x ? ones + 1 : 0;
+    }
+    *n_bits = n;
     return GNUAIS_OK;
 }
 

@@ -63,6 +63,17 @@ __global__ void hdlc_reset_kernel(uint32_t *__restrict__ ctl, int N)
     ctl[(size_t) 5 * N + c] = 0;
 }
 
+// protodec_reset() alone (protodec.c:87-100): the machine's fields, the frame in progress; bits seen and frames started
+// keep counting (they order a channel's frames in time)
+__global__ void hdlc_fsm_reset_kernel(uint32_t *__restrict__ ctl, int N)
+{
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= N) return;
+    ctl[c] = ST_SKURR;
+    ctl[(size_t) N + c] = 0;
+    ctl[(size_t) 4 * N + c] = 0;
+}
+
 __device__ __forceinline__ uint32_t lowmask(int k)      // k in [0, 32]
 {
     return k >= 32 ? ~0u : ((1u << k) - 1u);
@@ -203,7 +214,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(7, 8))) void
                             }
                         } else {
                             ++lost2;                            // protodec.c:1112
-                            if (rec_ok) rec[0] = 0;
+                            if (rec_ok) {                       // not a candidate (no CAND_VALID); its bits stay on record for d->buffer
+                                rec[CAND_HDR + (rawpos >> 5)] = cur;
+                                rec[0] = (uint32_t) rawpos << 17;
+                            }
                         }
                         HDLC_RESET();
                         last = x;                               // protodec.c:1119
@@ -583,6 +597,12 @@ hipError_t launch_hdlc_crc(const HdlcLaunch &a, hipStream_t stream)
     hipLaunchKernelGGL(hdlc_crc_kernel, dim3((unsigned) ((a.N + K3_CH - 1) / K3_CH)), dim3(256), K3_DYN_LDS,
                        stream, a.cand, a.cand_first, a.cand_count, a.counters,
                        (uint32_t *) a.frames, a.frame_count, a.frame_cap, a.N, a.K, a.chunks, k3_passes(a.K_call > 0 ? a.K_call : a.K));
+    return hipGetLastError();
+}
+
+hipError_t launch_hdlc_fsm_reset(uint32_t *ctl, int N, hipStream_t stream)
+{
+    hipLaunchKernelGGL(hdlc_fsm_reset_kernel, dim3((N + 255) / 256), dim3(256), 0, stream, ctl, N);
     return hipGetLastError();
 }
 

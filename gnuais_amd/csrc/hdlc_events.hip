@@ -60,24 +60,11 @@ __device__ __forceinline__ int wave_max_i(int v, int lanes, int lane)
 // NA[EW], CB[EW], E6[EW], SF[EW], PS[EW + 1] (stuffed 0s before word q)
 constexpr int EV_ROWS = (EW + 2) + 4 * EW + (EW + 1);
 
-#ifndef EV_BITMAPS32
-#define EV_BITMAPS32 1              // 0: the pack's bitmaps through 64-bit shifts of {word, word before} (rounds 2-4; kept for the A/B)
-#endif
-#ifndef EV_HUNT_TWICE
-#define EV_HUNT_TWICE 1             // the hunting section also at the bottom of an event turn (see there); 0 for the A/B
-#endif
-#ifndef EV_WAVES_PER_EU
-#define EV_WAVES_PER_EU 0           // 0: whatever the kernel wants (116 VGPRs); 7 (72 VGPRs) spilt and lost
-#endif
-#if EV_WAVES_PER_EU > 0
-#define EV_OCC __attribute__((amdgpu_waves_per_eu(EV_WAVES_PER_EU, 8)))
-#else
-#define EV_OCC
-#endif
+// (the kernel takes the registers it wants -- 120; held to 96 / 80 / 72 it spilt and lost: profiles/r04_deframer_bitmaps_and_stage_masks.txt)
 // TPB: lanes per workgroup when the launcher knows them (8 / 16 / 32 / 64: every LDS row offset is then an immediate of
 // its ds instruction); 0: taken from blockDim
 template <int TPB>
-__global__ __launch_bounds__(64) EV_OCC void hdlc_events_kernel(
+__global__ __launch_bounds__(64) void hdlc_events_kernel(
     const uint32_t *__restrict__ segbits, const uint32_t *__restrict__ segcnt,
     uint32_t *__restrict__ ctl, uint32_t *__restrict__ cand, uint32_t *__restrict__ cand_first,
     uint32_t *__restrict__ cand_count, int32_t *__restrict__ counters,
@@ -144,7 +131,10 @@ __global__ __launch_bounds__(64) EV_OCC void hdlc_events_kernel(
              }                                                                          \
          } else {                                                                       \
              ++lost2;                                                                   \
-             if (rec_ok) rec[0] = 0;                                                    \
+             if (rec_ok) {      /* not a candidate (no CAND_VALID); its bits stay on record for d->buffer */ \
+                 rec[CAND_HDR + (rawpos >> 5)] = cur;                                   \
+                 rec[0] = (uint32_t) rawpos << 17;                                      \
+             }                                                                          \
          }                                                                              \
          HDLC_RESET();                                                                  \
          last = (x_); } while (0)
@@ -245,14 +235,13 @@ __global__ __launch_bounds__(64) EV_OCC void hdlc_events_kernel(
         // (protodec.c:1011-1015: antallenner + 1 of them, five when bitstuff is up), else `last`
         const int m_in = (state == ST_DATA) ? (bitstuff ? 5 : (last ? antallenner + 1 : 0)) : 0;
         uint32_t prevw = (state == ST_DATA) ? (m_in ? ~0u << (32 - m_in) : 0u) : (last << 31);
-        uint32_t prevA = 0, ps = 0, nzNA = 0, nzCB = 0, nzE6 = 0;
+        uint32_t ps = 0, nzNA = 0, nzCB = 0, nzE6 = 0;
         XW(-1) = prevw;
 #pragma unroll
         for (int q = 0; q < EW; ++q) XW(q) = pf[q];
         pf_ready = false;
         if (seg + 1 < n_seg) fetch(seg + 1);    // the next pack is on its way while this one is walked
         const int nwq = __builtin_amdgcn_readfirstlane((int) wave_max_i((tile_end + 31) >> 5, tpb, tx));
-#if EV_BITMAPS32
         // Every "bit i of (v << d) is bit i-d of v" below takes the bits that come in from the word before out of THAT
         // word's value of the same quantity (one v_alignbit_b32 each), instead of carrying the chain through 64-bit
         // shifts and ANDs of {this word, the word before}: the same bits -- no term reaches further back than the word
@@ -293,39 +282,6 @@ __global__ __launch_bounds__(64) EV_OCC void hdlc_events_kernel(
             pA = A; pa2 = a2; pa4 = a4; pa8 = a8; pu2 = u2; pt = t5;
             prevw = xw;
         }
-        (void) prevA;
-#else
-#pragma unroll 1
-        for (int q = 0; q < EW; ++q) {
-            if (q >= nwq) {                 // beyond every lane's bits: empty
-                XW(q) = 0; NAa[q * tpb] = 0; CBa[q * tpb] = 0; E6a[q * tpb] = 0; SFa[q * tpb] = 0; PSa[q * tpb] = ps;
-                continue;
-            }
-            const uint32_t vm = lowmask(tile_end - 32 * q);
-            const uint32_t xw = XW(q) & vm;
-            const uint32_t A = (xw ^ ((xw << 1) | (prevw >> 31))) & vm;           // x[k] != x[k-1]
-            // bit i of (v << d) is bit i-d of v: the previous word supplies the bits before this one
-            const uint64_t a64 = ((uint64_t) A << 32) | prevA;
-            const uint64_t a2 = a64 & (a64 << 1), a4 = a2 & (a2 << 2), a8 = a4 & (a4 << 4), a15 = a8 & (a8 << 7);
-            const uint64_t x64 = ((uint64_t) xw << 32) | prevw;
-            const uint64_t u2 = x64 & (x64 << 1), u4 = u2 & (u2 << 2);              // 1s at k-1..k, k-3..k
-            const uint32_t na = ~A & vm, cb = (uint32_t) (a15 >> 32) & ~xw & vm;
-            const uint32_t e6 = (uint32_t) ((u4 & (u2 << 4)) >> 32) & vm;           // 1s at k-5..k
-            const uint32_t sf = (uint32_t) (((u4 & (x64 << 4)) << 1) >> 32) & ~xw & vm;   // 1s at k-5..k-1, 0 at k
-            XW(q) = xw;
-            NAa[q * tpb] = na;
-            CBa[q * tpb] = cb;
-            E6a[q * tpb] = e6;
-            SFa[q * tpb] = sf;
-            PSa[q * tpb] = ps;
-            ps += (uint32_t) __popc(sf);
-            nzNA |= (na ? 1u : 0u) << q;
-            nzCB |= (cb ? 1u : 0u) << q;
-            nzE6 |= (e6 ? 1u : 0u) << q;
-            prevA = A;
-            prevw = xw;
-        }
-#endif
         XW(EW) = 0;
         PSa[EW * tpb] = ps;
 
@@ -498,16 +454,12 @@ __global__ __launch_bounds__(64) EV_OCC void hdlc_events_kernel(
                         rs = t; hunt0 = false;
                         pos = t + 1;
                     } else {
-#ifdef EV_NO_RAW_COPY      /* timing experiment only (wrong records): what would a deframer cost that leaves the raw bits where they are? */
-                        rawpos += e - pos;
-#else
                         for (int p = pos; p < e;) {
                             const int sh = p & 31;
                             const int take = (32 - sh < e - p) ? 32 - sh : e - p;
                             RAW_APPEND((XW(p >> 5) >> sh) & lowmask(take), take);
                             p += take;
                         }
-#endif
                         bufferpos += stored;
                         if (e6 < tile_end) {                    // the sixth 1
                             state = ST_STOPSIGN;
@@ -548,9 +500,7 @@ __global__ __launch_bounds__(64) EV_OCC void hdlc_events_kernel(
                     if (state != st0) slow = false;
                     pos += 1;
                 }
-#if EV_HUNT_TWICE
                 if (state == ST_SKURR && !slow && pos < tile_end) hunt();
-#endif
             }
         }
         seenbase += (uint32_t) tile_end;

@@ -115,6 +115,7 @@ hipError_t launch_hdlc_deframe(const HdlcLaunch &a, hipStream_t stream); // K2b,
 hipError_t launch_hdlc_events(const HdlcLaunch &a, hipStream_t stream);  // K2b, event by event (hdlc_events.hip)
 hipError_t launch_hdlc_crc(const HdlcLaunch &a, hipStream_t stream);     // K3
 hipError_t launch_hdlc_reset(uint32_t *ctl, int N, hipStream_t stream);
+hipError_t launch_hdlc_fsm_reset(uint32_t *ctl, int N, hipStream_t stream);   // protodec_reset() only: counters and time stay
 
 // ---- utilities (util.hip) ---------------------------------------------------
 hipError_t launch_tile_channels(const int16_t *base, int n_base, int len, int16_t *out,
@@ -127,10 +128,7 @@ hipError_t launch_crc16_bits(const uint8_t *bits, int n_bytes, uint16_t *crc, ui
 
 // K1s evaluates the NC = 12 central taps in direct form with symmetric pre-adds (fir_slice.hip); the
 // host's error bound for y_c follows the same order of operations (gnuais_capi.hip)
-#ifndef K1S_DIRECT_12
-#define K1S_DIRECT_12 1
-#endif
-#define K1S_DIRECT(nc) (K1S_DIRECT_12 && (nc) <= 12)
+constexpr bool K1S_DIRECT(int nc) { return nc <= 12; }
 
 // ---- f1 on the device (nmea_device.hip) ---------------------------------------
 size_t nmea_scratch_bytes(int n_frames, int n_chunks = 0);

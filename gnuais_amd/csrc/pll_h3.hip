@@ -61,10 +61,7 @@ constexpr int H3_BLK = 128;                    // samples per block: one uint4 o
 constexpr int H3_WORDS = H3_BLK / 32;
 constexpr int H3_STRIP = H3_BLK + 12;          // bytes per lane and slot (positions + an 8-byte store's overhang + read-ahead)
 constexpr int H3_SEG_BLKS = SEG_LEN / H3_BLK;  // 16
-#ifndef PLLH3_HELPERS
-#define PLLH3_HELPERS 3
-#endif
-constexpr int H3_NH = PLLH3_HELPERS;           // helpers (2 or 3; a wave each)
+constexpr int H3_NH = 3;                       // helpers (a wave each; two: 0.347 against 0.326 ms alone, level in the pipeline)
 constexpr int H3_SLOTS = 2 * H3_NH;            // slot of block b: b % H3_SLOTS (helper b % 3 owns slots h and h + 3)
 constexpr int H3_NPACK = 4;                    // pack buffers (segment s in buffer s & 3)
 // slot: 64 strips, cnt[64], rows (one word + padding)
@@ -78,20 +75,8 @@ static_assert(SEG_LEN % H3_BLK == 0 && H3_NEED_LDS <= PLL_LDS_BYTES, "segments a
 // hand-over counters (all monotonic)
 enum { F_RDONE = 1, F_SEGPUB = 2, F_WRITTEN = 3, F_LAST = 4, F_SCAN = 8 /* +h */ };
 
-#ifdef PLLH3_BUDGET
-// Measurement build only (EXTRA=-DPLLH3_BUDGET; scripts/pll_wave_budget.py h3): clock ticks per workgroup --
-//   0 recurrence: total   1 ... waiting for a helper's scan   3 ... in the rows   4 rows of four   5 blocks
-//   6 recurrence: its span on the constant 100 MHz clock (core clock = [0] / [6] x 100 MHz)
-//   8 helper 0: total   9 ... scanning   10 ... waiting for a free slot   12 ... writing packs
-__device__ unsigned long long pllh3_budget[4096 * 16];
-#define BUDGET(i, v) do { if (lane == 0 && blockIdx.x < 4096) pllh3_budget[blockIdx.x * 16 + (i)] = (v); } while (0)
-#define TICK() ((unsigned long long) clock64())
-#else
-#define BUDGET(i, v) do { } while (0)
-#define TICK() 0ull
-#pragma clang diagnostic ignored "-Wunused-variable"
-#pragma clang diagnostic ignored "-Wunused-but-set-variable"
-#endif
+// (A measurement build of this kernel -- clock ticks per phase of the recurrence wave and of helper 0, on both clocks --
+// produced profiles/r05_pll_wave_budget.txt; the instrumentation is in git history, commit b1fc8e6.)
 
 // One block's transition lists: D = S ^ (S >> 1)
 // (receiver.c:113) expanded byte by byte through the table, one unaligned ds_write_b64 per byte into the lane's strip.
@@ -277,12 +262,9 @@ __global__ __launch_bounds__(64 * (1 + H3_NH)) __attribute__((amdgpu_waves_per_e
         uint32_t pw;
         H3_LOAD_BLOCK(h);
         bool dead = false;
-        unsigned long long hb_scan = 0, hb_wait = 0, hb_wr = 0;
-        const unsigned long long hb_t0 = TICK();
         for (int bs = h; !dead; bs += H3_NH) {
             if (bs >= n_blk && !(h == 0 && wseg < n_seg)) break;
             if (h == 0) {                                          // finished packs leave, in order (the only place)
-                const unsigned long long t3 = TICK();
                 while (wseg < n_seg && peek(F_SEGPUB) >= wseg + 1) {
                     uint32_t *pk = pack + (wseg & (H3_NPACK - 1)) * PLL_PACKW * 64 + lane;
                     const uint32_t nb = nbuf[(wseg & 3) * 64 + lane];          // slices of the segment = bits of the pack
@@ -290,21 +272,17 @@ __global__ __launch_bounds__(64 * (1 + H3_NH)) __attribute__((amdgpu_waves_per_e
                                         segcnt + (size_t) cg * n_seg_alloc + wseg);
                     lds_flag_store(flag + F_WRITTEN, (uint32_t) (++wseg));
                 }
-                hb_wr += TICK() - t3;
                 if (bs >= n_blk) {                                 // nothing left but the call's last packs: wait for them
                     if (expired()) dead = true;
                     __builtin_amdgcn_s_sleep(4);
                     continue;
                 }
             }
-            const unsigned long long t0 = TICK();
             while (peek(F_RDONE) < bs - (H3_SLOTS - 1) && !dead) { // slot bs % H3_SLOTS was block bs - H3_SLOTS's: walked?
                 if (expired()) dead = true;
                 __builtin_amdgcn_s_sleep(8);                       // (a block takes the recurrence ~2000 ticks)
             }
             if (dead) break;
-            const unsigned long long t1 = TICK();
-            hb_wait += t1 - t0;
             {
                 uint32_t S[H3_WORDS] = {q.x, q.y, q.z, q.w};
                 uint32_t prev = bs == 0 ? sign0[lane] : (pw & 1u);
@@ -317,7 +295,6 @@ __global__ __launch_bounds__(64 * (1 + H3_NH)) __attribute__((amdgpu_waves_per_e
                     if (live) prevst[cg] = prev;
                 }
             }
-            hb_scan += TICK() - t1;
         }
         if (h == 0) {
             while (lds_flag_load(flag + F_LAST) == 0 && !dead)
@@ -326,7 +303,6 @@ __global__ __launch_bounds__(64 * (1 + H3_NH)) __attribute__((amdgpu_waves_per_e
                 for (int s = n_seg; s < n_seg_alloc; ++s) segcnt[(size_t) cg * n_seg_alloc + s] = 0;
                 lastbit[cg] = (sign1[lane] ^ par) & 1u;
             }
-            BUDGET(8, TICK() - hb_t0); BUDGET(9, hb_scan); BUDGET(10, hb_wait); BUDGET(12, hb_wr);
         }
         return;
     }
@@ -336,11 +312,6 @@ __global__ __launch_bounds__(64 * (1 + H3_NH)) __attribute__((amdgpu_waves_per_e
     const uint32_t Q = (uint32_t) __builtin_amdgcn_readfirstlane((int) ((pllinc / 16u) << 8));   // receiver.c:84,115,117
     const uint32_t K8 = pllinc << 8;              // p * pllinc * 2^8 < 2^32 and pllinc * 2^8 < 2^24 (create refuses pllinc > 14426)
     bool dead = false;
-    unsigned long long rc_wscan = 0, rc_rows = 0, rc_nrows = 0, rc_nblk = 0;
-    const unsigned long long rc_t0 = TICK();
-#ifdef PLLH3_BUDGET
-    const unsigned long long rc_w0 = wall_clock64();
-#endif
     for (int s = 0; s < n_seg && !dead; ++s) {
         while (peek(F_WRITTEN) < s - (H3_NPACK - 1) && !dead) {    // pack buffer s & 3 was segment s - 4's: long written
             if (expired()) dead = true;
@@ -350,7 +321,6 @@ __global__ __launch_bounds__(64 * (1 + H3_NH)) __attribute__((amdgpu_waves_per_e
         uint32_t *pk = pack + (s & (H3_NPACK - 1)) * PLL_PACKW * 64 + lane;   // this lane's pack word 0 (word stride 64)
         const int b1 = (s + 1) * H3_SEG_BLKS < n_blk ? (s + 1) * H3_SEG_BLKS : n_blk;
         for (int b = s * H3_SEG_BLKS; b < b1 && !dead; ++b) {
-            const unsigned long long s0 = TICK();
             // the helper's counter, the lane's count and the block's rows in ONE trip to the LDS: the three reads are
             // executed in this order, so a counter that says "scanned" vouches for the two values read behind it
             const uint8_t *slot = slots + (b % H3_SLOTS) * H3_SLOT_BYTES;
@@ -369,8 +339,6 @@ __global__ __launch_bounds__(64 * (1 + H3_NH)) __attribute__((amdgpu_waves_per_e
                 __builtin_amdgcn_s_sleep(1);
             }
             if (dead) break;
-            const unsigned long long s1 = TICK();
-            rc_wscan += s1 - s0;
             segbase += X >> 24;                                // slice numbers inside the block start at 0
             X &= 0x00ffffffu;
             if (ng) {
@@ -383,11 +351,6 @@ __global__ __launch_bounds__(64 * (1 + H3_NH)) __attribute__((amdgpu_waves_per_e
             } else {
                 lds_flag_store(flag + F_RDONE, (uint32_t) (b + 1));
             }
-#ifdef PLLH3_BUDGET
-            rc_rows += TICK() - s1;
-            rc_nrows += ng;
-            rc_nblk += 1;
-#endif
             const int blen = L - b * H3_BLK < H3_BLK ? L - b * H3_BLK : H3_BLK;
             X += (uint32_t) blen * K8;                         // to the next block's first sample
         }
@@ -398,19 +361,7 @@ __global__ __launch_bounds__(64 * (1 + H3_NH)) __attribute__((amdgpu_waves_per_e
         lds_flag_store(flag + F_SEGPUB, (uint32_t) (s + 1));
     }
     if (live && !dead) pllst[cg] = (X >> 8) & 0xffffu;
-    BUDGET(0, TICK() - rc_t0); BUDGET(1, rc_wscan); BUDGET(3, rc_rows); BUDGET(4, rc_nrows); BUDGET(5, rc_nblk);
-#ifdef PLLH3_BUDGET
-    BUDGET(6, wall_clock64() - rc_w0);           // the same span on the constant 100 MHz clock: ticks / this = the core clock
-#endif
 }
-
-#ifdef PLLH3_BUDGET
-extern "C" int gnuais_debug_pllh3_budget(unsigned long long *out, int n_wg)
-{
-    if (n_wg > 4096) n_wg = 4096;
-    return (int) hipMemcpyFromSymbol(out, HIP_SYMBOL(pllh3_budget), sizeof(unsigned long long) * 16 * (size_t) n_wg);
-}
-#endif
 
 int pll_need_lds() { return H3_NEED_LDS; }
 

@@ -46,9 +46,7 @@ constexpr int TP_BLK = 256;                 // samples per block = 8 sign words 
 constexpr int TP_SEG_BLKS = SEG_LEN / TP_BLK;
 constexpr int TP_WAVES = 16;                // waves of a workgroup (one channel)
 constexpr int TP_HALF = 32;                 // candidates on either side of the centre (in steps of 2)
-#ifndef TP_CHUNK_DEFAULT
-#define TP_CHUNK_DEFAULT 32
-#endif
+constexpr int TP_CHUNK = 32;                // blocks per chunk: one table, one walk, one re-centring (16 and 64 measured: level / slower)
 
 // the 256 transition bits of block b of channel c as four 64-bit words, OLDEST sample in bit 0 of d[0]; `carry` = the
 // sign of the sample before the block; returns the sign of the block's last valid sample.  receiver.c:113 curr != prev.
@@ -121,15 +119,8 @@ __device__ __forceinline__ uint32_t tp_run_block(const uint32_t Rw[8], uint32_t 
 
 } // namespace
 
-#ifdef PLLTP_BUDGET
-// Measurement build only (EXTRA=-DPLLTP_BUDGET; scripts/plltp_budget.py): 100 MHz stamps of a workgroup's phases
-__device__ unsigned long long plltp_budget[4096 * 16];
-#define TP_STAMP(i) do { if (threadIdx.x == 0 && blockIdx.x < 4096) plltp_budget[blockIdx.x * 16 + (i)] = wall_clock64(); } while (0)
-#define TP_ACC(i, v) do { if (threadIdx.x == 0 && blockIdx.x < 4096) plltp_budget[blockIdx.x * 16 + (i)] = (v); } while (0)
-#else
-#define TP_STAMP(i) do { } while (0)
-#define TP_ACC(i, v) do { } while (0)
-#endif
+// (A measurement build -- 100 MHz stamps of a workgroup's phases -- produced profiles/r05_pll_tp_budget.txt; the
+// instrumentation is in git history, commit b1fc8e6.)
 
 // One workgroup per channel.  LDS: the chunk's table, the blocks' transition bits, per-block transition counts / true
 // c_in / last signs, the bit packs.  CHUNK: blocks per chunk (one table, one walk, one re-centring), at most 64.
@@ -158,10 +149,6 @@ __global__ __launch_bounds__(64 * TP_WAVES) void pll_tp_kernel(
     const float rq = 1.0f / (float) q;
     const uint32_t pll0 = pllst[c] & 0xffffu;                 // receiver.h:40
     const uint32_t prev0 = prevst[c] & 1u;                    // receiver.h:44
-    TP_STAMP(0);
-#ifdef PLLTP_BUDGET
-    unsigned long long tb_p1 = 0, tb_walk = 0, tb_t = 0, tb_rounds = 0;
-#endif
 
     for (int i = (int) threadIdx.x; i < n_seg * PACK_STRIDE; i += 64 * TP_WAVES) pack[i] = 0;
 
@@ -196,7 +183,6 @@ __global__ __launch_bounds__(64 * TP_WAVES) void pll_tp_kernel(
         if (threadIdx.x == 0) cin[0] = 0;                     // c = 0 at the call's first sample, by definition
     }
     __syncthreads();
-    TP_STAMP(1);
 
     // ---- chunks: pass 1 (all waves), walk (one wave).  Block b's candidates are lo(b) + 2 k, lo(b) = centre + (transitions
     // between the chunk's first sample and the block) % 2 - 64: the parity c has there.
@@ -205,10 +191,6 @@ __global__ __launch_bounds__(64 * TP_WAVES) void pll_tp_kernel(
         const int b1 = b0 + CHUNK < n_blk ? b0 + CHUNK : n_blk;
         const int32_t cc = cin[b0];                           // the true c at the chunk's first sample: the centre
         const uint32_t cnt0 = cnt[b0];
-#ifdef PLLTP_BUDGET
-        tb_t = wall_clock64();
-        ++tb_rounds;
-#endif
         for (int b = b0 + wave; b < b1; b += TP_WAVES) {
             const uint4 r0 = *reinterpret_cast<const uint4 *>(bits + 8 * b), r1 = *reinterpret_cast<const uint4 *>(bits + 8 * b + 4);
             const uint32_t Rw[8] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w};
@@ -222,10 +204,6 @@ __global__ __launch_bounds__(64 * TP_WAVES) void pll_tp_kernel(
             tab[(b - b0) * 64 + lane] = 2 * (c_out - lo_next);          // byte offset in the next row when inside [0, 256)
         }
         __syncthreads();
-#ifdef PLLTP_BUDGET
-        tb_p1 += wall_clock64() - tb_t;
-        tb_t = wall_clock64();
-#endif
         if (wave == 0) {
             // the walk: uniform over the wave (every lane carries the same value), one dependent LDS read per block;
             // lane i collects the value at the END of block b0 + i
@@ -243,15 +221,7 @@ __global__ __launch_bounds__(64 * TP_WAVES) void pll_tp_kernel(
         }
         __syncthreads();
         b0 = __builtin_amdgcn_readfirstlane((int) ctl[0]);
-#ifdef PLLTP_BUDGET
-        tb_walk += wall_clock64() - tb_t;
-#endif
     }
-    TP_STAMP(2);
-    TP_ACC(8, tb_p1);
-    TP_ACC(9, tb_walk);
-    TP_ACC(10, tb_rounds);
-    TP_ACC(11, (unsigned long long) cnt[n_blk]);
 
     // ---- pass 3: lane = block.  Toggle bit floor(U(t) / 2^16) - (slices before the segment) of the segment's pack for
     // every transition (receiver.c:124-132 restated, see the header).
@@ -278,7 +248,6 @@ __global__ __launch_bounds__(64 * TP_WAVES) void pll_tp_kernel(
         }
     }
     __syncthreads();
-    TP_STAMP(3);
 
     // ---- the packs leave: one lane per segment forms its words, then the parity is carried from segment to segment
     // (pll_h3.hip's pack writer: a transition after a segment's last slice toggles the first bit of the next segment that
@@ -303,7 +272,6 @@ __global__ __launch_bounds__(64 * TP_WAVES) void pll_tp_kernel(
         nbs[n_seg + s] = pd;
     }
     __syncthreads();
-    TP_STAMP(4);
     if (wave == 0) {
         // lane = segment, 64 at a time: which segments have bits and which hand a toggle on, as two masks; the carried
         // parity then runs along the masks in scalar code
@@ -333,21 +301,12 @@ __global__ __launch_bounds__(64 * TP_WAVES) void pll_tp_kernel(
         }
     }
     __syncthreads();
-    TP_STAMP(5);
     for (int i = (int) threadIdx.x; i < n_seg * PACK_STRIDE; i += 64 * TP_WAVES)
         segbits[((size_t) c * n_seg_alloc + (size_t) (i / PACK_STRIDE)) * PACK_STRIDE + (size_t) (i % PACK_STRIDE)] = pack[i];
     for (int s = (int) threadIdx.x; s < n_seg_alloc; s += 64 * TP_WAVES)
         segcnt[(size_t) c * n_seg_alloc + s] = s < n_seg ? nbs[s] : 0u;
-    TP_STAMP(6);
 }
 
-#ifdef PLLTP_BUDGET
-extern "C" int gnuais_debug_plltp_budget(unsigned long long *out, int n_wg)
-{
-    if (n_wg < 0 || n_wg > 4096) return -1;
-    return (int) hipMemcpyFromSymbol(out, HIP_SYMBOL(plltp_budget), sizeof(unsigned long long) * 16 * (size_t) n_wg);
-}
-#endif
 
 namespace {
 
@@ -375,21 +334,14 @@ hipError_t launch_pll_tp(const PllLaunch &a, hipStream_t stream)
     const int n_blk = (a.L + TP_BLK - 1) / TP_BLK;
     const int n_seg = (((a.L + 31) >> 5) + SEG_WORDS - 1) / SEG_WORDS;
     const size_t lds = tp_lds_bytes(n_blk, n_seg);
-    static int chunk = 0;
-    if (!chunk) {
-        const char *e = getenv("GNUAIS_TP_CHUNK");
-        chunk = e ? atoi(e) : TP_CHUNK_DEFAULT;
-        if (chunk != 16 && chunk != 32 && chunk != 64) chunk = TP_CHUNK_DEFAULT;
-    }
-    auto kern = chunk == 16 ? pll_tp_kernel<16> : chunk == 64 ? pll_tp_kernel<64> : pll_tp_kernel<32>;
-    static bool raised[64][3] = {};
+    auto kern = pll_tp_kernel<TP_CHUNK>;
+    static bool raised[64] = {};
     int dev = 0;
     (void) hipGetDevice(&dev);
-    const int ki = chunk == 16 ? 0 : chunk == 64 ? 2 : 1;
-    if (dev >= 0 && dev < 64 && !raised[dev][ki]) {
+    if (dev >= 0 && dev < 64 && !raised[dev]) {
         const hipError_t e = hipFuncSetAttribute((const void *) kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;
-        raised[dev][ki] = true;
+        raised[dev] = true;
     }
     hipLaunchKernelGGL(kern, dim3(a.N), dim3(64 * TP_WAVES), lds, stream, a.sgn, a.pll, a.prev, a.lastbit,
                        a.segbits, a.segcnt, a.N, a.L, a.n_seg, a.pllinc);

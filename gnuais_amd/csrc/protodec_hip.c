@@ -3,6 +3,8 @@
  *
  *   src/filter.h:64-68     filter_init  filter_free  filter_run  filter_run_buf
  *   src/protodec.h:76      protodec_decode            (src/protodec.c:988-1122, the HDLC deframer)
+ *   src/protodec.h:74      protodec_reset             (src/protodec.c:87-100) -- reaches the machine on the device
+ *   src/protodec.c:78      protodec_deinit            -- flushes, releases the device objects, frees d's buffers
  *   src/protodec.c:106,120 protodec_sdlc_crc  protodec_calculate_crc
  *
  * This is the inverse of receiver_hip.c: there the reference's receiver.c / filter.c are replaced and its
@@ -15,8 +17,10 @@
  *
  * Linking: the reference's protodec.c defines protodec_decode / protodec_calculate_crc / protodec_sdlc_crc next to
  * the message layer this file needs from it (protodec_initialize, protodec_getdata, ...).  Compile that one file
- * with the three names renamed (-Dprotodec_decode=ref_protodec_decode ...: nothing of its source changes) and leave
- * filter.c out; INTEGRATION.md has the link line, and the test suite builds and runs exactly that.
+ * with the five names renamed (-Dprotodec_decode=gnuais_ref_protodec_decode ... -Dprotodec_reset=gnuais_ref_protodec_reset
+ * -Dprotodec_deinit=gnuais_ref_protodec_deinit: nothing of its source changes; its protodec_initialize() then calls
+ * the renamed reset, which is right -- no device object exists before the first bit) and leave filter.c out;
+ * INTEGRATION.md has the link line, and the test suite builds and runs exactly that.
  *
  * protodec_decode() semantics.  The reference consumes `count` bits and returns with d current; its receiver.c
  * calls it once per BIT (receiver.c:130), and a device round trip per bit is unusable at any rate.  So bits queue
@@ -28,8 +32,9 @@
  * antallenner, bitstuff, last, bufferpos, receivedframes, lostframes, lostframes2) are current as of the last flush:
  * at most one buffer behind; gnuais_protodec_flush(d) (NULL: every decoder) brings them up to the last bit -- call
  * it before reading the counters at shutdown (ais.c:296-310).  gnuais_protodec_set_batching(1) restores the strict
- * per-call behaviour (every call returns with d current; slow).  d->buffer (the raw bits of a frame in progress)
- * is not mirrored.
+ * per-call behaviour (every call returns with d current; slow).  d->buffer (protodec.h:52: the stored bits of the
+ * frame in progress, or of the last frame that reached its stop bit) is refreshed at every flush as well
+ * (gnuais_batch_frame_bits); the one case it is left as it was: a frame given up at 449 bits.
  *
  * Threads: the two tables are hashed by object address and guarded by one mutex, which is NOT held while the
  * reference's protodec_getdata() runs (it writes to the serial port, takes the cache's lock and flushes stdout);
@@ -57,6 +62,9 @@ struct filter {
 	int pointer;
 };
 void protodec_getdata(int bufferlengde, struct demod_state_t *d);
+#endif
+#ifndef ST_SKURR
+#define ST_SKURR 1                      /* src/protodec.h:30 */
 #endif
 #include "gnuais_hip.h"
 
@@ -421,6 +429,18 @@ static void flush_locked(struct d_ent *e)
 	d->bitstuff = st.bitstuff;
 	d->last = (char) st.last;
 	d->bufferpos = st.bufferpos;
+	if (d->buffer) {                                /* protodec.c:1019: the cells a host may look at */
+		unsigned char cells[DEMOD_BUFFER_LEN];
+		int nb = -1;
+		if (gnuais_batch_frame_bits(e->b, 0, cells, DEMOD_BUFFER_LEN, &nb) != GNUAIS_OK)
+			die("protodec_decode: gnuais_batch_frame_bits");
+		if (nb >= 0) {
+			if (nb > DEMOD_BUFFER_LEN)
+				nb = DEMOD_BUFFER_LEN;
+			memset(d->buffer, 0, DEMOD_BUFFER_LEN);         /* protodec.c:1080 at the frame's start */
+			memcpy(d->buffer, cells, (size_t) nb);
+		}
+	}
 }
 
 /* every decoder with queued bits, in creation order.  The order is SNAPSHOT under the table lock with a reference
@@ -466,6 +486,51 @@ void protodec_decode(char *in, int count, struct demod_state_t *d)
 		flush_locked(e);
 	pthread_mutex_unlock(&e->lock);
 	d_unref(e);
+}
+
+/* src/protodec.c:87-100.  The bits d was given before this call are decoded first (with the state they met), then the
+ * machine on the device and d's own fields go back to ST_SKURR; counters stay.  A d that has not seen a bit yet has no
+ * device object: only its fields are set, which is all the reference does. */
+void protodec_reset(struct demod_state_t *d)
+{
+	struct d_ent *e;
+	pthread_mutex_lock(&tab_lock);
+	e = ptab_get(&d_tab, d);
+	if (e)
+		e->refs++;
+	pthread_mutex_unlock(&tab_lock);
+	if (e) {
+		pthread_mutex_lock(&e->lock);
+		flush_locked(e);
+		if (!e->released && gnuais_batch_protodec_reset(e->b) != GNUAIS_OK)
+			die("protodec_reset");
+		pthread_mutex_unlock(&e->lock);
+		d_unref(e);
+	}
+	d->state = ST_SKURR;
+	d->nskurr = 0;
+	d->ndata = 0;
+	d->npreamble = 0;
+	d->nstartsign = 0;
+	d->nstopsign = 0;
+	d->antallpreamble = 0;
+	d->antallenner = 0;
+	d->last = 0;
+	d->bitstuff = 0;
+	d->bufferpos = 0;
+}
+
+void gnuais_protodec_release(struct demod_state_t *d);
+
+/* src/protodec.c:78-85, after whatever d still holds has been decoded and delivered and its device objects are gone */
+void protodec_deinit(struct demod_state_t *d)
+{
+	gnuais_protodec_release(d);
+	hfree(d->buffer);
+	hfree(d->rbuffer);
+	hfree(d->serbuffer);
+	hfree(d->ipcbuffer);
+	hfree(d->nmea);
 }
 
 /* additive, not reference names: how many bits may wait per decoder (1: every call returns with d current;

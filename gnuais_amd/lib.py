@@ -53,6 +53,8 @@ SYMBOLS = {
     "gnuais_batch_maxval": (_I, [_P, _P]),
     "gnuais_batch_pll_state": (_I, [_P, _P]),
     "gnuais_batch_fsm_state": (_I, [_P, _P]),
+    "gnuais_batch_protodec_reset": (_I, [_P]),
+    "gnuais_batch_frame_bits": (_I, [_P, _I, _P, _I, C.POINTER(_I)]),
     "gnuais_batch_history": (_I, [_P, _P]),
     "gnuais_batch_n_channels": (_I, [_P]),
     "gnuais_batch_n_taps": (_I, [_P]),

@@ -289,6 +289,18 @@ class ReceiverBatch:
     def fsm_state(self) -> np.ndarray:
         return self._struct_array(self._lib.gnuais_batch_fsm_state, FSM_DTYPE)
 
+    def protodec_reset(self):
+        """protodec_reset() (protodec.c:87-100) for every decoder: back to ST_SKURR, counters stay."""
+        check(self._lib.gnuais_batch_protodec_reset(self._h))
+
+    def frame_bits(self, channel: int):
+        """d->buffer of one channel (protodec.h:52): the stored bits of the frame in progress or of the last frame that
+        reached its stop bit, one per byte; None when neither is on record."""
+        out = np.zeros(450, dtype=np.uint8)
+        n = C.c_int(0)
+        check(self._lib.gnuais_batch_frame_bits(self._h, int(channel), out.ctypes.data, out.size, C.byref(n)))
+        return None if n.value < 0 else out[:min(n.value, out.size)].copy()
+
     def maxval(self) -> np.ndarray:
         out = np.zeros(self.n_channels, dtype=np.int16)
         check(self._lib.gnuais_batch_maxval(self._h, out.ctypes.data))

@@ -178,6 +178,13 @@ int  gnuais_batch_total_received(gnuais_batch *b, long long *total);
 int  gnuais_batch_maxval(gnuais_batch *b, int16_t *h_out /* [n_channels] */);
 int  gnuais_batch_pll_state(gnuais_batch *b, gnuais_pll_state *h_out /* [n_channels] */);
 int  gnuais_batch_fsm_state(gnuais_batch *b, gnuais_fsm_state *h_out /* [n_channels] */);
+/* protodec_reset() (src/protodec.c:87-100) for every decoder of the batch: back to ST_SKURR, the frame in progress
+ * dropped, counters untouched.  Synchronises. */
+int  gnuais_batch_protodec_reset(gnuais_batch *b);
+/* d->buffer of one channel (src/protodec.h:52, written at protodec.c:1019): the stored bits, one per byte, of the frame
+ * in progress or -- between frames -- of the last frame that reached its stop bit; *n_bits = their number (may exceed
+ * cap: the first cap are written), -1 when neither is on record (no frame yet; the last one given up at 449 bits). */
+int  gnuais_batch_frame_bits(gnuais_batch *b, int channel, uint8_t *h_bits, int cap, int *n_bits);
 /* the last n_taps input samples per channel, oldest first (live part of
  * struct filter.buffer, src/filter.h:60): h_out int16 [n_channels][n_taps] */
 int  gnuais_batch_history(gnuais_batch *b, int16_t *h_out);
@@ -316,14 +323,18 @@ int  gnuais_batch_mean_timing(gnuais_batch *b, float *ms5, int *n_calls);
  *   "pll_variant"   0 = by channel count (default: the time-parallel form, pll_tp.hip, up to 1536 channels; pll_h3.hip above);
  *                   7 / 8 force one
  *   "hdlc_variant"  1 = the event-driven deframer (default); 0 = the bit-serial one
- *   "hdlc_lpw"      channels per deframer wave, 1..64 (default: 16, or 64 where the batch fills the chip)
+ *   "hdlc_lpw"      channels per deframer wave, 1..64 (default by channel count: as few as keep the launch at <= 512 waves --
+ *                   1, 2, 4, 8 or 16 -- up to 1536 channels, 16 up to 8192, 64 where the batch fills the chip)
  *   "streaming"     0 leaves the streamed delivery (gnuais_batch_stream_nmea switches it on)
  *   "timing_stride" with set_timing on, time every n-th call only (the event records of a timed call cost stream time)
  *   "stage_mask"    measurement only: bit 0 FIR/slicer, 1 PLL/NRZI, 3 deframer, 4 unstuff/CRC; results are wrong unless 0x1f */
 int  gnuais_batch_set_option(gnuais_batch *b, const char *name, int value);
-/* Optional, once, before real work: time the stage -> stream assignments on `d_samples` (about 1.3 s
- * of pipelined calls: two greedy searches and a longer head-to-head with the default) and keep the fastest; RESETS the batch.  Which hardware queue a stream gets
- * depends on what else the process created before, is not queryable, and matters by up to 1.7x. */
+/* Optional, once, before real work, for processes that created HIP streams of their own before the batch: time the
+ * stage -> stream assignments on `d_samples` (about 1.3 s of pipelined calls: two greedy searches and a longer
+ * head-to-head with the default) and keep a searched assignment only if it beats the default by 3 % or more; RESETS the
+ * batch.  Which hardware queue a stream gets depends on what else the process created before, is not queryable, and
+ * matters by up to 1.7x; in a process without streams of its own the default assignment (the creation order inside
+ * gnuais_batch_create) is the best one found on every box measured (bench.py reports both: uncalibrated_ms_per_step). */
 int  gnuais_batch_autotune(gnuais_batch *b, const int16_t *d_samples, int len, void *stream,
 			   float *ms_per_call);
 /* The same for the delivery loop (gnuais_batch_run + gnuais_batch_stream_nmea): places the stream of the

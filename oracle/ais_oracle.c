@@ -474,6 +474,8 @@ size_t ais_oracle_frame_count(const ais_oracle *o) { return o->n_frames; }
 const ais_frame *ais_oracle_frames(const ais_oracle *o) { return o->frames; }
 void ais_oracle_clear_frames(ais_oracle *o) { o->n_frames = 0; }
 const ais_hdlc *ais_oracle_hdlc(const ais_oracle *o, int ch) { return &o->hd[ch]; }
+/* protodec.c:87-100 called from outside (protodec_reset() is a public name, protodec.h:74) */
+void ais_oracle_protodec_reset(ais_oracle *o, int ch) { hdlc_reset(&o->hd[ch]); }
 
 static int frame_cmp(const void *a, const void *b)
 {

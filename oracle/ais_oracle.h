@@ -97,6 +97,7 @@ const ais_frame *ais_oracle_frames(const ais_oracle *o);
 void ais_oracle_sort_frames(ais_oracle *o);   /* (channel, end_bit) = reference order */
 void ais_oracle_clear_frames(ais_oracle *o);
 const ais_hdlc *ais_oracle_hdlc(const ais_oracle *o, int ch);
+void ais_oracle_protodec_reset(ais_oracle *o, int ch);   /* protodec.c:87-100 */
 void ais_oracle_get_pll(const ais_oracle *o, int ch, uint32_t *pll, int *prev, int *lastbit);
 void ais_oracle_get_history(const ais_oracle *o, int ch, int16_t *out_n_taps);
 

@@ -13,10 +13,10 @@ import os, re, subprocess, sys, tempfile
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = os.path.join(root, "gnuais_amd", "csrc", "fir_sign_pk.hip")
 inc = open(os.path.join(root, "gnuais_amd", "csrc", "fir_sign_pk_asm.inc")).read()
-base = {nc: int(re.search(rf"#define PK{nc}_VGPR_BASE (\d+)", inc).group(1)) for nc in (12, 40, 48)}
+base = {nc: int(re.search(rf"#define PK{nc}_VGPR_BASE (\d+)", inc).group(1)) for nc in (40, 48)}
 # the highest register the generated streams name: the wave must have been allocated at least that many
 ring_top = {nc: max(int(r) for r in re.findall(r'"v(\d+)"', re.search(rf"#define PK{nc}_CLOBBERS (.*)", inc).group(1)))
-            for nc in (12, 40, 48)}
+            for nc in (40, 48)}
 if len(sys.argv) > 1:
     text = open(sys.argv[1]).read().splitlines()
 else:
@@ -27,7 +27,7 @@ else:
                                "-w", src, "-o", out])
         text = open(out).read().splitlines()
 bad = 0
-for nc in (12, 40, 48):
+for nc in (40, 48):
     inside = in_asm = found = False
     top = -1                     # highest register of the compiler's own code below the streams' block
     above = -1                   # ... and above it

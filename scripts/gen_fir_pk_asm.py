@@ -15,7 +15,7 @@ Order inside a half: the pair whose slot is read next goes first and the pair th
 no packed instruction sits next to an instruction that depends on it (the assembler adds no wait states in inline asm).
 """
 import os
-NCS = (12, 40, 48)
+NCS = (40, 48)
 BASE = {12: 72, 40: int(os.environ.get("PK40_BASE", "44")), 48: int(os.environ.get("PK48_BASE", "44"))}      # first register of the ring per instantiation
 GAP = 8     # what the compiler's own code may use ends at least GAP registers below the ring (PK*_VGPR_BUDGET, for the
             # record: nothing enforces it in the language -- scripts/check_pk_registers.py, run by the Makefile on every

@@ -120,6 +120,29 @@ int gnuais_batch_fsm_state(gnuais_batch *b, gnuais_fsm_state *h_out)
 	return GNUAIS_OK;
 }
 
+int gnuais_batch_protodec_reset(gnuais_batch *b)
+{
+	int c;
+	for (c = 0; c < b->n_ch; c++)
+		ais_oracle_protodec_reset(b->o, c);
+	return GNUAIS_OK;
+}
+
+/* the reference's d->buffer as the oracle keeps it: bufferpos cells inside a frame, the last frame's cells between */
+int gnuais_batch_frame_bits(gnuais_batch *b, int channel, uint8_t *h_bits, int cap, int *n_bits)
+{
+	const ais_hdlc *h = ais_oracle_hdlc(b->o, channel);
+	int n = h->bufferpos, i;
+	if (h->state != 4 && h->state != 5) {
+		*n_bits = -1;                           /* the double keeps no record of closed frames */
+		return GNUAIS_OK;
+	}
+	for (i = 0; i < n && i < cap; i++)
+		h_bits[i] = h->buffer[i];
+	*n_bits = n;
+	return GNUAIS_OK;
+}
+
 int gnuais_batch_pll_state(gnuais_batch *b, gnuais_pll_state *h_out)
 {
 	int c;

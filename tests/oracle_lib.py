@@ -179,6 +179,17 @@ class Oracle:
                                            "bitstuff", "last", "bufferpos", "receivedframes",
                                            "lostframes", "lostframes2", "bits_seen")}
 
+    def frame_cells(self, ch: int) -> np.ndarray:
+        """d->buffer[0 .. bufferpos) (protodec.h:52): the stored bits of the frame the decoder is in"""
+        s = self.lib.ais_oracle_hdlc(self.h, ch).contents
+        return np.frombuffer(bytes(s.buffer), dtype=np.uint8)[: s.bufferpos].copy()
+
+    def protodec_reset(self):
+        """protodec_reset() (protodec.c:87-100) on every channel's decoder"""
+        self.lib.ais_oracle_protodec_reset.argtypes = [C.c_void_p, C.c_int]
+        for c in range(self.n_ch):
+            self.lib.ais_oracle_protodec_reset(self.h, c)
+
     def counters(self) -> np.ndarray:
         out = np.zeros((self.n_ch, 3), dtype=np.int32)
         for c in range(self.n_ch):

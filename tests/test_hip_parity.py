@@ -749,6 +749,41 @@ def test_reset_restores_initial_state():
     assert b.drain_frames().tobytes() == frames_of(g["frames"]).tobytes()
 
 
+@pytest.mark.parametrize("hdlc_variant", [1, 0])
+def test_protodec_reset_and_frame_cells_vs_oracle(hdlc_variant):
+    """gnuais_batch_protodec_reset() = protodec_reset() (protodec.c:87-100) on every decoder, in the middle of frames:
+    state, counters and every later frame as the oracle's; gnuais_batch_frame_bits() = d->buffer[0 .. bufferpos)
+    (protodec.h:52, protodec.c:1019) of every channel that is inside a frame, after every ragged call."""
+    n_ch, total = 70, 24 * 1280
+    x = np.stack([synth.make_stream(total, seed=47, channel=c, occupancy=0.9, sigma=(800.0, 3000.0)[c % 2])[0]
+                  for c in range(n_ch)], axis=1)
+    b = batch(n_ch, max_len=4096)
+    b.set_option("hdlc_variant", hdlc_variant)
+    o = Oracle(n_ch)
+    chunks = [777, 1020, 333, 2048, 1500, 913] * 6
+    chunks.append(total - sum(chunks))
+    pos = inside = 0
+    for i, n in enumerate(chunks):
+        b.run(dev(x[pos:pos + n]))
+        o.run(x[pos:pos + n])
+        pos += n
+        assert fsm_rows(b) == oracle_fsm_rows(o, n_ch)
+        for c in range(n_ch):
+            if o.hdlc(c)["state"] in (4, 5):
+                got = b.frame_bits(c)
+                assert got is not None and np.array_equal(got, o.frame_cells(c)), (i, c)
+                inside += 1
+        if i % 5 == 2:
+            b.protodec_reset()
+            o.protodec_reset()
+            assert fsm_rows(b) == oracle_fsm_rows(o, n_ch)
+    assert inside > 500
+    assert b.drain_frames().tobytes() == o.frames().tobytes()
+    assert np.array_equal(np.stack([b.counters()[k] for k in ("receivedframes", "lostframes", "lostframes2")], axis=1),
+                          o.counters())
+    assert o.counters()[:, 0].sum() > 300
+
+
 def test_dropin_receiver_run_matches_golden(tmp_path):
     """The C drop-in (init_receiver/receiver_run/free_receiver over the C ABI) driven
     like src/ais.c drives the reference: stereo raw file, 1020-frame chunks."""
