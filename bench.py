@@ -169,7 +169,7 @@ class DistSync:
 
 
 def measure(cfg, args, local, rank, sync, steps, warmup, isolated=True, post=False, keep_input=False, kernel_leg=True,
-            options=None):
+            options=None, uncalibrated=False):
     """One workload on this rank's GPU.  Returns a dict of raw measurements."""
     import torch
     from gnuais_amd import ReceiverBatch, params, synth, tile_channels
@@ -192,6 +192,17 @@ def measure(cfg, args, local, rank, sync, steps, warmup, isolated=True, post=Fal
     # The hardware queue a stream gets depends on what the process created before and decides a good
     # part of the pipeline's speed; the library measures it on this input.
     b.set_option("stage_mask", cfg["stage_mask"])    # before the calibration: its calls run this workload's stages only
+    uncal = None
+    if uncalibrated:
+        # what a plain gnuais_batch_run() caller gets: the same region with the library's default stage -> stream assignment
+        for _ in range(max(warmup, 4)):
+            step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        torch.cuda.synchronize()
+        uncal = (time.perf_counter() - t0) / steps * 1e3
     b.autotune(x, stream)
     for k_, v_ in (options or {}).items():
         b.set_option(k_, v_)
@@ -227,7 +238,7 @@ def measure(cfg, args, local, rank, sync, steps, warmup, isolated=True, post=Fal
     dt = time.perf_counter() - t0
     rx1 = b.total_received()
     out = {"n_ch": n_ch, "len": total, "dt": dt, "dt_own": dt_own, "steps": steps, "msgs": float(rx1 - rx0),
-           "kernel_ms_isolated": iso}
+           "kernel_ms_isolated": iso, "uncalibrated_ms_per_step": uncal}
     # `kernel_ms`: the same loop again, long enough for a stable mean -- a 20-step region sampled on every 4th call gives
     # five samples per kernel, and which of two stages of nearly equal length "dominates" then flips from run to run
     leg = KERNEL_LEG_CALLS if kernel_leg else 12
@@ -387,15 +398,14 @@ def roofline_of(m, ms_per_step=None, traffic=None, n_taps=36):
     duration (the per-channel recurrences: one wave per 16-64 channels, serial through the call)."""
     alg = m["n_ch"] * m["len"] * 2.0
     km = {k: v for k, v in m["kernel_ms"].items() if v and v > 0}
-    dom = max(km, key=km.get)
-    # a tie (within 2 %) goes to the FIR: the kernel that moves the call's bytes, and the one the HBM fraction is about
-    if "fir_slice" in km and km["fir_slice"] >= 0.98 * km[dom]:
-        dom = "fir_slice"
+    order = sorted(km, key=km.get, reverse=True)
+    dom = order[0]                  # the longest, whichever it is; the FIR's own figures are under "fir" either way
     ach = alg / (km[dom] * 1e-3) / 1e9
     r = {"bound": "hbm" if (traffic and not traffic.get("error")) else None, "kernel": dom, "kernel_ms": km[dom], "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
          "frac": ach / HBM_PEAK_GBS, "traffic": None, "algorithmic_bytes_per_launch": alg,
          "algorithmic_flops_per_launch": m["n_ch"] * m["len"] * 2.0 * n_taps,
          "kernel_ms_samples": m.get("kernel_ms_calls"),
+         "runner_up": ({"kernel": order[1], "kernel_ms": km[order[1]]} if len(order) > 1 else None),
          "why_this_kernel": "largest mean duration of the chain's kernels in the pipelined loop (all of them process "
                             "the same N x L samples per launch)"}
     if "fir_slice" in km:
@@ -579,6 +589,7 @@ def pmc_traffic(args, config, device=0):
                 mfma_ms = c.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / (N_SIMD * clock) * 1e3
                 floor_ms += mfma_ms
                 valu[k] = {"insts_per_launch": c.get("SQ_INSTS_VALU"), "active_quad_cycles": c["SQ_ACTIVE_INST_VALU"],
+                           "issue_floor_ms_at_4_cycles": c["SQ_ACTIVE_INST_VALU"] * 4.0 / (N_SIMD * clock) * 1e3 + mfma_ms,
                            "waves": c.get("SQ_WAVES"), "launch_ms_in_this_pass": ms, "clock_ghz": clock / 1e9,
                            "clock_from": "GRBM_GUI_ACTIVE / 8 XCDs / duration" if c.get("GRBM_GUI_ACTIVE") else "spec",
                            "issue_floor_ms": floor_ms, "mfma_busy_ms": mfma_ms, "busy_frac": floor_ms / ms, "cycles_per_instruction_priced": inst_cycles,
@@ -657,7 +668,8 @@ def compact_line(out, detail_path=None):
     goes to the detail file.  Guaranteed shorter than COMPACT_LIMIT bytes: optional blocks are dropped, last first,
     until it is (tests/test_bench_line.py holds it to that on canned measurements)."""
     c = _pick(out, ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
-                    "vs_baseline", "dtype", "data", "valid_crc_msgs_per_s", "x_realtime_channels"))
+                    "vs_baseline", "dtype", "data", "valid_crc_msgs_per_s", "x_realtime_channels", "uncalibrated_ms_per_step",
+                    "error"))
     c.setdefault("vs_baseline", None)
     cfg = out.get("config") or {}
     c["config"] = _pick(cfg, ("workload", "channels_per_gpu", "samples_per_channel", "parallelism"))
@@ -665,6 +677,8 @@ def compact_line(out, detail_path=None):
     rr = _pick(r, ("bound", "kernel", "kernel_ms", "achieved", "peak", "unit", "frac", "traffic", "traffic_chain",
                    "algorithmic_bytes_per_launch"))
     rr.setdefault("traffic", None)
+    if isinstance(r.get("runner_up"), dict):
+        rr["runner_up"] = _pick(r["runner_up"], ("kernel", "kernel_ms"))
     if isinstance(r.get("chain"), dict):
         rr["chain"] = _pick(r["chain"], ("ms_per_step", "achieved", "frac"))
     if isinstance(r.get("fir"), dict):
@@ -764,7 +778,7 @@ def rank_main(rank, local, world, args, sync):
         cfg = dict(cfg, len=args.len)
     want_cpu = rank == 0 and world == 1 and args.cpu and args.config == "C3"
     m = measure(cfg, args, local, rank, sync, args.steps, args.warmup, post=(rank == 0), keep_input=want_cpu,
-                kernel_leg=args.kernel_leg)
+                kernel_leg=args.kernel_leg, uncalibrated=(world == 1))
     x_cpu, x_wide = m.pop("x_cpu", None), m.pop("x_wide", None)
     per_rank = {"rank": rank, "device": local, "ms_per_step": m["dt_own"] / m["steps"] * 1e3}
     red = sync.reduce(m["dt"], m["msgs"], float(m["n_ch"]) * m["len"] * m["steps"], per_rank)
@@ -794,6 +808,9 @@ def rank_main(rank, local, world, args, sync):
         "float_path": float_path(args, local) if (world == 1 and args.e2e and args.config == "C3") else None,
         "steady_state": m.get("steady_state"),
         "stage_masks": m.get("stage_masks"),
+        "uncalibrated_ms_per_step": m.get("uncalibrated_ms_per_step"),
+        "uncalibrated_what": "the same K steps BEFORE gnuais_batch_autotune(): the library's default stage -> stream "
+                             "assignment, what a plain gnuais_batch_run() caller gets",
         "note": "the receive path slices the sign of the filter output and never stores the pre-slicer "
                 "floats; gnuais_batch_filter() produces them (bit-exact, tests/test_hip_parity.py)",
     }
@@ -856,6 +873,8 @@ def node_main(world, args):
             slabs.append(tile_channels(torch.from_numpy(base).to(f"cuda:{d}"), n))
     for d in set(devs):
         torch.cuda.synchronize(d)
+    for w in node.warnings():
+        sys.stderr.write("bench.py: " + w + "\n")
     node.set_option("stage_mask", cfg["stage_mask"])
     node.autotune(slabs)
 
@@ -919,6 +938,58 @@ def node_main(world, args):
     emit(out, args)
 
 
+def preflight(devs, cfg):
+    """Before any allocation: is every device this run names there, and has it room for its shards?  -> None or a text
+    that names the device and both figures.  (Per shard: the input slab N x L x 2 bytes + the batch's hand-off sets,
+    candidate ring and frame ring -- gnuais_batch_create checks its own share again, exactly.)"""
+    try:
+        import torch
+    except Exception as e:                              # noqa: BLE001
+        return "torch is not importable: %s" % e
+    if not torch.cuda.is_available():
+        return "no HIP device is visible (torch.cuda.is_available() is False); the chain has no CPU path"
+    have = torch.cuda.device_count()
+    bad = sorted(set(d for d in devs if d < 0 or d >= have))
+    if bad:
+        return "device index %s requested, %d device(s) visible (HIP_VISIBLE_DEVICES=%s)" % (
+            bad, have, os.environ.get("HIP_VISIBLE_DEVICES", "unset"))
+    per_shard = cfg["channels"] * cfg["len"] * 2.0 * 1.6 + cfg["channels"] * 90e3
+    for d in sorted(set(devs)):
+        try:
+            free_b, total_b = torch.cuda.mem_get_info(d)
+        except Exception as e:                          # noqa: BLE001
+            return "device %d does not answer (mem_get_info: %s)" % (d, e)
+        need = per_shard * devs.count(d)
+        if need > free_b:
+            return "device %d: %d shard(s) of %d channels x %d samples need about %.1f GB, %.1f GB free of %.1f" % (
+                d, devs.count(d), cfg["channels"], cfg["len"], need / 1e9, free_b / 1e9, total_b / 1e9)
+    return None
+
+
+def fail_line(args, world, what, per_rank=None):
+    """A run that cannot start still ends in ONE parseable line (value null, `error` says why) and a non-zero status."""
+    cfg = CONFIGS[args.config]
+    out = {"metric": "Msamples/s demodulated (N-channel batch, full chain)", "value": None, "unit": "Msamples/s",
+           "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": None, "higher_is_better": True,
+           "scaling": "weak", "vs_baseline": None, "dtype": "f32 FIR on int16 samples; u32 PLL/HDLC/CRC", "data": "synthetic",
+           "config": {"workload": cfg["what"]}, "error": what}
+    if per_rank:
+        out["per_gpu"] = per_rank
+    sys.stderr.write("bench.py: " + what + "\n")
+    sys.stderr.flush()
+    print(json.dumps(out, separators=(",", ":")), flush=True)
+    sys.exit(3)
+
+
+def _cfg_of(args):
+    cfg = CONFIGS[args.config]
+    if args.channels:
+        cfg = dict(cfg, channels=args.channels)
+    if args.len:
+        cfg = dict(cfg, len=args.len)
+    return cfg
+
+
 def _worker(rank, world, args, barrier, queue):
     devs = [int(d) for d in args.devices.split(",")] if args.devices else list(range(world))
     rank_main(rank, devs[rank % len(devs)], world, args, LocalSync(rank, world, barrier, queue))
@@ -948,9 +1019,11 @@ def main():
                     help="also run the message-layer legs (message_lines, end_to_end, float_path); off by default: the "
                          "default command stays under a minute")
     ap.add_argument("--no-e2e", dest="e2e", action="store_false", help="(the default; kept for old command lines)")
-    ap.add_argument("--traffic-others", action="store_true",
-                    help="rocprofv3 --pmc child runs for C2 and C5 too (six more passes)")
-    ap.add_argument("--full", action="store_true", help="everything: --e2e --traffic-others")
+    ap.add_argument("--no-traffic-others", dest="traffic_others", action="store_false",
+                    help="skip the rocprofv3 --pmc child runs for C2 and C5 (six passes; other_configs.*.traffic stays null)")
+    ap.add_argument("--traffic-others", dest="traffic_others", action="store_true", help="(the default; kept for old command lines)")
+    ap.set_defaults(traffic_others=True)
+    ap.add_argument("--full", action="store_true", help="everything: --e2e as well")
     ap.add_argument("--detail", default="", help="where the full measurements go (default: bench_detail.json here)")
     ap.add_argument("--print-detail", action="store_true",
                     help="also print the full measurements as an EARLIER stdout line (the compact line stays last)")
@@ -968,18 +1041,43 @@ def main():
         local = int(os.environ.get("LOCAL_RANK", "0"))
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
-        torch.cuda.set_device(local)
+        # every rank looks at its own device first and all of them learn what the others found BEFORE anything is
+        # allocated or timed: a rank that cannot run says so in the final line instead of leaving the others in a barrier
+        mine = preflight([local], _cfg_of(args))
+        if mine is None:
+            torch.cuda.set_device(local)
+        found = [None] * world
+        try:
+            dist.init_process_group("gloo", rank=rank, world_size=world, init_method="tcp://%s:%d" % (
+                os.environ["MASTER_ADDR"], int(os.environ["MASTER_PORT"]) + 1))
+            dist.all_gather_object(found, {"rank": rank, "device": local, "error": mine})
+            dist.destroy_process_group()
+        except Exception as e:                          # noqa: BLE001
+            found = [{"rank": rank, "device": local, "error": mine or ("preflight exchange failed: %s" % e)}]
+        if any(f and f.get("error") for f in found):
+            if rank == 0:
+                fail_line(args, world, "; ".join("rank %d (device %d): %s" % (f["rank"], f["device"], f["error"])
+                                                for f in found if f and f.get("error")), found)
+            sys.exit(3)
         dist.init_process_group("nccl", rank=rank, world_size=world)
         rank_main(rank, local, world, args, DistSync(dist, torch.device("cuda", local), rank, world))
         dist.destroy_process_group()
         return
 
     world = max(1, args.gpus)
+    devs = [int(d) for d in args.devices.split(",")] if args.devices else list(range(world))
+    devs = [devs[g % len(devs)] for g in range(world)]
+    bad = preflight(devs, _cfg_of(args))
+    if bad:
+        fail_line(args, world, bad)
     if world == 1:
-        rank_main(0, 0, 1, args, LocalSync(0, 1, None, None))
+        rank_main(0, devs[0] if args.devices else 0, 1, args, LocalSync(0, 1, None, None))
         return
     if not args.procs:
-        node_main(world, args)                  # one process: the library's node object drives every device
+        try:
+            node_main(world, args)              # one process: the library's node object drives every device
+        except Exception as e:                  # noqa: BLE001   (GnuaisError carries the shard's own text: "device 3 (channels ..): ...")
+            fail_line(args, world, "%s: %s" % (type(e).__name__, e))
         return
     # one worker process per device (receivers share nothing, src/ais.c:141-147):
     # independent batches and launches, a barrier around the timed region, no process group

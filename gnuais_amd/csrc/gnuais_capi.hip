@@ -486,19 +486,35 @@ int gnuais_batch_create(gnuais_batch **out, int device, int n_channels, const fl
 
     const size_t N = (size_t) b->N;
     hipError_t e = hipSuccess;
+    b->n_seg = (b->sgn_words + SEG_WORDS - 1) / SEG_WORDS;
+    b->cand_K = std::max(64, b->bits_words * 32 / 30 + 2);
+    if (const char *v = getenv("GNUAIS_NBUF")) b->nbuf = std::min((int) gnuais_batch::NBUF, std::max(2, atoi(v)));
+    {   // preflight: what this batch is about to allocate against what the device has free -- a batch that does not fit
+        // says so with both figures at once instead of failing somewhere inside a dozen allocations
+        const size_t per_set = sizeof(uint32_t) * (sgn_words_alloc(b->sgn_words, b->N) + N * (size_t) b->n_seg * (PACK_STRIDE + 1) + 2 * N);
+        const size_t need = gnuais_batch::HB * (sizeof(int16_t) * N * b->NT + sizeof(int) * N) + (size_t) b->nbuf * per_set +
+                            sizeof(uint32_t) * N * ((size_t) b->cand_K * CAND_WORDS + HDLC_CTL_WORDS + 6) +
+                            sizeof(gnuais_frame) * (size_t) b->frame_cap;
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && need > free_b) {
+            char msg[256];
+            snprintf(msg, sizeof msg, "create: %d channels x %d samples need %.2f GB of device memory, device %d has %.2f GB free of %.2f",
+                     b->N, b->max_len, need / 1e9, device, free_b / 1e9, total_b / 1e9);
+            delete b;
+            return fail(GNUAIS_E_HIP, msg);
+        }
+    }
     auto alloc = [&](void **p, size_t bytes) {
         if (e == hipSuccess) e = hipMalloc(p, bytes);
         if (e == hipSuccess) e = hipMemset(*p, 0, bytes);
     };
     for (int q = 0; q < gnuais_batch::HB; ++q) alloc((void **) &b->hist[q], sizeof(int16_t) * N * b->NT);
-    b->n_seg = (b->sgn_words + SEG_WORDS - 1) / SEG_WORDS;
     b->seg_words = (int) (((uint64_t) SEG_WORDS * 32 * step / 65536 + 2 + 31) / 32) + 1;
     if (b->seg_words > 16) {       // K2b keeps one segment pack (<= 16 words) in registers
         gnuais_batch_destroy(b);
         return fail(GNUAIS_E_ARG, "create: pllinc too large (more than one slice per ~4.6 samples)");
     }
     // the hand-off sets in use (`nbuf`; more are allocated when set_option raises it: a C5 set is 0.4 GB of sign words)
-    if (const char *v = getenv("GNUAIS_NBUF")) b->nbuf = std::min((int) gnuais_batch::NBUF, std::max(2, atoi(v)));
     if (e == hipSuccess) e = alloc_sets(b, b->nbuf);
     alloc((void **) &b->pll, sizeof(uint32_t) * N);
     alloc((void **) &b->lastbit, sizeof(uint32_t) * N);
@@ -508,7 +524,6 @@ int gnuais_batch_create(gnuais_batch **out, int device, int n_channels, const fl
     // 30 bits (16 alternating bits to leave ST_SKURR, protodec.c:1030-1043, six ones each for the
     // opening and the closing flag, a bit in ST_STOPSIGN), so this many slots hold whatever a call
     // can produce, adversarial bit streams included (real traffic: <= 38 frames per second)
-    b->cand_K = std::max(64, b->bits_words * 32 / 30 + 2);
     alloc((void **) &b->cand, sizeof(uint32_t) * N * (size_t) b->cand_K * CAND_WORDS);
     alloc((void **) &b->frame_count, sizeof(uint32_t) * 4);
     alloc((void **) &b->counters, sizeof(int32_t) * N * 3);

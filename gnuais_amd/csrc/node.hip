@@ -168,6 +168,7 @@ struct gnuais_node {
     int N = 0, max_len = 0;
     std::vector<Shard *> shards;
     std::vector<gnuais_frame> scratch;
+    std::string warnings;           // what create could not do without failing (one line per shard)
 };
 
 extern "C" {
@@ -252,9 +253,22 @@ int gnuais_node_create(gnuais_node **out, const int *devices, int n_devices, int
         gnuais_node_destroy(nd);
         return node_fail(rc, keep);
     }
+    // not fatal, but worth knowing before a scaling curve is read: a shard whose host thread stayed where the OS put it
+    // (no NUMA node in sysfs, no CPU of that node in this process's affinity mask, GNUAIS_NODE_PIN=0)
+    for (size_t g = 0; g < nd->shards.size(); ++g) {
+        const Shard *s = nd->shards[g];
+        if (s->pinned_cpus == 0 && nd->shards.size() > 1) {
+            char line[200];
+            snprintf(line, sizeof line, "shard %zu (device %d, pci %s): host thread not pinned (numa_node %d)\n", g, s->device,
+                     s->pci[0] ? s->pci : "?", s->numa_node);
+            nd->warnings += line;
+        }
+    }
     *out = nd;
     return GNUAIS_OK;
 }
+
+const char *gnuais_node_warnings(const gnuais_node *nd) { return nd ? nd->warnings.c_str() : ""; }
 
 int gnuais_node_n_devices(const gnuais_node *nd) { return nd ? (int) nd->shards.size() : 0; }
 int gnuais_node_n_channels(const gnuais_node *nd) { return nd ? nd->N : 0; }

@@ -106,6 +106,7 @@ SYMBOLS = {
     "gnuais_node_set_option": (_I, [_P, C.c_char_p, _I]),
     "gnuais_node_autotune": (_I, [_P, _P, _I, _P, C.POINTER(C.c_float)]),
     "gnuais_node_last_error": (C.c_char_p, []),
+    "gnuais_node_warnings": (C.c_char_p, [_P]),
     "gnuais_node_mark": (_I, [_P]),
     "gnuais_node_shard_stats": (_I, [_P, _I, _P]),
     "gnuais_last_error": (C.c_char_p, []),

@@ -124,6 +124,10 @@ class ReceiverNode:
         """start a per-shard measurement (gnuais_node_mark)"""
         self._raise(self._lib.gnuais_node_mark(self._h))
 
+    def warnings(self):
+        """what gnuais_node_create() could not do without failing (unpinned host threads), one text per shard"""
+        return [l for l in self._lib.gnuais_node_warnings(self._h).decode().splitlines() if l]
+
     def shard_stats(self):
         """after sync(): per shard, where its host thread runs and how long it was busy since mark()"""
         C = self._C

@@ -415,6 +415,10 @@ int  gnuais_node_set_option(gnuais_node *nd, const char *name, int value);      
 int  gnuais_node_autotune(gnuais_node *nd, const int16_t *const *d_samples, int len, void *const *streams,
 			  float *best_ms_max);
 const char *gnuais_node_last_error(void);   /* of the calling thread: which device failed and why */
+/* what gnuais_node_create() could not do without failing, one line per shard ("" when nothing): a shard's host thread that
+ * could not be pinned to its device's NUMA node.  gnuais_node_create itself fails -- with the device and both figures in
+ * gnuais_node_last_error() -- for a device index that is not visible and for a shard that does not fit its device's free memory. */
+const char *gnuais_node_warnings(const gnuais_node *nd);
 /* Where a shard runs and how it fared, for whoever times a node (a slow device must show by itself): every shard's
  * host thread is pinned, when it starts, to the CPUs of the NUMA node its device hangs off (the device's PCI address
  * -> /sys/bus/pci/devices/<addr>/numa_node -> /sys/devices/system/node/node<n>/cpulist, intersected with what the

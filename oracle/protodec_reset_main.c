@@ -68,6 +68,8 @@ int main(int argc, char **argv)
 		skip_type[i] = 0;                       /* print every message type */
 	d = malloc(sizeof *d);
 	protodec_initialize(d, NULL, NULL, 'A');        /* protodec.c:54-76 */
+	memset(d->buffer, 0, DEMOD_BUFFER_LEN);         /* hmalloc'ed and never cleared before the first frame (protodec.c:70):
+	                                                 * the two programs must start from the same cells */
 	protodec_reset(d);                              /* before the first bit: nothing to reach yet */
 	for (i = 0; i < n; i++) {
 		if (r < n_resets && resets[r] == i) {

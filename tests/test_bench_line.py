@@ -67,3 +67,41 @@ def test_a_node_line_without_pmc_fits():
     out.pop("other_configs", None)
     c = _check(bench.compact_line(out))
     assert c["roofline"]["traffic"] is None and c["n_gpus"] == 8
+
+
+def test_a_run_that_cannot_start_ends_in_one_line_quickly():
+    """bench.py's preflight (device count, free memory per shard): on a host without a HIP device -- and for a device index
+    that does not exist -- the run ends within seconds in ONE parseable line whose `error` says why, status 3, no hang."""
+    import subprocess
+    import time
+    import torch
+    cmds = [["--gpus", "8", "--steps", "1", "--warmup", "1"]]
+    if torch.cuda.is_available():
+        cmds = [["--gpus", "2", "--devices", "0,%d" % (torch.cuda.device_count() + 3), "--steps", "1", "--warmup", "1"]]
+    for extra in cmds:
+        t = time.perf_counter()
+        p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + extra, capture_output=True, timeout=120)
+        took = time.perf_counter() - t
+        assert p.returncode == 3, p.stderr.decode()[-500:]
+        line = p.stdout.decode().strip().splitlines()[-1]
+        c = json.loads(line)
+        assert c["value"] is None and c["n_gpus"] == int(extra[1]) and c["error"]
+        assert ("visible" in c["error"]) or ("device" in c["error"])
+        assert took < 60, took
+
+
+def test_preflight_names_the_device_and_both_figures(monkeypatch):
+    """bench.preflight() over a stand-in for torch.cuda: a missing index, a device without room, a healthy node."""
+    import types
+    import torch
+    fake = types.SimpleNamespace(is_available=lambda: True, device_count=lambda: 4,
+                                 mem_get_info=lambda d: ((2 << 30) if d == 2 else (200 << 30), 288 << 30))
+    monkeypatch.setattr(torch, "cuda", fake)
+    cfg = bench.CONFIGS["C3"]
+    assert bench.preflight([0, 1, 3], cfg) is None
+    e = bench.preflight(list(range(8)), cfg)
+    assert "[4, 5, 6, 7]" in e and "4 device(s) visible" in e
+    e = bench.preflight([0, 2], cfg)
+    assert e.startswith("device 2:") and "GB free" in e and "16384 channels" in e
+    e = bench.preflight([1] * 200, cfg)                 # 200 shards on one device do not fit 200 GB
+    assert e.startswith("device 1: 200 shard(s)")
