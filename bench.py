@@ -195,7 +195,7 @@ def measure(cfg, args, local, rank, sync, steps, warmup, isolated=True, post=Fal
     uncal = None
     if uncalibrated:
         # what a plain gnuais_batch_run() caller gets: the same region with the library's default stage -> stream assignment
-        for _ in range(max(warmup, 4)):
+        for _ in range(max(warmup, 200)):       # as warm as the calibration's ~1400 calls leave the chip for the headline region
             step()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
@@ -809,8 +809,8 @@ def rank_main(rank, local, world, args, sync):
         "steady_state": m.get("steady_state"),
         "stage_masks": m.get("stage_masks"),
         "uncalibrated_ms_per_step": m.get("uncalibrated_ms_per_step"),
-        "uncalibrated_what": "the same K steps BEFORE gnuais_batch_autotune(): the library's default stage -> stream "
-                             "assignment, what a plain gnuais_batch_run() caller gets",
+        "uncalibrated_what": "the same K steps BEFORE gnuais_batch_autotune() (after 200 warm-up calls): the library's default "
+                             "stage -> stream assignment, what a plain gnuais_batch_run() caller gets",
         "note": "the receive path slices the sign of the filter output and never stores the pre-slicer "
                 "floats; gnuais_batch_filter() produces them (bit-exact, tests/test_hip_parity.py)",
     }

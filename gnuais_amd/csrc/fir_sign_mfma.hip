@@ -1,36 +1,40 @@
 // fir_sign_mfma.hip -- K1s for LONG tables on the matrix pipe (gfx950): the sign-exact slicer standing in for
 // filter_run_buf() + the `out > 0` test of receiver_run() (gnuais src/filter.c:106-143, src/receiver.c:109-111,126), 48
-// central taps, as an EXACT INTEGER Toeplitz product on v_mfma_i32_32x32x16_i8.
+// central taps, as an EXACT INTEGER Toeplitz product on v_mfma_i32_32x32x32_i8 (gfx950's double-K int8 product: 32 window
+// rows per instruction at the cost of the 16 rows of CDNA3's 32x32x16 form, which rounds 5 used).
 //
 // Same contract as fir_sign_pk.hip (bit-identical sign words, peak, history carry); what changes is how y_c, the sum over
 // the 48 central taps, is formed -- and what it costs: the packed kernel issues 20-24 v_pk_fma_f32 per sample and is
-// VALU-bound (3.4 ms per C5 call); here a step of 32 outputs x 64 channels is 60 matrix instructions and ~16 vector
-// instructions per output and channel (2.9 ms; what binds it is in the step loop's comment).
+// VALU-bound (3.4 ms per C5 call); here a step of 32 outputs x 64 channels is 36 matrix instructions and ~16 vector
+// instructions per output and channel (what binds it is in the step loop's comment).
 //
 //   y_c[n] = sum_q tc[q] * x[n - dc + q],  q < 48.   Taps as 24-bit integers tq = round(tc * S) (S a power of two, sum |tq| <
 //   2^23), three signed int8 digits t2 t1 t0; samples as two int8 digits, x = 256 hs + l' + 128 (hs = x >> 8, l' = (x & 255)
 //   - 128).  With Y = sum tq x (exact, |Y| < 2^38):
 //       y' = A3 2^16 + A2 2^8 + A1 + (A0 >> 8) = floor(Y / 256),
 //       A3 = sum t2 hs,  A2 = sum t2 l' + t1 hs,  A1 = sum t1 l' + t0 hs,  A0 = sum t0 l' + 128 sum tq
-//   -- six matrix products per block of 16 window rows, int32 accumulators (A3 and A0 first; A3 2^8 and A0 >> 8 are what A2
+//   -- six matrix products per block of 32 window rows, int32 accumulators (A3 and A0 first; A3 2^8 and A0 >> 8 are what A2
 //   and A1 accumulate on), no rounding anywhere: the only error against
 //   the real central sum is the taps' quantisation (|tq / S - tc| <= 0.5 / S each), which the host adds to the
 //   certification bound, and the floor (< 1 unit of 256 / S).
-//   A step of 32 outputs reads window rows n0 - dc .. n0 - dc + 79: five blocks of 16, the first three are the previous
-//   step's last three.  A[i][k] = tq[16 b + k - i] (Toeplitz, constant: 30 VGPRs), B[k][n] = a sample digit of row k, channel n.
-//   A wave owns 64 channels as 32 PAIRS (lanes n and n + 32 hold the pair 2n, 2n+1 -- one dword per row -- for rows r0 + 8 hh
-//   + j, hh = lane / 32) and T outputs.
+//   A step of 32 outputs reads window rows n0 - dc .. n0 - dc + 79: three blocks of 32 (the last 16 rows meet zero taps),
+//   the first two are the previous step's last two.  A[i][k] = tq[32 b + k - i] (Toeplitz, constant), B[k][n] = a sample
+//   digit of row k, channel n.  Which of a lane's 16 operand bytes is which k does not matter as long as A and B agree
+//   (the product sums over k): byte j of half hh = lane / 32 is k = 16 hh + j in both.
+//   A wave owns 64 channels as 32 PAIRS (lanes n and n + 32 hold the pair 2n, 2n+1 -- one dword per row -- for rows r0 + 16 hh
+//   + j) and T outputs.
 //
 // The certification threshold follows a running maximum M of |x| over EVERY row a reference window of the step touches
 // (behind AND ahead: the rows of the next step are loaded and converted one step early), so nothing is priced at full
 // scale; a channel whose M is 0 has y = +0 exactly (bit 0, nothing to settle).  Outputs with |y'| below the threshold are
 // noted per lane and settled with the reference's ordered sum (filter.h:40-49) lane-parallel, as in fir_sign_pk.hip.
 //
-// Only segments whose windows lie inside the call's input run here (t0 >= T); the call's first segment, with its
-// history rows, is the packed kernel's (launch_fir_sign_pk with max_segments = 1).
+// Only outputs whose windows lie inside the call's input run here (t0 >= first >= d, dc + 64); the call's head, with its
+// history rows, is the packed kernel's (launch_fir_sign_pk with T = first, max_segments = 1), on a stream beside this launch.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <math.h>
+#include <type_traits>
 #include "kernels.h"
 
 namespace gnuais {
@@ -42,18 +46,18 @@ typedef int mf_v4i __attribute__((ext_vector_type(4)));
 extern "C" __device__ int mf_ld_b32(mf_v4i, int, int, int) __asm("llvm.amdgcn.raw.buffer.load.i32");
 extern "C" __device__ float mf_load_format_f32(mf_v4i rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.load.format.f32");
 
-constexpr int MF_NC = 48, MF_NB = 5, MF_PEND = 8, MF_EXACT_BATCH = 8;
+constexpr int MF_NC = 48, MF_NB = 3, MF_BR = 16, MF_PEND = 8, MF_EXACT_BATCH = 8;   // MF_BR: rows of a block a lane holds
 
-struct Blk {                 // one block of 16 window rows, this lane's 8 rows x 2 channels
-    long l[2], h[2];         // [set]: the eight l' / hs digits of the even / odd channel of the pair
+struct Blk {                 // one block of 32 window rows, this lane's 16 rows x 2 channels
+    mf_v4i l[2], h[2];       // [set]: the sixteen l' / hs digits of the even / odd channel of the pair
 };
 
-// d[j] = row j: bytes (l' even, hs even, l' odd, hs odd)  ->  per digit the eight rows' bytes
-__device__ __forceinline__ void mf_transpose8(const uint32_t *d, Blk &o)
+// d[j] = row j: bytes (l' even, hs even, l' odd, hs odd)  ->  per digit the sixteen rows' bytes
+__device__ __forceinline__ void mf_transpose16(const uint32_t *d, Blk &o)
 {
-    uint32_t e[2][4];
+    uint32_t e[4][4];
 #pragma unroll
-    for (int g = 0; g < 2; ++g) {
+    for (int g = 0; g < 4; ++g) {
         const uint32_t d0 = d[4 * g], d1 = d[4 * g + 1], d2 = d[4 * g + 2], d3 = d[4 * g + 3];
         // v_perm_b32(a, b, sel): selector bytes 0-3 pick from b, 4-7 from a
         const uint32_t t0 = __builtin_amdgcn_perm(d1, d0, 0x05010400u);   // d0.b0 d1.b0 d0.b1 d1.b1
@@ -65,10 +69,13 @@ __device__ __forceinline__ void mf_transpose8(const uint32_t *d, Blk &o)
         e[g][2] = __builtin_amdgcn_perm(t3, t1, 0x05040100u);             // b2
         e[g][3] = __builtin_amdgcn_perm(t3, t1, 0x07060302u);             // b3
     }
-    o.l[0] = (long) (((unsigned long) e[1][0] << 32) | e[0][0]);
-    o.h[0] = (long) (((unsigned long) e[1][1] << 32) | e[0][1]);
-    o.l[1] = (long) (((unsigned long) e[1][2] << 32) | e[0][2]);
-    o.h[1] = (long) (((unsigned long) e[1][3] << 32) | e[0][3]);
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        o.l[0][g] = (int) e[g][0];
+        o.h[0][g] = (int) e[g][1];
+        o.l[1][g] = (int) e[g][2];
+        o.h[1][g] = (int) e[g][3];
+    }
 }
 
 __device__ __forceinline__ uint32_t mf_spread16(uint32_t p)     // nibbles n3 n2 n1 n0 -> 0 n3 0 n2 0 n1 0 n0
@@ -88,17 +95,30 @@ __device__ __forceinline__ uint32_t mf_pk_min(uint32_t a, uint32_t b)
     return __builtin_bit_cast(uint32_t, __builtin_elementwise_min(__builtin_bit_cast(mf_v2s, a), __builtin_bit_cast(mf_v2s, b)));
 }
 
+typedef unsigned short mf_v2u __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t mf_pk_max_u(uint32_t a, uint32_t b)
+{
+    return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(mf_v2u, a), __builtin_bit_cast(mf_v2u, b)));
+}
+// v_permlane32_swap_b32 (gfx950): the upper half of a changes places with the lower half of b -- afterwards a = (a.lo, b.lo),
+// b = (a.hi, b.hi) (lower lanes | upper lanes).  A half-wave exchange in the VALU: no LDS trip, no lgkmcnt wait.
+__device__ __forceinline__ void mf_swap32(uint32_t &a, uint32_t &b)
+{
+    const auto r = __builtin_amdgcn_permlane32_swap(a, b, false, false);
+    a = r[0];
+    b = r[1];
+}
+
 } // namespace
 
-// One wave per (64 channels, segment of T outputs).  PF: steps the loads run ahead of the step that converts them.
-template <int PF>
+// One wave per (64 channels, segment of T outputs).
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void fir_sign_mfma_kernel(
     const int16_t *__restrict__ x, uint32_t *__restrict__ sgn, int *__restrict__ maxval, int16_t *__restrict__ hist_out,
     int *__restrict__ maxval_next, const float *__restrict__ te_mem, const MfmaTaps *__restrict__ cs, int N, int L, int T, int d,
-    int NTaps, int NE, int seg0, float eps_seen_u, float eps_abs_u)
+    int NTaps, int NE, int first, float eps_seen_u, float eps_abs_u)
 {
     const int lane = (int) threadIdx.x, n = lane & 31, hh = lane >> 5;
-    const int t0 = ((int) blockIdx.y + seg0) * T;
+    const int t0 = first + (int) blockIdx.y * T;       // the call's first `first` outputs (windows into the history) are the packed kernel's
     if (t0 >= L) return;
     const int g = (int) blockIdx.x;
     const int t1 = (t0 + T < L) ? t0 + T : L;
@@ -107,15 +127,18 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     const uint32_t rowb = (uint32_t) N * 2u;
 
     // the Toeplitz operands wait in LDS (in registers they are 30 of a wave's 256; the compiler keeps what fits)
-    __shared__ long As[MF_NB * 3][64];
+    mf_v4i Ar[MF_NB * 3];
 #pragma unroll
-    for (int q = 0; q < MF_NB * 3; ++q) As[q][lane] = cs->a[q / 3][q % 3][lane];
-#define MF_A(b, dgt) As[(b) * 3 + (dgt)][lane]
+    for (int q = 0; q < MF_NB * 3; ++q) {
+        Ar[q] = *reinterpret_cast<const mf_v4i *>(cs->a[q / 3][q % 3][lane]);
+        asm volatile("" : "+v"(Ar[q]));                 // 36 registers that stay what they are (left to itself the compiler parks some in LDS and waits for them before every product)
+    }
+#define MF_A(b, dgt) Ar[(b) * 3 + (dgt)]
     const int K0 = cs->k0;                             // 128 * sum tq
 
     // the window rows through a descriptor based at the segment's first row (the whole input may exceed 4 GB); rows past
     // the call read as zero
-    const int row0 = t0 - dc - 48;                     // first row of pair k0 - 3 (>= 0: t0 >= T >= dc + 48, launcher)
+    const int row0 = t0 - dc - 64;                     // first row of block 0 (>= 0: t0 >= first >= dc + 64, launcher)
     mf_v4i rs;
     {
         const unsigned long long p = (unsigned long long) (x + (size_t) row0 * (size_t) N);
@@ -125,44 +148,38 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
         rs[2] = (int) (span > 0xffffffffull ? 0xffffffffu : (uint32_t) span);
         rs[3] = 0x00020000;
     }
-    const int voff = (g * 64 + 2 * n) * 2 + hh * 8 * (int) rowb;
-    auto load_block = [&](int r0, uint32_t *dd) __attribute__((always_inline)) {      // rows r0 + 8 hh + j (relative to row0)
+    const int voff = (g * 64 + 2 * n) * 2 + hh * MF_BR * (int) rowb;
+    auto load_block = [&](int r0, uint32_t *dd) __attribute__((always_inline)) {      // rows r0 + 16 hh + j (relative to row0)
 #pragma unroll
-        for (int j = 0; j < 8; ++j) dd[j] = (uint32_t) mf_ld_b32(rs, voff, (int) ((uint32_t) (r0 + j) * rowb), 0);
+        for (int j = 0; j < MF_BR; ++j) dd[j] = (uint32_t) mf_ld_b32(rs, voff, (int) ((uint32_t) (r0 + j) * rowb), 0);
     };
     // a block's digits and the packed maxima / minima of its 16 rows (both halves of the wave), even channel in the low half
     uint32_t peak_pk = 0;                              // packed running maximum of the samples seen (filter.c:118-119)
-    auto maxima = [&](const uint32_t *d0, const uint32_t *d1, uint32_t &pmx, uint32_t &pmn) __attribute__((always_inline)) {   // of a pair of blocks
+    // the packed largest |x| (unsigned 16 bit: 32768 fits) of a block's 32 rows, even channel in the low half; the
+    // positive peak is kept per lane (its two halves meet after the loop)
+    auto maxima = [&](const uint32_t *d0, uint32_t &am) __attribute__((always_inline)) {
         uint32_t mx = d0[0], mn = d0[0];
 #pragma unroll
-        for (int j = 1; j < 8; ++j) {
+        for (int j = 1; j < MF_BR; ++j) {
             mx = mf_pk_max(mx, d0[j]);
             mn = mf_pk_min(mn, d0[j]);
         }
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            mx = mf_pk_max(mx, d1[j]);
-            mn = mf_pk_min(mn, d1[j]);
-        }
-        mx = mf_pk_max(mx, (uint32_t) __shfl_xor((int) mx, 32));
-        mn = mf_pk_min(mn, (uint32_t) __shfl_xor((int) mn, 32));
         peak_pk = mf_pk_max(peak_pk, mx);
-        pmx = mx;
-        pmn = mn;
+        // max(mx, 0) and -min(mn, 0) as unsigned halves (-(-32768) wraps to 0x8000 = 32768: right as an unsigned value)
+        const uint32_t up = mf_pk_max(mx, 0u);
+        const uint32_t dn = __builtin_bit_cast(uint32_t, (mf_v2s) (__builtin_bit_cast(mf_v2s, 0u) - __builtin_bit_cast(mf_v2s, mf_pk_min(mn, 0u))));
+        uint32_t a = mf_pk_max_u(up, dn), b = a;
+        mf_swap32(a, b);                                // a = (own.lo, own.lo), b = (own.hi, own.hi): every lane sees both halves
+        am = mf_pk_max_u(a, b);
     };
     auto digits = [&](const uint32_t *dd, Blk &o) __attribute__((always_inline)) {
-        uint32_t f[8];
+        mf_transpose16(dd, o);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) f[j] = dd[j] ^ 0x00800080u;       // low byte -> l' (offset binary -> two's complement)
-        mf_transpose8(f, o);
+        for (int g4 = 0; g4 < 4; ++g4) {                // low byte -> l' (offset binary -> two's complement), on the transposed words
+            o.l[0][g4] ^= (int) 0x80808080u;
+            o.l[1][g4] ^= (int) 0x80808080u;
+        }
     };
-    // largest |x| of the even (s = 0) / odd channel in a packed (max, min) pair
-    auto absmax = [&](uint32_t pmx, uint32_t pmn, int s) __attribute__((always_inline)) -> int {
-        const int mx = s ? ((int) pmx >> 16) : (int) (short) (pmx & 0xffffu);
-        const int mn = s ? ((int) pmn >> 16) : (int) (short) (pmn & 0xffffu);
-        return mx > -mn ? mx : -mn;
-    };
-
     // exact re-evaluation of one output of ANY channel of the group (filter.h:40-49 order), window through a typed
     // descriptor (16-bit SSCALED) based at the segment's first reference row
     const int e_row = t0 - d;                          // >= 0 (launcher)
@@ -192,32 +209,23 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
         return sum > 0.0f;
     };
 
-    // ---- prologue: pairs k0 - 3 .. k0 + 1 (rows row0 .. row0 + 159); B[0..4] = the first step's blocks, B[5..6] the next step's.
-    // Pair k = the two blocks that step k is the first to use (as its B[3], B[4]).  A step's reference windows reach from the
-    // first row of pair k - 3 (J0 <= 48 rows before its first central row) to less than 65 rows past its last central row:
-    // the last row of pair k + 2.
-    Blk B[7];
-    uint32_t pmx[6], pmn[6];                           // packed maxima / minima of pairs k - 3 .. k + 2 ([5] = the newest)
+    // ---- prologue.  Block m = rows row0 + 32 m .. + 31.  Step k (outputs t0 + 32 k ..) multiplies blocks k + 2 .. k + 4 (its
+    // central rows start at block k + 2); its reference windows reach from J0 <= 48 rows before that -- inside block k -- to
+    // less than 127 rows past the first central row: inside block k + 5.  So: B[0..2] = blocks 2..4, the maxima of blocks
+    // 0..4, and block 5 on its way (block k + 5 gives its maximum to step k and its digits to step k + 1).
+    Blk B[MF_NB + 1];                                  // a ring: step k's blocks are B[k % 4], B[(k + 1) % 4], B[(k + 2) % 4]; the fourth slot takes block k + 5's digits
+    uint32_t pam[6];                                   // packed largest |x| of blocks k .. k + 5 ([5] = the newest)
     {
-        uint32_t r0[8], r1[8];
+        uint32_t r0[MF_BR];
 #pragma unroll
         for (int p = 0; p < 5; ++p) {
             load_block(32 * p, r0);
-            load_block(32 * p + 16, r1);
-            maxima(r0, r1, pmx[p], pmn[p]);
-            // pair k0 - 3 + p: blocks are B operands from pair k0 - 2's second block on
-            if (p == 1) { digits(r1, B[0]); }
-            else if (p == 2) { digits(r0, B[1]); digits(r1, B[2]); }
-            else if (p == 3) { digits(r0, B[3]); digits(r1, B[4]); }
-            else if (p == 4) { digits(r0, B[5]); digits(r1, B[6]); }
+            maxima(r0, pam[p]);
+            if (p >= 2) digits(r0, B[p - 2]);
         }
     }
-    uint32_t raw[PF][2][8];
-#pragma unroll
-    for (int p = 0; p < PF; ++p) {                     // pairs k0 + 2 .. : rows row0 + 160 + 32 p
-        load_block(160 + 32 * p, raw[p][0]);
-        load_block(160 + 32 * p + 16, raw[p][1]);
-    }
+    uint32_t raw[MF_BR];                               // block 5, on its way (two blocks in flight: 16 more registers, measured slower)
+    load_block(160, raw);
 
     uint32_t wq[4] = {0u, 0u, 0u, 0u};
     __shared__ uint16_t pend[MF_PEND * 64];
@@ -282,103 +290,114 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     // per SIMD with the products software-pipelined beside the previous set's flags (sched_group_barrier) took 3.65 ms
     // (accumulators in AccVGPRs: a copy per element read), eight-wave workgroups whose SIMD partners alternate products
     // and flags between s_barriers 3.6 ms.
-    // y' = ((A3 2^8 + A2) 2^8) + (A1 + (A0 >> 8)): the outer accumulators first (ten products, alternating), their shifted values
-    // are what the inner accumulators start from (twenty products, alternating) -- two accumulators per output instead of four,
+    // y' = ((A3 2^8 + A2) 2^8) + (A1 + (A0 >> 8)): the outer accumulators first (six products, alternating), their shifted values
+    // are what the inner accumulators start from (twelve products, alternating) -- two accumulators per output instead of four,
     // three vector instructions per output to form y' instead of four; no product straight behind one on the same accumulator
-    auto products = [&](int s, mf_v16i &c2, mf_v16i &c1) __attribute__((always_inline)) {
-        mf_v16i a3 = {0}, a0;
+    mf_v16i ksplat;
 #pragma unroll
-        for (int v = 0; v < 16; ++v) a0[v] = K0;
+    for (int v = 0; v < 16; ++v) ksplat[v] = K0;
+    asm volatile("" : "+v"(ksplat));                    // sixteen registers that stay what they are: the compiler must not rebuild them per step
+    auto products = [&](auto RC, int s, mf_v16i &c2, mf_v16i &c1) __attribute__((always_inline)) {
+        constexpr int R = decltype(RC)::value;
+        mf_v16i a3 = {0}, a0 = ksplat;                  // (the first product reads ksplat as its C operand: no copy)
 #pragma unroll
         for (int b = 0; b < MF_NB; ++b) {
-            a3 = __builtin_amdgcn_mfma_i32_32x32x16_i8(MF_A(b, 2), B[b].h[s], a3, 0, 0, 0);
-            a0 = __builtin_amdgcn_mfma_i32_32x32x16_i8(MF_A(b, 0), B[b].l[s], a0, 0, 0, 0);
+            a3 = __builtin_amdgcn_mfma_i32_32x32x32_i8(MF_A(b, 2), B[(R + b) & 3].h[s], a3, 0, 0, 0);
+            a0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(MF_A(b, 0), B[(R + b) & 3].l[s], a0, 0, 0, 0);
         }
 #pragma unroll
         for (int v = 0; v < 16; ++v) {
-            c2[v] = (int) ((uint32_t) a3[v] << 8);
+            c2[v] = (int) (((uint32_t) a3[v] << 8) + 0x00800000u);     // + 2^23: y' below comes out as y + 2^31, bit 31 = (y >= 0)
             c1[v] = a0[v] >> 8;
         }
 #pragma unroll
         for (int b = 0; b < MF_NB; ++b) {
-            c2 = __builtin_amdgcn_mfma_i32_32x32x16_i8(MF_A(b, 2), B[b].l[s], c2, 0, 0, 0);
-            c1 = __builtin_amdgcn_mfma_i32_32x32x16_i8(MF_A(b, 1), B[b].l[s], c1, 0, 0, 0);
-            c2 = __builtin_amdgcn_mfma_i32_32x32x16_i8(MF_A(b, 1), B[b].h[s], c2, 0, 0, 0);
-            c1 = __builtin_amdgcn_mfma_i32_32x32x16_i8(MF_A(b, 0), B[b].h[s], c1, 0, 0, 0);
+            c2 = __builtin_amdgcn_mfma_i32_32x32x32_i8(MF_A(b, 2), B[(R + b) & 3].l[s], c2, 0, 0, 0);
+            c1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(MF_A(b, 1), B[(R + b) & 3].l[s], c1, 0, 0, 0);
+            c2 = __builtin_amdgcn_mfma_i32_32x32x32_i8(MF_A(b, 1), B[(R + b) & 3].h[s], c2, 0, 0, 0);
+            c1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(MF_A(b, 0), B[(R + b) & 3].h[s], c1, 0, 0, 0);
         }
     };
-    // sixteen outputs' sign and threshold bits, spread to their places in the 32-output word, + the partner lane's half
+    // sixteen outputs' sign and threshold bits, spread to their places in the 32-output word, + the partner lane's half.
+    // All in integers: yb = y + 2^31 (the bias rides in c2), so bit 31 IS "y >= 0", and |y| < E  <=>  (yb - (2^31 - E)) <u 2 E.
+    // E = ceil(eps): for an integer |y|, |y| < eps <=> |y| < ceil(eps) -- the float form's set exactly.  Open outputs are rare
+    // (1e-4), so the sixteen compares only feed ONE wave-wide "any" (v_cmp + s_or); the per-lane word of them is built when
+    // there is one.  Per output: v_lshl_add, v_alignbit, v_sub, v_cmp (the float form: five, four of them VOP3).
     auto flags = [&](const mf_v16i &c2, const mf_v16i &c1, float eps, uint32_t &word, uint32_t &ambw)
         __attribute__((always_inline)) {
-        uint32_t neg = 0, amb = 0;
+        const uint32_t negE = (uint32_t) -(int) __builtin_ceilf(eps);
+        const uint32_t mid = 0x80000000u;
+        uint32_t pos = 0, amb = 0;
 #pragma unroll
         for (int v = 0; v < 16; ++v) {
-            const int y = (int) ((uint32_t) c2[v] << 8) + c1[v];                                           // floor(Y / 256)
-            const float yf = (float) y;
-            neg = __builtin_amdgcn_alignbit(neg, (uint32_t) y, 31);
-            amb = __builtin_amdgcn_alignbit(amb, __float_as_uint(__builtin_fabsf(yf) - eps), 31);
+            const uint32_t yb = ((uint32_t) c2[v] << 8) + (uint32_t) c1[v];                                // floor(Y / 256) + 2^31
+            uint32_t t;
+            asm("v_sad_u32 %0, %1, %2, %3" : "=v"(t) : "v"(yb), "s"(mid), "v"(negE));                     // |y| - E
+            pos = __builtin_amdgcn_alignbit(pos, yb, 31);
+            amb = __builtin_amdgcn_alignbit(amb, t, 31);
         }
-        // this lane: outputs (v % 4) + 8 (v / 4) + 4 hh, v = 0 first = bit 15
-        const uint32_t sn = mf_spread16(~neg), sa = mf_spread16(amb);
-        const uint32_t pn = (uint32_t) __shfl_xor((int) sn, 32), pa = (uint32_t) __shfl_xor((int) sa, 32);
-        word = hh == 0 ? (sn << 4) | pn : (pn << 4) | sn;
-        ambw = hh == 0 ? (sa << 4) | pa : (pa << 4) | sa;
+        // this lane: outputs (v % 4) + 8 (v / 4) + 4 hh, v = 0 first = bit 15; the partner lane's half joins in the step
+        word = mf_spread16(pos);
+        ambw = mf_spread16(amb);
     };
 
-    for (int n0 = t0; n0 < t1; n0 += 32 * PF) {
+    // One step.  R = step number mod 4 picks the ring slots at compile time (the loop below is unrolled four steps deep: no
+    // block is ever moved).  Block k + 5 -- asked for a step ago -- gives its maximum and its digits right behind the first
+    // set's products and its registers take the NEXT step's rows at once: those loads have the rest of the step to land.
+    // The finished word of step k leaves in step k + 1, BEFORE that step's loads are issued: the memory counter is in order, so
+    // a store issued behind the loads would be waited for with them at the next step's top (and the compiler, conservative
+    // behind flush()'s branches, waits for everything outstanding).
+    uint32_t held_w = 0, held_am = 0;
+    auto step = [&](auto RC, const int orel) __attribute__((always_inline)) {     // outputs t0 + orel .. + 31
+        constexpr int R = decltype(RC)::value;
+        mf_v16i c2, c1;
+        uint32_t word0 = 0, amb0 = 0, word1 = 0, amb1 = 0;
+        int M0 = 0, M1 = 0;
+        products(RC, 0, c2, c1);
+        {
+            maxima(raw, pam[5]);
+            digits(raw, B[(R + 3) & 3]);
+            __builtin_amdgcn_sched_barrier(0);          // the block's registers are free from here: nothing of it sinks below
+            if (orel > 0) flush(orel - 32, held_w, held_am);
+            // (no condition around the loads: rows past the end read as zero through the descriptor)
+            load_block(orel + 160 + 32, raw);
+            __builtin_amdgcn_sched_barrier(0);
+            // the running maximum over blocks k .. k + 5: every row a reference window of this step's outputs touches
+            uint32_t am = pam[0];
 #pragma unroll
-        for (int j = 0; j < PF; ++j) {
-            const int p = j;
-            if (n0 + 32 * j < t1) {
-                mf_v16i c2, c1;
-                uint32_t word0 = 0, amb0 = 0, word1 = 0, amb1 = 0;
-                int M0 = 0, M1 = 0;
-                products(0, c2, c1);
-                {
-                    maxima(raw[p][0], raw[p][1], pmx[5], pmn[5]);     // pair k + 2: asked for PF steps ago
-                    // the running maximum over pairs k - 3 .. k + 2: every row a reference window of this step's outputs touches
-                    uint32_t mx = pmx[0], mn = pmn[0];
-#pragma unroll
-                    for (int q = 1; q < 6; ++q) {
-                        mx = mf_pk_max(mx, pmx[q]);
-                        mn = mf_pk_min(mn, pmn[q]);
-                    }
-                    M0 = absmax(mx, mn, 0);
-                    M1 = absmax(mx, mn, 1);
-                    flags(c2, c1, __builtin_fmaf(eps_seen_u, (float) M0, eps_abs_u), word0, amb0);
-                }
-                products(1, c2, c1);
-                {
-                    flags(c2, c1, __builtin_fmaf(eps_seen_u, (float) M1, eps_abs_u), word1, amb1);
-                    // lane hh = 0 keeps the even channel's word, hh = 1 the odd one's; a channel without a nonzero sample in
-                    // reach has y = +0 exactly: not positive (receiver.c:111), nothing to settle
-                    uint32_t w = hh == 0 ? word0 : word1, am = hh == 0 ? amb0 : amb1;
-                    if ((hh == 0 ? M0 : M1) == 0) {
-                        w = 0;
-                        am = 0;
-                    }
-                    flush(n0 + 32 * j - t0, w, am);
-#pragma unroll
-                    for (int q = 0; q < 5; ++q) {
-                        pmx[q] = pmx[q + 1];
-                        pmn[q] = pmn[q + 1];
-                    }
-                    // shift: the next step's blocks (a ring of eight blocks walked by a four-step loop turn saves these moves and
-                    // costs the registers they save: 3.06 against 2.87-3.03 ms); pair k + 2's digits
-#pragma unroll
-                    for (int b = 0; b < 5; ++b) B[b] = B[b + 2];
-                    digits(raw[p][0], B[5]);
-                    digits(raw[p][1], B[6]);
-                    // (no condition around the loads: rows past the end read as zero through the descriptor)
-                    const int rel = (n0 + 32 * j - t0) + 160 + 32 * PF;
-                    load_block(rel, raw[p][0]);
-                    load_block(rel + 16, raw[p][1]);
-                }
-            }
+            for (int q = 1; q < 6; ++q) am = mf_pk_max_u(am, pam[q]);
+            M0 = (int) (am & 0xffffu);
+            M1 = (int) (am >> 16);
+            flags(c2, c1, __builtin_fmaf(eps_seen_u, (float) M0, eps_abs_u), word0, amb0);
         }
+        products(RC, 1, c2, c1);
+        flags(c2, c1, __builtin_fmaf(eps_seen_u, (float) M1, eps_abs_u), word1, amb1);
+        // lane hh = 0 keeps the even channel's word (set 0), hh = 1 the odd one's (set 1); each needs its partner lane's half of
+        // THAT set: one half-wave swap of (set 0, set 1) puts (own.lo, partner... ) where both find theirs -- after it word0 holds
+        // the outputs 0-3 of every 8 (the lower lanes' rows) and word1 the outputs 4-7, of the set the lane keeps
+        mf_swap32(word0, word1);
+        mf_swap32(amb0, amb1);
+        uint32_t w = (word0 << 4) | word1, am = (amb0 << 4) | amb1;
+        // a channel without a nonzero sample in reach has y = +0 exactly: not positive (receiver.c:111), nothing to settle
+        if ((hh == 0 ? M0 : M1) == 0) {
+            w = 0;
+            am = 0;
+        }
+        held_w = w;
+        held_am = am;
+#pragma unroll
+        for (int q = 0; q < 5; ++q) pam[q] = pam[q + 1];
+    };
+    for (int n0 = t0; n0 < t1; n0 += 128) {
+        step(std::integral_constant<int, 0>{}, n0 - t0);
+        if (n0 + 32 < t1) step(std::integral_constant<int, 1>{}, n0 + 32 - t0);
+        if (n0 + 64 < t1) step(std::integral_constant<int, 2>{}, n0 + 64 - t0);
+        if (n0 + 96 < t1) step(std::integral_constant<int, 3>{}, n0 + 96 - t0);
     }
+    flush(((t1 - t0 + 31) / 32 - 1) * 32, held_w, held_am);
 
     // ---- peak, carry
+    peak_pk = mf_pk_max(peak_pk, (uint32_t) __shfl_xor((int) peak_pk, 32));        // the two halves' rows
     int peak = hh ? ((int) peak_pk >> 16) : (int) (short) (peak_pk & 0xffffu);
     if (t1 == L) {                                     // the call's last rows, which no window of this segment has read
         // (the loop's maxima reach row L - dc + 111 at least; dc = d - J0 grows with trailing zero taps, so the rescan
@@ -420,20 +439,21 @@ bool fir_sign_mfma_taps(const float *tc48, MfmaTaps *out, double *scale, double 
     for (int b = 0; b < MF_NB; ++b)
         for (int lane = 0; lane < 64; ++lane) {
             const int i = lane & 31;
-            unsigned long v[3] = {0, 0, 0};
-            for (int j = 0; j < 8; ++j) {
-                const int k = 8 * (lane >> 5) + j, q = 16 * b + k - i;
+            uint32_t v[3][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
+            for (int j = 0; j < MF_BR; ++j) {
+                const int k = MF_BR * (lane >> 5) + j, q = 32 * b + k - i;
                 long t = (q >= 0 && q < MF_NC) ? tq[q] : 0;
                 // signed digits: t = 65536 t2 + 256 t1 + t0, each in [-128, 127]
                 const long t0 = ((t + 128) & 255) - 128; t = (t - t0) >> 8;
                 const long t1 = ((t + 128) & 255) - 128; t = (t - t1) >> 8;
                 const long t2 = t;
                 if (t2 < -128 || t2 > 127) return false;
-                v[0] |= (unsigned long) (uint8_t) (int8_t) t0 << (8 * j);
-                v[1] |= (unsigned long) (uint8_t) (int8_t) t1 << (8 * j);
-                v[2] |= (unsigned long) (uint8_t) (int8_t) t2 << (8 * j);
+                v[0][j >> 2] |= (uint32_t) (uint8_t) (int8_t) t0 << (8 * (j & 3));
+                v[1][j >> 2] |= (uint32_t) (uint8_t) (int8_t) t1 << (8 * (j & 3));
+                v[2][j >> 2] |= (uint32_t) (uint8_t) (int8_t) t2 << (8 * (j & 3));
             }
-            for (int dgt = 0; dgt < 3; ++dgt) out->a[b][dgt][lane] = (long) v[dgt];
+            for (int dgt = 0; dgt < 3; ++dgt)
+                for (int w = 0; w < 4; ++w) out->a[b][dgt][lane][w] = (int) v[dgt][w];
         }
     out->k0 = (int) (128 * sumtq);
     *scale = S;
@@ -443,20 +463,21 @@ bool fir_sign_mfma_taps(const float *tc48, MfmaTaps *out, double *scale, double 
 
 int launch_fir_sign_mfma_quantum() { return 128; }
 
-// segments seg0 .. of T outputs (the packed kernel has run segment 0): a.mfma = the device copy of the taps, a.eps_seen /
-// a.eps_ahead = the threshold in units of y' per unit of |x| / absolute
-hipError_t launch_fir_sign_mfma(const FirLaunch &a, int seg0, hipStream_t stream)
+// outputs first .. L - 1 in segments of T (the packed kernel takes the call's first `first` outputs, whose windows reach
+// into the history): a.mfma = the device copy of the taps, a.eps_seen / a.eps_ahead = the threshold in units of y' per unit of
+// |x| / absolute
+hipError_t launch_fir_sign_mfma(const FirLaunch &a, int first, hipStream_t stream)
 {
     const int J0 = (a.NE - MF_NC) / 2, dc = a.d - J0;
-    if (a.dump || a.NC != MF_NC || a.T % 128 || a.NE < MF_NC || (a.NE - MF_NC) % 2 || !a.te_mem || !a.mfma || a.N % 64 || seg0 < 1 ||
-        a.T < dc + 48 || a.T < a.d || a.L < a.NT || a.T > 65280 || !(a.eps_seen > 0.0f) || dc < 0 || J0 > 48 ||
+    if (a.dump || a.NC != MF_NC || a.T % 128 || a.NE < MF_NC || (a.NE - MF_NC) % 2 || !a.te_mem || !a.mfma || a.N % 64 || first % 128 ||
+        first < dc + 64 || first < a.d || a.L < a.NT || a.T > 65280 || !(a.eps_seen > 0.0f) || dc < 0 || J0 > 48 ||
         (unsigned long long) (a.T + a.NE + 512) * (unsigned long long) a.N * 2ull >= 0x7fffffffull)
         return hipErrorInvalidValue;
-    const int segs = (a.L + a.T - 1) / a.T - seg0;
+    const int segs = (a.L - first + a.T - 1) / a.T;
     if (segs <= 0) return hipSuccess;
     dim3 grid(a.N / 64, segs), block(64);
-    hipLaunchKernelGGL(fir_sign_mfma_kernel<2>, grid, block, 0, stream, a.x, a.sgn, a.maxval, a.hist_out, a.maxval_next, a.te_mem,
-                       a.mfma, a.N, a.L, a.T, a.d, a.NT, a.NE, seg0, a.eps_seen, a.eps_ahead);
+    hipLaunchKernelGGL(fir_sign_mfma_kernel, grid, block, 0, stream, a.x, a.sgn, a.maxval, a.hist_out, a.maxval_next, a.te_mem,
+                       a.mfma, a.N, a.L, a.T, a.d, a.NT, a.NE, first, a.eps_seen, a.eps_ahead);
     return hipGetLastError();
 }
 

@@ -799,20 +799,30 @@ static int run_fir(gnuais_batch *b, const int16_t *x, int len, float *dump, hipS
             // segment settles at its end grow with it; profiles/r05_c5_forty_central_taps.txt)
             f.T = ((b->fir_T <= 768 ? (f.NC == 40 ? 1920 : 3072) : b->fir_T) + qp - 1) / qp * qp;
             f.T = std::min(f.T, 65280 / qp * qp);           // the kernel notes open outputs as 16-bit offsets into the segment
-            // the matrix-pipe kernel takes every segment but the call's first (whose windows reach into the history)
+            // The matrix-pipe kernel takes everything but the call's head -- the outputs whose windows reach into the history
+            // rows --, which stays the packed kernel's: the fewest whole packed loop turns (and whole 16-byte sign stores) that
+            // cover d and dc + 64 rows (640 outputs for the 192 kHz table: one wave per 64 channels walks it alone, 0.1 ms for
+            // 256 waves on 1024 SIMDs; round 5's whole first segment of 1920 took 0.3).  (Beside the matrix-pipe launch on a side
+            // stream, between two events: 2.44 instead of 2.51 ms per C5 call, but one pipelined run in six came out with a frame
+            // more or less -- not kept; profiles/r06_c5_matrix_pipe_k32.txt.)
             const int dc48 = f.d - (f.NE - 48) / 2;
-            const bool mfma = b->fir_mfma && b->mfma_ok && b->N % 64 == 0 && f.T % launch_fir_sign_mfma_quantum() == 0 && len > f.T &&
-                              len >= b->NT && f.T >= dc48 + 48 && f.T >= f.d &&
+            const int qh = qp % launch_fir_sign_mfma_quantum() == 0 ? qp : qp * launch_fir_sign_mfma_quantum();
+            const int head = (std::max(dc48 + 64, f.d) + qh - 1) / qh * qh;
+            const bool mfma = b->fir_mfma && b->mfma_ok && b->N % 64 == 0 && f.T % launch_fir_sign_mfma_quantum() == 0 && len > head &&
+                              len >= b->NT && head <= 65280 &&
                               (unsigned long long) (f.T + f.NE + 512) * (unsigned long long) b->N * 2ull < 0x7fffffffull;
-            if (mfma) f.max_segments = 1;
-            HIP_TRY(launch_fir_sign_pk(f, s));
             if (mfma) {
-                FirLaunch m = f;
+                FirLaunch h = f, m = f;
+                h.T = head;
+                h.max_segments = 1;
                 m.NC = 48;
                 m.mfma = b->d_mfma;
                 m.eps_seen = b->mfma_eps_seen_u;
                 m.eps_ahead = b->mfma_eps_abs_u;
-                HIP_TRY(launch_fir_sign_mfma(m, 1, s));
+                HIP_TRY(launch_fir_sign_pk(h, s));
+                HIP_TRY(launch_fir_sign_mfma(m, head, s));
+            } else {
+                HIP_TRY(launch_fir_sign_pk(f, s));
             }
             b->hist_cur = (b->hist_cur + 1) % gnuais_batch::HB;
             b->max_last = b->max_cur;

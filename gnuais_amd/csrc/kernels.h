@@ -37,11 +37,11 @@ int launch_fir_sign_quantum(int NC);           // T must be a multiple of this
 hipError_t launch_fir_sign(const FirLaunch &a, hipStream_t stream);
 // K1s in transposed form on register pairs (fir_sign_pk.hip): NC 12 (32-tap table), 40 or 48
 int launch_fir_sign_pk_quantum(int NC);
-// K1s, 48 central taps as an exact integer Toeplitz product on the matrix pipe (fir_sign_mfma.hip): segments seg0 .. of a call
-struct MfmaTaps { long a[5][3][64]; int k0; };      // [block of 16 window rows][tap digit 0..2][lane]: the A operands; 128 * sum of the integer taps
+// K1s, 48 central taps as an exact integer Toeplitz product on the matrix pipe (fir_sign_mfma.hip): outputs first .. of a call
+struct alignas(16) MfmaTaps { int a[3][3][64][4]; int k0; };   // [block of 32 window rows][tap digit 0..2][lane][16 bytes]: the A operands; 128 * sum of the integer taps
 bool fir_sign_mfma_taps(const float *tc48, MfmaTaps *out, double *scale, double *bound_q);
 int launch_fir_sign_mfma_quantum();
-hipError_t launch_fir_sign_mfma(const FirLaunch &a, int seg0, hipStream_t stream);
+hipError_t launch_fir_sign_mfma(const FirLaunch &a, int first, hipStream_t stream);
 hipError_t launch_fir_sign_pk(const FirLaunch &a, hipStream_t stream);
 hipError_t launch_fir_generic(const FirLaunch &a, hipStream_t stream);
 hipError_t launch_fir_history(const int16_t *x, const int16_t *hist_in, int16_t *hist_out,

@@ -412,8 +412,8 @@ def test_chain_192k_sparse_impulses_and_ragged_ends(pk_taps):
 
 @pytest.mark.parametrize("n_ch", [64, 192])
 def test_chain_192k_on_the_matrix_pipe(n_ch):
-    """fir_sign_mfma.hip: with whole groups of 64 channels and calls longer than a segment, the 144-tap table's slicer
-    runs every segment but a call's first as an integer Toeplitz product on the matrix pipe.  Messages at several noise
+    """fir_sign_mfma.hip: with whole groups of 64 channels and calls longer than the head the packed kernel keeps (640
+    outputs), the 144-tap table's slicer runs everything behind that head as an integer Toeplitz product on the matrix pipe.  Messages at several noise
     levels, noise alone from 3 to 20 000 rms, full-scale random samples, digital silence with sparse impulses, silence
     that ends and begins inside a segment, constant levels: bits, frames, counters, PLL carry == oracle; calls of one
     and of several segments, ragged, and short calls in between (the packed kernel alone)."""
@@ -451,6 +451,8 @@ def test_chain_192k_on_the_matrix_pipe(n_ch):
     b.close()
     run_both(x, [total], n_ch, **kw)
     run_both(x, [1921, 1920, 100, 3841, total - 7782], n_ch, **kw)
+    # around the head the packed kernel keeps (640 outputs for this table): calls that end on it, one short of it, one past it
+    run_both(x, [640, 641, 639, 768, 1281, 2560, total - 6529], n_ch, **kw)
     run_both(x, [total], n_ch, options={"fir_pk_taps": 48}, **kw)
     run_both(x, [total], n_ch, options={"fir_mfma": 0}, **kw)
 
@@ -757,11 +759,12 @@ def test_protodec_reset_and_frame_cells_vs_oracle(hdlc_variant):
     n_ch, total = 70, 24 * 1280
     x = np.stack([synth.make_stream(total, seed=47, channel=c, occupancy=0.9, sigma=(800.0, 3000.0)[c % 2])[0]
                   for c in range(n_ch)], axis=1)
-    b = batch(n_ch, max_len=4096)
+    b = batch(n_ch, max_len=8192)
     b.set_option("hdlc_variant", hdlc_variant)
     o = Oracle(n_ch)
-    chunks = [777, 1020, 333, 2048, 1500, 913] * 6
+    chunks = [777, 1020, 333, 2048, 1500, 913] * 4
     chunks.append(total - sum(chunks))
+    assert chunks[-1] > 0
     pos = inside = 0
     for i, n in enumerate(chunks):
         b.run(dev(x[pos:pos + n]))
