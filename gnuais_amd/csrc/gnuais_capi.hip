@@ -553,11 +553,13 @@ int gnuais_batch_create(gnuais_batch **out, int device, int n_channels, const fl
         // created here shares its pipe with the caller's (FIR) queue.  With the PLL stage or
         // the deframer there a C3 call takes 0.81-0.83 ms, with K3 there 0.90-0.93 (K3 is the
         // stage whose completion the host waits on before it reuses a hand-off set), with the spare
-        // stream there 0.87.  Hence: the spare, K2b, K3, and the PLL stage last.  GNUAIS_STREAM_ORDER (four digits,
-        // stage indices 0 = K2 .. 3 = K3 in creation order) overrides, for processes that have
-        // created streams of their own before.
+        // stream there 0.87.  That was with four streams per batch; with the twelve of the pool below the picture turns
+        // (round 6, four fresh processes, C3: the PLL stage on the fourth stream 0.65-0.67 ms per step, on the first 0.503 =
+        // what gnuais_batch_autotune() finds, 0.498-0.505; profiles/r06_stream_assignment.txt).  Hence: the PLL stage first,
+        // then the spare, K2b, K3.  GNUAIS_STREAM_ORDER (four digits, stage indices 0 = K2 .. 3 = K3 in creation order)
+        // overrides, for processes that have created streams of their own before.
         const char *order = getenv("GNUAIS_STREAM_ORDER");
-        if (!order || strlen(order) != 4) order = "1230";
+        if (!order || strlen(order) != 4) order = "0123";
         int made = 0;
         for (int q = 0; q < 4; ++q) {
             const int idx = (order[q] - '0') & 3;
@@ -1919,6 +1921,12 @@ int gnuais_batch_info(const gnuais_batch *b, const char *name, double *value)
     else if (!strcmp(name, "compute_units")) *value = b->n_cu;
     else if (!strcmp(name, "device")) *value = b->device;
     else if (!strcmp(name, "segments")) *value = b->n_seg;
+    else if (!strncmp(name, "stream_of_stage_", 16) && name[16] >= '0' && name[16] <= '3' && !name[17]) {
+        // which of the batch's POOL candidate streams (creation order) serves stage 0 K2, 1 spare, 2 K2b, 3 K3 right now
+        *value = -1;
+        for (int q = 0; q < gnuais_batch::POOL; ++q)
+            if (b->pool[q] == b->s_k[name[16] - '0']) *value = q;
+    }
     else if (!strcmp(name, "stream_depth")) *value = gnuais_batch::NRING - 1;
     else return fail(GNUAIS_E_ARG, "info: unknown name");
     return GNUAIS_OK;
