@@ -94,6 +94,8 @@ void filter_run(struct filter *f, float in, float *out);
 void protodec_decode(char *in, int count, struct demod_state_t *d);
 unsigned short protodec_sdlc_crc(const unsigned char *data, unsigned len);
 int protodec_calculate_crc(int length_bits, struct demod_state_t *d);
+void protodec_reset(struct demod_state_t *d);
+void protodec_deinit(struct demod_state_t *d);
 void gnuais_protodec_flush(struct demod_state_t *d);
 void gnuais_protodec_release(struct demod_state_t *d);
 void gnuais_protodec_set_batching(int bits);
@@ -367,6 +369,35 @@ static void run_shims(const char *dir)
 	gnuais_protodec_release(&d);
 	gnuais_protodec_release(&e);
 	gnuais_protodec_release(&e);                    /* twice: a no-op */
+	{       /* protodec_reset() / protodec_deinit() of the shim (protodec.c:78-100): a decoder reset every 997 bits -- inside
+		 * frames too --, its d->buffer cells looked at every 500, its buffers freed by protodec_deinit */
+		struct demod_state_t r;
+		unsigned long long h = 1469598103934665603ull;
+		int k, inside = 0;
+		protodec_initialize(&r, NULL, NULL, 'R');
+		r.serbuffer = malloc(8);                /* the three buffers the test's protodec_initialize leaves out: deinit frees them */
+		r.ipcbuffer = malloc(8);
+		r.nmea = malloc(8);
+		protodec_reset(&r);                     /* before the first bit: no device object yet */
+		for (i = 0; i < nbits; i++) {
+			char b = (char) bits[i];
+			if (i % 997 == 500)
+				protodec_reset(&r);
+			protodec_decode(&b, 1, &r);
+			if (i % 500 == 499) {
+				gnuais_protodec_flush(&r);
+				if (r.state == 4 || r.state == 5) {
+					inside++;
+					for (k = 0; k < r.bufferpos; k++)
+						h = (h ^ r.buffer[k]) * 1099511628211ull;
+				}
+			}
+		}
+		gnuais_protodec_flush(&r);
+		fprintf(out, "R: received %d lost %d lost2 %d state %d inside %d cells %016llx\n", r.receivedframes, r.lostframes,
+			r.lostframes2, r.state, inside, h);
+		protodec_deinit(&r);
+	}
 	{       /* the CRC names: "123456789" and a frame with its FCS appended */
 		unsigned char msg[9] = "123456789", body[8] = { 0x04, 0x43, 0x12, 0x34, 0x56, 0x78, 0x9a, 0xbc };
 		unsigned short fcs;

@@ -116,6 +116,26 @@ def test_reference_named_shims_over_the_test_double_under_the_sanitizers(run):
     body = bytes([0x04, 0x43, 0x12, 0x34, 0x56, 0x78])
     assert good[3:] == [format(b, "08b") for b in body]                # the payload, most significant bit first
     assert "calculate_crc bad 0 nonpositive 0 0 huge 0" in got
+    # protodec_reset() every 997 bits / d->buffer every 500 / protodec_deinit(): what the oracle says for the same bit stream
+    from oracle_lib import Oracle
+    bits = np.asarray(g["bits0"] if "bits0" in g else [], dtype=np.uint8)
+    line = [l for l in got if l.startswith("R: ")]
+    assert len(line) == 1
+    if len(bits):
+        o = Oracle(1)
+        h, inside = 1469598103934665603, 0
+        for i in range(len(bits)):
+            if i % 997 == 500:
+                o.protodec_reset()
+            o.decode_bits(0, bits[i:i + 1])
+            if i % 500 == 499 and o.hdlc(0)["state"] in (4, 5):
+                inside += 1
+                for v in o.frame_cells(0):
+                    h = ((h ^ int(v)) * 1099511628211) & 0xffffffffffffffff
+        st = o.hdlc(0)
+        assert line[0] == (f"R: received {st['receivedframes']} lost {st['lostframes']} lost2 {st['lostframes2']} "
+                           f"state {st['state']} inside {inside} cells {h:016x}")
+        assert inside > 0
 
 
 def _check_shims_from_two_threads(d, g):
