@@ -74,7 +74,7 @@ def effective_cpus():
     return n
 
 
-def cpu_baseline(x_host, n_sample_ch, total, x_wide=None):
+def cpu_baseline(x_host, n_sample_ch, total, x_wide=None, post_stage=False):
     """The reference's own code (oracle/_ref, kind 'reference') -- or the C
     restatement (kind 'port') when the prebuilt reference is absent -- timed on a
     bounded sample of the same workload on this host, single thread."""
@@ -125,6 +125,26 @@ def cpu_baseline(x_host, n_sample_ch, total, x_wide=None):
                                    "kind": "port", "sample": f"{x_wide.shape[1]} of the bench's channels x {total} "
                                    "samples, de-interleaved beforehand (planar), channels partitioned over threads",
                                    "seconds": round(dt, 2), "msgs": int(o.counters()[:, 0].sum())}
+    if post_stage:
+        # row f3's host post-stage ("measure host post-stage msgs/s"): the reference's per-message path
+        # (protodec_getdata -> serial_write, printf + fflush, cache) against the batched adapter (sinks_batch.c) in front of
+        # the SAME unchanged sink functions, identical frame records, /dev/null behind both -- scripts/time_sinks.py, bounded
+        import subprocess
+        try:
+            out = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "time_sinks.py"), "200000", "100000"],
+                                 capture_output=True, timeout=180, cwd=ROOT).stdout.decode()
+            ps = {}
+            for line in out.splitlines():
+                if "M msgs/s" not in line:
+                    continue
+                label, rest = line.split(":", 1)
+                ps[" ".join(label.split())] = float(rest.split()[0]) * 1e6
+            if ps:
+                res["post_stage"] = {"msgs_per_s": ps, "unit": "msgs/s", "cores": 1,
+                                     "what": "host side behind the frame records, 200 000 frames: the reference's own "
+                                             "per-message path vs the batched adapter feeding the same sink functions"}
+        except Exception as e:                          # noqa: BLE001
+            res["post_stage"] = {"error": str(e)}
     return res
 
 
@@ -694,6 +714,10 @@ def compact_line(out, detail_path=None):
         for k in ("all_cores", "all_cores_planar"):
             if isinstance(cb.get(k), dict):
                 cc[k] = _pick(cb[k], ("value", "cores"))
+        if isinstance(cb.get("post_stage"), dict) and isinstance(cb["post_stage"].get("msgs_per_s"), dict):
+            ps = cb["post_stage"]["msgs_per_s"]
+            cc["post_stage"] = {"reference": ps.get("reference per-message path, all sinks"),
+                                "batched": ps.get("batched adapter, all sinks")}
         c["cpu_baseline"] = cc
     optional = []                   # (key, value), most dispensable LAST
     if isinstance(out.get("kernel_ms"), dict):
@@ -845,7 +869,7 @@ def rank_main(rank, local, world, args, sync):
                                                     n_taps=144 if CONFIGS[name]["wide"] else 36)}
         out["other_configs"] = others
     if x_cpu is not None:
-        out["cpu_baseline"] = cpu_baseline(x_cpu, args.cpu_channels, m["len"], x_wide)
+        out["cpu_baseline"] = cpu_baseline(x_cpu, args.cpu_channels, m["len"], x_wide, post_stage=args.e2e)
     out["bench_seconds"] = time.perf_counter() - T_START
     emit(out, args)
 
@@ -1015,10 +1039,10 @@ def main():
                     help="skip the 120-call leg behind the timed region that kernel_ms is averaged over")
     ap.add_argument("--no-traffic", dest="traffic", action="store_false",
                     help="skip the rocprofv3 --pmc child runs that fill roofline.traffic")
-    ap.add_argument("--e2e", dest="e2e", action="store_true", default=False,
-                    help="also run the message-layer legs (message_lines, end_to_end, float_path); off by default: the "
-                         "default command stays under a minute")
-    ap.add_argument("--no-e2e", dest="e2e", action="store_false", help="(the default; kept for old command lines)")
+    ap.add_argument("--e2e", dest="e2e", action="store_true", default=True,
+                    help="(the default) the message-layer legs too: message_lines, end_to_end (run + streamed NMEA text into "
+                         "pinned host memory every step), float_path; the sinks' host post-stage rides with the CPU baseline")
+    ap.add_argument("--no-e2e", dest="e2e", action="store_false", help="skip them (the profiler's child runs do)")
     ap.add_argument("--no-traffic-others", dest="traffic_others", action="store_false",
                     help="skip the rocprofv3 --pmc child runs for C2 and C5 (six passes; other_configs.*.traffic stays null)")
     ap.add_argument("--traffic-others", dest="traffic_others", action="store_true", help="(the default; kept for old command lines)")

@@ -354,7 +354,7 @@ def test_bench_eight_shards_on_one_device_prints_eight_rows():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     out = subprocess.check_output([sys.executable, os.path.join(root, "bench.py"), "--gpus", "8", "--devices",
                                    ",".join(["0"] * 8), "--steps", "6", "--warmup", "2", "--channels", "2048",
-                                   "--len", "9600", "--base", "64", "--no-cpu"], timeout=600)
+                                   "--len", "9600", "--base", "64", "--no-cpu", "--no-e2e"], timeout=600)
     last = out.decode().strip().splitlines()[-1]
     assert len(last) < 4096
     line = json.loads(last)
@@ -512,7 +512,7 @@ def test_bench_two_workers_prints_n_gpus_2():
     for mode in (["--procs"], []):                          # worker processes; the in-process node object
         out = subprocess.check_output([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--devices", devs,
                                        "--steps", "6", "--warmup", "2", "--channels", "2048", "--len", "9600",
-                                       "--base", "64", "--no-cpu", "--no-traffic"] + mode, timeout=600)
+                                       "--base", "64", "--no-cpu", "--no-traffic", "--no-e2e"] + mode, timeout=600)
         line = json.loads(out.decode().strip().splitlines()[-1])
         assert line["n_gpus"] == 2 and len(line["per_gpu"]) == 2
         assert line["value"] > 0 and line["valid_crc_msgs_per_s"] > 0
