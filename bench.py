@@ -230,17 +230,6 @@ def measure(cfg, args, local, rank, sync, steps, warmup, isolated=True, post=Fal
         step()
     torch.cuda.synchronize()
 
-    iso = None
-    if isolated:        # one call at a time, nothing overlapping: context only
-        b.set_timing(True)
-        acc = {k: [] for k in b.KERNELS}
-        for _ in range(3):
-            step()
-            t = b.last_timing()
-            for k in acc:
-                acc[k].append(t[k])
-        torch.cuda.synchronize()
-        iso = {k: float(np.mean(v)) for k, v in acc.items()}
     rx0 = b.total_received()
 
     # timed region: exactly K steps, asynchronous, nothing else on the streams -- the per-kernel HIP events the library
@@ -257,6 +246,18 @@ def measure(cfg, args, local, rank, sync, steps, warmup, isolated=True, post=Fal
     sync.barrier()
     dt = time.perf_counter() - t0
     rx1 = b.total_received()
+    iso = None
+    if isolated:        # one call at a time, nothing overlapping: context only (BEHIND the region: its syncs leave the chip idle)
+        b.set_timing(True)
+        acc = {k: [] for k in b.KERNELS}
+        for _ in range(3):
+            step()
+            t = b.last_timing()
+            for k in acc:
+                acc[k].append(t[k])
+        torch.cuda.synchronize()
+        b.set_timing(False)
+        iso = {k: float(np.mean(v)) for k, v in acc.items()}
     out = {"n_ch": n_ch, "len": total, "dt": dt, "dt_own": dt_own, "steps": steps, "msgs": float(rx1 - rx0),
            "kernel_ms_isolated": iso, "uncalibrated_ms_per_step": uncal}
     # `kernel_ms`: the same loop again, long enough for a stable mean -- a 20-step region sampled on every 4th call gives
