@@ -1,6 +1,6 @@
 #!/bin/bash
 # The round's closing run on the GPU box: the GPU suite, smoke, the profiles of the bench command (scripts/collect_profiles.sh <tag>).
-TAG=${1:-r05}
+TAG=${1:-r06}
 mkdir -p gpurun_out/$TAG
 ( time timeout 1800 python -m pytest tests -m gpu -x -q 2>&1 | tail -4 ) > gpurun_out/${TAG}_pytest.txt 2>&1
 cat gpurun_out/${TAG}_pytest.txt
