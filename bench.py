@@ -1071,18 +1071,26 @@ def main():
         mine = preflight([local], _cfg_of(args))
         if mine is None:
             torch.cuda.set_device(local)
-        found = [None] * world
+        # through a plain TCP store next to the launcher's (no process group yet: RCCL cannot be initialised on a rank without
+        # a device, and a second group behind a destroyed one does not come up under torch.distributed.run)
+        import datetime
+        found = [{"rank": rank, "device": local, "error": mine}]
         try:
-            dist.init_process_group("gloo", rank=rank, world_size=world, init_method="tcp://%s:%d" % (
-                os.environ["MASTER_ADDR"], int(os.environ["MASTER_PORT"]) + 1))
-            dist.all_gather_object(found, {"rank": rank, "device": local, "error": mine})
-            dist.destroy_process_group()
-        except Exception as e:                          # noqa: BLE001
-            found = [{"rank": rank, "device": local, "error": mine or ("preflight exchange failed: %s" % e)}]
-        if any(f and f.get("error") for f in found):
+            store = dist.TCPStore(os.environ["MASTER_ADDR"], int(os.environ["MASTER_PORT"]) + 1, world, rank == 0,
+                                  timeout=datetime.timedelta(seconds=120))
+            store.set("pre%d" % rank, json.dumps(found[0]))
+            found = [json.loads(store.get("pre%d" % r)) for r in range(world)]
+            store.set("ack%d" % rank, "1")
             if rank == 0:
+                for r in range(world):                  # the store lives in rank 0: stay until everybody has read it
+                    store.get("ack%d" % r)
+        except Exception as e:                          # noqa: BLE001   (a busy port must not stop a healthy node: go on with what this rank knows)
+            sys.stderr.write("bench.py: rank %d: preflight exchange failed (%s); continuing on this rank's own check\n" % (rank, e))
+            found = [{"rank": rank, "device": local, "error": mine}]
+        if any(f.get("error") for f in found):
+            if rank == 0 or (mine is not None and len(found) == 1):
                 fail_line(args, world, "; ".join("rank %d (device %d): %s" % (f["rank"], f["device"], f["error"])
-                                                for f in found if f and f.get("error")), found)
+                                                for f in found if f.get("error")), found)
             sys.exit(3)
         dist.init_process_group("nccl", rank=rank, world_size=world)
         rank_main(rank, local, world, args, DistSync(dist, torch.device("cuda", local), rank, world))

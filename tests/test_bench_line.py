@@ -105,3 +105,31 @@ def test_preflight_names_the_device_and_both_figures(monkeypatch):
     assert e.startswith("device 2:") and "GB free" in e and "16384 channels" in e
     e = bench.preflight([1] * 200, cfg)                 # 200 shards on one device do not fit 200 GB
     assert e.startswith("device 1: 200 shard(s)")
+
+
+def test_ranks_of_torch_distributed_run_that_cannot_start_say_so_together():
+    """Under `python -m torch.distributed.run` (how the driver starts N > 1): every rank checks its own device, the ranks
+    exchange what they found through a TCP store BEFORE any process group exists, and rank 0 prints ONE line whose `error`
+    names every failing rank -- within seconds, status 3, nobody left in a barrier.  (Here: no rank has a device.)"""
+    import socket
+    import subprocess
+    import time
+    import torch
+    if torch.cuda.is_available():
+        import pytest
+        pytest.skip("GPU present: the ranks would start")
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    t = time.perf_counter()
+    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+                        "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1",
+                        "--warmup", "1"], capture_output=True, timeout=180)
+    took = time.perf_counter() - t
+    assert p.returncode != 0 and took < 90, took
+    lines = [l for l in p.stdout.decode().splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    c = json.loads(lines[0])
+    assert c["value"] is None and c["n_gpus"] == 2
+    assert "rank 0 (device 0)" in c["error"] and "rank 1 (device 1)" in c["error"]
+    assert [g["rank"] for g in c["per_gpu"]] == [0, 1]
