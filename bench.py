@@ -802,11 +802,17 @@ def rank_main(rank, local, world, args, sync):
     if args.len:
         cfg = dict(cfg, len=args.len)
     want_cpu = rank == 0 and world == 1 and args.cpu and args.config == "C3"
+    # the FIRST collective brings RCCL up (communicator, buffers, kernels: hundreds of ms with the device idle); it must not be
+    # the barrier that opens the timed region -- behind it the first steps ran at idle clocks (0.59 instead of 0.50 ms per step)
+    sync.barrier()
     m = measure(cfg, args, local, rank, sync, args.steps, args.warmup, post=(rank == 0), keep_input=want_cpu,
                 kernel_leg=args.kernel_leg, uncalibrated=(world == 1))
     x_cpu, x_wide = m.pop("x_cpu", None), m.pop("x_wide", None)
     per_rank = {"rank": rank, "device": local, "ms_per_step": m["dt_own"] / m["steps"] * 1e3}
-    red = sync.reduce(m["dt"], m["msgs"], float(m["n_ch"]) * m["len"] * m["steps"], per_rank)
+    # every rank left the opening barrier together and clocked its own K steps up to its own synchronize; the job's time is
+    # the MAX of those over the ranks (the reduction) -- not a clock that also contains the closing barrier's own latency
+    # (an RCCL barrier is 0.1 ms per step of a 20-step region)
+    red = sync.reduce(m["dt_own"], m["msgs"], float(m["n_ch"]) * m["len"] * m["steps"], per_rank)
     if rank != 0:
         return
     dt, msgs, samples, ranks = red
