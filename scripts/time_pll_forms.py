@@ -49,7 +49,7 @@ def measure(variant, mask, extra):
     return short, steady, {k: round(float(live[k]), 3) for k in ("fir_slice", "pll", "hdlc_deframe", "hdlc_crc")}
 
 
-for a in sys.argv[1:] or ["3:31"]:
+for a in sys.argv[1:] or ["8:31"]:
     parts = a.split(":")
     variant, mask = int(parts[0]), int(parts[1], 0)
     extra = dict(kv.split("=") for kv in parts[2:])
