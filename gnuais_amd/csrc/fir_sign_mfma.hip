@@ -5,8 +5,8 @@
 //
 // Same contract as fir_sign_pk.hip (bit-identical sign words, peak, history carry); what changes is how y_c, the sum over
 // the 48 central taps, is formed -- and what it costs: the packed kernel issues 20-24 v_pk_fma_f32 per sample and is
-// VALU-bound (3.4 ms per C5 call); here a step of 32 outputs x 64 channels is 36 matrix instructions and ~16 vector
-// instructions per output and channel (what binds it is in the step loop's comment).
+// VALU-bound (3.4 ms per C5 call); here a step of 32 outputs x 64 channels is 36 matrix instructions and 370 vector
+// instructions (11.5 per output row; what binds it is in the step loop's comment): 2.0 ms per C5 call.
 //
 //   y_c[n] = sum_q tc[q] * x[n - dc + q],  q < 48.   Taps as 24-bit integers tq = round(tc * S) (S a power of two, sum |tq| <
 //   2^23), three signed int8 digits t2 t1 t0; samples as two int8 digits, x = 256 hs + l' + 128 (hs = x >> 8, l' = (x & 255)
@@ -30,7 +30,7 @@
 // noted per lane and settled with the reference's ordered sum (filter.h:40-49) lane-parallel, as in fir_sign_pk.hip.
 //
 // Only outputs whose windows lie inside the call's input run here (t0 >= first >= d, dc + 64); the call's head, with its
-// history rows, is the packed kernel's (launch_fir_sign_pk with T = first, max_segments = 1), on a stream beside this launch.
+// history rows, is the packed kernel's (launch_fir_sign_pk with T = first, max_segments = 1), launched ahead of this one.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <math.h>
@@ -284,12 +284,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
         }
     };
 
-    // ---- steps of 32 outputs.  Measured (profiles/r05_c5_matrix_pipe.txt): the matrix pipe is busy 32 cycles per product =
-    // 1.2 ms per C5 call, but the kernel is bound by its ~16 vector instructions per output (digits, maxima, and 7 per output to
-    // put the int32 accumulators together and read sign and threshold off them): two waves per SIMD take 2.9 ms.  One wave
-    // per SIMD with the products software-pipelined beside the previous set's flags (sched_group_barrier) took 3.65 ms
-    // (accumulators in AccVGPRs: a copy per element read), eight-wave workgroups whose SIMD partners alternate products
-    // and flags between s_barriers 3.6 ms.
+    // ---- steps of 32 outputs.  Measured (profiles/r06_c5_matrix_pipe_k32.txt, rocprofv3 --pmc): the matrix pipe is busy 32
+    // cycles per product = 0.74 ms per C5 call (42 % of the launch); the two waves of a SIMD together issue during 75 % of its
+    // cycles -- the kernel is bound by its 370 vector instructions per step (96 to put the four digit levels together, 96 to
+    // read sign and threshold, 80 for digits and maxima), 2.03 ms alone.  The compiler already runs the second set's products
+    // beside the first set's flags (two accumulator pairs).  Round 5: one wave per SIMD software-pipelined by hand
+    // (sched_group_barrier) and eight-wave workgroups alternating products / flags between s_barriers were slower;
+    // round 6: three waves per SIMD (168 registers) spill, two blocks in flight are slower than one.
     // y' = ((A3 2^8 + A2) 2^8) + (A1 + (A0 >> 8)): the outer accumulators first (six products, alternating), their shifted values
     // are what the inner accumulators start from (twelve products, alternating) -- two accumulators per output instead of four,
     // three vector instructions per output to form y' instead of four; no product straight behind one on the same accumulator
