@@ -249,7 +249,7 @@ def measure(cfg, args, local, rank, sync, steps, warmup, isolated=True, post=Fal
     iso = None
     if isolated:        # one call at a time, nothing overlapping: context only (BEHIND the region: its syncs leave the chip idle)
         b.set_timing(True)
-        acc = {k: [] for k in b.KERNELS}
+        acc = {k: [] for k in b.KERNELS + ("total",)}
         for _ in range(3):
             step()
             t = b.last_timing()
@@ -258,8 +258,10 @@ def measure(cfg, args, local, rank, sync, steps, warmup, isolated=True, post=Fal
         torch.cuda.synchronize()
         b.set_timing(False)
         iso = {k: float(np.mean(v)) for k, v in acc.items()}
+        iso_total = iso.pop("total")
     out = {"n_ch": n_ch, "len": total, "dt": dt, "dt_own": dt_own, "steps": steps, "msgs": float(rx1 - rx0),
-           "kernel_ms_isolated": iso, "uncalibrated_ms_per_step": uncal}
+           "kernel_ms_isolated": iso, "uncalibrated_ms_per_step": uncal,
+           "call_latency_isolated_ms": iso_total if isolated else None}
     # `kernel_ms`: the same loop again, long enough for a stable mean -- a 20-step region sampled on every 4th call gives
     # five samples per kernel, and which of two stages of nearly equal length "dominates" then flips from run to run
     leg = KERNEL_LEG_CALLS if kernel_leg else 12
@@ -276,6 +278,7 @@ def measure(cfg, args, local, rank, sync, steps, warmup, isolated=True, post=Fal
         b.set_timing(False)
         b.set_option("timing_stride", 1)
         out["kernel_ms"] = {k: float(live2[k]) for k in b.KERNELS}
+        out["call_latency_in_loop_ms"] = float(live2["total"])      # a call's first kernel start -> its last kernel's end
         out["kernel_ms_calls"] = int(live2["calls"])
         out["kernel_ms_leg"] = {"calls": leg, "events_on_every": KERNEL_LEG_STRIDE, "ms_per_step": t_leg / leg * 1e3,
                                 "what": "the timed loop continued for %d calls with the library's per-kernel HIP events on "
@@ -725,6 +728,8 @@ def compact_line(out, detail_path=None):
         optional.append(("kernel_ms", out["kernel_ms"]))
     if isinstance(out.get("steady_state"), dict):
         optional.append(("steady_state", _pick(out["steady_state"], ("steps", "ms_per_step"))))
+    if isinstance(out.get("call_latency_ms"), dict):
+        optional.append(("call_latency_ms", _pick(out["call_latency_ms"], ("isolated", "in_loop"))))
     if isinstance(out.get("stage_masks"), dict):
         optional.append(("stage_masks", {k: v for k, v in out["stage_masks"].items() if k not in ("what", "steps")}))
     oc = out.get("other_configs")
@@ -840,6 +845,9 @@ def rank_main(rank, local, world, args, sync):
         "steady_state": m.get("steady_state"),
         "stage_masks": m.get("stage_masks"),
         "uncalibrated_ms_per_step": m.get("uncalibrated_ms_per_step"),
+        "call_latency_ms": {"isolated": m.get("call_latency_isolated_ms"), "in_loop": m.get("call_latency_in_loop_ms"),
+                            "what": "one call, first kernel's start to last kernel's end (HIP events): alone on the chip / "
+                                    "inside the pipelined loop, where three calls are in flight"},
         "uncalibrated_what": "the same K steps BEFORE gnuais_batch_autotune() (after 200 warm-up calls): the library's default "
                              "stage -> stream assignment, what a plain gnuais_batch_run() caller gets",
         "note": "the receive path slices the sign of the filter output and never stores the pre-slicer "
